@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Throughput of the `--com disco` hot path on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One STEP = one pass of the hot path over one batch of synthetic scenes already
+resident in HBM: batched dense rebuild of the sparse voxel lists (K1/a2) ->
+MotionNet encoder -> DiscoGraph fusion (warp, pairwise attention, agent
+softmax, weighted sum) -> decoder -> cls/reg heads.  Workload = BASELINE.json
+configs[1]: 5 agents, batch 4, 256x256x13 BEV, no KD, eval forward.
+
+Multi-GPU: scene-parallel -- every rank runs its own batch of scenes, no
+collective on the data path -> "scaling": "weak".
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+`roofline` (dominant kernel = the fp32-MFMA implicit-GEMM conv, HIP-event timed
+inside the timed region on the launch stream) and `cpu_baseline` (the CPU
+oracle, i.e. a port: the reference itself is not in the mount).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+AGENTS, BATCH, MAP_HW = 5, 4, 256
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not record per-launch HIP events in the timed region")
+    ap.add_argument("--layers", action="store_true", help="also print the per-layer table (stderr)")
+    return ap.parse_args()
+
+
+def cpu_baseline(state_dict, threads):
+    """Times the CPU oracle (kind 'port') on ONE scene (5 agents, 256x256x13,
+    batch 1), 1 warm-up + best of 3.  Bounded sample of the same workload."""
+    from oracle.disconet_ref import RefConfig, build_ref_model
+    from disconet_amd.synthetic import make_scene_batch
+    torch.set_num_threads(threads)
+    ref = build_ref_model(RefConfig(MAP_HW), kd_flag=0, num_agent=AGENTS)
+    ref.load_state_dict(state_dict, strict=False)
+    bevs, trans, na = make_scene_batch(1, AGENTS, MAP_HW)
+    best = float("inf")
+    with torch.no_grad():
+        ref(bevs, trans, na, 1)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = ref(bevs, trans, na, 1)
+            best = min(best, time.perf_counter() - t0)
+    return {"value": round(1.0 / best, 4), "unit": "scenes/s", "cores": threads, "kind": "port",
+            "sample": "1 scene (5 agents, 256x256x13, batch 1), eval fwd, fp32, best of 3 after 1 "
+                      "warm-up; torch-CPU oracle (reference source not in the mount)"}, (bevs, trans, na, out)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from disconet_amd import Config, DiscoNet, ops
+    from disconet_amd.profiling import KernelTimer, timing
+    from disconet_amd.synthetic import make_sparse_scene_batch, make_trans_matrices, randomize_bn_stats
+
+    torch.manual_seed(0)
+    model = DiscoNet(Config(map_hw=MAP_HW), kd_flag=0, num_agent=AGENTS)
+    randomize_bn_stats(model)
+    model.eval().cuda()
+    state_dict_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    # synthetic scenes, resident in HBM before the timed region
+    indices, offsets, _ = make_sparse_scene_batch(BATCH, AGENTS, MAP_HW)
+    indices, offsets = indices.cuda(), offsets.cuda()
+    trans = make_trans_matrices(BATCH, AGENTS, jitter_seed=rank).cuda()
+    na = torch.full((BATCH, AGENTS), AGENTS, dtype=torch.int64).cuda()
+    dims = (MAP_HW, MAP_HW, 13)
+    n_img = AGENTS * BATCH
+
+    def step():
+        bevs = ops.scatter_dense(indices, offsets, n_img, dims)
+        with torch.no_grad():
+            return model(bevs, trans, na, BATCH)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = None if args.no_kernel_events else KernelTimer()
+    fence()
+    t0 = time.perf_counter()
+    if timer is not None:
+        with timing(timer):
+            for _ in range(args.steps):
+                out = step()
+    else:
+        for _ in range(args.steps):
+            out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    scenes = world * BATCH * args.steps
+    result = {
+        "metric": "scenes/sec (5-agent 256x256 BEV)",
+        "value": round(scenes / elapsed, 3),
+        "unit": "scenes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "DiscoNet det eval forward (--com disco), 5-agent, batch 4 per GPU, "
+                               "256x256x13 BEV, no KD, sparse voxel lists -> dense -> enc -> "
+                               "DiscoGraph fusion -> dec -> cls/reg heads",
+                   "agents": AGENTS, "batch_per_gpu": BATCH, "bev": [MAP_HW, MAP_HW, 13],
+                   "parallelism": "scene-parallel x%d (no data-path collective)" % world},
+    }
+
+    if rank == 0:
+        if timer is not None:
+            summ = timer.summary()
+            conv = {k: v for k, v in summ.items() if v["kernel"] == "conv_mfma_kernel"}
+            flops = sum(v["flops"] for v in conv.values())
+            ms = sum(v["ms_total"] for v in conv.values())
+            launches = sum(v["calls"] for v in conv.values())
+            achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            result["roofline"] = {
+                "kernel": "conv_mfma_kernel (fp32 MFMA implicit-GEMM conv, all %d launches/step)"
+                          % (launches // args.steps),
+                "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "flop_per_step": flops / args.steps, "kernel_ms_per_step": round(ms / args.steps, 4),
+                "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
+            }
+            other = {k: round(v["ms_total"] / args.steps, 4) for k, v in summ.items()
+                     if v["kernel"] != "conv_mfma_kernel"}
+            result["roofline"]["other_kernels_ms_per_step"] = other
+            if args.layers:
+                print("%-12s %8s %10s %9s %8s" % ("layer", "ms/step", "GFLOP/step", "TFLOP/s", "GB/s"),
+                      file=sys.stderr)
+                for k, v in summ.items():
+                    m = v["ms_total"] / args.steps
+                    print("%-12s %8.4f %10.3f %9.2f %8.1f" % (
+                        k, m, v["flops"] / args.steps / 1e9,
+                        v["flops"] / (v["ms_total"] * 1e-3) / 1e12 if v["ms_total"] else 0,
+                        v["bytes"] / (v["ms_total"] * 1e-3) / 1e9 if v["ms_total"] else 0), file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            base, (bevs1, trans1, na1, ref_out) = cpu_baseline(state_dict_cpu, threads)
+            # the same scene through the HIP path: parity of the measured configuration
+            with torch.no_grad():
+                got = model(bevs1.cuda(), trans1.cuda(), na1.cuda(), 1)
+            base["parity_max_abs_err"] = {k: float((got[k].cpu() - ref_out[k]).abs().max())
+                                          for k in ("cls", "loc")}
+            result["cpu_baseline"] = base
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

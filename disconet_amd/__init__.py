@@ -1,0 +1,10 @@
+"""MI355X-native `--com disco` (DiscoNet) collaborative-perception hot path.
+
+Host side (this package) mirrors the reference's Python class surface; all
+compute is in libdisconet_hip.so (disconet_amd/csrc, C ABI in
+include/disconet_hip.h).  See DESIGN.md.
+"""
+from .config import Config
+from .model import DiscoNet
+
+__all__ = ["Config", "DiscoNet"]

@@ -1,0 +1,80 @@
+"""ctypes binding of libdisconet_hip.so (include/disconet_hip.h).
+
+There is no fallback: if the shared object is missing or a call fails, this
+module raises.  The library is built in-tree by disconet_amd/csrc/build.py
+(`python -m disconet_amd.csrc.build` or `__graft_entry__.build()`).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdisconet_hip.so")
+
+
+class DnError(RuntimeError):
+    pass
+
+
+class ConvDesc(Structure):
+    """struct dn_conv_desc"""
+    _fields_ = [(n, c_int32) for n in (
+        "n_images", "h_in", "w_in", "c0", "c1", "up0", "c_out", "ksize", "stride", "relu",
+        "ld0", "ld1", "ldo")]
+
+
+class MlpTailParams(Structure):
+    """struct dn_mlp_tail_params"""
+    _fields_ = [(n, c_void_p) for n in (
+        "bn1_scale", "bn1_shift", "w2", "s2", "t2", "w3", "s3", "t3", "w4", "b4")]
+
+
+# name -> (restype, argtypes); must list every symbol include/disconet_hip.h declares
+SIGNATURES = {
+    "dn_version": (c_int, []),
+    "dn_last_error": (c_char_p, []),
+    "dn_voxelize_occupy": (c_int, [c_void_p, c_int, c_int, POINTER(c_double), POINTER(c_double),
+                                   POINTER(c_int), c_void_p, c_void_p]),
+    "dn_voxel_compact_workspace": (c_size_t, [POINTER(c_int)]),
+    "dn_voxel_compact": (c_int, [c_void_p, POINTER(c_int), c_void_p, c_int, c_void_p, c_void_p,
+                                 c_void_p]),
+    "dn_scatter_dense": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_int), c_void_p,
+                                 c_void_p]),
+    "dn_conv_packed_weight_floats": (c_size_t, [POINTER(ConvDesc)]),
+    "dn_conv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
+    "dn_fold_bn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                           c_void_p, c_void_p, c_void_p]),
+    "dn_conv2d": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_void_p]),
+    "dn_warp_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_void_p, c_void_p]),
+    "dn_disco_fuse_tail": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   POINTER(MlpTailParams), c_int, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object (once) and bind every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DnError(
+            "libdisconet_hip.so is not built (%s). Run `python -m disconet_amd.csrc.build` "
+            "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing: loud by design
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dn_last_error()
+        raise DnError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,30 @@
+// Shared helpers of libdisconet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "disconet_hip.h"
+
+namespace dn {
+
+char* err_buf();   // thread-local, 512 bytes
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(DN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return DN_OK;
+}
+
+}  // namespace dn
+
+#define DN_REQUIRE(cond, ...) \
+  do { if (!(cond)) return dn::fail(DN_ERR_ARG, __VA_ARGS__); } while (0)

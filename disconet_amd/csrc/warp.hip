@@ -1,0 +1,136 @@
+// K4: pose-based two-pass bilinear warp of neighbour feature maps into the ego
+// frame (rotate -> zero-pad -> translate).  HBM/L2-bound gather.
+//
+// Layout: NHWC, so the C channels of one pixel are contiguous; one wavefront
+// handles one output pixel at a time with each lane carrying a float4 of
+// channels (C = 256 -> exactly one 1 KiB coalesced row per tap).  All tap
+// coordinates of a pixel are wave-uniform, so the bounds tests are scalar
+// branches, not divergent lanes.
+//
+// The two resampling passes cannot be merged algebraically (the rotated map is
+// zero-padded before it is translated; SURVEY.md Appx A.4), but they can be
+// fused in one launch: out2(p) reads <= 4 integer pixels q of the rotated map,
+// and each in-frame out1(q) is re-derived from <= 4 source taps with exactly
+// the per-element arithmetic of the two-pass form (the intermediate map is
+// never written to HBM; the 4x re-derivation is L2-resident work).
+//
+// Replaces upstream:coperception/models/det/base/* :: feature_transformation
+// (SURVEY.md §8 a5).
+#include "dn_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct Bilinear {
+  int x0, y0;          // north-west integer tap
+  float w_nw, w_ne, w_sw, w_se;
+};
+
+// grid_sample(bilinear, align_corners=False) tap set for normalised (gx, gy)
+__device__ inline Bilinear bilinear_taps(float gx, float gy, int w, int h) {
+  const float ix = ((gx + 1.f) * w - 1.f) * 0.5f;
+  const float iy = ((gy + 1.f) * h - 1.f) * 0.5f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  Bilinear b;
+  b.x0 = (int)fx;
+  b.y0 = (int)fy;
+  const float ex = fx + 1.f, ey = fy + 1.f;  // south-east corner
+  b.w_nw = (ex - ix) * (ey - iy);
+  b.w_ne = (ix - fx) * (ey - iy);
+  b.w_sw = (ex - ix) * (iy - fy);
+  b.w_se = (ix - fx) * (iy - fy);
+  return b;
+}
+
+__device__ inline f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// bilinear sample of src (one image, [h][w][c]) at taps b, channels c4*4..+3
+__device__ inline f32x4 sample_src(const float* src, const Bilinear& b, int w, int h, int c,
+                                   int c4) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const bool x0ok = b.x0 >= 0 && b.x0 < w, x1ok = b.x0 + 1 >= 0 && b.x0 + 1 < w;
+  const bool y0ok = b.y0 >= 0 && b.y0 < h, y1ok = b.y0 + 1 >= 0 && b.y0 + 1 < h;
+  // order matches torch's CPU kernel: nw, ne, sw, se
+  if (y0ok && x0ok) acc += ld4(src + ((size_t)b.y0 * w + b.x0) * c + 4 * c4) * b.w_nw;
+  if (y0ok && x1ok) acc += ld4(src + ((size_t)b.y0 * w + b.x0 + 1) * c + 4 * c4) * b.w_ne;
+  if (y1ok && x0ok) acc += ld4(src + ((size_t)(b.y0 + 1) * w + b.x0) * c + 4 * c4) * b.w_sw;
+  if (y1ok && x1ok) acc += ld4(src + ((size_t)(b.y0 + 1) * w + b.x0 + 1) * c + 4 * c4) * b.w_se;
+  return acc;
+}
+
+constexpr int PIX_PER_BLOCK = 32;
+
+__global__ void __launch_bounds__(256)
+warp_neighbors_kernel(const float* __restrict__ feat, const float* __restrict__ trans,
+                      const int32_t* __restrict__ num_agent, int batch, int agents, int h, int w,
+                      int c, int only_v2i, float* __restrict__ warped) {
+  const int jj = blockIdx.y;              // neighbour slot 0..A-2
+  const int bi = blockIdx.z;              // b * A + i
+  const int b = bi / agents, i = bi % agents;
+  const int j = jj + (jj >= i ? 1 : 0);
+  const int n_live = num_agent[b];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4n = c >> 2;
+  const int hw = h * w;
+  float* dst = warped + ((size_t)bi * (agents - 1) + jj) * hw * c;
+
+  const bool live = i < n_live && j < n_live && !(only_v2i && i != 0 && j != 0);
+  const float* src = feat + ((size_t)j * batch + b) * hw * c;   // agent-major image j*B+b
+
+  const float* m = trans + (((size_t)b * agents + i) * agents + j) * 16;
+  const float r00 = m[0], r01 = m[1], r10 = m[4], r11 = m[5];
+  const float x_trans = (4.f * m[3]) / 128.f;
+  const float y_trans = -(4.f * m[7]) / 128.f;
+
+  for (int pp = wave; pp < PIX_PER_BLOCK; pp += 4) {
+    const int p = blockIdx.x * PIX_PER_BLOCK + pp;
+    if (p >= hw) break;
+    const int py = p / w, px = p % w;
+    float* out = dst + (size_t)p * c;
+    if (!live) {
+      for (int c4 = lane; c4 < c4n; c4 += 64)
+        *reinterpret_cast<f32x4*>(out + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
+    // pass 2 (translation): normalised base coords of pixel centres
+    const float bx = (2.f * px + 1.f) / w - 1.f;
+    const float by = (2.f * py + 1.f) / h - 1.f;
+    const Bilinear t2 = bilinear_taps(bx + x_trans, by + y_trans, w, h);
+    // the four rotated-map pixels q this output reads, and their source taps
+    Bilinear t1[4];
+    bool qok[4];
+    float qw[4] = {t2.w_nw, t2.w_ne, t2.w_sw, t2.w_se};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int qx = t2.x0 + (k & 1), qy = t2.y0 + (k >> 1);
+      qok[k] = qx >= 0 && qx < w && qy >= 0 && qy < h;
+      const float qbx = (2.f * qx + 1.f) / w - 1.f;
+      const float qby = (2.f * qy + 1.f) / h - 1.f;
+      t1[k] = bilinear_taps(r00 * qbx + r01 * qby, r10 * qbx + r11 * qby, w, h);
+    }
+    for (int c4 = lane; c4 < c4n; c4 += 64) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (qok[k]) acc += sample_src(src, t1[k], w, h, c, c4) * qw[k];
+      *reinterpret_cast<f32x4*>(out + 4 * c4) = acc;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dn_warp_neighbors(const float* feat, const float* trans, const int32_t* num_agent,
+                                 int batch, int agents, int h, int w, int c, int only_v2i,
+                                 float* warped, void* stream) {
+  DN_REQUIRE(feat && trans && num_agent && warped, "warp: null pointer");
+  DN_REQUIRE(batch > 0 && agents > 0 && h > 0 && w > 0, "warp: empty problem");
+  DN_REQUIRE(c > 0 && c % 4 == 0, "warp: channel count %d must be a multiple of 4", c);
+  if (agents < 2) return DN_OK;   // no neighbours to warp
+  const int hw = h * w;
+  dim3 grid((hw + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, agents - 1, batch * agents);
+  hipLaunchKernelGGL(warp_neighbors_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, trans,
+                     num_agent, batch, agents, h, w, c, only_v2i, warped);
+  return dn::check_launch("warp_neighbors_kernel");
+}

@@ -1,0 +1,188 @@
+"""Tensor-level wrappers over the C ABI (include/disconet_hip.h).
+
+torch is plumbing here: device memory, the current HIP stream, nothing else.
+Every function requires float32 CUDA(HIP) tensors and launches on torch's
+current stream.  No CPU fallback: a CPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, MlpTailParams, check
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.DnError("disconet_amd ops need tensors on the MI355X (got a %s tensor); "
+                               "there is no CPU path" % t.device)
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _lib.DnError("%s must be contiguous float32 (got %s, contiguous=%s)"
+                           % (name, t.dtype, t.is_contiguous()))
+
+
+# ---------------------------------------------------------------------------
+# K1
+# ---------------------------------------------------------------------------
+def _geom(voxel_size, extents):
+    vs = (ctypes.c_double * 3)(*[float(v) for v in voxel_size])
+    ext = (ctypes.c_double * 6)(*[float(e) for row in extents for e in row])
+    return vs, ext
+
+
+def voxelize_occupy(pts, voxel_size, extents, dims):
+    """pts [N, >=3] float32 cuda -> dense [X, Y, Z] float32 occupancy."""
+    _need_gpu(pts)
+    _f32c(pts, "pts")
+    vs, ext = _geom(voxel_size, extents)
+    d = (ctypes.c_int * 3)(*[int(v) for v in dims])
+    dense = torch.empty(tuple(int(v) for v in dims), dtype=torch.float32, device=pts.device)
+    check(_lib.load().dn_voxelize_occupy(_ptr(pts), pts.shape[0], pts.shape[1], vs, ext, d,
+                                         _ptr(dense), _stream()), "dn_voxelize_occupy")
+    return dense
+
+
+def voxel_compact(dense, capacity=None):
+    """dense [X, Y, Z] -> (indices [M, 3] int32 in lexsort(x, y, z) order)."""
+    _need_gpu(dense)
+    _f32c(dense, "dense")
+    lib = _lib.load()
+    d = (ctypes.c_int * 3)(*dense.shape)
+    capacity = int(dense.numel() if capacity is None else capacity)
+    ws = torch.empty(max(1, lib.dn_voxel_compact_workspace(d)), dtype=torch.uint8, device=dense.device)
+    idx = torch.empty((capacity, 3), dtype=torch.int32, device=dense.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dense.device)
+    check(lib.dn_voxel_compact(_ptr(dense), d, _ptr(idx), capacity, _ptr(cnt), _ptr(ws), _stream()),
+          "dn_voxel_compact")
+    m = int(cnt.item())
+    return idx[:min(m, capacity)], m
+
+
+def scatter_dense(indices, offsets, n_images, dims):
+    """Batched dense rebuild: indices [Mtot, 3] int32, offsets [n_images + 1] int32
+    -> dense [n_images, 1, X, Y, Z] float32 (the bevs layout of the reference)."""
+    _need_gpu(indices, offsets)
+    if indices.dtype != torch.int32 or offsets.dtype != torch.int32:
+        raise _lib.DnError("scatter_dense needs int32 indices/offsets")
+    d = (ctypes.c_int * 3)(*[int(v) for v in dims])
+    dense = torch.empty((n_images, 1) + tuple(int(v) for v in dims), dtype=torch.float32,
+                        device=indices.device)
+    check(_lib.load().dn_scatter_dense(_ptr(indices), _ptr(offsets), n_images, indices.shape[0], d,
+                                       _ptr(dense), _stream()), "dn_scatter_dense")
+    return dense
+
+
+# ---------------------------------------------------------------------------
+# K2/K3/K7
+# ---------------------------------------------------------------------------
+def conv_desc(n_images, h_in, w_in, c0, c_out, ksize, stride=1, relu=True, c1=0, up0=False,
+              ld0=None, ld1=None, ldo=None):
+    d = ConvDesc()
+    d.n_images, d.h_in, d.w_in = n_images, h_in, w_in
+    d.c0, d.c1, d.up0 = c0, c1, int(bool(up0))
+    d.c_out, d.ksize, d.stride, d.relu = c_out, ksize, stride, int(bool(relu))
+    d.ld0 = c0 if ld0 is None else ld0
+    d.ld1 = c1 if ld1 is None else ld1
+    d.ldo = c_out if ldo is None else ldo
+    return d
+
+
+def conv_out_hw(d):
+    pad = d.ksize // 2
+    return ((d.h_in + 2 * pad - d.ksize) // d.stride + 1,
+            (d.w_in + 2 * pad - d.ksize) // d.stride + 1)
+
+
+def pack_conv_weights(d, weight):
+    """weight [c_out, c_in, k, k] (or a Conv3d (1,1,1) weight) -> packed float32 buffer."""
+    _need_gpu(weight)
+    w = weight.detach().reshape(d.c_out, d.c0 + d.c1, d.ksize, d.ksize).contiguous().float()
+    lib = _lib.load()
+    n = lib.dn_conv_packed_weight_floats(ctypes.byref(d))
+    if n == 0:
+        check(-1, "dn_conv_packed_weight_floats")
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    check(lib.dn_conv_pack_weights(ctypes.byref(d), _ptr(w), _ptr(packed), _stream()),
+          "dn_conv_pack_weights")
+    return packed
+
+
+def fold_bn(bias, bn=None, channels=None):
+    """-> (scale, shift) float32 device vectors for y = acc * scale + shift."""
+    ref = bias if bias is not None else bn.weight
+    _need_gpu(ref)
+    channels = channels or ref.numel()
+    scale = torch.empty(channels, dtype=torch.float32, device=ref.device)
+    shift = torch.empty(channels, dtype=torch.float32, device=ref.device)
+    b = bias.detach().float().contiguous() if bias is not None else None
+    if bn is not None:
+        args = [bn.weight.detach().float().contiguous(), bn.bias.detach().float().contiguous(),
+                bn.running_mean.float().contiguous(), bn.running_var.float().contiguous()]
+        eps = float(bn.eps)
+    else:
+        args, eps = [None] * 4, 0.0
+    check(_lib.load().dn_fold_bn(_ptr(b), *[_ptr(t) for t in args], eps, channels, _ptr(scale),
+                                 _ptr(shift), _stream()), "dn_fold_bn")
+    return scale, shift
+
+
+def conv2d(d, src0, packed, scale, shift, src1=None, out=None):
+    """NHWC float32 conv; returns [n_images, h_out, w_out, c_out] (ldo == c_out)."""
+    _need_gpu(src0, packed, scale, shift, src1)
+    ho, wo = conv_out_hw(d)
+    if out is None:
+        out = torch.empty((d.n_images, ho, wo, d.ldo), dtype=torch.float32, device=src0.device)
+    check(_lib.load().dn_conv2d(ctypes.byref(d), _ptr(src0), _ptr(src1), _ptr(packed), _ptr(scale),
+                                _ptr(shift), _ptr(out), _stream()), "dn_conv2d")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# K4-K6
+# ---------------------------------------------------------------------------
+def warp_neighbors(feat, trans, num_agent, batch, agents, only_v2i=False):
+    """feat [A*B, h, w, C] agent-major NHWC -> warped [B, A, A-1, h, w, C]."""
+    _need_gpu(feat, trans, num_agent)
+    _f32c(feat, "feat")
+    _f32c(trans, "trans_matrices")
+    n, h, w, c = feat.shape
+    warped = torch.empty((batch, agents, max(agents - 1, 0), h, w, c), dtype=torch.float32,
+                         device=feat.device)
+    check(_lib.load().dn_warp_neighbors(_ptr(feat), _ptr(trans), _ptr(num_agent), batch, agents, h,
+                                        w, c, int(only_v2i), _ptr(warped), _stream()),
+          "dn_warp_neighbors")
+    return warped
+
+
+def disco_fuse_tail(feat, warped, g, fw, num_agent, tail_params, batch, agents, only_v2i=False,
+                    want_weights=False):
+    _need_gpu(feat, g, num_agent)
+    n, h, w, c = feat.shape
+    fused = torch.empty_like(feat)
+    weights = (torch.zeros((batch, agents, agents, h * w), dtype=torch.float32, device=feat.device)
+               if want_weights else None)
+    check(_lib.load().dn_disco_fuse_tail(_ptr(feat), _ptr(warped), _ptr(g), _ptr(fw),
+                                         _ptr(num_agent), ctypes.byref(tail_params), batch, agents,
+                                         h * w, c, int(only_v2i), _ptr(fused), _ptr(weights),
+                                         _stream()), "dn_disco_fuse_tail")
+    return (fused, weights) if want_weights else fused
+
+
+def make_tail_params(tensors):
+    """tensors: dict name -> float32 device tensor for every dn_mlp_tail_params field."""
+    p = MlpTailParams()
+    for name, _ in MlpTailParams._fields_:
+        setattr(p, name, tensors[name].data_ptr())
+    return p

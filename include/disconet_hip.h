@@ -1,0 +1,161 @@
+/*
+ * disconet_hip.h -- C ABI of libdisconet_hip.so, the MI355X (gfx950) kernels of
+ * the coperception `--com disco` detector hot path.
+ *
+ * The reference has NO FFI for this path: it is pure Python over torch ops
+ * (SURVEY.md §2.2, §8(b)); its source is not in the mount
+ * (/root/reference/coperception/ is an empty submodule dir,
+ * /root/reference/.gitmodules:1-3), so each entry point cites the upstream
+ * function it replaces by path (no line numbers exist to cite) and the mounted
+ * call sites that reach it: /root/reference/README.md:54-63 (train_codet.py
+ * --com disco) and README.md:68-75 (test_codet.py --com disco).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns every buffer (incl. workspaces); nothing is allocated,
+ *     nothing synchronises; all work is enqueued on `stream` (a hipStream_t
+ *     passed as void*, NULL = the default stream);
+ *   - activations are NHWC float32 (channels-last): [image][y][x][channel];
+ *     images of a batch are agent-major (image = agent * B + b), the order the
+ *     reference's tools build with torch.cat over agents;
+ *   - return 0 on success, negative on error; dn_last_error() returns a
+ *     thread-local message for the last failing call on this thread;
+ *   - re-entrant; no global mutable state.
+ */
+#ifndef DISCONET_HIP_H
+#define DISCONET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DN_OK 0
+#define DN_ERR_ARG (-1)
+#define DN_ERR_LAUNCH (-2)
+#define DN_ERR_UNSUPPORTED (-3)
+
+int dn_version(void);
+const char* dn_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * K1 -- point cloud -> BEV occupancy.
+ * Replaces upstream:coperception/utils/data_util.py :: voxelize_occupy
+ * (Appx A.2): strict extent filter on raw floats,
+ * floor(xyz / voxel_size) with a float64 divide, index = q - floor(lo/voxel).
+ *   pts        [n_pts][pt_stride] float32, x,y,z in columns 0..2
+ *   voxel_size_host[3], extents_host[6] = {xlo,xhi,ylo,yhi,zlo,zhi}  (host doubles)
+ *   dims_host[3]   = grid dims (X, Y, Z); dense is [X][Y][Z] float32, set to
+ *                    0/1 by this call (it zero-fills first).
+ * ------------------------------------------------------------------------ */
+int dn_voxelize_occupy(const float* pts, int n_pts, int pt_stride,
+                       const double* voxel_size_host, const double* extents_host,
+                       const int* dims_host, float* dense, void* stream);
+
+/* Sorted-unique voxel index list of a dense grid, in the reference's
+ * lexsort(x, then y, then z) order (= linear order of the [X][Y][Z] grid).
+ *   indices   [capacity][3] int32 out;  count: int32 out (device)
+ *   workspace: dn_voxel_compact_workspace(dims) bytes. */
+size_t dn_voxel_compact_workspace(const int* dims_host);
+int dn_voxel_compact(const float* dense, const int* dims_host, int32_t* indices,
+                     int capacity, int32_t* count, void* workspace, void* stream);
+
+/* Replaces upstream:coperception/datasets/V2XSimDet.py :: __getitem__ (dense
+ * rebuild) for a whole batch: image g owns rows
+ * offsets[g]..offsets[g+1] of indices[.][3]; dense[g][X][Y][Z] = 1 there, else 0. */
+int dn_scatter_dense(const int32_t* indices, const int32_t* offsets, int n_images,
+                     int n_indices_total, const int* dims_host, float* dense, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K2/K3/K7 -- implicit-GEMM convolution on fp32 MFMA with fused
+ * (bias + eval-BatchNorm) affine and ReLU epilogue.
+ * Replaces the conv2d/conv3d(1,1,1) + batch_norm + relu (+ interpolate x2
+ * nearest + cat) sequences of upstream:coperception/models/det/backbone/
+ * Backbone.py :: Backbone.encode / .decode and of ClassificationHead /
+ * SingleRegressionHead (Appx A.6).
+ *
+ * The logical input is cat([up(src0), src1], channel): src0 has c0 channels
+ * and, when up0 != 0, is stored at (h_in/2, w_in/2) and nearest-upsampled x2
+ * on the fly; src1 (c1 channels, may be 0/NULL) is at (h_in, w_in).
+ * ------------------------------------------------------------------------ */
+typedef struct dn_conv_desc {
+  int32_t n_images;
+  int32_t h_in, w_in;    /* logical conv input size (after the x2 upsample) */
+  int32_t c0, c1;        /* channels taken from src0 / src1 */
+  int32_t up0;           /* src0 is half resolution, upsample x2 nearest */
+  int32_t c_out;
+  int32_t ksize;         /* 1 or 3 (padding = ksize/2) */
+  int32_t stride;        /* 1 or 2 */
+  int32_t relu;          /* apply ReLU after the affine */
+  int32_t ld0, ld1, ldo; /* floats per pixel of src0 / src1 / out (>= channels) */
+} dn_conv_desc;
+
+/* floats needed for the packed weights of this conv */
+size_t dn_conv_packed_weight_floats(const dn_conv_desc* d);
+/* weight_oihw: [c_out][c0+c1][ksize][ksize] float32 (torch Conv2d layout; a
+ * Conv3d (1,1,1) weight has the same bytes) -> packed tile-major layout. */
+int dn_conv_pack_weights(const dn_conv_desc* d, const float* weight_oihw,
+                         float* packed, void* stream);
+/* scale/shift of y = relu?(acc * scale + shift) from conv bias and BatchNorm
+ * running stats; gamma/beta/mean/var may all be NULL (no BN: scale=1,
+ * shift=bias); bias may be NULL (0). */
+int dn_fold_bn(const float* bias, const float* gamma, const float* beta,
+               const float* mean, const float* var, float eps, int channels,
+               float* scale, float* shift, void* stream);
+int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* src1,
+              const float* packed, const float* scale, const float* shift,
+              float* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K4 -- pose-based two-pass bilinear warp of neighbour feature maps.
+ * Replaces upstream:coperception/models/det/base/* :: feature_transformation
+ * (+ build_neighbors_feature_list) (Appx A.4): rotate
+ * (affine_grid + grid_sample, bilinear, zeros, align_corners=False), zero-pad,
+ * then translate by (4*t_x/128, -4*t_y/128) in normalised units.
+ *   feat   [A*B][H][W][C]  agent-major layer-`layer` maps
+ *   trans  [B][A][A][4][4] float32,  trans[b][i][j] maps j -> i
+ *   num_agent [B] int32 live-agent count per sample
+ *   warped [B][A][A-1][H][W][C]; slot (b,i,jj), jj = j - (j > i), receives
+ *          warp(j -> i); slots of dead agents are zero-filled.
+ *   only_v2i != 0: only pairs with i == 0 or j == 0 are warped (others zero).
+ * ------------------------------------------------------------------------ */
+int dn_warp_neighbors(const float* feat, const float* trans, const int32_t* num_agent,
+                      int batch, int agents, int h, int w, int c, int only_v2i,
+                      float* warped, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K5 tail + K6 -- per-pixel attention MLP tail, softmax over agents, weighted
+ * sum.  Replaces PixelWeightedFusionSoftmax.forward layers 2-4 and the fusion
+ * loop body of upstream:coperception/models/det/DiscoNet.py :: DiscoNet.forward
+ * (Appx A.5).  Layer 1 (1x1 conv 2C -> 128) is split as
+ * W1 = [W1_ego | W1_nbr] and evaluated with dn_conv2d:
+ *   g      [A*B][H*W][256] = [ x.W1_ego^T + b1  |  x.W1_nbr^T ]   (from feat)
+ *   fw     [B][A][A-1][H*W][128] = warped . W1_nbr^T
+ * The tail computes, per ego i < num_agent[b], per pixel, for neighbours
+ * k = ego, then j ascending (j != i):
+ *   h1 = relu(bn1(E + F_k)); h2 = relu(bn2(W2 h1 + b2)); h3 = relu(bn3(W3 h2 + b3));
+ *   s_k = relu(W4 h3 + b4); w_k = exp(s_k) / sum exp(s_.)   (no max-shift)
+ *   fused = sum_k w_k * nbr_k
+ * and copies feat for dead agents.  mlp params (device, float32):
+ *   bn1_scale/shift[128] (BN affine only, bias b1 is already in E),
+ *   w2[32][128], s2/t2[32] (bias+BN folded), w3[8][32], s3/t3[8], w4[8], b4[1].
+ * ------------------------------------------------------------------------ */
+typedef struct dn_mlp_tail_params {
+  const float* bn1_scale; const float* bn1_shift;
+  const float* w2; const float* s2; const float* t2;
+  const float* w3; const float* s3; const float* t3;
+  const float* w4; const float* b4;
+} dn_mlp_tail_params;
+
+int dn_disco_fuse_tail(const float* feat, const float* warped, const float* g,
+                       const float* fw, const int32_t* num_agent,
+                       const dn_mlp_tail_params* p, int batch, int agents, int hw, int c,
+                       int only_v2i, float* fused, float* weights_out, /* <- may be NULL;
+                       [B][A][A][hw] softmax weights, slot k order */ void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISCONET_HIP_H */

@@ -1,0 +1,83 @@
+"""Seeded parity cases shared by the golden generator (tests/golden/make_golden.py)
+and the tests.  Everything here is TEST infrastructure and may import oracle/."""
+import math
+
+import numpy as np
+import torch
+
+from disconet_amd.synthetic import make_point_cloud, make_scene_batch
+from oracle.disconet_ref import RefConfig, build_ref_model
+
+VOXEL_SIZE = (0.25, 0.25, 0.4)
+EXTENTS = np.array([[-32.0, 32.0], [-32.0, 32.0], [-3.0, 2.0]])
+DIMS = (256, 256, 13)
+
+
+def voxel_cloud():
+    return make_point_cloud(20000, seed=3)
+
+
+# --- warp unit poses: 4x4 matrices j -> i -----------------------------------
+def _pose(yaw, tx, ty):
+    m = np.eye(4, dtype=np.float32)
+    c, s = math.cos(yaw), math.sin(yaw)
+    m[0, 0], m[0, 1], m[1, 0], m[1, 1] = c, -s, s, c
+    m[0, 3], m[1, 3] = tx, ty
+    return m
+
+
+WARP_POSES = {
+    "identity": _pose(0.0, 0.0, 0.0),
+    "rot90": _pose(math.pi / 2, 0.0, 0.0),
+    "shift_whole_px": _pose(0.0, 4.0, -6.0),       # 2 m per pixel at 32x32 -> 2, -3 px
+    "shift_half_px": _pose(0.0, 1.0, 3.0),
+    "rot_and_shift": _pose(0.3, 5.5, -2.25),
+    "out_of_frame": _pose(0.1, 500.0, 500.0),
+}
+
+
+def warp_feature(c=8, hw=32, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(1, c, hw, hw, generator=g)
+
+
+# --- model cases ---------------------------------------------------------------
+MODEL_CASES = {
+    # BASELINE.json configs[0]: 2-agent, batch 1, 128x128 BEV, 4 synthetic frames
+    "cfg1_f0": dict(map_hw=128, agents=2, batch=1, live=None, jitter=None),
+    "cfg1_f1": dict(map_hw=128, agents=2, batch=1, live=None, jitter=101),
+    "cfg1_f2": dict(map_hw=128, agents=2, batch=1, live=None, jitter=102),
+    "cfg1_f3": dict(map_hw=128, agents=2, batch=1, live=None, jitter=103),
+    # ragged: 4 agent slots, batch 2, sample 0 has 3 live agents, sample 1 has 2
+    "ragged_a4": dict(map_hw=128, agents=4, batch=2, live=[3, 2], jitter=7),
+}
+
+
+def model_inputs(case):
+    c = MODEL_CASES[case]
+    return make_scene_batch(c["batch"], c["agents"], c["map_hw"], live=c["live"],
+                            jitter_seed=c["jitter"])
+
+
+def ref_model(map_hw, agents, kd_flag=1, init="kaiming", **kw):
+    return build_ref_model(RefConfig(map_hw), seed=0, init=init, kd_flag=kd_flag,
+                           num_agent=agents, **kw)
+
+
+def subsample(name, t):
+    """Small deterministic slice of an output tensor kept in the golden file."""
+    t = t.detach().cpu().numpy()
+    if name == "cls":
+        return t[:, ::197, :]
+    if name == "loc":
+        return t[:, ::11, ::13]
+    return t[:, ::5, ::3, ::3]     # NCHW feature maps
+
+
+def run_ref(case, model=None):
+    c = MODEL_CASES[case]
+    model = model or ref_model(c["map_hw"], c["agents"])
+    bevs, trans, na = model_inputs(case)
+    with torch.no_grad():
+        res, x8, x7, x6, x5, fused = model(bevs, trans, na, c["batch"])
+    return {"cls": res["cls"], "loc": res["loc"], "x8": x8, "x5": x5, "fused": fused}

@@ -1,0 +1,70 @@
+"""Regenerates the golden fixtures from the CPU oracle (oracle/).
+
+    python tests/golden/make_golden.py
+
+PARITY UNPINNED: /root/reference contains no source, tests or vectors for this
+path, so these vectors pin the *oracle* (this repo's
+restatement of SURVEY.md Appendix A) against drift -- torch version, refactors
+-- not the reference itself.  Fixtures are data only: expected outputs (small
+strided slices) for inputs that tests/cases.py re-creates from seeds.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle.disconet_ref import feature_transformation  # noqa: E402
+from oracle.voxel_ref import voxelize_occupy  # noqa: E402
+from tests import cases  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    # 1. voxelizer
+    pts = cases.voxel_cloud()
+    dense, idx = voxelize_occupy(pts, cases.VOXEL_SIZE, cases.EXTENTS, return_indices=True)
+    np.savez_compressed(os.path.join(HERE, "voxel_20k.npz"),
+                        pts_sha256=sha(pts), indices=idx.astype(np.int32),
+                        dense_sha256=sha(dense), n_occupied=int(dense.sum()))
+    print("voxel:", pts.shape, "->", idx.shape, "occupied", int(dense.sum()))
+
+    # 2. warp unit cases
+    feat = cases.warp_feature()
+    out = {}
+    for name, pose in cases.WARP_POSES.items():
+        com = feat.unsqueeze(0)                      # [B=1, A=1, C, H, W]
+        all_warp = torch.from_numpy(pose)[None]      # [A=1, 4, 4]
+        w = feature_transformation(0, 0, com, all_warp, tuple(feat.shape))
+        out[name] = w.numpy()
+        print("warp", name, float(np.abs(out[name]).max()))
+    np.savez_compressed(os.path.join(HERE, "warp_unit.npz"), **out)
+
+    # 3. model cases
+    models = {}
+    store = {}
+    for case, c in cases.MODEL_CASES.items():
+        key = (c["map_hw"], c["agents"])
+        if key not in models:
+            models[key] = cases.ref_model(*key)
+        outs = cases.run_ref(case, models[key])
+        for name, t in outs.items():
+            store["%s/%s" % (case, name)] = cases.subsample(name, t)
+            store["%s/%s_absmax" % (case, name)] = np.float32(t.abs().max())
+        print("model", case, {k: tuple(v.shape) for k, v in outs.items()})
+    np.savez_compressed(os.path.join(HERE, "model_cases.npz"), **store)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""K2/K3/K7: the MFMA implicit-GEMM conv against torch-CPU fp32 conv2d (the
+plain fp32 reference of the same op) -- tolerance 1e-4 absolute on O(1) data."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _run(n, h, w, c0, c_out, k, stride=1, relu=True, c1=0, up0=False, bn=True, seed=0):
+    from disconet_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    cin = c0 + c1
+    wgt = torch.randn(c_out, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    bias = torch.randn(c_out, generator=g) * 0.1
+    h0, w0 = (h // 2, w // 2) if up0 else (h, w)
+    x0 = torch.randn(n, c0, h0, w0, generator=g)
+    x1 = torch.randn(n, c1, h, w, generator=g) if c1 else None
+    xin = F.interpolate(x0, scale_factor=(2, 2)) if up0 else x0
+    if c1:
+        xin = torch.cat((xin, x1), 1)
+    y = F.conv2d(xin, wgt, bias, stride=stride, padding=k // 2)
+    bn_mod = None
+    if bn:
+        bn_mod = torch.nn.BatchNorm2d(c_out).eval()
+        bn_mod.running_mean.copy_(torch.randn(c_out, generator=g) * 0.1)
+        bn_mod.running_var.copy_(torch.rand(c_out, generator=g) + 0.5)
+        with torch.no_grad():
+            bn_mod.weight.copy_(torch.rand(c_out, generator=g) + 0.5)
+            bn_mod.bias.copy_(torch.randn(c_out, generator=g) * 0.1)
+            y = bn_mod(y)
+    if relu:
+        y = F.relu(y)
+    d = ops.conv_desc(n, h, w, c0, c_out, k, stride, relu, c1=c1, up0=up0)
+    packed = ops.pack_conv_weights(d, wgt.cuda())
+    scale, shift = ops.fold_bn(bias.cuda(), bn_mod.cuda() if bn_mod else None, c_out)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    out = ops.conv2d(d, nhwc(x0), packed, scale, shift, src1=nhwc(x1) if c1 else None)
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2)
+    err = (got - y).abs().max().item()
+    assert got.shape == y.shape
+    assert err <= TOL, "max abs err %.3e (ref absmax %.3f)" % (err, y.abs().max().item())
+    return err
+
+
+@pytest.mark.parametrize("c0,c_out", [(13, 32), (32, 32), (32, 64), (64, 64), (64, 128),
+                                      (128, 256), (256, 512)])
+def test_conv3x3_stride1(c0, c_out):
+    _run(2, 32, 32, c0, c_out, 3)
+
+
+@pytest.mark.parametrize("c0,c_out", [(32, 64), (64, 128), (128, 256), (256, 512)])
+def test_conv3x3_stride2(c0, c_out):
+    _run(2, 32, 32, c0, c_out, 3, stride=2)
+
+
+@pytest.mark.parametrize("c0,c1,c_out", [(512, 256, 256), (256, 128, 128), (128, 64, 64),
+                                         (64, 32, 32)])
+def test_conv3x3_upsample_concat(c0, c1, c_out):
+    _run(2, 32, 32, c0, c_out, 3, c1=c1, up0=True)
+
+
+@pytest.mark.parametrize("c0,c_out,relu,bn", [(32, 12, False, False), (32, 36, False, False),
+                                              (64, 64, True, True), (128, 128, True, True),
+                                              (256, 256, False, False), (256, 128, False, False)])
+def test_conv1x1(c0, c_out, relu, bn):
+    _run(2, 32, 32, c0, c_out, 1, relu=relu, bn=bn)
+
+
+@pytest.mark.parametrize("h,w", [(8, 8), (20, 44), (17, 33), (256, 256)])
+def test_conv3x3_ragged_and_full_size_tiles(h, w):
+    # sizes that do not divide the 8x32 / 8x16 tiles exercise the edge guards;
+    # 256x256 is the BASELINE plane size
+    _run(1, h, w, 32, 32, 3)
+    if h % 2 == 0 and h < 256:
+        _run(1, h, w, 32, 64, 3, stride=2)
+
+
+def test_conv_rejects_bad_arguments():
+    from disconet_amd import ops, _lib
+    d = ops.conv_desc(1, 8, 8, 32, 32, 5)
+    with pytest.raises(_lib.DnError):
+        ops.pack_conv_weights(d, torch.zeros(32, 32, 5, 5, device="cuda"))
+    with pytest.raises(_lib.DnError):
+        ops.conv2d(ops.conv_desc(1, 8, 8, 32, 32, 3), torch.zeros(1, 8, 8, 32), None, None, None)

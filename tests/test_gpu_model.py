@@ -1,0 +1,100 @@
+"""Whole `--com disco` forward through the C ABI vs the CPU oracle and the
+committed goldens.  Tolerance: 1e-4 absolute (BASELINE.json north_star) on
+kaiming-initialised weights that keep activations O(1)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _product(ref, map_hw, agents, kd_flag=1, **kw):
+    from disconet_amd import Config, DiscoNet
+    m = DiscoNet(Config(map_hw=map_hw), kd_flag=kd_flag, num_agent=agents, **kw).eval()
+    m.load_state_dict({"module." + k: v for k, v in ref.state_dict().items()})
+    return m.cuda()
+
+
+def _gpu_outputs(m, bevs, trans, na, batch):
+    with torch.no_grad():
+        res, x8, x7, x6, x5, fused = m(bevs.cuda(), trans.cuda(), na.cuda(), batch)
+    torch.cuda.synchronize()
+    return {"cls": res["cls"].cpu(), "loc": res["loc"].cpu(), "x8": x8.cpu(), "x5": x5.cpu(),
+            "fused": fused.cpu()}
+
+
+@pytest.mark.parametrize("case", list(cases.MODEL_CASES))
+def test_model_vs_oracle_and_golden(case, golden_dir):
+    c = cases.MODEL_CASES[case]
+    ref = cases.ref_model(c["map_hw"], c["agents"])
+    want = cases.run_ref(case, ref)
+    m = _product(ref, c["map_hw"], c["agents"])
+    bevs, trans, na = cases.model_inputs(case)
+    got = _gpu_outputs(m, bevs, trans, na, c["batch"])
+    g = np.load(os.path.join(golden_dir, "model_cases.npz"))
+    for name in want:
+        assert got[name].shape == want[name].shape, name
+        err = (got[name] - want[name]).abs().max().item()
+        assert err <= TOL, "%s/%s max abs err %.3e" % (case, name, err)
+        gerr = np.abs(cases.subsample(name, got[name]) - g["%s/%s" % (case, name)]).max()
+        assert gerr <= TOL, "%s/%s golden err %.3e" % (case, name, gerr)
+
+
+def test_model_256_five_agents_default_init():
+    """BASELINE plane size, torch default init (the bench's weights), batch 1."""
+    from disconet_amd.synthetic import make_scene_batch
+    ref = cases.ref_model(256, 5, init="torch")
+    bevs, trans, na = make_scene_batch(1, 5, 256)
+    with torch.no_grad():
+        res, x8, x7, x6, x5, fused = ref(bevs, trans, na, 1)
+    m = _product(ref, 256, 5)
+    got = _gpu_outputs(m, bevs, trans, na, 1)
+    for name, w in (("cls", res["cls"]), ("loc", res["loc"]), ("x8", x8), ("fused", fused)):
+        err = (got[name] - w).abs().max().item()
+        assert err <= TOL, "%s max abs err %.3e" % (name, err)
+
+
+def test_kd_flag_zero_returns_dict_and_only_v2i():
+    c = cases.MODEL_CASES["ragged_a4"]
+    ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=0, only_v2i=True)
+    bevs, trans, na = cases.model_inputs("ragged_a4")
+    with torch.no_grad():
+        want = ref(bevs, trans, na, c["batch"])
+    m = _product(ref, c["map_hw"], c["agents"], kd_flag=0, only_v2i=True)
+    with torch.no_grad():
+        got = m(bevs.cuda(), trans.cuda(), na.cuda(), c["batch"])
+    assert isinstance(got, dict) and set(got) == {"loc", "cls"}
+    for k in got:
+        assert (got[k].cpu() - want[k]).abs().max().item() <= TOL
+
+
+def test_batch_position_independence_at_baseline_size():
+    """configs[1] size (5 agents, batch 4, 256x256x13): a scene's result must not
+    depend on which batch slot it sits in -- bitwise (fixed summation order)."""
+    from disconet_amd import Config, DiscoNet
+    from disconet_amd.synthetic import make_scene_batch
+    torch.manual_seed(0)
+    A, B = 5, 4
+    m = DiscoNet(Config(), kd_flag=0, num_agent=A).eval().cuda()
+    bevs, trans, na = make_scene_batch(B, A, 256, jitter_seed=3)
+    with torch.no_grad():
+        full = m(bevs.cuda(), trans.cuda(), na.cuda(), B)
+        sel = torch.tensor([a * B + 2 for a in range(A)])
+        one = m(bevs[sel].cuda(), trans[2:3].cuda(), na[2:3].cuda(), 1)
+    assert torch.equal(full["cls"][sel.cuda()], one["cls"])
+    assert torch.equal(full["loc"][sel.cuda()], one["loc"])
+    assert torch.isfinite(full["cls"]).all() and torch.isfinite(full["loc"]).all()
+
+
+def test_cpu_tensors_fail_loudly():
+    from disconet_amd import Config, DiscoNet, _lib
+    from disconet_amd.synthetic import make_scene_batch
+    m = DiscoNet(Config(map_hw=128), kd_flag=0, num_agent=2).eval()
+    bevs, trans, na = make_scene_batch(1, 2, 128)
+    with pytest.raises(_lib.DnError):
+        m(bevs, trans, na, 1)

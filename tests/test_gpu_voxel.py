@@ -1,0 +1,79 @@
+"""K1 on the MI355X vs the numpy oracle: bit-exact integer/occupancy results."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from disconet_amd import ops
+    return ops
+
+
+def test_voxelize_matches_oracle_bit_exact(golden_dir):
+    from oracle.voxel_ref import voxelize_occupy
+    ops = _ops()
+    pts = cases.voxel_cloud()
+    dense_ref, idx_ref = voxelize_occupy(pts, cases.VOXEL_SIZE, cases.EXTENTS, return_indices=True)
+    dense = ops.voxelize_occupy(torch.from_numpy(pts).cuda(), cases.VOXEL_SIZE, cases.EXTENTS, cases.DIMS)
+    assert np.array_equal(dense.cpu().numpy(), dense_ref)
+    idx, m = ops.voxel_compact(dense)
+    assert m == len(idx_ref)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref.astype(np.int32))
+    g = np.load(os.path.join(golden_dir, "voxel_20k.npz"))
+    assert np.array_equal(idx.cpu().numpy(), g["indices"])
+
+
+def test_voxelize_xyz_only_and_empty():
+    from oracle.voxel_ref import voxelize_occupy
+    ops = _ops()
+    pts = cases.voxel_cloud()[:, :3].copy()
+    dense_ref = voxelize_occupy(pts, cases.VOXEL_SIZE, cases.EXTENTS)
+    dense = ops.voxelize_occupy(torch.from_numpy(pts).cuda(), cases.VOXEL_SIZE, cases.EXTENTS, cases.DIMS)
+    assert np.array_equal(dense.cpu().numpy(), dense_ref)
+    empty = ops.voxelize_occupy(torch.zeros((0, 4), device="cuda"), cases.VOXEL_SIZE, cases.EXTENTS, cases.DIMS)
+    assert float(empty.sum()) == 0.0
+    idx, m = ops.voxel_compact(empty)
+    assert m == 0 and idx.shape == (0, 3)
+
+
+def test_voxelize_boundary_points():
+    from oracle.voxel_ref import voxelize_occupy
+    ops = _ops()
+    pts = np.array([[-32.0, 0, 0, 0], [32.0, 0, 0, 0], [0, 0, 2.0, 0], [0, 0, -3.0, 0],
+                    [0.25, 0.5, 0.4, 0], [-0.25, -0.5, -0.4, 0], [31.99, 31.99, 1.99, 0],
+                    [-31.99, -31.99, -2.99, 0]], dtype=np.float32)
+    _, idx_ref = voxelize_occupy(pts, cases.VOXEL_SIZE, cases.EXTENTS, return_indices=True)
+    dense = ops.voxelize_occupy(torch.from_numpy(pts).cuda(), cases.VOXEL_SIZE, cases.EXTENTS, cases.DIMS)
+    idx, m = ops.voxel_compact(dense)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref.astype(np.int32))
+
+
+def test_full_size_properties():
+    """BASELINE size (60k points / agent): idempotence, sortedness, round trip
+    sparse -> dense -> sparse, batched dense rebuild == per-agent voxelize."""
+    from disconet_amd.synthetic import make_point_cloud
+    ops = _ops()
+    denses, lists = [], []
+    for a in range(5):
+        pts = torch.from_numpy(make_point_cloud(60000, seed=40 + a)).cuda()
+        d1 = ops.voxelize_occupy(pts, cases.VOXEL_SIZE, cases.EXTENTS, cases.DIMS)
+        d2 = ops.voxelize_occupy(torch.cat([pts, pts.flip(0)]), cases.VOXEL_SIZE, cases.EXTENTS, cases.DIMS)
+        assert torch.equal(d1, d2)                       # duplicates / order are irrelevant
+        assert set(torch.unique(d1).tolist()) <= {0.0, 1.0}
+        idx, m = ops.voxel_compact(d1)
+        assert m == int(d1.sum().item())
+        lin = (idx[:, 0].long() * 256 + idx[:, 1].long()) * 13 + idx[:, 2].long()
+        assert bool((lin[1:] > lin[:-1]).all())          # strictly increasing = sorted + unique
+        denses.append(d1)
+        lists.append(idx)
+    offsets = torch.tensor([0] + list(np.cumsum([len(l) for l in lists])), dtype=torch.int32).cuda()
+    bevs = ops.scatter_dense(torch.cat(lists), offsets, 5, cases.DIMS)
+    assert bevs.shape == (5, 1, 256, 256, 13)
+    for a in range(5):
+        assert torch.equal(bevs[a, 0], denses[a])
