@@ -47,10 +47,10 @@ SIGNATURES = {
     "dn_conv2d": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p]),
     "dn_warp_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                  c_int, c_void_p, c_void_p]),
+                                  c_int, c_int, c_int, c_void_p, c_void_p]),
     "dn_disco_fuse_tail": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    POINTER(MlpTailParams), c_int, c_int, c_int, c_int, c_int,
-                                   c_void_p, c_void_p, c_void_p]),
+                                   c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

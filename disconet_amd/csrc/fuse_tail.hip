@@ -30,7 +30,7 @@ struct TailArgs {
   const float* feat; const float* warped; const float* g; const float* fw;
   const int32_t* num_agent;
   dn_mlp_tail_params p;
-  int batch, agents, hw, c, only_v2i;
+  int batch, agents, hw, c, only_v2i, ego_first, ego_count;
   float* fused; float* weights_out;
 };
 
@@ -45,12 +45,12 @@ disco_fuse_tail_kernel(const TailArgs a) {
   __shared__ int nbr_of[MAX_NBR];         // neighbour agent index per slot k
 
   const int tid = threadIdx.x;
-  const int bi = blockIdx.y;
-  const int b = bi / a.agents, i = bi % a.agents;
+  const int bi = blockIdx.y;                             // b * ego_count + (i - ego_first)
+  const int b = bi / a.ego_count, il = bi % a.ego_count, i = a.ego_first + il;
   const int p0 = blockIdx.x * PIX;
   const int n_live = a.num_agent[b];
-  const int img = i * a.batch + b;                       // agent-major image index
-  const float* ego = a.feat + (size_t)img * a.hw * a.c;
+  const int img = il * a.batch + b;                      // agent-major index among LOCAL egos
+  const float* ego = a.feat + ((size_t)i * a.batch + b) * a.hw * a.c;   // feat holds all agents
   float* out = a.fused + (size_t)img * a.hw * a.c;
 
   if (i >= n_live) {
@@ -164,19 +164,22 @@ disco_fuse_tail_kernel(const TailArgs a) {
 extern "C" int dn_disco_fuse_tail(const float* feat, const float* warped, const float* g,
                                   const float* fw, const int32_t* num_agent,
                                   const dn_mlp_tail_params* p, int batch, int agents, int hw,
-                                  int c, int only_v2i, float* fused, float* weights_out,
-                                  void* stream) {
+                                  int c, int only_v2i, int ego_first, int ego_count,
+                                  float* fused, float* weights_out, void* stream) {
   DN_REQUIRE(feat && g && num_agent && p && fused, "fuse_tail: null pointer");
   DN_REQUIRE(agents < 2 || (warped && fw), "fuse_tail: neighbours present but warped/fw null");
   DN_REQUIRE(batch > 0 && agents > 0 && hw > 0 && c > 0, "fuse_tail: empty problem");
+  DN_REQUIRE(ego_first >= 0 && ego_count > 0 && ego_first + ego_count <= agents,
+             "fuse_tail: ego range [%d, %d) outside 0..%d", ego_first, ego_first + ego_count, agents);
   DN_REQUIRE(agents <= MAX_NBR, "fuse_tail: at most %d agents supported (got %d)", MAX_NBR, agents);
   DN_REQUIRE(p->bn1_scale && p->bn1_shift && p->w2 && p->s2 && p->t2 && p->w3 && p->s3 &&
                  p->t3 && p->w4 && p->b4, "fuse_tail: null MLP parameter");
   TailArgs a;
   a.feat = feat; a.warped = warped; a.g = g; a.fw = fw; a.num_agent = num_agent; a.p = *p;
   a.batch = batch; a.agents = agents; a.hw = hw; a.c = c; a.only_v2i = only_v2i;
+  a.ego_first = ego_first; a.ego_count = ego_count;
   a.fused = fused; a.weights_out = weights_out;
-  dim3 grid((hw + PIX - 1) / PIX, batch * agents);
+  dim3 grid((hw + PIX - 1) / PIX, batch * ego_count);
   hipLaunchKernelGGL(disco_fuse_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   return dn::check_launch("disco_fuse_tail_kernel");
 }

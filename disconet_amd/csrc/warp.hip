@@ -64,10 +64,11 @@ constexpr int PIX_PER_BLOCK = 32;
 __global__ void __launch_bounds__(256)
 warp_neighbors_kernel(const float* __restrict__ feat, const float* __restrict__ trans,
                       const int32_t* __restrict__ num_agent, int batch, int agents, int h, int w,
-                      int c, int only_v2i, float* __restrict__ warped) {
+                      int c, int only_v2i, int ego_first, int ego_count,
+                      float* __restrict__ warped) {
   const int jj = blockIdx.y;              // neighbour slot 0..A-2
-  const int bi = blockIdx.z;              // b * A + i
-  const int b = bi / agents, i = bi % agents;
+  const int bi = blockIdx.z;              // b * ego_count + (i - ego_first)
+  const int b = bi / ego_count, i = ego_first + bi % ego_count;
   const int j = jj + (jj >= i ? 1 : 0);
   const int n_live = num_agent[b];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -123,14 +124,16 @@ warp_neighbors_kernel(const float* __restrict__ feat, const float* __restrict__ 
 
 extern "C" int dn_warp_neighbors(const float* feat, const float* trans, const int32_t* num_agent,
                                  int batch, int agents, int h, int w, int c, int only_v2i,
-                                 float* warped, void* stream) {
-  DN_REQUIRE(feat && trans && num_agent && warped, "warp: null pointer");
+                                 int ego_first, int ego_count, float* warped, void* stream) {
   DN_REQUIRE(batch > 0 && agents > 0 && h > 0 && w > 0, "warp: empty problem");
+  DN_REQUIRE(feat && trans && num_agent && (warped || agents < 2), "warp: null pointer");
   DN_REQUIRE(c > 0 && c % 4 == 0, "warp: channel count %d must be a multiple of 4", c);
+  DN_REQUIRE(ego_first >= 0 && ego_count > 0 && ego_first + ego_count <= agents,
+             "warp: ego range [%d, %d) outside 0..%d", ego_first, ego_first + ego_count, agents);
   if (agents < 2) return DN_OK;   // no neighbours to warp
   const int hw = h * w;
-  dim3 grid((hw + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, agents - 1, batch * agents);
+  dim3 grid((hw + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, agents - 1, batch * ego_count);
   hipLaunchKernelGGL(warp_neighbors_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, trans,
-                     num_agent, batch, agents, h, w, c, only_v2i, warped);
+                     num_agent, batch, agents, h, w, c, only_v2i, ego_first, ego_count, warped);
   return dn::check_launch("warp_neighbors_kernel");
 }

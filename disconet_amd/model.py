@@ -140,8 +140,9 @@ class _Layer:
         flops = 2.0 * n * ho * wo * self.c_out * self.c_in * self.ksize * self.ksize
         nbytes = 4.0 * (src0.numel() + (src1.numel() if src1 is not None else 0)
                         + n * ho * wo * self.c_out + self.c_out * self.c_in * self.ksize ** 2)
+        out = torch.empty((n, ho, wo, self.c_out), dtype=torch.float32, device=src0.device)
         with region(self.name, "conv_mfma_kernel", flops, nbytes):
-            return ops.conv2d(d, src0, self.packed, self.scale, self.shift, src1=src1)
+            return ops.conv2d(d, src0, self.packed, self.scale, self.shift, src1=src1, out=out)
 
 
 class DiscoNet(nn.Module):
@@ -282,22 +283,31 @@ class DiscoNet(nn.Module):
             x3 = P["decompress"].run(P["compress"].run(x3))
         return [x0, x1, x2, x3, x4]
 
-    def fuse(self, feat, trans_matrices, num_agent, batch_size, P, want_weights=False):
-        """DiscoGraph fusion of the layer-`layer` maps (agent-major NHWC)."""
+    def fuse(self, feat, trans_matrices, num_agent, batch_size, P, want_weights=False,
+             ego_first=0, ego_count=None):
+        """DiscoGraph fusion of the layer-`layer` maps.  `feat` holds the maps of
+        ALL agents (agent-major NHWC); the result covers the egos
+        [ego_first, ego_first + ego_count) -- every agent on one GPU, this rank's
+        agents when a scene is sharded one agent per GPU (sharded.py)."""
         A = self.agent_num
+        E = A if ego_count is None else ego_count
         n, h, w, c = feat.shape
+        B = batch_size
         map_bytes = 4.0 * h * w * c
-        pairs = batch_size * A * (A - 1)
+        pairs = B * E * (A - 1)
+        warped = torch.empty((B, E, max(A - 1, 0), h, w, c), dtype=torch.float32,
+                             device=feat.device)
         with region("warp", "warp_neighbors_kernel", 0.0, map_bytes * (n + pairs)):
-            warped = ops.warp_neighbors(feat, trans_matrices, num_agent, batch_size, A,
-                                        self.only_v2i)
-        g = P["mlp_g"].run(feat)
+            ops.warp_neighbors(feat, trans_matrices, num_agent, B, A, self.only_v2i,
+                               ego_first, E, out=warped)
+        g = P["mlp_g"].run(feat[ego_first * B:(ego_first + E) * B])
         fw = None
         if A > 1:
             fw = P["mlp_f"].run(warped.view(pairs, h, w, c))
-        with region("fuse_tail", "disco_fuse_tail_kernel", 0.0, map_bytes * (2 * n + pairs)):
-            return ops.disco_fuse_tail(feat, warped, g, fw, num_agent, P["_tail"], batch_size, A,
-                                       self.only_v2i, want_weights)
+        fused = torch.empty((E * B, h, w, c), dtype=torch.float32, device=feat.device)
+        with region("fuse_tail", "disco_fuse_tail_kernel", 0.0, map_bytes * (2 * E * B + pairs)):
+            return ops.disco_fuse_tail(feat, warped, g, fw, num_agent, P["_tail"], B, A,
+                                       self.only_v2i, want_weights, ego_first, E, out=fused)
 
     def decode(self, enc, P):
         x0, x1, x2, x3, x4 = enc
@@ -306,6 +316,14 @@ class DiscoNet(nn.Module):
         x7 = P["conv7_2"].run(P["conv7_1"].run(x6, x1, up0=True))
         x8 = P["conv8_2"].run(P["conv8_1"].run(x7, x0, up0=True))
         return x8, x7, x6, x5
+
+    def heads(self, x8, P):
+        cls = P["cls2"].run(P["cls1"].run(x8))          # [N, H, W, A_loc*cat]  (NHWC: the
+        loc = P["reg2"].run(P["reg1"].run(x8))          #  reference's permute(0,2,3,1) is free)
+        n, h, w = cls.shape[0], cls.shape[1], cls.shape[2]
+        cls_preds = cls.view(n, -1, self.category_num)
+        loc_preds = loc.view(n, h, w, self.anchor_num_per_loc, self.out_seq_len, self.box_code_size)
+        return {"loc": loc_preds, "cls": cls_preds}
 
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size=1):
         if self.training:
@@ -325,12 +343,7 @@ class DiscoNet(nn.Module):
         enc[self.layer] = fused
         x8, x7, x6, x5 = self.decode(enc, P)
 
-        cls = P["cls2"].run(P["cls1"].run(x8))          # [N, H, W, A_loc*cat]  (NHWC: the
-        loc = P["reg2"].run(P["reg1"].run(x8))          #  reference's permute(0,2,3,1) is free)
-        n, h, w = cls.shape[0], cls.shape[1], cls.shape[2]
-        cls_preds = cls.view(n, -1, self.category_num)
-        loc_preds = loc.view(n, h, w, self.anchor_num_per_loc, self.out_seq_len, self.box_code_size)
-        result = {"loc": loc_preds, "cls": cls_preds}
+        result = self.heads(x8, P)
         if self.kd_flag == 1:
             # NCHW-shaped, channels-last-strided views of the NHWC buffers
             nchw = lambda t: t.permute(0, 3, 1, 2)

@@ -152,31 +152,37 @@ def conv2d(d, src0, packed, scale, shift, src1=None, out=None):
 # ---------------------------------------------------------------------------
 # K4-K6
 # ---------------------------------------------------------------------------
-def warp_neighbors(feat, trans, num_agent, batch, agents, only_v2i=False):
-    """feat [A*B, h, w, C] agent-major NHWC -> warped [B, A, A-1, h, w, C]."""
+def warp_neighbors(feat, trans, num_agent, batch, agents, only_v2i=False, ego_first=0,
+                   ego_count=None, out=None):
+    """feat [A*B, h, w, C] agent-major NHWC (all agents) -> warped
+    [B, ego_count, A-1, h, w, C] for the egos [ego_first, ego_first + ego_count)."""
     _need_gpu(feat, trans, num_agent)
     _f32c(feat, "feat")
     _f32c(trans, "trans_matrices")
+    ego_count = agents if ego_count is None else ego_count
     n, h, w, c = feat.shape
-    warped = torch.empty((batch, agents, max(agents - 1, 0), h, w, c), dtype=torch.float32,
-                         device=feat.device)
+    warped = out if out is not None else torch.empty(
+        (batch, ego_count, max(agents - 1, 0), h, w, c), dtype=torch.float32, device=feat.device)
     check(_lib.load().dn_warp_neighbors(_ptr(feat), _ptr(trans), _ptr(num_agent), batch, agents, h,
-                                        w, c, int(only_v2i), _ptr(warped), _stream()),
-          "dn_warp_neighbors")
+                                        w, c, int(only_v2i), ego_first, ego_count, _ptr(warped),
+                                        _stream()), "dn_warp_neighbors")
     return warped
 
 
 def disco_fuse_tail(feat, warped, g, fw, num_agent, tail_params, batch, agents, only_v2i=False,
-                    want_weights=False):
+                    want_weights=False, ego_first=0, ego_count=None, out=None):
+    """feat: maps of ALL agents; g / warped / fw and the result: the served egos only."""
     _need_gpu(feat, g, num_agent)
+    ego_count = agents if ego_count is None else ego_count
     n, h, w, c = feat.shape
-    fused = torch.empty_like(feat)
-    weights = (torch.zeros((batch, agents, agents, h * w), dtype=torch.float32, device=feat.device)
-               if want_weights else None)
+    fused = out if out is not None else torch.empty((ego_count * batch, h, w, c),
+                                                     dtype=torch.float32, device=feat.device)
+    weights = (torch.zeros((batch, ego_count, agents, h * w), dtype=torch.float32,
+                           device=feat.device) if want_weights else None)
     check(_lib.load().dn_disco_fuse_tail(_ptr(feat), _ptr(warped), _ptr(g), _ptr(fw),
                                          _ptr(num_agent), ctypes.byref(tail_params), batch, agents,
-                                         h * w, c, int(only_v2i), _ptr(fused), _ptr(weights),
-                                         _stream()), "dn_disco_fuse_tail")
+                                         h * w, c, int(only_v2i), ego_first, ego_count, _ptr(fused),
+                                         _ptr(weights), _stream()), "dn_disco_fuse_tail")
     return (fused, weights) if want_weights else fused
 
 

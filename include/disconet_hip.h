@@ -117,13 +117,17 @@ int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* src1,
  *   feat   [A*B][H][W][C]  agent-major layer-`layer` maps
  *   trans  [B][A][A][4][4] float32,  trans[b][i][j] maps j -> i
  *   num_agent [B] int32 live-agent count per sample
- *   warped [B][A][A-1][H][W][C]; slot (b,i,jj), jj = j - (j > i), receives
- *          warp(j -> i); slots of dead agents are zero-filled.
+ *   ego_first, ego_count: the egos i in [ego_first, ego_first + ego_count) this
+ *          call serves (all of them on one GPU: 0, A; one agent per GPU when the
+ *          agents of a scene are sharded across ranks).
+ *   warped [B][ego_count][A-1][H][W][C]; slot (b, i - ego_first, jj),
+ *          jj = j - (j > i), receives warp(j -> i); slots of dead agents are
+ *          zero-filled.
  *   only_v2i != 0: only pairs with i == 0 or j == 0 are warped (others zero).
  * ------------------------------------------------------------------------ */
 int dn_warp_neighbors(const float* feat, const float* trans, const int32_t* num_agent,
                       int batch, int agents, int h, int w, int c, int only_v2i,
-                      float* warped, void* stream);
+                      int ego_first, int ego_count, float* warped, void* stream);
 
 /* ------------------------------------------------------------------------
  * K5 tail + K6 -- per-pixel attention MLP tail, softmax over agents, weighted
@@ -131,8 +135,10 @@ int dn_warp_neighbors(const float* feat, const float* trans, const int32_t* num_
  * loop body of upstream:coperception/models/det/DiscoNet.py :: DiscoNet.forward
  * (Appx A.5).  Layer 1 (1x1 conv 2C -> 128) is split as
  * W1 = [W1_ego | W1_nbr] and evaluated with dn_conv2d:
- *   g      [A*B][H*W][256] = [ x.W1_ego^T + b1  |  x.W1_nbr^T ]   (from feat)
- *   fw     [B][A][A-1][H*W][128] = warped . W1_nbr^T
+ *   g      [ego_count*B][H*W][256] = [ x.W1_ego^T + b1 | x.W1_nbr^T ] of the served
+ *          egos' own maps (image = (i - ego_first) * B + b)
+ *   fw     [B][ego_count][A-1][H*W][128] = warped . W1_nbr^T
+ *   feat   [A*B][H*W][C] maps of ALL agents; fused [ego_count*B][H*W][C]
  * The tail computes, per ego i < num_agent[b], per pixel, for neighbours
  * k = ego, then j ascending (j != i):
  *   h1 = relu(bn1(E + F_k)); h2 = relu(bn2(W2 h1 + b2)); h3 = relu(bn3(W3 h2 + b3));
@@ -152,8 +158,9 @@ typedef struct dn_mlp_tail_params {
 int dn_disco_fuse_tail(const float* feat, const float* warped, const float* g,
                        const float* fw, const int32_t* num_agent,
                        const dn_mlp_tail_params* p, int batch, int agents, int hw, int c,
-                       int only_v2i, float* fused, float* weights_out, /* <- may be NULL;
-                       [B][A][A][hw] softmax weights, slot k order */ void* stream);
+                       int only_v2i, int ego_first, int ego_count, float* fused,
+                       float* weights_out, /* <- may be NULL; [B][ego_count][A][hw] softmax
+                       weights in neighbour-list order */ void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,135 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every
+symbol include/disconet_hip.h declares, the class surface / checkpoint names
+match the reference's, and the product path fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import ROOT
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "disconet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from disconet_amd import _lib
+    names = _header_functions()
+    assert len(names) >= 12
+    lib = _lib.load()
+    for n in names:
+        assert n in _lib.SIGNATURES, "binding missing for %s" % n
+        assert getattr(lib, n) is not None
+    assert set(_lib.SIGNATURES) == set(names)
+    assert lib.dn_version() >= 100
+
+
+def test_struct_layouts_match_header():
+    from disconet_amd import _lib
+    assert ctypes.sizeof(_lib.ConvDesc) == 13 * 4
+    assert ctypes.sizeof(_lib.MlpTailParams) == 10 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_argument_errors_are_reported_not_thrown():
+    """Error behaviour of the C ABI: negative return + dn_last_error(), no abort."""
+    from disconet_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    d.n_images, d.h_in, d.w_in, d.c0, d.c_out, d.ksize, d.stride = 1, 8, 8, 32, 32, 5, 1
+    d.ld0, d.ldo = 32, 32
+    assert lib.dn_conv_packed_weight_floats(ctypes.byref(d)) == 0
+    assert b"ksize" in lib.dn_last_error()
+    rc = lib.dn_conv2d(ctypes.byref(d), None, None, None, None, None, None, None)
+    assert rc == -1
+    rc = lib.dn_warp_neighbors(None, None, None, 1, 2, 32, 32, 256, 0, 0, 2, None, None)
+    assert rc == -1 and b"null" in lib.dn_last_error()
+    dims = (ctypes.c_int * 3)(256, 256, 13)
+    assert lib.dn_voxel_compact_workspace(dims) == ((256 * 256 * 13 + 1023) // 1024) * 4
+    vs = (ctypes.c_double * 3)(0.25, 0.25, 0.4)
+    ext = (ctypes.c_double * 6)(-32, 32, -32, 32, -3, 2)
+    bad = (ctypes.c_int * 3)(256, 256, 12)
+    assert lib.dn_voxelize_occupy(None, 0, 4, vs, ext, bad, ctypes.c_void_p(16), None) == -1
+    assert b"dims" in lib.dn_last_error()
+
+
+def test_reference_state_dict_names_load():
+    from disconet_amd import Config, DiscoNet
+    from oracle.disconet_ref import RefConfig, build_ref_model
+    ref = build_ref_model(RefConfig(128), kd_flag=1, num_agent=2)
+    m = DiscoNet(Config(map_hw=128), kd_flag=1, num_agent=2).eval()
+    # DataParallel-style prefix + the reference's duplicate backbone parameters
+    sd = {"module." + k: v for k, v in ref.state_dict().items()}
+    assert "module.decoder.conv_pre_1.weight" in sd and "module.u_encoder.conv5_1.weight" in sd
+    res = m.load_state_dict(sd)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref.state_dict()[k]), k
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"classification.conv9.weight": torch.zeros(1)}, strict=True)
+    for key in ("u_encoder.conv3d_1.conv3d.weight", "u_encoder.conv3d_2.bn3d.running_var",
+                "decoder.bn8_2.weight", "pixel_weighted_fusion.conv1_4.bias",
+                "classification.conv2.weight", "regression.box_prediction.3.bias"):
+        assert key in m.state_dict()
+
+
+def test_constructor_surface_and_config_values():
+    import inspect
+    from disconet_amd import Config, DiscoNet
+    sig = inspect.signature(DiscoNet.__init__)
+    assert list(sig.parameters)[1:] == ["config", "layer", "in_channels", "kd_flag", "num_agent",
+                                        "compress_level", "only_v2i"]
+    assert [sig.parameters[k].default for k in list(sig.parameters)[2:]] == [3, 13, True, 5, 0, False]
+    fsig = inspect.signature(DiscoNet.forward)
+    assert list(fsig.parameters)[1:] == ["bevs", "trans_matrices", "num_agent_tensor", "batch_size"]
+    c = Config("train", binary=True, only_det=True)
+    assert c.map_dims == [256, 256, 13] and c.voxel_size == (0.25, 0.25, 0.4)
+    assert len(c.anchor_size) == 6 and c.category_num == 2 and c.box_code_size == 6
+    assert np.array_equal(c.area_extents, np.array([[-32, 32], [-32, 32], [-3, 2]]))
+
+
+def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch):
+    from disconet_amd import Config, DiscoNet, _lib, ops
+    from disconet_amd.synthetic import make_scene_batch
+    m = DiscoNet(Config(map_hw=128), kd_flag=0, num_agent=2).eval()
+    bevs, trans, na = make_scene_batch(1, 2, 128)
+    with pytest.raises(_lib.DnError):
+        m(bevs, trans, na, 1)
+    with pytest.raises(_lib.DnError):
+        ops.voxelize_occupy(torch.zeros(4, 4), (0.25, 0.25, 0.4), np.array([[-32, 32]] * 2 + [[-3, 2]]),
+                            (256, 256, 13))
+    with pytest.raises(NotImplementedError):
+        m.train()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdisconet_hip.so")
+    with pytest.raises(_lib.DnError, match="not built"):
+        _lib.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "disconet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_synthetic_generator_is_deterministic_and_agent_major():
+    from disconet_amd.synthetic import make_scene_batch, make_sparse_scene_batch
+    b1, t1, n1 = make_scene_batch(2, 3, 64, live=[3, 2], jitter_seed=5)
+    b2, t2, n2 = make_scene_batch(2, 3, 64, live=[3, 2], jitter_seed=5)
+    assert torch.equal(b1, b2) and torch.equal(t1, t2) and torch.equal(n1, n2)
+    assert b1.shape == (6, 1, 64, 64, 13) and t1.shape == (2, 3, 3, 4, 4)
+    assert b1[2 * 2 + 1].sum() == 0            # agent 2 of sample 1 is padded (image = a*B + b)
+    assert b1[2 * 2 + 0].sum() > 0
+    # trans[b, i, j] = T_i^-1 T_j  =>  trans[b, i, j] @ trans[b, j, i] = I
+    prod = t1[0, 0, 2].double() @ t1[0, 2, 0].double()
+    assert torch.allclose(prod, torch.eye(4, dtype=torch.float64), atol=1e-5)
+    idx, off, bevs = make_sparse_scene_batch(1, 2, 64)
+    assert off[-1] == idx.shape[0] == int(bevs.sum())
