@@ -166,18 +166,27 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer = None if args.no_kernel_events else KernelTimer()
+    # ---- timed region #1: exactly K steps, nothing but the hot path -> `value`
     fence()
     t0 = time.perf_counter()
-    if timer is not None:
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    # ---- timed region #2 (rank 0): the same K steps with a HIP-event pair around
+    # every launch, on the launch stream -> per-kernel durations for the roofline.
+    # Kept apart from region #1 because each event record drains the queue (~30 us
+    # per launch), which would understate `value` by ~15 %.
+    timer = None
+    if rank == 0 and not args.no_kernel_events:
+        timer = KernelTimer()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         with timing(timer):
             for _ in range(args.steps):
                 out = step()
-    else:
-        for _ in range(args.steps):
-            out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        elapsed_events = time.perf_counter() - t1
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -220,6 +229,7 @@ def main():
                 "traffic": None,
                 "flop_per_step": flops / args.steps, "kernel_ms_per_step": round(ms / args.steps, 4),
                 "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
+                "ms_per_step_with_events": round(1e3 * elapsed_events / args.steps, 4),
             }
             other = {k: round(v["ms_total"] / args.steps, 4) for k, v in summ.items()
                      if v["kernel"] != "conv_mfma_kernel"}

@@ -10,6 +10,11 @@
 // the input is fetched once per chunk instead of once per tap (no im2col
 // materialisation, no 9x re-read).
 //
+// Software pipeline: the global loads of chunk c+1 are issued into registers
+// BEFORE the MFMA block of chunk c and written to LDS after it, so HBM/L2
+// latency hides under the 64-cycle MFMAs; 2-3 workgroups per CU cover each
+// other's barrier bubbles.
+//
 // MFMA operand mapping (cdna_hip_programming.md §3): for 32x32x2 lane l holds
 // A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].  Both LDS images keep K
 // contiguous per row, so one ds_read_b128 per operand feeds four MFMAs: lane
@@ -17,6 +22,10 @@
 // permutation shared by A and B, which only changes the fp32 summation order.
 // Row stride KC+4 floats keeps every 16-lane ds_read_b128 group on 16
 // distinct 16-byte slots (conflict-free for stride 1).
+//
+// Packed weights are tile-independent: [chunk of KCP cin][tap][c_out padded to
+// 32][KCP], KCP = 16 for 3x3 and 32 for 1x1; a tile with KC | KCP reads
+// sub-rows, so the tile shape can be chosen per launch from the problem size.
 //
 // Replaces the conv2d/conv3d(1x1x1)+batch_norm+relu(+interpolate+cat) chains of
 // upstream:coperception/models/det/backbone/Backbone.py.
@@ -39,7 +48,10 @@ struct ConvArgs {
   int ld0, ld1, ldo;
   int nchunks, tiles_x, tiles_y;
   int vec0, vec1;
+  int cout_pad;   // rows per (chunk, tap) in the packed weights
 };
+
+constexpr int kcp_of(int ksize) { return ksize == 3 ? 16 : 32; }
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
           int WTM, int WTN>
@@ -52,12 +64,17 @@ struct ConvTile {
   static constexpr int PS = KC + 4;
   static constexpr int TAPS = KS * KS;
   static constexpr int KV = KC / 4;
+  static constexpr int KCP = kcp_of(KS);
+  static constexpr int A_VEC = PH * PW * KV;            // float4 slots of the patch
+  static constexpr int B_VEC = TAPS * BN * KV;          // float4 slots of the weights
+  static constexpr int A_IT = (A_VEC + NT - 1) / NT;
+  static constexpr int B_IT = (B_VEC + NT - 1) / NT;
   static constexpr int A_FLOATS = PH * PW * PS;
   static constexpr int B_FLOATS = TAPS * BN * PS;
   static constexpr size_t LDS_BYTES = (size_t)(A_FLOATS + B_FLOATS) * sizeof(float);
   static_assert(BM == WAVES_M * WTM * 32, "pixel tile must match the wave layout");
   static_assert(BN == WAVES_N * WTN * 32, "channel tile must match the wave layout");
-  static_assert(KC % 8 == 0, "KC must cover whole b128 operand pairs");
+  static_assert(KC % 8 == 0 && KCP % KC == 0, "KC must cover b128 operand pairs and divide KCP");
 };
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
@@ -65,7 +82,7 @@ template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int W
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, 2)
 conv_mfma_kernel(const ConvArgs a) {
   using T = ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>;
-  constexpr int NT = T::NT, PW = T::PW, PH = T::PH, PS = T::PS, TAPS = T::TAPS, KV = T::KV;
+  constexpr int NT = T::NT, PW = T::PW, PS = T::PS, TAPS = T::TAPS, KV = T::KV, KCP = T::KCP;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
@@ -84,7 +101,7 @@ conv_mfma_kernel(const ConvArgs a) {
   bid /= a.tiles_x;
   const int tile_y = bid % a.tiles_y;
   const int img = bid / a.tiles_y;
-  const int cb = blockIdx.y;
+  const int n0 = blockIdx.y * BN;
   const int oy0 = tile_y * TH, ox0 = tile_x * TW;
   const int iy0 = oy0 * STRIDE - T::PAD, ix0 = ox0 * STRIDE - T::PAD;
 
@@ -108,47 +125,97 @@ conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
-  const float* wblk = a.wpk + (size_t)cb * a.nchunks * (TAPS * BN * KC);
+  f32x4 ra[T::A_IT], rb[T::B_IT];   // the next chunk, in flight from global memory
+  unsigned amask = 0, bmask = 0;    // which of those slots hold real data (else zero-fill)
 
-  for (int ch = 0; ch < a.nchunks; ++ch) {
+  // Branch-free staging: every lane always loads from a clamped, in-bounds
+  // address and the result is zeroed by a select, so the loads of a chunk issue
+  // back to back with no s_waitcnt between them (a divergent "if in-bounds"
+  // around each load makes hipcc drain vmcnt at every join).
+  auto load_chunk = [&](int ch) {
     const int cbeg = ch * KC;
-    __syncthreads();  // everyone is done reading the previous chunk
-    {
-      // ---- stage the halo patch of this channel chunk
-      const bool from0 = cbeg < a.c0;
-      const float* src = from0 ? a.src0 : a.src1;
-      const int cs = from0 ? cbeg : cbeg - a.c0;
-      const int ld = from0 ? a.ld0 : a.ld1;
-      const int up = from0 ? a.up0 : 0;
-      const int cvalid = (from0 ? a.c0 : a.c1) - cs;  // channels left in this source
-      const int vec = from0 ? a.vec0 : a.vec1;
-      const int hs = up ? (a.h_in >> 1) : a.h_in;
-      const int ws = up ? (a.w_in >> 1) : a.w_in;
-      for (int idx = tid; idx < PH * PW * KV; idx += NT) {
+    const bool from0 = cbeg < a.c0;
+    const float* src = from0 ? a.src0 : a.src1;
+    const int cs = from0 ? cbeg : cbeg - a.c0;
+    const int ld = from0 ? a.ld0 : a.ld1;
+    const int up = from0 ? a.up0 : 0;
+    const int cvalid = (from0 ? a.c0 : a.c1) - cs;   // channels left in this source (>= 1)
+    const int vec = from0 ? a.vec0 : a.vec1;
+    const int hs = up ? (a.h_in >> 1) : a.h_in;
+    const int ws = up ? (a.w_in >> 1) : a.w_in;
+    const float* img_base = src + (size_t)img * hs * ws * ld + cs;
+    amask = 0;
+    bmask = 0;
+    if (vec) {
+#pragma unroll
+      for (int it = 0; it < T::A_IT; ++it) {
+        const int idx = tid + it * NT;
         const int p = idx / KV, q = idx % KV;
         const int iy = iy0 + p / PW, ix = ix0 + p % PW;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) {
-          const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
-          const float* gp = src + ((size_t)(img * hs + sy) * ws + sx) * ld + cs + 4 * q;
-          if (vec && 4 * q + 4 <= cvalid) {
-            v = *reinterpret_cast<const f32x4*>(gp);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (4 * q + e < cvalid) v[e] = gp[e];
-          }
-        }
-        *reinterpret_cast<f32x4*>(&As[p * PS + 4 * q]) = v;
+        const bool ok = idx < T::A_VEC && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in &&
+                        4 * q + 4 <= cvalid;
+        const int cy = min(max(iy, 0), a.h_in - 1), cx = min(max(ix, 0), a.w_in - 1);
+        const int sy = up ? (cy >> 1) : cy, sx = up ? (cx >> 1) : cx;
+        const int cq = min(4 * q, cvalid - 4);        // vec => cvalid is a multiple of 4
+        ra[it] = *reinterpret_cast<const f32x4*>(img_base + ((size_t)sy * ws + sx) * ld + cq);
+        amask |= (ok ? 1u : 0u) << it;
       }
-      // ---- stage the weights of this chunk (pre-packed, contiguous)
-      const f32x4* wsrc = reinterpret_cast<const f32x4*>(wblk + (size_t)ch * (TAPS * BN * KC));
-      for (int idx = tid; idx < TAPS * BN * KV; idx += NT) {
-        const int row = idx / KV, q = idx % KV;
-        *reinterpret_cast<f32x4*>(&Bs[row * PS + 4 * q]) = wsrc[idx];
+    } else {
+#pragma unroll
+      for (int it = 0; it < T::A_IT; ++it) {
+        const int idx = tid + it * NT;
+        const int p = idx / KV, q = idx % KV;
+        const int iy = iy0 + p / PW, ix = ix0 + p % PW;
+        const bool ok = idx < T::A_VEC && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+        const int cy = min(max(iy, 0), a.h_in - 1), cx = min(max(ix, 0), a.w_in - 1);
+        const int sy = up ? (cy >> 1) : cy, sx = up ? (cx >> 1) : cx;
+        const float* gp = img_base + ((size_t)sy * ws + sx) * ld;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[it][e] = gp[min(4 * q + e, cvalid - 1)];
+        // channel tail of a non-multiple-of-4 source: the packed weights are zero
+        // there, so only the pixel predicate is needed (activations are finite)
+        amask |= (ok ? 1u : 0u) << it;
       }
     }
-    __syncthreads();
+    // weights: packed [chunk KCP][tap][cout_pad][KCP]; this tile reads the KC-wide
+    // sub-row (ch % (KCP/KC)) of rows n0..n0+BN
+    const int chp = cbeg / KCP, sub = cbeg % KCP;
+    const float* wsrc = a.wpk + (size_t)chp * TAPS * a.cout_pad * KCP + sub;
+#pragma unroll
+    for (int it = 0; it < T::B_IT; ++it) {
+      const int idx = min(tid + it * NT, T::B_VEC - 1);
+      const int row = idx / KV, q = idx % KV;     // row = tap * BN + n
+      const int tap = row / BN, n = row % BN;
+      const bool ok = n0 + n < a.cout_pad;
+      const int nn = min(n0 + n, a.cout_pad - 1);
+      rb[it] = *reinterpret_cast<const f32x4*>(wsrc + ((size_t)tap * a.cout_pad + nn) * KCP + 4 * q);
+      bmask |= (ok ? 1u : 0u) << it;
+    }
+  };
+
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int it = 0; it < T::A_IT; ++it) {
+      const int idx = tid + it * NT;
+      const f32x4 v = ((amask >> it) & 1u) ? ra[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < T::A_VEC) *reinterpret_cast<f32x4*>(&As[(idx / KV) * PS + 4 * (idx % KV)]) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < T::B_IT; ++it) {
+      const int idx = tid + it * NT;
+      const f32x4 v = ((bmask >> it) & 1u) ? rb[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < T::B_VEC) *reinterpret_cast<f32x4*>(&Bs[(idx / KV) * PS + 4 * (idx % KV)]) = v;
+    }
+  };
+
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+    const bool more = ch + 1 < a.nchunks;
+    if (more) load_chunk(ch + 1);   // in flight while the MFMAs below run
+    __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
@@ -172,12 +239,19 @@ conv_mfma_kernel(const ConvArgs a) {
                                                                   acc[wm][wn], 0, 0, 0);
       }
     }
+
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      __syncthreads();   // every wave is done reading this chunk from LDS
+      store_chunk();
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: C/D layout col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5)
 #pragma unroll
   for (int wn = 0; wn < WTN; ++wn) {
-    const int co = cb * BN + (wave_n * WTN + wn) * 32 + li;
+    const int co = n0 + (wave_n * WTN + wn) * 32 + li;
     const bool cok = co < a.c_out;
     const float sc = cok ? a.scale[co] : 0.f;
     const float sh = cok ? a.shift[co] : 0.f;
@@ -199,25 +273,64 @@ conv_mfma_kernel(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// tile configurations
+// tile menu and per-launch selection
 // ---------------------------------------------------------------------------
-enum CfgId { CFG_3A, CFG_3B, CFG_3C, CFG_3S2, CFG_1A, CFG_1B, CFG_1C };
+enum CfgId {
+  T3_256x32,   // 8x32 px, 32 ch : the 32-channel full-resolution layers
+  T3_256x64,   // 8x32 px, 64 ch
+  T3_128x128,  // 8x16 px, 128 ch: most operand reuse, fewest weight re-reads
+  T3_128x64,   // 8x16 px, 64 ch
+  T3_64x64,    // 8x8 px,  64 ch : small maps -> enough workgroups to fill 256 CUs
+  T3S2_128x64, // stride 2
+  T3S2_64x64,
+  T1_256x32, T1_256x64, T1_128x128, T1_64x64,
+  CFG_COUNT
+};
 
 struct Cfg {
   CfgId id;
-  int th, tw, bn, kc, taps;
+  int th, tw, bn;
 };
 
+const Cfg kCfgs[CFG_COUNT] = {
+    {T3_256x32, 8, 32, 32},  {T3_256x64, 8, 32, 64},   {T3_128x128, 8, 16, 128},
+    {T3_128x64, 8, 16, 64},  {T3_64x64, 8, 8, 64},     {T3S2_128x64, 8, 16, 64},
+    {T3S2_64x64, 8, 8, 64},  {T1_256x32, 8, 32, 32},   {T1_256x64, 8, 32, 64},
+    {T1_128x128, 8, 16, 128}, {T1_64x64, 8, 8, 64},
+};
+
+inline int out_dim(int in, int ksize, int stride) {
+  const int pad = ksize / 2;
+  return (in + 2 * pad - ksize) / stride + 1;
+}
+
+// MFMA-bound cost model: workgroups are dealt round-robin to the 256 CUs and a
+// CU runs its workgroups' MFMAs on the same 4 SIMDs, so time ~ ceil(blocks/256)
+// x (pixels x channels per tile); ties go to the larger tile (fewer weight and
+// halo re-reads).  Tiles wider than the padded channel count waste MFMAs and
+// are charged for it by construction.
 Cfg select_cfg(const dn_conv_desc& d) {
-  if (d.ksize == 3) {
-    if (d.stride == 2) return {CFG_3S2, 8, 16, 64, 8, 9};
-    if (d.c_out <= 32) return {CFG_3A, 8, 32, 32, 16, 9};
-    if (d.c_out <= 64) return {CFG_3B, 8, 32, 64, 16, 9};
-    return {CFG_3C, 8, 16, 128, 8, 9};
+  const int ho = out_dim(d.h_in, d.ksize, d.stride), wo = out_dim(d.w_in, d.ksize, d.stride);
+  const CfgId* cand;
+  int ncand;
+  // preference order: ties go to the earlier entry
+  static const CfgId c3[] = {T3_128x128, T3_256x64, T3_128x64, T3_64x64, T3_256x32};
+  static const CfgId c3s2[] = {T3S2_128x64, T3S2_64x64};
+  static const CfgId c1[] = {T1_128x128, T1_256x64, T1_64x64, T1_256x32};
+  if (d.ksize == 3 && d.stride == 2) { cand = c3s2; ncand = 2; }
+  else if (d.ksize == 3) { cand = c3; ncand = 5; }
+  else { cand = c1; ncand = 4; }
+  Cfg best = kCfgs[cand[0]];
+  double best_cost = 1e300;
+  for (int k = 0; k < ncand; ++k) {
+    const Cfg& c = kCfgs[cand[k]];
+    const long tiles = (long)d.n_images * ((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
+    const long blocks = tiles * ((d.c_out + c.bn - 1) / c.bn);
+    const double rounds = (double)((blocks + 255) / 256);
+    const double cost = rounds * c.th * c.tw * c.bn;
+    if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
   }
-  if (d.c_out <= 32) return {CFG_1A, 8, 32, 32, 32, 1};
-  if (d.c_out <= 64) return {CFG_1B, 8, 32, 64, 32, 1};
-  return {CFG_1C, 8, 16, 128, 32, 1};
+  return best;
 }
 
 int validate(const dn_conv_desc* d) {
@@ -231,28 +344,27 @@ int validate(const dn_conv_desc* d) {
              "conv: pixel strides smaller than channel counts");
   DN_REQUIRE(!d->up0 || (d->h_in % 2 == 0 && d->w_in % 2 == 0),
              "conv: x2-upsampled source needs even h_in/w_in");
-  const Cfg c = select_cfg(*d);
-  DN_REQUIRE(d->c1 == 0 || d->c0 % c.kc == 0,
-             "conv: concat needs c0 (%d) to be a multiple of the chunk (%d)", d->c0, c.kc);
+  DN_REQUIRE(d->c1 == 0 || d->c0 % kcp_of(d->ksize) == 0,
+             "conv: concat needs c0 (%d) to be a multiple of %d", d->c0, kcp_of(d->ksize));
   return DN_OK;
 }
 
-int nchunks_of(const dn_conv_desc& d, const Cfg& c) { return (d.c0 + d.c1 + c.kc - 1) / c.kc; }
-int ncb_of(const dn_conv_desc& d, const Cfg& c) { return (d.c_out + c.bn - 1) / c.bn; }
+inline int cout_pad_of(const dn_conv_desc& d) { return (d.c_out + 31) / 32 * 32; }
+inline int nchunks_packed(const dn_conv_desc& d) {
+  return (d.c0 + d.c1 + kcp_of(d.ksize) - 1) / kcp_of(d.ksize);
+}
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk,
-                                    int c_out, int c_in, int ks, int bn, int kc, int nchunks,
+                                    int c_out, int c_in, int taps, int cout_pad, int kcp,
                                     long total) {
-  const int taps = ks * ks;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
     long r = idx;
-    const int k = r % kc; r /= kc;
-    const int n = r % bn; r /= bn;
-    const int tap = r % taps; r /= taps;
-    const int ch = r % nchunks;
-    const int cb = r / nchunks;
-    const int co = cb * bn + n, ci = ch * kc + k;
+    const int k = r % kcp; r /= kcp;
+    const int co = r % cout_pad; r /= cout_pad;
+    const int tap = r % taps;
+    const int chp = r / taps;
+    const int ci = chp * kcp + k;
     float v = 0.f;
     if (co < c_out && ci < c_in) v = w[((size_t)co * c_in + ci) * taps + tap];
     wpk[idx] = v;
@@ -277,17 +389,26 @@ __global__ void fold_bn_kernel(const float* bias, const float* gamma, const floa
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
           int WTM, int WTN>
-int launch(const ConvArgs& a, int ncb, hipStream_t stream) {
+int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   using T = ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>;
   auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>;
   static_assert(T::LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)T::LDS_BYTES);
-  if (e != hipSuccess)
-    return dn::fail(DN_ERR_LAUNCH, "conv: hipFuncSetAttribute(%zu B LDS): %s", T::LDS_BYTES,
-                    hipGetErrorString(e));
-  dim3 grid((unsigned)(a.n_images * a.tiles_y * a.tiles_x), (unsigned)ncb);
+  // opt in to > 64 KiB of dynamic LDS once per instantiation (idempotent; a race
+  // between two first callers only repeats the same attribute write)
+  static bool lds_ready = false;
+  if (!lds_ready) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)T::LDS_BYTES);
+    if (e != hipSuccess)
+      return dn::fail(DN_ERR_LAUNCH, "conv: hipFuncSetAttribute(%zu B LDS): %s", T::LDS_BYTES,
+                      hipGetErrorString(e));
+    lds_ready = true;
+  }
+  a.nchunks = (d.c0 + d.c1 + KC - 1) / KC;
+  a.tiles_x = (a.w_out + TW - 1) / TW;
+  a.tiles_y = (a.h_out + TH - 1) / TH;
+  dim3 grid((unsigned)(a.n_images * a.tiles_y * a.tiles_x), (unsigned)((d.c_out + BN - 1) / BN));
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, stream, a);
   return dn::check_launch("conv_mfma_kernel");
 }
@@ -296,20 +417,18 @@ int launch(const ConvArgs& a, int ncb, hipStream_t stream) {
 
 extern "C" size_t dn_conv_packed_weight_floats(const dn_conv_desc* d) {
   if (validate(d) != DN_OK) return 0;
-  const Cfg c = select_cfg(*d);
-  return (size_t)ncb_of(*d, c) * nchunks_of(*d, c) * c.taps * c.bn * c.kc;
+  return (size_t)nchunks_packed(*d) * d->ksize * d->ksize * cout_pad_of(*d) * kcp_of(d->ksize);
 }
 
 extern "C" int dn_conv_pack_weights(const dn_conv_desc* d, const float* weight_oihw,
                                     float* packed, void* stream) {
   if (int rc = validate(d)) return rc;
   DN_REQUIRE(weight_oihw && packed, "conv pack: null pointer");
-  const Cfg c = select_cfg(*d);
   const long total = (long)dn_conv_packed_weight_floats(d);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                     weight_oihw, packed, d->c_out, d->c0 + d->c1, d->ksize, c.bn, c.kc,
-                     nchunks_of(*d, c), total);
+                     weight_oihw, packed, d->c_out, d->c0 + d->c1, d->ksize * d->ksize,
+                     cout_pad_of(*d), kcp_of(d->ksize), total);
   return dn::check_launch("pack_weights_kernel");
 }
 
@@ -334,28 +453,30 @@ extern "C" int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* 
   ConvArgs a;
   a.src0 = src0; a.src1 = src1; a.wpk = packed; a.scale = scale; a.shift = shift; a.out = out;
   a.n_images = d->n_images; a.h_in = d->h_in; a.w_in = d->w_in;
-  const int pad = d->ksize / 2;
-  a.h_out = (d->h_in + 2 * pad - d->ksize) / d->stride + 1;
-  a.w_out = (d->w_in + 2 * pad - d->ksize) / d->stride + 1;
+  a.h_out = out_dim(d->h_in, d->ksize, d->stride);
+  a.w_out = out_dim(d->w_in, d->ksize, d->stride);
   a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0; a.c_out = d->c_out; a.relu = d->relu;
   a.ld0 = d->ld0; a.ld1 = d->ld1; a.ldo = d->ldo;
-  a.nchunks = nchunks_of(*d, c);
-  a.tiles_x = (a.w_out + c.tw - 1) / c.tw;
-  a.tiles_y = (a.h_out + c.th - 1) / c.th;
+  a.cout_pad = cout_pad_of(*d);
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec0 = (d->c0 % 4 == 0 && d->ld0 % 4 == 0 && aligned16(src0)) ? 1 : 0;
   a.vec1 = (d->c1 > 0 && d->c1 % 4 == 0 && d->ld1 % 4 == 0 && aligned16(src1)) ? 1 : 0;
   DN_REQUIRE(aligned16(packed), "conv: packed weights must be 16-byte aligned");
-  const int ncb = ncb_of(*d, c);
   hipStream_t s = (hipStream_t)stream;
   switch (c.id) {
-    case CFG_3A:  return launch<3, 1, 8, 32, 32, 16, 4, 1, 2, 1>(a, ncb, s);
-    case CFG_3B:  return launch<3, 1, 8, 32, 64, 16, 4, 1, 2, 2>(a, ncb, s);
-    case CFG_3C:  return launch<3, 1, 8, 16, 128, 8, 2, 2, 2, 2>(a, ncb, s);
-    case CFG_3S2: return launch<3, 2, 8, 16, 64, 8, 2, 2, 2, 1>(a, ncb, s);
-    case CFG_1A:  return launch<1, 1, 8, 32, 32, 32, 4, 1, 2, 1>(a, ncb, s);
-    case CFG_1B:  return launch<1, 1, 8, 32, 64, 32, 4, 1, 2, 2>(a, ncb, s);
-    case CFG_1C:  return launch<1, 1, 8, 16, 128, 32, 2, 2, 2, 2>(a, ncb, s);
+    //                           KS S  TH TW  BN  KC WM WN WTM WTN
+    case T3_256x32:   return launch<3, 1, 8, 32, 32, 16, 4, 1, 2, 1>(a, *d, s);
+    case T3_256x64:   return launch<3, 1, 8, 32, 64, 16, 4, 1, 2, 2>(a, *d, s);
+    case T3_128x128:  return launch<3, 1, 8, 16, 128, 8, 2, 2, 2, 2>(a, *d, s);
+    case T3_128x64:   return launch<3, 1, 8, 16, 64, 16, 2, 2, 2, 1>(a, *d, s);
+    case T3_64x64:    return launch<3, 1, 8, 8, 64, 16, 2, 2, 1, 1>(a, *d, s);
+    case T3S2_128x64: return launch<3, 2, 8, 16, 64, 8, 2, 2, 2, 1>(a, *d, s);
+    case T3S2_64x64:  return launch<3, 2, 8, 8, 64, 8, 2, 2, 1, 1>(a, *d, s);
+    case T1_256x32:   return launch<1, 1, 8, 32, 32, 32, 4, 1, 2, 1>(a, *d, s);
+    case T1_256x64:   return launch<1, 1, 8, 32, 64, 32, 4, 1, 2, 2>(a, *d, s);
+    case T1_128x128:  return launch<1, 1, 8, 16, 128, 32, 2, 2, 2, 2>(a, *d, s);
+    case T1_64x64:    return launch<1, 1, 8, 8, 64, 32, 2, 2, 1, 1>(a, *d, s);
+    default: break;
   }
   return dn::fail(DN_ERR_UNSUPPORTED, "conv: no tile configuration");
 }

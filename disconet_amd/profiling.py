@@ -13,15 +13,25 @@ class KernelTimer:
         self.records = []          # (tag, kernel, flops, bytes, start_event, end_event)
 
     def summary(self):
-        """-> {tag: dict(kernel, calls, ms_total, flops, bytes)} after a device sync."""
+        """-> {tag: dict(kernel, calls, ms_total, ms_median, flops, bytes)} after a
+        device sync.  ms_total = calls x median launch duration: the median drops
+        the rare launch whose event pair straddles a host-side stall (GC, allocator)
+        instead of charging that stall to the kernel."""
         torch.cuda.synchronize()
-        out = {}
+        out, samples = {}, {}
         for tag, kernel, flops, nbytes, e0, e1 in self.records:
-            r = out.setdefault(tag, dict(kernel=kernel, calls=0, ms_total=0.0, flops=0.0, bytes=0.0))
+            r = out.setdefault(tag, dict(kernel=kernel, calls=0, ms_total=0.0, ms_mean=0.0,
+                                         flops=0.0, bytes=0.0))
             r["calls"] += 1
-            r["ms_total"] += e0.elapsed_time(e1)
+            samples.setdefault(tag, []).append(e0.elapsed_time(e1))
             r["flops"] += flops
             r["bytes"] += nbytes
+        for tag, r in out.items():
+            xs = sorted(samples[tag])
+            med = xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+            r["ms_median"] = med
+            r["ms_total"] = med * r["calls"]
+            r["ms_mean"] = sum(xs) / len(xs)
         return out
 
 
