@@ -49,9 +49,16 @@ struct ConvArgs {
   int nchunks, tiles_x, tiles_y;
   int vec0, vec1;
   int cout_pad;   // rows per (chunk, tap) in the packed weights
+  int ncb;        // output-channel blocks per spatial tile
+  int total_tiles;  // n_images * tiles_y * tiles_x * ncb work items
+};
+
+struct TileCoord {
+  int img, oy0, ox0, n0;
 };
 
 constexpr int kcp_of(int ksize) { return ksize == 3 ? 16 : 32; }
+constexpr int kNumCUs = 256;   // MI355X
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
           int WTM, int WTN>
@@ -96,14 +103,25 @@ conv_mfma_kernel(const ConvArgs a) {
   const int li = lane & 31;
   const int lh = lane >> 5;
 
-  int bid = blockIdx.x;
-  const int tile_x = bid % a.tiles_x;
-  bid /= a.tiles_x;
-  const int tile_y = bid % a.tiles_y;
-  const int img = bid / a.tiles_y;
-  const int n0 = blockIdx.y * BN;
-  const int oy0 = tile_y * TH, ox0 = tile_x * TW;
-  const int iy0 = oy0 * STRIDE - T::PAD, ix0 = ox0 * STRIDE - T::PAD;
+  // Persistent workgroups: gridDim.x = resident workgroups (occupancy x 256 CUs);
+  // each walks the work items lid, lid + G, ... so the loads of the next tile hide
+  // under the MFMAs of the current one instead of every workgroup of a
+  // generation hitting HBM at the same time.  Work item = (spatial tile, channel
+  // block), channel block fastest; the bid -> lid remap puts consecutive items
+  // (same halo patch, different channels) on one XCD's L2 (block b runs on XCD
+  // b % 8 -- a speed assumption only).
+  const int G = gridDim.x;
+  const int lid = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+  auto decode = [&](int item) {
+    TileCoord tc;
+    tc.n0 = (item % a.ncb) * BN;
+    int sp = item / a.ncb;
+    tc.ox0 = (sp % a.tiles_x) * TW;
+    sp /= a.tiles_x;
+    tc.oy0 = (sp % a.tiles_y) * TH;
+    tc.img = sp / a.tiles_y;
+    return tc;
+  };
 
   int a_off[WTM], b_off[WTN];
 #pragma unroll
@@ -118,12 +136,6 @@ conv_mfma_kernel(const ConvArgs a) {
   }
 
   f32x16 acc[WTM][WTN];
-#pragma unroll
-  for (int wm = 0; wm < WTM; ++wm)
-#pragma unroll
-    for (int wn = 0; wn < WTN; ++wn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
   f32x4 ra[T::A_IT], rb[T::B_IT];   // the next chunk, in flight from global memory
   unsigned amask = 0, bmask = 0;    // which of those slots hold real data (else zero-fill)
@@ -132,7 +144,9 @@ conv_mfma_kernel(const ConvArgs a) {
   // address and the result is zeroed by a select, so the loads of a chunk issue
   // back to back with no s_waitcnt between them (a divergent "if in-bounds"
   // around each load makes hipcc drain vmcnt at every join).
-  auto load_chunk = [&](int ch) {
+  auto load_chunk = [&](const TileCoord& tc, int ch) {
+    const int img = tc.img, n0 = tc.n0;
+    const int iy0 = tc.oy0 * STRIDE - T::PAD, ix0 = tc.ox0 * STRIDE - T::PAD;
     const int cbeg = ch * KC;
     const bool from0 = cbeg < a.c0;
     const float* src = from0 ? a.src0 : a.src1;
@@ -208,13 +222,59 @@ conv_mfma_kernel(const ConvArgs a) {
     }
   };
 
-  load_chunk(0);
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+      for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+  };
+
+  // epilogue: C/D layout col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5)
+  auto epilogue = [&](const TileCoord& tc) {
+#pragma unroll
+    for (int wn = 0; wn < WTN; ++wn) {
+      const int co = tc.n0 + (wave_n * WTN + wn) * 32 + li;
+      const bool cok = co < a.c_out;
+      const float sc = cok ? a.scale[co] : 0.f;
+      const float sh = cok ? a.shift[co] : 0.f;
+#pragma unroll
+      for (int wm = 0; wm < WTM; ++wm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int m = (wave_m * WTM + wm) * 32 + row;
+          const int oy = tc.oy0 + m / TW, ox = tc.ox0 + m % TW;
+          if (cok && oy < a.h_out && ox < a.w_out) {
+            float v = acc[wm][wn][r] * sc + sh;
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.out[((size_t)(tc.img * a.h_out + oy) * a.w_out + ox) * a.ldo + co] = v;
+          }
+        }
+      }
+    }
+  };
+
+  int item = lid;
+  if (item >= a.total_tiles) return;
+  TileCoord cur = decode(item);
+  int ch = 0;
+  zero_acc();
+  load_chunk(cur, 0);
   store_chunk();
   __syncthreads();
 
-  for (int ch = 0; ch < a.nchunks; ++ch) {
-    const bool more = ch + 1 < a.nchunks;
-    if (more) load_chunk(ch + 1);   // in flight while the MFMAs below run
+  while (true) {
+    // the next (tile, chunk) of this workgroup's flattened work list
+    int nch = ch + 1, nitem = item;
+    if (nch == a.nchunks) { nch = 0; nitem = item + G; }
+    const bool more = nitem < a.total_tiles;
+    TileCoord nxt = cur;
+    if (more) {
+      if (nch == 0) nxt = decode(nitem);
+      load_chunk(nxt, nch);   // in flight while the MFMAs below run
+    }
     __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
@@ -239,36 +299,19 @@ conv_mfma_kernel(const ConvArgs a) {
                                                                   acc[wm][wn], 0, 0, 0);
       }
     }
-
     __builtin_amdgcn_sched_barrier(0);
-    if (more) {
-      __syncthreads();   // every wave is done reading this chunk from LDS
-      store_chunk();
-      __syncthreads();
-    }
-  }
 
-  // ---- epilogue: C/D layout col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5)
-#pragma unroll
-  for (int wn = 0; wn < WTN; ++wn) {
-    const int co = n0 + (wave_n * WTN + wn) * 32 + li;
-    const bool cok = co < a.c_out;
-    const float sc = cok ? a.scale[co] : 0.f;
-    const float sh = cok ? a.shift[co] : 0.f;
-#pragma unroll
-    for (int wm = 0; wm < WTM; ++wm) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = (wave_m * WTM + wm) * 32 + row;
-        const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-        if (cok && oy < a.h_out && ox < a.w_out) {
-          float v = acc[wm][wn][r] * sc + sh;
-          if (a.relu) v = fmaxf(v, 0.f);
-          a.out[((size_t)(img * a.h_out + oy) * a.w_out + ox) * a.ldo + co] = v;
-        }
-      }
+    if (ch == a.nchunks - 1) {   // tile finished: write it out, start the next from zero
+      epilogue(cur);
+      zero_acc();
     }
+    if (!more) break;
+    __syncthreads();   // every wave is done reading this chunk from LDS
+    store_chunk();
+    __syncthreads();
+    item = nitem;
+    ch = nch;
+    cur = nxt;
   }
 }
 
@@ -395,20 +438,30 @@ int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   static_assert(T::LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   // opt in to > 64 KiB of dynamic LDS once per instantiation (idempotent; a race
   // between two first callers only repeats the same attribute write)
-  static bool lds_ready = false;
-  if (!lds_ready) {
+  static int blocks_per_cu = 0;
+  if (blocks_per_cu == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)T::LDS_BYTES);
     if (e != hipSuccess)
       return dn::fail(DN_ERR_LAUNCH, "conv: hipFuncSetAttribute(%zu B LDS): %s", T::LDS_BYTES,
                       hipGetErrorString(e));
-    lds_ready = true;
+    // resident workgroups per CU = the persistent grid's size.  No inter-workgroup
+    // synchronisation depends on it: an over-estimate only queues the surplus.
+    int occ = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, T::NT, T::LDS_BYTES);
+    if (e != hipSuccess || occ < 1) occ = 1;
+    blocks_per_cu = occ > 4 ? 4 : occ;
   }
   a.nchunks = (d.c0 + d.c1 + KC - 1) / KC;
   a.tiles_x = (a.w_out + TW - 1) / TW;
   a.tiles_y = (a.h_out + TH - 1) / TH;
-  dim3 grid((unsigned)(a.n_images * a.tiles_y * a.tiles_x), (unsigned)((d.c_out + BN - 1) / BN));
+  a.ncb = (d.c_out + BN - 1) / BN;
+  const long total = (long)a.n_images * a.tiles_y * a.tiles_x * a.ncb;
+  DN_REQUIRE(total < (1L << 31), "conv: too many tiles (%ld)", total);
+  a.total_tiles = (int)total;
+  const long resident = (long)blocks_per_cu * kNumCUs;
+  dim3 grid((unsigned)(total < resident ? total : resident));
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, stream, a);
   return dn::check_launch("conv_mfma_kernel");
 }
