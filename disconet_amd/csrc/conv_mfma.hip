@@ -13,7 +13,17 @@
 // Software pipeline: the global loads of chunk c+1 are issued into registers
 // BEFORE the MFMA block of chunk c and written to LDS after it, so HBM/L2
 // latency hides under the 64-cycle MFMAs; 2-3 workgroups per CU cover each
-// other's barrier bubbles.
+// other's barrier bubbles.  Staging uses buffer loads: the per-lane byte
+// offsets of a tile are computed ONCE, a chunk only changes the scalar offset,
+// and halo / tail slots carry an out-of-range offset so the hardware bounds
+// check returns the zero padding (no per-chunk address math, clamps or selects
+// -- measured as ~20 % of the kernel when done on the VALU).
+//
+// Orientation: the MFMA's M dimension carries OUTPUT CHANNELS and N carries
+// pixels (D[i = channel][j = pixel]); lane l then owns one pixel (l&31) and, per
+// register quad, 4 consecutive channels -> the epilogue is 16-byte stores
+// (4 per 32x32 tile instead of 16 dword stores; the dword form cost ~25 % of the
+// 32-channel full-resolution layers).
 //
 // MFMA operand mapping (cdna_hip_programming.md §3): for 32x32x2 lane l holds
 // A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].  Both LDS images keep K
@@ -49,16 +59,11 @@ struct ConvArgs {
   int nchunks, tiles_x, tiles_y;
   int vec0, vec1;
   int cout_pad;   // rows per (chunk, tap) in the packed weights
-  int ncb;        // output-channel blocks per spatial tile
-  int total_tiles;  // n_images * tiles_y * tiles_x * ncb work items
-};
-
-struct TileCoord {
-  int img, oy0, ox0, n0;
+  int wpk_bytes;  // size of the packed weights (buffer bounds)
+  int vec_out;    // out / scale / shift allow 16-byte accesses
 };
 
 constexpr int kcp_of(int ksize) { return ksize == 3 ? 16 : 32; }
-constexpr int kNumCUs = 256;   // MI355X
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
           int WTM, int WTN>
@@ -84,10 +89,21 @@ struct ConvTile {
   static_assert(KC % 8 == 0 && KCP % KC == 0, "KC must cover b128 operand pairs and divide KCP");
 };
 
+// ABL != 0 builds ablation variants for tools/conv_ablate.hip only (the product
+// always launches ABL = 0): 1 = no steady-state global loads / LDS stores /
+// barriers, 2 = 1 + no epilogue stores, 3 = no epilogue stores, 4 = MFMA operands
+// from registers instead of LDS, 5 = 1 + 2 + 4 (pure MFMA stream), 6 = global
+// loads issued but never written to LDS (no barriers), 7 = LDS stores + barriers
+// but no global loads.
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
-          int WTM, int WTN>
+          int WTM, int WTN, int ABL = 0>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, 2)
 conv_mfma_kernel(const ConvArgs a) {
+  constexpr bool kNoStream = ABL == 1 || ABL == 2 || ABL == 5;
+  constexpr bool kNoLdsStore = ABL == 6;
+  constexpr bool kNoGlobal = ABL == 7;
+  constexpr bool kNoStore = ABL == 2 || ABL == 3 || ABL == 5;
+  constexpr bool kNoLds = ABL == 4 || ABL == 5;
   using T = ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>;
   constexpr int NT = T::NT, PW = T::PW, PS = T::PS, TAPS = T::TAPS, KV = T::KV, KCP = T::KCP;
 
@@ -103,25 +119,14 @@ conv_mfma_kernel(const ConvArgs a) {
   const int li = lane & 31;
   const int lh = lane >> 5;
 
-  // Persistent workgroups: gridDim.x = resident workgroups (occupancy x 256 CUs);
-  // each walks the work items lid, lid + G, ... so the loads of the next tile hide
-  // under the MFMAs of the current one instead of every workgroup of a
-  // generation hitting HBM at the same time.  Work item = (spatial tile, channel
-  // block), channel block fastest; the bid -> lid remap puts consecutive items
-  // (same halo patch, different channels) on one XCD's L2 (block b runs on XCD
-  // b % 8 -- a speed assumption only).
-  const int G = gridDim.x;
-  const int lid = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
-  auto decode = [&](int item) {
-    TileCoord tc;
-    tc.n0 = (item % a.ncb) * BN;
-    int sp = item / a.ncb;
-    tc.ox0 = (sp % a.tiles_x) * TW;
-    sp /= a.tiles_x;
-    tc.oy0 = (sp % a.tiles_y) * TH;
-    tc.img = sp / a.tiles_y;
-    return tc;
-  };
+  int bid = blockIdx.x;
+  const int tile_x = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int tile_y = bid % a.tiles_y;
+  const int img = bid / a.tiles_y;
+  const int n0 = blockIdx.y * BN;
+  const int oy0 = tile_y * TH, ox0 = tile_x * TW;
+  const int iy0 = oy0 * STRIDE - T::PAD, ix0 = ox0 * STRIDE - T::PAD;
 
   int a_off[WTM], b_off[WTN];
 #pragma unroll
@@ -136,146 +141,110 @@ conv_mfma_kernel(const ConvArgs a) {
   }
 
   f32x16 acc[WTM][WTN];
-
-  f32x4 ra[T::A_IT], rb[T::B_IT];   // the next chunk, in flight from global memory
-  unsigned amask = 0, bmask = 0;    // which of those slots hold real data (else zero-fill)
-
-  // Branch-free staging: every lane always loads from a clamped, in-bounds
-  // address and the result is zeroed by a select, so the loads of a chunk issue
-  // back to back with no s_waitcnt between them (a divergent "if in-bounds"
-  // around each load makes hipcc drain vmcnt at every join).
-  auto load_chunk = [&](const TileCoord& tc, int ch) {
-    const int img = tc.img, n0 = tc.n0;
-    const int iy0 = tc.oy0 * STRIDE - T::PAD, ix0 = tc.ox0 * STRIDE - T::PAD;
-    const int cbeg = ch * KC;
-    const bool from0 = cbeg < a.c0;
-    const float* src = from0 ? a.src0 : a.src1;
-    const int cs = from0 ? cbeg : cbeg - a.c0;
-    const int ld = from0 ? a.ld0 : a.ld1;
-    const int up = from0 ? a.up0 : 0;
-    const int cvalid = (from0 ? a.c0 : a.c1) - cs;   // channels left in this source (>= 1)
-    const int vec = from0 ? a.vec0 : a.vec1;
-    const int hs = up ? (a.h_in >> 1) : a.h_in;
-    const int ws = up ? (a.w_in >> 1) : a.w_in;
-    const float* img_base = src + (size_t)img * hs * ws * ld + cs;
-    amask = 0;
-    bmask = 0;
-    if (vec) {
 #pragma unroll
-      for (int it = 0; it < T::A_IT; ++it) {
-        const int idx = tid + it * NT;
-        const int p = idx / KV, q = idx % KV;
-        const int iy = iy0 + p / PW, ix = ix0 + p % PW;
-        const bool ok = idx < T::A_VEC && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in &&
-                        4 * q + 4 <= cvalid;
-        const int cy = min(max(iy, 0), a.h_in - 1), cx = min(max(ix, 0), a.w_in - 1);
-        const int sy = up ? (cy >> 1) : cy, sx = up ? (cx >> 1) : cx;
-        const int cq = min(4 * q, cvalid - 4);        // vec => cvalid is a multiple of 4
-        ra[it] = *reinterpret_cast<const f32x4*>(img_base + ((size_t)sy * ws + sx) * ld + cq);
-        amask |= (ok ? 1u : 0u) << it;
+  for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+    for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+
+  const f32x4 abl_const = {li * 1e-3f, 0.5f, -0.25f, lh * 1.f};   // ablation operands only
+  f32x4 ra[T::A_IT], rb[T::B_IT];   // the next chunk, in flight from global memory
+
+  // ---- per-tile staging state: buffer descriptors + per-lane byte offsets
+  constexpr unsigned OOB = 0xFFFFFFFFu;   // >= num_records: the load returns 0
+  const int hs0 = a.up0 ? (a.h_in >> 1) : a.h_in, ws0 = a.up0 ? (a.w_in >> 1) : a.w_in;
+  const size_t img0_floats = (size_t)hs0 * ws0 * a.ld0, img1_floats = (size_t)a.h_in * a.w_in * a.ld1;
+  const auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.src0 + img * img0_floats), 0, (int)(img0_floats * 4), 0x00020000);
+  const auto rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.c1 ? a.src1 + img * img1_floats : a.src0), 0,
+      a.c1 ? (int)(img1_floats * 4) : 0, 0x00020000);
+  const auto rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, a.wpk_bytes,
+                                                        0x00020000);
+  unsigned voff_a0[T::A_IT], voff_a1[T::A_IT], voff_b[T::B_IT];
+#pragma unroll
+  for (int it = 0; it < T::A_IT; ++it) {
+    const int idx = tid + it * NT;
+    const int p = idx / KV, q = idx % KV;
+    const int iy = iy0 + p / PW, ix = ix0 + p % PW;
+    const bool ok = idx < T::A_VEC && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+    const int sy = a.up0 ? (iy >> 1) : iy, sx = a.up0 ? (ix >> 1) : ix;
+    voff_a0[it] = ok ? (unsigned)(((sy * ws0 + sx) * a.ld0 + 4 * q) * 4) : OOB;
+    voff_a1[it] = ok ? (unsigned)(((iy * a.w_in + ix) * a.ld1 + 4 * q) * 4) : OOB;
+  }
+#pragma unroll
+  for (int it = 0; it < T::B_IT; ++it) {
+    const int idx = tid + it * NT;
+    const int row = idx / KV, q = idx % KV;     // row = tap * BN + n
+    const int tap = row / BN, n = row % BN;
+    const bool ok = idx < T::B_VEC && n0 + n < a.cout_pad;
+    voff_b[it] = ok ? (unsigned)((((tap * a.cout_pad + n0 + n) * KCP) + 4 * q) * 4) : OOB;
+  }
+
+  auto ld128 = [](auto rsrc, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+  };
+  auto ld32x4 = [](auto rsrc, unsigned voff, int soff) {
+    // a channel count that is not a multiple of 4 (the 13-bin voxel input): dword
+    // loads.  Channels past the source's count read the neighbouring pixel (or 0
+    // past the image) and meet zero weights.
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                           rsrc, voff == 0xFFFFFFFFu ? voff : voff + 4 * e, soff, 0));
+    return v;
+  };
+
+  auto load_chunk = [&](int ch) {
+    const int cbeg = ch * KC;
+    if (cbeg < a.c0) {
+      const int soff = cbeg * 4;
+      if (a.vec0) {
+#pragma unroll
+        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld128(rsrc0, voff_a0[it], soff);
+      } else {
+#pragma unroll
+        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld32x4(rsrc0, voff_a0[it], soff);
       }
     } else {
+      const int soff = (cbeg - a.c0) * 4;
+      if (a.vec1) {
 #pragma unroll
-      for (int it = 0; it < T::A_IT; ++it) {
-        const int idx = tid + it * NT;
-        const int p = idx / KV, q = idx % KV;
-        const int iy = iy0 + p / PW, ix = ix0 + p % PW;
-        const bool ok = idx < T::A_VEC && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
-        const int cy = min(max(iy, 0), a.h_in - 1), cx = min(max(ix, 0), a.w_in - 1);
-        const int sy = up ? (cy >> 1) : cy, sx = up ? (cx >> 1) : cx;
-        const float* gp = img_base + ((size_t)sy * ws + sx) * ld;
+        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld128(rsrc1, voff_a1[it], soff);
+      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ra[it][e] = gp[min(4 * q + e, cvalid - 1)];
-        // channel tail of a non-multiple-of-4 source: the packed weights are zero
-        // there, so only the pixel predicate is needed (activations are finite)
-        amask |= (ok ? 1u : 0u) << it;
+        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld32x4(rsrc1, voff_a1[it], soff);
       }
     }
     // weights: packed [chunk KCP][tap][cout_pad][KCP]; this tile reads the KC-wide
     // sub-row (ch % (KCP/KC)) of rows n0..n0+BN
-    const int chp = cbeg / KCP, sub = cbeg % KCP;
-    const float* wsrc = a.wpk + (size_t)chp * TAPS * a.cout_pad * KCP + sub;
+    const int wsoff = ((cbeg / KCP) * TAPS * a.cout_pad * KCP + cbeg % KCP) * 4;
 #pragma unroll
-    for (int it = 0; it < T::B_IT; ++it) {
-      const int idx = min(tid + it * NT, T::B_VEC - 1);
-      const int row = idx / KV, q = idx % KV;     // row = tap * BN + n
-      const int tap = row / BN, n = row % BN;
-      const bool ok = n0 + n < a.cout_pad;
-      const int nn = min(n0 + n, a.cout_pad - 1);
-      rb[it] = *reinterpret_cast<const f32x4*>(wsrc + ((size_t)tap * a.cout_pad + nn) * KCP + 4 * q);
-      bmask |= (ok ? 1u : 0u) << it;
-    }
+    for (int it = 0; it < T::B_IT; ++it) rb[it] = ld128(rsrcw, voff_b[it], wsoff);
   };
 
   auto store_chunk = [&]() {
 #pragma unroll
     for (int it = 0; it < T::A_IT; ++it) {
       const int idx = tid + it * NT;
-      const f32x4 v = ((amask >> it) & 1u) ? ra[it] : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (idx < T::A_VEC) *reinterpret_cast<f32x4*>(&As[(idx / KV) * PS + 4 * (idx % KV)]) = v;
+      if (idx < T::A_VEC) *reinterpret_cast<f32x4*>(&As[(idx / KV) * PS + 4 * (idx % KV)]) = ra[it];
     }
 #pragma unroll
     for (int it = 0; it < T::B_IT; ++it) {
       const int idx = tid + it * NT;
-      const f32x4 v = ((bmask >> it) & 1u) ? rb[it] : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (idx < T::B_VEC) *reinterpret_cast<f32x4*>(&Bs[(idx / KV) * PS + 4 * (idx % KV)]) = v;
+      if (idx < T::B_VEC) *reinterpret_cast<f32x4*>(&Bs[(idx / KV) * PS + 4 * (idx % KV)]) = rb[it];
     }
   };
 
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int wm = 0; wm < WTM; ++wm)
-#pragma unroll
-      for (int wn = 0; wn < WTN; ++wn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
-  };
-
-  // epilogue: C/D layout col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5)
-  auto epilogue = [&](const TileCoord& tc) {
-#pragma unroll
-    for (int wn = 0; wn < WTN; ++wn) {
-      const int co = tc.n0 + (wave_n * WTN + wn) * 32 + li;
-      const bool cok = co < a.c_out;
-      const float sc = cok ? a.scale[co] : 0.f;
-      const float sh = cok ? a.shift[co] : 0.f;
-#pragma unroll
-      for (int wm = 0; wm < WTM; ++wm) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int m = (wave_m * WTM + wm) * 32 + row;
-          const int oy = tc.oy0 + m / TW, ox = tc.ox0 + m % TW;
-          if (cok && oy < a.h_out && ox < a.w_out) {
-            float v = acc[wm][wn][r] * sc + sh;
-            if (a.relu) v = fmaxf(v, 0.f);
-            a.out[((size_t)(tc.img * a.h_out + oy) * a.w_out + ox) * a.ldo + co] = v;
-          }
-        }
-      }
-    }
-  };
-
-  int item = lid;
-  if (item >= a.total_tiles) return;
-  TileCoord cur = decode(item);
-  int ch = 0;
-  zero_acc();
-  load_chunk(cur, 0);
+  load_chunk(0);
   store_chunk();
   __syncthreads();
 
-  while (true) {
-    // the next (tile, chunk) of this workgroup's flattened work list
-    int nch = ch + 1, nitem = item;
-    if (nch == a.nchunks) { nch = 0; nitem = item + G; }
-    const bool more = nitem < a.total_tiles;
-    TileCoord nxt = cur;
-    if (more) {
-      if (nch == 0) nxt = decode(nitem);
-      load_chunk(nxt, nch);   // in flight while the MFMAs below run
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+    const bool more = !kNoStream && ch + 1 < a.nchunks;
+    if (more && !kNoGlobal) load_chunk(ch + 1);   // in flight while the MFMAs below run
 
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
@@ -285,33 +254,72 @@ conv_mfma_kernel(const ConvArgs a) {
         f32x4 av[WTM], bv[WTN];
 #pragma unroll
         for (int wm = 0; wm < WTM; ++wm)
-          av[wm] = *reinterpret_cast<const f32x4*>(&As[a_off[wm] + toff + 8 * s]);
+          av[wm] = kNoLds ? abl_const : *reinterpret_cast<const f32x4*>(&As[a_off[wm] + toff + 8 * s]);
 #pragma unroll
         for (int wn = 0; wn < WTN; ++wn)
-          bv[wn] = *reinterpret_cast<const f32x4*>(&Bs[tap * BN * PS + b_off[wn] + 8 * s]);
+          bv[wn] = kNoLds ? abl_const
+                          : *reinterpret_cast<const f32x4*>(&Bs[tap * BN * PS + b_off[wn] + 8 * s]);
+        // D[i = channel][j = pixel]: weights are the MFMA's A operand, pixels its B
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
             for (int wn = 0; wn < WTN; ++wn)
-              acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[wm][t], bv[wn][t],
+              acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[wn][t], av[wm][t],
                                                                   acc[wm][wn], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
 
-    if (ch == a.nchunks - 1) {   // tile finished: write it out, start the next from zero
-      epilogue(cur);
-      zero_acc();
+    if (more && kNoLdsStore) {
+#pragma unroll
+      for (int it = 0; it < T::A_IT; ++it) asm volatile("" ::"v"(ra[it]));
+#pragma unroll
+      for (int it = 0; it < T::B_IT; ++it) asm volatile("" ::"v"(rb[it]));
+    } else if (more) {
+      __syncthreads();   // every wave is done reading this chunk from LDS
+      store_chunk();
+      __syncthreads();
     }
-    if (!more) break;
-    __syncthreads();   // every wave is done reading this chunk from LDS
-    store_chunk();
-    __syncthreads();
-    item = nitem;
-    ch = nch;
-    cur = nxt;
+  }
+
+  // ---- epilogue.  C/D layout: column = lane&31 = pixel, row = (r&3) + 8*(r>>2) +
+  // 4*(lane>>5) = channel, so registers 4g..4g+3 are channels 8g+4h+{0..3} of this
+  // lane's pixel: one 16-byte store per quad.
+#pragma unroll
+  for (int wm = 0; wm < WTM; ++wm) {
+    const int m = (wave_m * WTM + wm) * 32 + li;
+    const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+    const bool pok = oy < a.h_out && ox < a.w_out;
+    float* orow = a.out + ((size_t)(img * a.h_out + oy) * a.w_out + ox) * a.ldo;
+#pragma unroll
+    for (int wn = 0; wn < WTN; ++wn) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = n0 + (wave_n * WTN + wn) * 32 + 8 * g + 4 * lh;
+        if (!pok || co >= a.c_out) continue;
+        if (a.vec_out && co + 4 <= a.c_out) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + co);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + co);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
+            if (a.relu) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (!kNoStore || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(orow + co) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (co + e < a.c_out) {
+              float v = acc[wm][wn][4 * g + e] * a.scale[co + e] + a.shift[co + e];
+              if (a.relu) v = fmaxf(v, 0.f);
+              if (!kNoStore || v == 12345.678f) orow[co + e] = v;
+            }
+          }
+        }
+      }
+    }
   }
 }
 
@@ -431,37 +439,27 @@ __global__ void fold_bn_kernel(const float* bias, const float* gamma, const floa
 }
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
-          int WTM, int WTN>
+          int WTM, int WTN, int ABL = 0>
 int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   using T = ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>;
-  auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>;
+  auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN, ABL>;
   static_assert(T::LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   // opt in to > 64 KiB of dynamic LDS once per instantiation (idempotent; a race
   // between two first callers only repeats the same attribute write)
-  static int blocks_per_cu = 0;
-  if (blocks_per_cu == 0) {
+  static bool lds_ready = false;
+  if (!lds_ready) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)T::LDS_BYTES);
     if (e != hipSuccess)
       return dn::fail(DN_ERR_LAUNCH, "conv: hipFuncSetAttribute(%zu B LDS): %s", T::LDS_BYTES,
                       hipGetErrorString(e));
-    // resident workgroups per CU = the persistent grid's size.  No inter-workgroup
-    // synchronisation depends on it: an over-estimate only queues the surplus.
-    int occ = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, T::NT, T::LDS_BYTES);
-    if (e != hipSuccess || occ < 1) occ = 1;
-    blocks_per_cu = occ > 4 ? 4 : occ;
+    lds_ready = true;
   }
   a.nchunks = (d.c0 + d.c1 + KC - 1) / KC;
   a.tiles_x = (a.w_out + TW - 1) / TW;
   a.tiles_y = (a.h_out + TH - 1) / TH;
-  a.ncb = (d.c_out + BN - 1) / BN;
-  const long total = (long)a.n_images * a.tiles_y * a.tiles_x * a.ncb;
-  DN_REQUIRE(total < (1L << 31), "conv: too many tiles (%ld)", total);
-  a.total_tiles = (int)total;
-  const long resident = (long)blocks_per_cu * kNumCUs;
-  dim3 grid((unsigned)(total < resident ? total : resident));
+  dim3 grid((unsigned)(a.n_images * a.tiles_y * a.tiles_x), (unsigned)((d.c_out + BN - 1) / BN));
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, stream, a);
   return dn::check_launch("conv_mfma_kernel");
 }
@@ -511,10 +509,17 @@ extern "C" int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* 
   a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0; a.c_out = d->c_out; a.relu = d->relu;
   a.ld0 = d->ld0; a.ld1 = d->ld1; a.ldo = d->ldo;
   a.cout_pad = cout_pad_of(*d);
+  a.wpk_bytes = (int)(dn_conv_packed_weight_floats(d) * sizeof(float));
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec0 = (d->c0 % 4 == 0 && d->ld0 % 4 == 0 && aligned16(src0)) ? 1 : 0;
   a.vec1 = (d->c1 > 0 && d->c1 % 4 == 0 && d->ld1 % 4 == 0 && aligned16(src1)) ? 1 : 0;
   DN_REQUIRE(aligned16(packed), "conv: packed weights must be 16-byte aligned");
+  a.vec_out = (d->ldo % 4 == 0 && aligned16(out) && aligned16(scale) && aligned16(shift)) ? 1 : 0;
+  // buffer descriptors address one image with 32-bit byte offsets
+  const size_t hs0 = d->up0 ? d->h_in / 2 : d->h_in, ws0 = d->up0 ? d->w_in / 2 : d->w_in;
+  DN_REQUIRE(hs0 * ws0 * d->ld0 * 4 < (1ull << 31) &&
+                 (size_t)d->h_in * d->w_in * (d->c1 ? d->ld1 : 1) * 4 < (1ull << 31),
+             "conv: one image must stay below 2 GiB");
   hipStream_t s = (hipStream_t)stream;
   switch (c.id) {
     //                           KS S  TH TW  BN  KC WM WN WTM WTN
