@@ -60,10 +60,14 @@ struct ConvArgs {
   int vec0, vec1;
   int cout_pad;   // rows per (chunk, tap) in the packed weights
   int wpk_bytes;  // size of the packed weights (buffer bounds)
+  int stagger_slots;   // resident workgroups per CU (0 = no start-up stagger)
+  int stagger_sleeps;  // s_sleep(16) iterations (~1024 cycles each) per slot step
+  int stagger_mode;    // 1: slot = block / 256, 2: slot = (block / 8) % slots
   int vec_out;    // out / scale / shift allow 16-byte accesses
 };
 
 constexpr int kcp_of(int ksize) { return ksize == 3 ? 16 : 32; }
+constexpr int kNumCUs = 256;   // MI355X
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
           int WTM, int WTN>
@@ -83,7 +87,10 @@ struct ConvTile {
   static constexpr int B_IT = (B_VEC + NT - 1) / NT;
   static constexpr int A_FLOATS = PH * PW * PS;
   static constexpr int B_FLOATS = TAPS * BN * PS;
-  static constexpr size_t LDS_BYTES = (size_t)(A_FLOATS + B_FLOATS) * sizeof(float);
+  static constexpr int CS = BN + 4;                      // epilogue staging row stride
+  static constexpr int C_FLOATS = BM * CS;
+  static constexpr size_t LDS_BYTES =
+      (size_t)(A_FLOATS + B_FLOATS > C_FLOATS ? A_FLOATS + B_FLOATS : C_FLOATS) * sizeof(float);
   static_assert(BM == WAVES_M * WTM * 32, "pixel tile must match the wave layout");
   static_assert(BN == WAVES_N * WTN * 32, "channel tile must match the wave layout");
   static_assert(KC % 8 == 0 && KCP % KC == 0, "KC must cover b128 operand pairs and divide KCP");
@@ -118,6 +125,18 @@ conv_mfma_kernel(const ConvArgs a) {
   const int wave_n = wave % WAVES_N;
   const int li = lane & 31;
   const int lh = lane >> 5;
+
+  // De-phase the workgroups that share a CU.  All workgroups of a launch start
+  // together and take the same time, so without this every co-resident group
+  // reaches its load burst, its barriers and its store burst at the same moment
+  // and the MFMA pipe idles through all of them.  The first generation
+  // (blockIdx < slots * 256; dispatch fills one slot per CU per 256 blocks -- a
+  // speed assumption only) sleeps slot/slots of a workgroup period; later
+  // generations inherit the offsets because they start as their predecessors end.
+  if (a.stagger_slots > 1 && blockIdx.y == 0 && (int)blockIdx.x < a.stagger_slots * kNumCUs) {
+    const int slot = a.stagger_mode == 2 ? (blockIdx.x / 8) % a.stagger_slots : blockIdx.x / kNumCUs;
+    for (int i = 0; i < slot * a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(16);
+  }
 
   int bid = blockIdx.x;
   const int tile_x = bid % a.tiles_x;
@@ -285,43 +304,75 @@ conv_mfma_kernel(const ConvArgs a) {
 
   // ---- epilogue.  C/D layout: column = lane&31 = pixel, row = (r&3) + 8*(r>>2) +
   // 4*(lane>>5) = channel, so registers 4g..4g+3 are channels 8g+4h+{0..3} of this
-  // lane's pixel: one 16-byte store per quad.
+  // lane's pixel.  The affine+ReLU'd tile is staged through LDS as [pixel][BN] and
+  // written out row-major: consecutive lanes cover consecutive 16-byte pieces of a
+  // pixel's channels and consecutive pixels of a tile row are contiguous in NHWC,
+  // so every store instruction is one contiguous run (per-lane stores at a pixel
+  // stride touch 32-64 lines each and cost ~25 % of the 32-channel layers).
+  constexpr int CS = T::CS;
+  float* Cs = smem;
+  __syncthreads();   // every wave is done with the last chunk's operands
 #pragma unroll
-  for (int wm = 0; wm < WTM; ++wm) {
-    const int m = (wave_m * WTM + wm) * 32 + li;
-    const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-    const bool pok = oy < a.h_out && ox < a.w_out;
-    float* orow = a.out + ((size_t)(img * a.h_out + oy) * a.w_out + ox) * a.ldo;
+  for (int wn = 0; wn < WTN; ++wn) {
 #pragma unroll
-    for (int wn = 0; wn < WTN; ++wn) {
+    for (int g = 0; g < 4; ++g) {
+      const int cl = (wave_n * WTN + wn) * 32 + 8 * g + 4 * lh;   // channel within the tile
+      const int co = n0 + cl;
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (a.vec_out && co + 4 <= a.c_out) {
+        sc = *reinterpret_cast<const f32x4*>(a.scale + co);
+        sh = *reinterpret_cast<const f32x4*>(a.shift + co);
+      } else {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = n0 + (wave_n * WTN + wn) * 32 + 8 * g + 4 * lh;
-        if (!pok || co >= a.c_out) continue;
-        if (a.vec_out && co + 4 <= a.c_out) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + co);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + co);
-          f32x4 v;
+        for (int e = 0; e < 4; ++e)
+          if (co + e < a.c_out) { sc[e] = a.scale[co + e]; sh[e] = a.shift[co + e]; }
+      }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
-            if (a.relu) v[e] = fmaxf(v[e], 0.f);
-          }
-          if (!kNoStore || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(orow + co) = v;
-        } else {
+      for (int wm = 0; wm < WTM; ++wm) {
+        const int m = (wave_m * WTM + wm) * 32 + li;
+        f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (co + e < a.c_out) {
-              float v = acc[wm][wn][4 * g + e] * a.scale[co + e] + a.shift[co + e];
-              if (a.relu) v = fmaxf(v, 0.f);
-              if (!kNoStore || v == 12345.678f) orow[co + e] = v;
-            }
-          }
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
+          if (a.relu) v[e] = fmaxf(v[e], 0.f);
         }
+        *reinterpret_cast<f32x4*>(&Cs[m * CS + cl]) = v;
+      }
+    }
+  }
+  __syncthreads();
+  const int ncol = min(BN, a.c_out - n0);                // valid channels of this tile
+  if (a.vec_out && (ncol & 3) == 0) {
+    const int nc4 = ncol >> 2;
+    for (int idx = tid; idx < T::BM * nc4; idx += NT) {
+      const int m = idx / nc4, c4 = idx % nc4;
+      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+      if (oy < a.h_out && ox < a.w_out) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[m * CS + 4 * c4]);
+        if (!kNoStore || v[0] == 12345.678f)
+          *reinterpret_cast<f32x4*>(a.out + ((size_t)(img * a.h_out + oy) * a.w_out + ox) * a.ldo +
+                                    n0 + 4 * c4) = v;
+      }
+    }
+  } else {
+    for (int idx = tid; idx < T::BM * ncol; idx += NT) {
+      const int m = idx / ncol, c = idx % ncol;
+      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+      if (oy < a.h_out && ox < a.w_out) {
+        const float v = Cs[m * CS + c];
+        if (!kNoStore || v == 12345.678f)
+          a.out[((size_t)(img * a.h_out + oy) * a.w_out + ox) * a.ldo + n0 + c] = v;
       }
     }
   }
 }
+
+// start-up stagger (tools/conv_ablate.hip sweeps these): measured on MI355X, mode 1
+// (slot = block / 256) takes the 2-workgroup/CU 256x64 tile from 90 to 105-116
+// TFLOP/s and is neutral elsewhere; mode 2 (slot = (block / 8) % slots) hurts.
+// In the full forward the effect was within noise, so it ships disabled.
+int g_stagger = 0;
+float g_stagger_scale = 0.5f;
 
 // ---------------------------------------------------------------------------
 // tile menu and per-launch selection
@@ -447,6 +498,7 @@ int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   // opt in to > 64 KiB of dynamic LDS once per instantiation (idempotent; a race
   // between two first callers only repeats the same attribute write)
   static bool lds_ready = false;
+  static int occupancy = 1;
   if (!lds_ready) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -454,11 +506,23 @@ int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
     if (e != hipSuccess)
       return dn::fail(DN_ERR_LAUNCH, "conv: hipFuncSetAttribute(%zu B LDS): %s", T::LDS_BYTES,
                       hipGetErrorString(e));
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, T::NT, T::LDS_BYTES) == hipSuccess &&
+        occ >= 1)
+      occupancy = occ > 8 ? 8 : occ;
     lds_ready = true;
   }
   a.nchunks = (d.c0 + d.c1 + KC - 1) / KC;
   a.tiles_x = (a.w_out + TW - 1) / TW;
   a.tiles_y = (a.h_out + TH - 1) / TH;
+  {
+    // workgroup period ~ occupancy x its own MFMA cycles (the co-resident groups
+    // share the 4 MFMA pipes); stagger step = period / occupancy = its MFMA cycles
+    const long mfma_cycles = (long)a.nchunks * T::TAPS * (KC / 8) * 4 * WTM * WTN * 64;
+    a.stagger_slots = g_stagger ? occupancy : 0;
+    a.stagger_mode = g_stagger;
+    a.stagger_sleeps = (int)(mfma_cycles * g_stagger_scale / 1024);
+  }
   dim3 grid((unsigned)(a.n_images * a.tiles_y * a.tiles_x), (unsigned)((d.c_out + BN - 1) / BN));
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, stream, a);
   return dn::check_launch("conv_mfma_kernel");
