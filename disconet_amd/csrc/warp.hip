@@ -45,17 +45,26 @@ __device__ inline Bilinear bilinear_taps(float gx, float gy, int w, int h) {
 
 __device__ inline f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// bilinear sample of src (one image, [h][w][c]) at taps b, channels c4*4..+3
+// bilinear sample of src (one image, [h][w][c]) at taps b, channels c4*4..+3.
+// Branch-free: every tap is loaded from a clamped in-frame address and its weight
+// is zeroed when the tap is outside, so the 4 loads (16 per output pixel) issue
+// back to back instead of draining vmcnt at every divergent join.  A zero weight
+// times a finite in-frame value is exactly the zero padding.
 __device__ inline f32x4 sample_src(const float* src, const Bilinear& b, int w, int h, int c,
                                    int c4) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const bool x0ok = b.x0 >= 0 && b.x0 < w, x1ok = b.x0 + 1 >= 0 && b.x0 + 1 < w;
   const bool y0ok = b.y0 >= 0 && b.y0 < h, y1ok = b.y0 + 1 >= 0 && b.y0 + 1 < h;
+  const int x0 = min(max(b.x0, 0), w - 1), x1 = min(max(b.x0 + 1, 0), w - 1);
+  const int y0 = min(max(b.y0, 0), h - 1), y1 = min(max(b.y0 + 1, 0), h - 1);
+  const f32x4 v_nw = ld4(src + ((size_t)y0 * w + x0) * c + 4 * c4);
+  const f32x4 v_ne = ld4(src + ((size_t)y0 * w + x1) * c + 4 * c4);
+  const f32x4 v_sw = ld4(src + ((size_t)y1 * w + x0) * c + 4 * c4);
+  const f32x4 v_se = ld4(src + ((size_t)y1 * w + x1) * c + 4 * c4);
   // order matches torch's CPU kernel: nw, ne, sw, se
-  if (y0ok && x0ok) acc += ld4(src + ((size_t)b.y0 * w + b.x0) * c + 4 * c4) * b.w_nw;
-  if (y0ok && x1ok) acc += ld4(src + ((size_t)b.y0 * w + b.x0 + 1) * c + 4 * c4) * b.w_ne;
-  if (y1ok && x0ok) acc += ld4(src + ((size_t)(b.y0 + 1) * w + b.x0) * c + 4 * c4) * b.w_sw;
-  if (y1ok && x1ok) acc += ld4(src + ((size_t)(b.y0 + 1) * w + b.x0 + 1) * c + 4 * c4) * b.w_se;
+  f32x4 acc = v_nw * ((y0ok && x0ok) ? b.w_nw : 0.f);
+  acc += v_ne * ((y0ok && x1ok) ? b.w_ne : 0.f);
+  acc += v_sw * ((y1ok && x0ok) ? b.w_sw : 0.f);
+  acc += v_se * ((y1ok && x1ok) ? b.w_se : 0.f);
   return acc;
 }
 
@@ -113,8 +122,7 @@ warp_neighbors_kernel(const float* __restrict__ feat, const float* __restrict__ 
     for (int c4 = lane; c4 < c4n; c4 += 64) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (qok[k]) acc += sample_src(src, t1[k], w, h, c, c4) * qw[k];
+      for (int k = 0; k < 4; ++k) acc += sample_src(src, t1[k], w, h, c, c4) * (qok[k] ? qw[k] : 0.f);
       *reinterpret_cast<f32x4*>(out + 4 * c4) = acc;
     }
   }

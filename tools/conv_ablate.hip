@@ -49,14 +49,6 @@ int run_shape(const char* name, int n, int h, int w, int c0, int c1, int up0, in
   const int iters = 20;
   float t[8];
   g_stagger = 0;
-  const float t_nostag = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 0>(a, d, iters);
-  for (int mode = 1; mode <= 2; ++mode)
-    for (float sc : {0.5f, 1.0f, 2.0f}) {
-      g_stagger = mode; g_stagger_scale = sc;
-      const float tt = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 0>(a, d, iters);
-      printf("   stagger mode %d scale %.1f: %8.1f us %7.1f TFLOP/s\n", mode, sc, tt * 1e3, flop / (tt * 1e-3) / 1e12);
-    }
-  g_stagger = 1; g_stagger_scale = 0.5f;
   t[0] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 0>(a, d, iters);
   t[1] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 1>(a, d, iters);
   t[2] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 2>(a, d, iters);
@@ -68,7 +60,6 @@ int run_shape(const char* name, int n, int h, int w, int c0, int c1, int up0, in
   const char* lab[8] = {"normal", "no-stream", "no-stream+no-store", "no-store", "no-lds-reads", "pure-mfma",
                         "global-loads-only", "lds-store+barrier-only"};
   printf("%s  tile %dx%d  (%.2f GFLOP)\n", name, TH * TW, BN, flop / 1e9);
-  printf("   ---- normal, no stagger       %8.1f us  %7.1f TFLOP/s\n", t_nostag * 1e3, flop / (t_nostag * 1e-3) / 1e12);
   for (int i = 0; i < 8; ++i) printf("   ABL%d %-20s %8.1f us  %7.1f TFLOP/s\n", i, lab[i], t[i] * 1e3, flop / (t[i] * 1e-3) / 1e12);
   hipFree(s0); hipFree(s1); hipFree(wp); hipFree(sc); hipFree(sh); hipFree(out);
   return 0;
