@@ -46,6 +46,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+struct TileCoord {
+  int img, oy0, ox0, n0;
+};
+
 struct ConvArgs {
   const float* src0;
   const float* src1;
@@ -60,9 +64,7 @@ struct ConvArgs {
   int vec0, vec1;
   int cout_pad;   // rows per (chunk, tap) in the packed weights
   int wpk_bytes;  // size of the packed weights (buffer bounds)
-  int stagger_slots;   // resident workgroups per CU (0 = no start-up stagger)
-  int stagger_sleeps;  // s_sleep(16) iterations (~1024 cycles each) per slot step
-  int stagger_mode;    // 1: slot = block / 256, 2: slot = (block / 8) % slots
+  int total_items;     // work items = channel blocks x images x tiles
   int vec_out;    // out / scale / shift allow 16-byte accesses
 };
 
@@ -91,6 +93,9 @@ struct ConvTile {
   static constexpr int C_FLOATS = BM * CS;
   static constexpr size_t LDS_BYTES =
       (size_t)(A_FLOATS + B_FLOATS > C_FLOATS ? A_FLOATS + B_FLOATS : C_FLOATS) * sizeof(float);
+  // workgroups per CU the 160 KiB LDS admits; the kernel is register-bounded to match
+  static constexpr int OCC_LDS = (int)(160 * 1024 / LDS_BYTES);
+  static constexpr int OCC = OCC_LDS < 2 ? 2 : (OCC_LDS > 4 ? 4 : OCC_LDS);
   static_assert(BM == WAVES_M * WTM * 32, "pixel tile must match the wave layout");
   static_assert(BN == WAVES_N * WTN * 32, "channel tile must match the wave layout");
   static_assert(KC % 8 == 0 && KCP % KC == 0, "KC must cover b128 operand pairs and divide KCP");
@@ -98,21 +103,21 @@ struct ConvTile {
 
 // ABL != 0 builds ablation variants for tools/conv_ablate.hip only (the product
 // always launches ABL = 0): 1 = no steady-state global loads / LDS stores /
-// barriers, 2 = 1 + no epilogue stores, 3 = no epilogue stores, 4 = MFMA operands
-// from registers instead of LDS, 5 = 1 + 2 + 4 (pure MFMA stream), 6 = global
-// loads issued but never written to LDS (no barriers), 7 = LDS stores + barriers
-// but no global loads.
+// barriers, 3 = no epilogue stores, 5 = 1 + 3 + MFMA operands from registers
+// (pure MFMA stream).
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
           int WTM, int WTN, int ABL = 0>
-__global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, 2)
+__global__ void __launch_bounds__(
+    (WAVES_M * WAVES_N * 64),
+    (ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>::OCC))
 conv_mfma_kernel(const ConvArgs a) {
-  constexpr bool kNoStream = ABL == 1 || ABL == 2 || ABL == 5;
-  constexpr bool kNoLdsStore = ABL == 6;
-  constexpr bool kNoGlobal = ABL == 7;
-  constexpr bool kNoStore = ABL == 2 || ABL == 3 || ABL == 5;
-  constexpr bool kNoLds = ABL == 4 || ABL == 5;
+  constexpr bool kNoStream = ABL == 1 || ABL == 5;
+  constexpr bool kNoStore = ABL == 3 || ABL == 5;
+  constexpr bool kNoLds = ABL == 5;
   using T = ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>;
   constexpr int NT = T::NT, PW = T::PW, PS = T::PS, TAPS = T::TAPS, KV = T::KV, KCP = T::KCP;
+  constexpr int ROWS_PER_IT = NT / KV;   // weight rows one staging iteration covers
+  static_assert(TAPS == 1 || ROWS_PER_IT % BN == 0, "weight staging must step whole taps");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
@@ -126,26 +131,26 @@ conv_mfma_kernel(const ConvArgs a) {
   const int li = lane & 31;
   const int lh = lane >> 5;
 
-  // De-phase the workgroups that share a CU.  All workgroups of a launch start
-  // together and take the same time, so without this every co-resident group
-  // reaches its load burst, its barriers and its store burst at the same moment
-  // and the MFMA pipe idles through all of them.  The first generation
-  // (blockIdx < slots * 256; dispatch fills one slot per CU per 256 blocks -- a
-  // speed assumption only) sleeps slot/slots of a workgroup period; later
-  // generations inherit the offsets because they start as their predecessors end.
-  if (a.stagger_slots > 1 && blockIdx.y == 0 && (int)blockIdx.x < a.stagger_slots * kNumCUs) {
-    const int slot = a.stagger_mode == 2 ? (blockIdx.x / 8) % a.stagger_slots : blockIdx.x / kNumCUs;
-    for (int i = 0; i < slot * a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(16);
-  }
-
-  int bid = blockIdx.x;
-  const int tile_x = bid % a.tiles_x;
-  bid /= a.tiles_x;
-  const int tile_y = bid % a.tiles_y;
-  const int img = bid / a.tiles_y;
-  const int n0 = blockIdx.y * BN;
-  const int oy0 = tile_y * TH, ox0 = tile_x * TW;
-  const int iy0 = oy0 * STRIDE - T::PAD, ix0 = ox0 * STRIDE - T::PAD;
+  // Work items = (channel block, image, tile_y, tile_x), tile_x fastest.  A launch
+  // gives every item its own workgroup (gridDim.x == total_items) or runs
+  // persistent workgroups that walk items blockIdx.x, + gridDim.x, ... and fetch
+  // the first chunk of their next tile under the MFMAs of the current tile's last
+  // chunk.  All workgroups of a launch start together and take the same time, so
+  // one-workgroup-per-item launches hit HBM with every prologue load of a
+  // "generation" at once (measured ~30 % of the 2-chunk layers); the persistent
+  // form spreads those loads under the MFMA stream.
+  const int G = gridDim.x;
+  const int spatial_items = a.n_images * a.tiles_y * a.tiles_x;
+  auto decode = [&](int item) {
+    TileCoord tc;
+    tc.n0 = (item / spatial_items) * BN;
+    int sp = item % spatial_items;
+    tc.ox0 = (sp % a.tiles_x) * TW;
+    sp /= a.tiles_x;
+    tc.oy0 = (sp % a.tiles_y) * TH;
+    tc.img = sp / a.tiles_y;
+    return tc;
+  };
 
   int a_off[WTM], b_off[WTN];
 #pragma unroll
@@ -160,46 +165,66 @@ conv_mfma_kernel(const ConvArgs a) {
   }
 
   f32x16 acc[WTM][WTN];
-#pragma unroll
-  for (int wm = 0; wm < WTM; ++wm)
-#pragma unroll
-    for (int wn = 0; wn < WTN; ++wn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
-
   const f32x4 abl_const = {li * 1e-3f, 0.5f, -0.25f, lh * 1.f};   // ablation operands only
   f32x4 ra[T::A_IT], rb[T::B_IT];   // the next chunk, in flight from global memory
 
-  // ---- per-tile staging state: buffer descriptors + per-lane byte offsets
+  // ---- staging state.  Buffer loads: per-lane byte offsets are computed once per
+  // tile (and once more where a concat layer switches source); a chunk only moves
+  // the scalar offset.  Halo / tail slots carry an out-of-range offset, so the
+  // hardware bounds check supplies the zero padding.
   constexpr unsigned OOB = 0xFFFFFFFFu;   // >= num_records: the load returns 0
   const int hs0 = a.up0 ? (a.h_in >> 1) : a.h_in, ws0 = a.up0 ? (a.w_in >> 1) : a.w_in;
   const size_t img0_floats = (size_t)hs0 * ws0 * a.ld0, img1_floats = (size_t)a.h_in * a.w_in * a.ld1;
-  const auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.src0 + img * img0_floats), 0, (int)(img0_floats * 4), 0x00020000);
-  const auto rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.c1 ? a.src1 + img * img1_floats : a.src0), 0,
-      a.c1 ? (int)(img1_floats * 4) : 0, 0x00020000);
+  auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0), 0, 0, 0x00020000);
+  auto rsrc1 = rsrc0;
   const auto rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, a.wpk_bytes,
                                                         0x00020000);
-  unsigned voff_a0[T::A_IT], voff_a1[T::A_IT], voff_b[T::B_IT];
+  unsigned voff_a[T::A_IT];   // patch slots of the source being read
+  unsigned voff_b;            // first weight row of this lane; later rows via the scalar offset
+  // weights of one staging iteration further on: whole taps for KS = 3, rows for 1x1
+  const int b_step = (TAPS == 1 ? ROWS_PER_IT : (ROWS_PER_IT / BN) * a.cout_pad) * KCP * 4;
+  const int src_switch = a.c1 > 0 ? a.c0 / KC : (1 << 30);   // first chunk read from src1
+
+  // The per-lane values below depend on the tile only through scalars; deriving
+  // them from an opaque copy of tid keeps hipcc from hoisting them out of the tile
+  // loop and holding ~40 extra VGPRs live across it.
+  auto opaque_tid = [&]() {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    return t;
+  };
+  auto setup_voff_a = [&](const TileCoord& tc, bool from1) {
+    const int t = opaque_tid();
+    const int iy0 = tc.oy0 * STRIDE - T::PAD, ix0 = tc.ox0 * STRIDE - T::PAD;
 #pragma unroll
-  for (int it = 0; it < T::A_IT; ++it) {
-    const int idx = tid + it * NT;
-    const int p = idx / KV, q = idx % KV;
-    const int iy = iy0 + p / PW, ix = ix0 + p % PW;
-    const bool ok = idx < T::A_VEC && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
-    const int sy = a.up0 ? (iy >> 1) : iy, sx = a.up0 ? (ix >> 1) : ix;
-    voff_a0[it] = ok ? (unsigned)(((sy * ws0 + sx) * a.ld0 + 4 * q) * 4) : OOB;
-    voff_a1[it] = ok ? (unsigned)(((iy * a.w_in + ix) * a.ld1 + 4 * q) * 4) : OOB;
-  }
-#pragma unroll
-  for (int it = 0; it < T::B_IT; ++it) {
-    const int idx = tid + it * NT;
-    const int row = idx / KV, q = idx % KV;     // row = tap * BN + n
-    const int tap = row / BN, n = row % BN;
-    const bool ok = idx < T::B_VEC && n0 + n < a.cout_pad;
-    voff_b[it] = ok ? (unsigned)((((tap * a.cout_pad + n0 + n) * KCP) + 4 * q) * 4) : OOB;
-  }
+    for (int it = 0; it < T::A_IT; ++it) {
+      const int idx = t + it * NT;
+      const int p = idx / KV, q = idx % KV;
+      const int iy = iy0 + p / PW, ix = ix0 + p % PW;
+      const bool ok = idx < T::A_VEC && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+      unsigned off;
+      if (from1) {
+        off = (unsigned)(((iy * a.w_in + ix) * a.ld1 + 4 * q) * 4);
+      } else {
+        const int sy = a.up0 ? (iy >> 1) : iy, sx = a.up0 ? (ix >> 1) : ix;
+        off = (unsigned)(((sy * ws0 + sx) * a.ld0 + 4 * q) * 4);
+      }
+      voff_a[it] = ok ? off : OOB;
+    }
+  };
+  auto setup_tile = [&](const TileCoord& tc) {
+    rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.src0 + tc.img * img0_floats), 0, (int)(img0_floats * 4), 0x00020000);
+    rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.c1 ? a.src1 + tc.img * img1_floats : a.src0), 0,
+        a.c1 ? (int)(img1_floats * 4) : 0, 0x00020000);
+    setup_voff_a(tc, false);
+    const int t = opaque_tid();
+    const int row = t / KV, q = t % KV;           // row = tap * BN + n
+    // rows past c_out's padded count read neighbouring weights: finite values that
+    // only reach output channels the epilogue never stores
+    voff_b = (unsigned)(((((row / BN) * a.cout_pad + tc.n0 + row % BN) * KCP) + 4 * q) * 4);
+  };
 
   auto ld128 = [](auto rsrc, unsigned voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
@@ -216,32 +241,34 @@ conv_mfma_kernel(const ConvArgs a) {
     return v;
   };
 
-  auto load_chunk = [&](int ch) {
+  // issue the global loads of chunk `ch` of tile `tc` into ra/rb
+  auto load_chunk = [&](const TileCoord& tc, int ch) {
     const int cbeg = ch * KC;
+    if (ch == src_switch) setup_voff_a(tc, true);
     if (cbeg < a.c0) {
       const int soff = cbeg * 4;
       if (a.vec0) {
 #pragma unroll
-        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld128(rsrc0, voff_a0[it], soff);
+        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld128(rsrc0, voff_a[it], soff);
       } else {
 #pragma unroll
-        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld32x4(rsrc0, voff_a0[it], soff);
+        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld32x4(rsrc0, voff_a[it], soff);
       }
     } else {
       const int soff = (cbeg - a.c0) * 4;
       if (a.vec1) {
 #pragma unroll
-        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld128(rsrc1, voff_a1[it], soff);
+        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld128(rsrc1, voff_a[it], soff);
       } else {
 #pragma unroll
-        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld32x4(rsrc1, voff_a1[it], soff);
+        for (int it = 0; it < T::A_IT; ++it) ra[it] = ld32x4(rsrc1, voff_a[it], soff);
       }
     }
     // weights: packed [chunk KCP][tap][cout_pad][KCP]; this tile reads the KC-wide
     // sub-row (ch % (KCP/KC)) of rows n0..n0+BN
     const int wsoff = ((cbeg / KCP) * TAPS * a.cout_pad * KCP + cbeg % KCP) * 4;
 #pragma unroll
-    for (int it = 0; it < T::B_IT; ++it) rb[it] = ld128(rsrcw, voff_b[it], wsoff);
+    for (int it = 0; it < T::B_IT; ++it) rb[it] = ld128(rsrcw, voff_b, wsoff + it * b_step);
   };
 
   auto store_chunk = [&]() {
@@ -257,14 +284,7 @@ conv_mfma_kernel(const ConvArgs a) {
     }
   };
 
-  load_chunk(0);
-  store_chunk();
-  __syncthreads();
-
-  for (int ch = 0; ch < a.nchunks; ++ch) {
-    const bool more = !kNoStream && ch + 1 < a.nchunks;
-    if (more && !kNoGlobal) load_chunk(ch + 1);   // in flight while the MFMAs below run
-
+  auto mfma_chunk = [&]() {
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int toff = ((tap / KS) * PW + (tap % KS)) * PS;
@@ -289,90 +309,132 @@ conv_mfma_kernel(const ConvArgs a) {
                                                                   acc[wm][wn], 0, 0, 0);
       }
     }
+  };
 
-    if (more && kNoLdsStore) {
-#pragma unroll
-      for (int it = 0; it < T::A_IT; ++it) asm volatile("" ::"v"(ra[it]));
-#pragma unroll
-      for (int it = 0; it < T::B_IT; ++it) asm volatile("" ::"v"(rb[it]));
-    } else if (more) {
-      __syncthreads();   // every wave is done reading this chunk from LDS
-      store_chunk();
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue.  C/D layout: column = lane&31 = pixel, row = (r&3) + 8*(r>>2) +
+  // Epilogue.  C/D layout: column = lane&31 = pixel, row = (r&3) + 8*(r>>2) +
   // 4*(lane>>5) = channel, so registers 4g..4g+3 are channels 8g+4h+{0..3} of this
   // lane's pixel.  The affine+ReLU'd tile is staged through LDS as [pixel][BN] and
   // written out row-major: consecutive lanes cover consecutive 16-byte pieces of a
   // pixel's channels and consecutive pixels of a tile row are contiguous in NHWC,
-  // so every store instruction is one contiguous run (per-lane stores at a pixel
-  // stride touch 32-64 lines each and cost ~25 % of the 32-channel layers).
+  // so every store instruction is one contiguous run.
   constexpr int CS = T::CS;
   float* Cs = smem;
-  __syncthreads();   // every wave is done with the last chunk's operands
+  auto epilogue = [&](const TileCoord& tc) {
+    const int t = opaque_tid();
+    const int eli = t & 31, elh = (t >> 5) & 1;
+    __syncthreads();   // every wave is done with the last chunk's operands
 #pragma unroll
-  for (int wn = 0; wn < WTN; ++wn) {
+    for (int wn = 0; wn < WTN; ++wn) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cl = (wave_n * WTN + wn) * 32 + 8 * g + 4 * lh;   // channel within the tile
-      const int co = n0 + cl;
-      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (a.vec_out && co + 4 <= a.c_out) {
-        sc = *reinterpret_cast<const f32x4*>(a.scale + co);
-        sh = *reinterpret_cast<const f32x4*>(a.shift + co);
-      } else {
+      for (int g = 0; g < 4; ++g) {
+        const int cl = (wave_n * WTN + wn) * 32 + 8 * g + 4 * elh;   // channel within the tile
+        const int co = tc.n0 + cl;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (a.vec_out && co + 4 <= a.c_out) {
+          sc = *reinterpret_cast<const f32x4*>(a.scale + co);
+          sh = *reinterpret_cast<const f32x4*>(a.shift + co);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (co + e < a.c_out) { sc[e] = a.scale[co + e]; sh[e] = a.shift[co + e]; }
-      }
-#pragma unroll
-      for (int wm = 0; wm < WTM; ++wm) {
-        const int m = (wave_m * WTM + wm) * 32 + li;
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
-          if (a.relu) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e)
+            if (co + e < a.c_out) { sc[e] = a.scale[co + e]; sh[e] = a.shift[co + e]; }
         }
-        *reinterpret_cast<f32x4*>(&Cs[m * CS + cl]) = v;
+#pragma unroll
+        for (int wm = 0; wm < WTM; ++wm) {
+          const int m = (wave_m * WTM + wm) * 32 + eli;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
+            if (a.relu) v[e] = fmaxf(v[e], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(&Cs[m * CS + cl]) = v;
+        }
       }
     }
-  }
+    __syncthreads();
+    const int ncol = min(BN, a.c_out - tc.n0);             // valid channels of this tile
+    float* obase = a.out + (size_t)tc.img * a.h_out * a.w_out * a.ldo + tc.n0;
+    if (a.vec_out && (ncol & 3) == 0) {
+      const int nc4 = ncol >> 2;
+      for (int idx = t; idx < T::BM * nc4; idx += NT) {
+        const int m = idx / nc4, c4 = idx % nc4;
+        const int oy = tc.oy0 + m / TW, ox = tc.ox0 + m % TW;
+        if (oy < a.h_out && ox < a.w_out) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[m * CS + 4 * c4]);
+          if (!kNoStore || v[0] == 12345.678f)
+            *reinterpret_cast<f32x4*>(obase + ((size_t)oy * a.w_out + ox) * a.ldo + 4 * c4) = v;
+        }
+      }
+    } else {
+      for (int idx = t; idx < T::BM * ncol; idx += NT) {
+        const int m = idx / ncol, c = idx % ncol;
+        const int oy = tc.oy0 + m / TW, ox = tc.ox0 + m % TW;
+        if (oy < a.h_out && ox < a.w_out) {
+          const float v = Cs[m * CS + c];
+          if (!kNoStore || v == 12345.678f) obase[((size_t)oy * a.w_out + ox) * a.ldo + c] = v;
+        }
+      }
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item >= a.total_items) return;
+  TileCoord cur = decode(item);
+  setup_tile(cur);
+  load_chunk(cur, 0);
+  store_chunk();
   __syncthreads();
-  const int ncol = min(BN, a.c_out - n0);                // valid channels of this tile
-  if (a.vec_out && (ncol & 3) == 0) {
-    const int nc4 = ncol >> 2;
-    for (int idx = tid; idx < T::BM * nc4; idx += NT) {
-      const int m = idx / nc4, c4 = idx % nc4;
-      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-      if (oy < a.h_out && ox < a.w_out) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[m * CS + 4 * c4]);
-        if (!kNoStore || v[0] == 12345.678f)
-          *reinterpret_cast<f32x4*>(a.out + ((size_t)(img * a.h_out + oy) * a.w_out + ox) * a.ldo +
-                                    n0 + 4 * c4) = v;
+
+  while (true) {
+#pragma unroll
+    for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+      for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+
+    bool has_next = false;
+    TileCoord nxt = cur;
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+      const bool last = ch + 1 == a.nchunks;
+      // what to prefetch under this chunk's MFMAs: the tile's next chunk, or the
+      // first chunk of the workgroup's next tile.  ONE load site: two would make
+      // hipcc merge the staging registers with copies that wait for the loads
+      // before the MFMA block instead of after it.
+      bool stage = !last && !kNoStream;
+      int stage_ch = ch + 1;
+      if (last && item + G < a.total_items) {
+        has_next = true;
+        nxt = decode(item + G);
+        setup_tile(nxt);
+        stage = true;
+        stage_ch = 0;
+      }
+      if (stage) load_chunk(nxt, stage_ch);   // nxt == cur until the tile's last chunk
+      mfma_chunk();
+      if (stage && !last) {
+        __syncthreads();   // every wave is done reading this chunk from LDS
+        store_chunk();
+        __syncthreads();
       }
     }
-  } else {
-    for (int idx = tid; idx < T::BM * ncol; idx += NT) {
-      const int m = idx / ncol, c = idx % ncol;
-      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-      if (oy < a.h_out && ox < a.w_out) {
-        const float v = Cs[m * CS + c];
-        if (!kNoStore || v == 12345.678f)
-          a.out[((size_t)(img * a.h_out + oy) * a.w_out + ox) * a.ldo + n0 + c] = v;
-      }
-    }
+    epilogue(cur);
+    if (!has_next) break;
+    __syncthreads();       // the staged output tile has been read back
+    store_chunk();         // next tile's chunk 0, loaded under the last MFMA block
+    __syncthreads();
+    item += G;
+    cur = nxt;
   }
 }
 
-// start-up stagger (tools/conv_ablate.hip sweeps these): measured on MI355X, mode 1
-// (slot = block / 256) takes the 2-workgroup/CU 256x64 tile from 90 to 105-116
-// TFLOP/s and is neutral elsewhere; mode 2 (slot = (block / 8) % slots) hurts.
-// In the full forward the effect was within noise, so it ships disabled.
-int g_stagger = 0;
-float g_stagger_scale = 0.5f;
+// Persistent-workgroup policy: 0 = never, 1 = measured policy, 2 = always
+// (tools/conv_ablate.hip flips it for A/B runs).  Measured on MI355X, batch 4:
+// persistence gains 4-13 % on the 256-pixel tiles with 2-4 chunks (the 32- and
+// 64-channel full/half-resolution layers, whose workgroups are short and many)
+// and loses 2-20 % on the stride-2 and long-K launches, whose tile-end barriers
+// cost more than the hidden prologue is worth.
+int g_persist = 1;
 
 // ---------------------------------------------------------------------------
 // tile menu and per-launch selection
@@ -515,15 +577,14 @@ int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   a.nchunks = (d.c0 + d.c1 + KC - 1) / KC;
   a.tiles_x = (a.w_out + TW - 1) / TW;
   a.tiles_y = (a.h_out + TH - 1) / TH;
-  {
-    // workgroup period ~ occupancy x its own MFMA cycles (the co-resident groups
-    // share the 4 MFMA pipes); stagger step = period / occupancy = its MFMA cycles
-    const long mfma_cycles = (long)a.nchunks * T::TAPS * (KC / 8) * 4 * WTM * WTN * 64;
-    a.stagger_slots = g_stagger ? occupancy : 0;
-    a.stagger_mode = g_stagger;
-    a.stagger_sleeps = (int)(mfma_cycles * g_stagger_scale / 1024);
-  }
-  dim3 grid((unsigned)(a.n_images * a.tiles_y * a.tiles_x), (unsigned)((d.c_out + BN - 1) / BN));
+  const long total = (long)a.n_images * a.tiles_y * a.tiles_x * ((d.c_out + BN - 1) / BN);
+  DN_REQUIRE(total < (1L << 31), "conv: too many tiles (%ld)", total);
+  a.total_items = (int)total;
+  // persistent grid: as many workgroups as are resident (no inter-workgroup sync
+  // depends on the count; an over-estimate only queues the surplus)
+  const long resident = (long)occupancy * kNumCUs;
+  const bool persist = g_persist == 2 || (g_persist == 1 && T::BM == 256 && a.nchunks >= 2 && a.nchunks <= 4);
+  dim3 grid((unsigned)((persist && total > resident) ? resident : total));
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, stream, a);
   return dn::check_launch("conv_mfma_kernel");
 }

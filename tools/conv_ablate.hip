@@ -48,19 +48,21 @@ int run_shape(const char* name, int n, int h, int w, int c0, int c1, int up0, in
   const double flop = 2.0 * n * ho * wo * cout * (c0 + c1) * KS * KS;
   const int iters = 20;
   float t[8];
-  g_stagger = 0;
+  g_persist = 0;
+  const float t_np = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 0>(a, d, iters);
+  g_persist = 2;
   t[0] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 0>(a, d, iters);
   t[1] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 1>(a, d, iters);
-  t[2] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 2>(a, d, iters);
+  t[2] = 0;
   t[3] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 3>(a, d, iters);
-  t[4] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 4>(a, d, iters);
+  t[4] = 0;
   t[5] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 5>(a, d, iters);
-  t[6] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 6>(a, d, iters);
-  t[7] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 7>(a, d, iters);
+  t[6] = 0; t[7] = 0;
   const char* lab[8] = {"normal", "no-stream", "no-stream+no-store", "no-store", "no-lds-reads", "pure-mfma",
                         "global-loads-only", "lds-store+barrier-only"};
   printf("%s  tile %dx%d  (%.2f GFLOP)\n", name, TH * TW, BN, flop / 1e9);
-  for (int i = 0; i < 8; ++i) printf("   ABL%d %-20s %8.1f us  %7.1f TFLOP/s\n", i, lab[i], t[i] * 1e3, flop / (t[i] * 1e-3) / 1e12);
+  printf("   ---- one workgroup per item    %8.1f us  %7.1f TFLOP/s\n", t_np * 1e3, flop / (t_np * 1e-3) / 1e12);
+  for (int i = 0; i < 8; ++i) if (t[i] > 0) printf("   ABL%d %-20s %8.1f us  %7.1f TFLOP/s\n", i, lab[i], t[i] * 1e3, flop / (t[i] * 1e-3) / 1e12);
   hipFree(s0); hipFree(s1); hipFree(wp); hipFree(sc); hipFree(sh); hipFree(out);
   return 0;
 }
