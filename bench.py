@@ -221,12 +221,22 @@ def main():
             ms = sum(v["ms_total"] for v in conv.values())
             launches = sum(v["calls"] for v in conv.values())
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic, traffic_src = None, None
+            try:   # HBM bytes per conv launch from the committed rocprofv3 --pmc passes
+                prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                              if f.endswith("_pmc_traffic.json"))[-1]
+                traffic = json.load(open(os.path.join(ROOT, "profiles", prof)))["hbm_bytes_per_launch"]
+                traffic_src = "profiles/" + prof
+            except (OSError, IndexError, KeyError, ValueError):
+                pass
             result["roofline"] = {
                 "kernel": "conv_mfma_kernel (fp32 MFMA implicit-GEMM conv, all %d launches/step)"
                           % (launches // args.steps),
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(sum(v["bytes"] for v in conv.values()) / max(launches, 1)),
                 "flop_per_step": flops / args.steps, "kernel_ms_per_step": round(ms / args.steps, 4),
                 "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
                 "ms_per_step_with_events": round(1e3 * elapsed_events / args.steps, 4),
