@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-launch HIP events in the timed region")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table (stderr)")
+    ap.add_argument("--math", choices=["f32", "f16x3"], default=os.environ.get("DISCONET_CONV_MATH", "f32"),
+                    help="conv arithmetic: exact-fp32 MFMA or split-f16 (3 f16 MFMAs / product)")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
     ap.add_argument("--cpu-baseline-child", nargs=3, metavar=("STATE", "OUT", "THREADS"),
                     help=argparse.SUPPRESS)
@@ -142,6 +144,7 @@ def main():
     torch.manual_seed(0)
     model = DiscoNet(Config(map_hw=MAP_HW), kd_flag=0, num_agent=AGENTS)
     randomize_bn_stats(model)
+    model.conv_math = args.math
     model.eval().cuda()
     state_dict_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
@@ -204,7 +207,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.math == "f32" else "f32 storage, split-f16x3 MFMA products, f32 accumulate",
         "data": "synthetic",
         "config": {"workload": "DiscoNet det eval forward (--com disco), 5-agent, batch 4 per GPU, "
                                "256x256x13 BEV, no KD, sparse voxel lists -> dense -> enc -> "

@@ -20,7 +20,7 @@ class ConvDesc(Structure):
     """struct dn_conv_desc"""
     _fields_ = [(n, c_int32) for n in (
         "n_images", "h_in", "w_in", "c0", "c1", "up0", "c_out", "ksize", "stride", "relu",
-        "ld0", "ld1", "ldo")]
+        "ld0", "ld1", "ldo", "math")]
 
 
 class MlpTailParams(Structure):

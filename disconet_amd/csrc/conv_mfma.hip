@@ -33,6 +33,20 @@
 // Row stride KC+4 floats keeps every 16-lane ds_read_b128 group on 16
 // distinct 16-byte slots (conflict-free for stride 1).
 //
+// Math modes (dn_conv_desc.math):
+//   0  exact fp32: v_mfma_f32_32x32x2_f32, bit-compatible with an fp32 fmaf chain
+//      (157 TFLOP/s peak = 1/16 of the f16/bf16 MFMA rate).
+//   1  split-f16: every fp32 operand x is split x = hi + lo with hi = half(x),
+//      lo = half(x - hi) (22-bit significand together; fp16 subnormals are kept by
+//      the MFMA, probed in tools/mfma_f16_probe.hip) and a product is evaluated as
+//      hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation:
+//      3 MFMAs of 32 cycles per 16 k instead of 8 of 64 cycles -> 5.3x the MFMA
+//      throughput at an error of ~2^-22 per product (the dropped lo*lo term),
+//      i.e. the same class as fp32 summation-order noise (whole-network max abs
+//      error 1e-5 on O(1) activations vs the 1e-4 parity bar).  Activations stay
+//      fp32 in HBM; weights are pre-split at pack time into [hi halves | lo halves]
+//      rows of the same byte size.
+//
 // Packed weights are tile-independent: [chunk of KCP cin][tap][c_out padded to
 // 32][KCP], KCP = 16 for 3x3 and 32 for 1x1; a tile with KC | KCP reads
 // sub-rows, so the tile shape can be chosen per launch from the problem size.
@@ -43,6 +57,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -106,11 +124,12 @@ struct ConvTile {
 // barriers, 3 = no epilogue stores, 5 = 1 + 3 + MFMA operands from registers
 // (pure MFMA stream).
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int ABL = 0>
+          int WTM, int WTN, int ABL = 0, int MATH = 0>
 __global__ void __launch_bounds__(
     (WAVES_M * WAVES_N * 64),
     (ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>::OCC))
 conv_mfma_kernel(const ConvArgs a) {
+  constexpr bool kSplit = MATH == 1;
   constexpr bool kNoStream = ABL == 1 || ABL == 5;
   constexpr bool kNoStore = ABL == 3 || ABL == 5;
   constexpr bool kNoLds = ABL == 5;
@@ -156,12 +175,12 @@ conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
   for (int wm = 0; wm < WTM; ++wm) {
     const int m = (wave_m * WTM + wm) * 32 + li;
-    a_off[wm] = ((m / TW) * STRIDE * PW + (m % TW) * STRIDE) * PS + 4 * lh;
+    a_off[wm] = ((m / TW) * STRIDE * PW + (m % TW) * STRIDE) * PS + ((kSplit && KC == 8) ? 2 : 4) * lh;
   }
 #pragma unroll
   for (int wn = 0; wn < WTN; ++wn) {
     const int n = (wave_n * WTN + wn) * 32 + li;
-    b_off[wn] = n * PS + 4 * lh;
+    b_off[wn] = n * PS + ((kSplit && KC == 8) ? 2 : 4) * lh;
   }
 
   f32x16 acc[WTM][WTN];
@@ -223,7 +242,10 @@ conv_mfma_kernel(const ConvArgs a) {
     const int row = t / KV, q = t % KV;           // row = tap * BN + n
     // rows past c_out's padded count read neighbouring weights: finite values that
     // only reach output channels the epilogue never stores
-    voff_b = (unsigned)(((((row / BN) * a.cout_pad + tc.n0 + row % BN) * KCP) + 4 * q) * 4);
+    // split-f16 rows are [KCP hi halves | KCP lo halves]; a KC-wide tile takes the 16-byte
+    // piece q from the hi part (q < KC/8) or from the lo part, linear when KC == KCP
+    const int piece = (kSplit && KC < KCP) ? (q < KC / 8 ? 4 * q : KCP / 2 + 4 * (q - KC / 8)) : 4 * q;
+    voff_b = (unsigned)(((((row / BN) * a.cout_pad + tc.n0 + row % BN) * KCP) + piece) * 4);
   };
 
   auto ld128 = [](auto rsrc, unsigned voff, int soff) {
@@ -266,7 +288,8 @@ conv_mfma_kernel(const ConvArgs a) {
     }
     // weights: packed [chunk KCP][tap][cout_pad][KCP]; this tile reads the KC-wide
     // sub-row (ch % (KCP/KC)) of rows n0..n0+BN
-    const int wsoff = ((cbeg / KCP) * TAPS * a.cout_pad * KCP + cbeg % KCP) * 4;
+    // sub-chunk inside a packed chunk: KC floats on for fp32 rows, KC halves on for split rows
+    const int wsoff = (cbeg / KCP) * TAPS * a.cout_pad * KCP * 4 + (cbeg % KCP) * (kSplit ? 2 : 4);
 #pragma unroll
     for (int it = 0; it < T::B_IT; ++it) rb[it] = ld128(rsrcw, voff_b, wsoff + it * b_step);
   };
@@ -275,7 +298,24 @@ conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < T::A_IT; ++it) {
       const int idx = tid + it * NT;
-      if (idx < T::A_VEC) *reinterpret_cast<f32x4*>(&As[(idx / KV) * PS + 4 * (idx % KV)]) = ra[it];
+      if (kSplit) {
+        // x = hi + lo, hi = half(x) (clamped to the finite fp16 range), lo = half(x - hi);
+        // row layout [KC hi halves | KC lo halves]: slot q owns halves 4q..4q+3 of each part
+        half4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = fminf(fmaxf(ra[it][e], -65504.f), 65504.f);
+          hi[e] = (_Float16)x;
+          lo[e] = (_Float16)(x - (float)hi[e]);
+        }
+        if (idx < T::A_VEC) {
+          float* rowp = &As[(idx / KV) * PS];
+          *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(rowp) + 4 * (idx % KV)) = hi;
+          *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(rowp) + KC + 4 * (idx % KV)) = lo;
+        }
+      } else {
+        if (idx < T::A_VEC) *reinterpret_cast<f32x4*>(&As[(idx / KV) * PS + 4 * (idx % KV)]) = ra[it];
+      }
     }
 #pragma unroll
     for (int it = 0; it < T::B_IT; ++it) {
@@ -288,25 +328,73 @@ conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int toff = ((tap / KS) * PW + (tap % KS)) * PS;
+      if constexpr (!kSplit) {
 #pragma unroll
-      for (int s = 0; s < KC / 8; ++s) {
-        f32x4 av[WTM], bv[WTN];
+        for (int s = 0; s < KC / 8; ++s) {
+          f32x4 av[WTM], bv[WTN];
 #pragma unroll
-        for (int wm = 0; wm < WTM; ++wm)
-          av[wm] = kNoLds ? abl_const : *reinterpret_cast<const f32x4*>(&As[a_off[wm] + toff + 8 * s]);
+          for (int wm = 0; wm < WTM; ++wm)
+            av[wm] = kNoLds ? abl_const : *reinterpret_cast<const f32x4*>(&As[a_off[wm] + toff + 8 * s]);
 #pragma unroll
-        for (int wn = 0; wn < WTN; ++wn)
-          bv[wn] = kNoLds ? abl_const
-                          : *reinterpret_cast<const f32x4*>(&Bs[tap * BN * PS + b_off[wn] + 8 * s]);
-        // D[i = channel][j = pixel]: weights are the MFMA's A operand, pixels its B
+          for (int wn = 0; wn < WTN; ++wn)
+            bv[wn] = kNoLds ? abl_const
+                            : *reinterpret_cast<const f32x4*>(&Bs[tap * BN * PS + b_off[wn] + 8 * s]);
+          // D[i = channel][j = pixel]: weights are the MFMA's A operand, pixels its B
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+              for (int wn = 0; wn < WTN; ++wn)
+                acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[wn][t], av[wm][t],
+                                                                    acc[wm][wn], 0, 0, 0);
+        }
+      } else if constexpr (KC >= 16) {
+        // split-f16, 16 k per MFMA: lane half g reads halves 16s+8g..+7 of the hi part
+        // and the same of the lo part (the k <-> slot map is shared by both operands)
+#pragma unroll
+        for (int s = 0; s < KC / 16; ++s) {
+          half8 ah[WTM], al[WTM], bh[WTN], bl[WTN];
+#pragma unroll
+          for (int wm = 0; wm < WTM; ++wm) {
+            ah[wm] = *reinterpret_cast<const half8*>(&As[a_off[wm] + toff + 8 * s]);
+            al[wm] = *reinterpret_cast<const half8*>(&As[a_off[wm] + toff + KC / 2 + 8 * s]);
+          }
+#pragma unroll
+          for (int wn = 0; wn < WTN; ++wn) {
+            bh[wn] = *reinterpret_cast<const half8*>(&Bs[tap * BN * PS + b_off[wn] + 8 * s]);
+            bl[wn] = *reinterpret_cast<const half8*>(&Bs[tap * BN * PS + b_off[wn] + KC / 2 + 8 * s]);
+          }
 #pragma unroll
           for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
-            for (int wn = 0; wn < WTN; ++wn)
-              acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[wn][t], av[wm][t],
-                                                                  acc[wm][wn], 0, 0, 0);
+            for (int wn = 0; wn < WTN; ++wn) {
+              acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[wn], ah[wm], acc[wm][wn], 0, 0, 0);
+              acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[wn], al[wm], acc[wm][wn], 0, 0, 0);
+              acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[wn], ah[wm], acc[wm][wn], 0, 0, 0);
+            }
+        }
+      } else {
+        // split-f16 with 8-channel chunks: the 8-k MFMA form, 4 halves per lane half
+        half4 ah[WTM], al[WTM], bh[WTN], bl[WTN];
+#pragma unroll
+        for (int wm = 0; wm < WTM; ++wm) {
+          ah[wm] = *reinterpret_cast<const half4*>(&As[a_off[wm] + toff]);
+          al[wm] = *reinterpret_cast<const half4*>(&As[a_off[wm] + toff + KC / 2]);
+        }
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn) {
+          bh[wn] = *reinterpret_cast<const half4*>(&Bs[tap * BN * PS + b_off[wn]]);
+          bl[wn] = *reinterpret_cast<const half4*>(&Bs[tap * BN * PS + b_off[wn] + KC / 2]);
+        }
+#pragma unroll
+        for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+          for (int wn = 0; wn < WTN; ++wn) {
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x8f16(bl[wn], ah[wm], acc[wm][wn], 0, 0, 0);
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x8f16(bh[wn], al[wm], acc[wm][wn], 0, 0, 0);
+            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x8f16(bh[wn], ah[wm], acc[wm][wn], 0, 0, 0);
+          }
       }
     }
   };
@@ -508,6 +596,7 @@ int validate(const dn_conv_desc* d) {
              "conv: pixel strides smaller than channel counts");
   DN_REQUIRE(!d->up0 || (d->h_in % 2 == 0 && d->w_in % 2 == 0),
              "conv: x2-upsampled source needs even h_in/w_in");
+  DN_REQUIRE(d->math == 0 || d->math == 1, "conv: math mode %d unknown (0 = fp32, 1 = split-f16)", d->math);
   DN_REQUIRE(d->c1 == 0 || d->c0 % kcp_of(d->ksize) == 0,
              "conv: concat needs c0 (%d) to be a multiple of %d", d->c0, kcp_of(d->ksize));
   return DN_OK;
@@ -535,6 +624,29 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// split-f16 rows: [kcp hi halves | kcp lo halves] in the bytes of kcp floats
+__global__ void pack_weights_split_kernel(const float* __restrict__ w, _Float16* __restrict__ wpk,
+                                          int c_out, int c_in, int taps, int cout_pad, int kcp,
+                                          long total) {
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int k = r % kcp; r /= kcp;
+    const int co = r % cout_pad; r /= cout_pad;
+    const int tap = r % taps;
+    const int chp = r / taps;
+    const int ci = chp * kcp + k;
+    float v = 0.f;
+    if (co < c_out && ci < c_in) v = w[((size_t)co * c_in + ci) * taps + tap];
+    v = fminf(fmaxf(v, -65504.f), 65504.f);
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const long row = idx / kcp;
+    wpk[row * 2 * kcp + k] = hi;
+    wpk[row * 2 * kcp + kcp + k] = lo;
+  }
+}
+
 __global__ void fold_bn_kernel(const float* bias, const float* gamma, const float* beta,
                                const float* mean, const float* var, float eps, int n,
                                float* scale, float* shift) {
@@ -552,10 +664,10 @@ __global__ void fold_bn_kernel(const float* bias, const float* gamma, const floa
 }
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int ABL = 0>
+          int WTM, int WTN, int ABL = 0, int MATH = 0>
 int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   using T = ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>;
-  auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN, ABL>;
+  auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN, ABL, MATH>;
   static_assert(T::LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   // opt in to > 64 KiB of dynamic LDS once per instantiation (idempotent; a race
   // between two first callers only repeats the same attribute write)
@@ -602,9 +714,14 @@ extern "C" int dn_conv_pack_weights(const dn_conv_desc* d, const float* weight_o
   DN_REQUIRE(weight_oihw && packed, "conv pack: null pointer");
   const long total = (long)dn_conv_packed_weight_floats(d);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                     weight_oihw, packed, d->c_out, d->c0 + d->c1, d->ksize * d->ksize,
-                     cout_pad_of(*d), kcp_of(d->ksize), total);
+  if (d->math == 1)
+    hipLaunchKernelGGL(pack_weights_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       weight_oihw, reinterpret_cast<_Float16*>(packed), d->c_out, d->c0 + d->c1,
+                       d->ksize * d->ksize, cout_pad_of(*d), kcp_of(d->ksize), total);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       weight_oihw, packed, d->c_out, d->c0 + d->c1, d->ksize * d->ksize,
+                       cout_pad_of(*d), kcp_of(d->ksize), total);
   return dn::check_launch("pack_weights_kernel");
 }
 
@@ -646,20 +763,24 @@ extern "C" int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* 
                  (size_t)d->h_in * d->w_in * (d->c1 ? d->ld1 : 1) * 4 < (1ull << 31),
              "conv: one image must stay below 2 GiB");
   hipStream_t s = (hipStream_t)stream;
+#define DN_CONV_CASE(ID, ...)                                                         \
+  case ID:                                                                            \
+    return d->math == 1 ? launch<__VA_ARGS__, 0, 1>(a, *d, s) : launch<__VA_ARGS__, 0, 0>(a, *d, s);
   switch (c.id) {
-    //                           KS S  TH TW  BN  KC WM WN WTM WTN
-    case T3_256x32:   return launch<3, 1, 8, 32, 32, 16, 4, 1, 2, 1>(a, *d, s);
-    case T3_256x64:   return launch<3, 1, 8, 32, 64, 16, 4, 1, 2, 2>(a, *d, s);
-    case T3_128x128:  return launch<3, 1, 8, 16, 128, 8, 2, 2, 2, 2>(a, *d, s);
-    case T3_128x64:   return launch<3, 1, 8, 16, 64, 16, 2, 2, 2, 1>(a, *d, s);
-    case T3_64x64:    return launch<3, 1, 8, 8, 64, 16, 2, 2, 1, 1>(a, *d, s);
-    case T3S2_128x64: return launch<3, 2, 8, 16, 64, 8, 2, 2, 2, 1>(a, *d, s);
-    case T3S2_64x64:  return launch<3, 2, 8, 8, 64, 8, 2, 2, 1, 1>(a, *d, s);
-    case T1_256x32:   return launch<1, 1, 8, 32, 32, 32, 4, 1, 2, 1>(a, *d, s);
-    case T1_256x64:   return launch<1, 1, 8, 32, 64, 32, 4, 1, 2, 2>(a, *d, s);
-    case T1_128x128:  return launch<1, 1, 8, 16, 128, 32, 2, 2, 2, 2>(a, *d, s);
-    case T1_64x64:    return launch<1, 1, 8, 8, 64, 32, 2, 2, 1, 1>(a, *d, s);
+    //                        KS S  TH TW  BN  KC WM WN WTM WTN
+    DN_CONV_CASE(T3_256x32,   3, 1, 8, 32, 32, 16, 4, 1, 2, 1)
+    DN_CONV_CASE(T3_256x64,   3, 1, 8, 32, 64, 16, 4, 1, 2, 2)
+    DN_CONV_CASE(T3_128x128,  3, 1, 8, 16, 128, 8, 2, 2, 2, 2)
+    DN_CONV_CASE(T3_128x64,   3, 1, 8, 16, 64, 16, 2, 2, 2, 1)
+    DN_CONV_CASE(T3_64x64,    3, 1, 8, 8, 64, 16, 2, 2, 1, 1)
+    DN_CONV_CASE(T3S2_128x64, 3, 2, 8, 16, 64, 8, 2, 2, 2, 1)
+    DN_CONV_CASE(T3S2_64x64,  3, 2, 8, 8, 64, 8, 2, 2, 1, 1)
+    DN_CONV_CASE(T1_256x32,   1, 1, 8, 32, 32, 32, 4, 1, 2, 1)
+    DN_CONV_CASE(T1_256x64,   1, 1, 8, 32, 64, 32, 4, 1, 2, 2)
+    DN_CONV_CASE(T1_128x128,  1, 1, 8, 16, 128, 32, 2, 2, 2, 2)
+    DN_CONV_CASE(T1_64x64,    1, 1, 8, 8, 64, 32, 2, 2, 1, 1)
     default: break;
   }
+#undef DN_CONV_CASE
   return dn::fail(DN_ERR_UNSUPPORTED, "conv: no tile configuration");
 }

@@ -20,6 +20,8 @@ forward path packs them once into the kernels' tile-major layouts and runs
 NHWC (channels-last) end to end.  There is no torch/CPU fallback: tensors must
 be on the GPU and the shared object must be built.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -111,16 +113,19 @@ class _RegHeadParams(nn.Module):
             nn.Conv2d(32, len(config.anchor_size) * config.box_code_size * out_seq_len, 1))
 
 
-class _Layer:
+class _ConvLayer:
     """One packed conv of the plan: weights in tile-major layout + folded affine."""
 
-    __slots__ = ("name", "packed", "scale", "shift", "c_in", "c_out", "ksize", "stride", "relu")
+    __slots__ = ("name", "packed", "scale", "shift", "c_in", "c_out", "ksize", "stride", "relu",
+                 "math")
 
-    def __init__(self, name, weight, bias, bn, ksize, stride=1, relu=True, scale_shift=None):
+    def __init__(self, name, weight, bias, bn, ksize, stride=1, relu=True, scale_shift=None,
+                 math=0):
         self.name = name
+        self.math = math
         c_out = weight.shape[0]
         c_in = weight.shape[1]
-        d = ops.conv_desc(1, 8, 8, c_in, c_out, ksize, stride, relu)
+        d = ops.conv_desc(1, 8, 8, c_in, c_out, ksize, stride, relu, math=math)
         self.packed = ops.pack_conv_weights(d, weight)
         if scale_shift is not None:
             self.scale, self.shift = scale_shift
@@ -134,7 +139,7 @@ class _Layer:
         c1 = src1.shape[3] if src1 is not None else 0
         assert c0 + c1 == self.c_in, (c0, c1, self.c_in)
         d = ops.conv_desc(n, h_in, w_in, c0, self.c_out, self.ksize, self.stride, self.relu,
-                          c1=c1, up0=up0)
+                          c1=c1, up0=up0, math=self.math)
         ho, wo = ops.conv_out_hw(d)
         # algorithmic work of this launch: true (unpadded) channel counts
         flops = 2.0 * n * ho * wo * self.c_out * self.c_in * self.ksize * self.ksize
@@ -167,6 +172,10 @@ class DiscoNet(nn.Module):
 
         self._plan = None
         self._plan_sig = None
+        # conv arithmetic: "f32" = exact-fp32 MFMA; "f16x3" = split-f16 (hi/lo halves, three f16
+        # MFMAs per product, fp32 accumulate; ~1e-5 max abs deviation over the whole network).
+        # Not a constructor argument so the reference's signature is untouched.
+        self.conv_math = os.environ.get("DISCONET_CONV_MATH", "f32")
 
     # ------------------------------------------------------------------
     # checkpoint compatibility
@@ -200,12 +209,19 @@ class DiscoNet(nn.Module):
     # plan: packed weights + folded BN, rebuilt when any parameter changes
     # ------------------------------------------------------------------
     def _signature(self):
-        return tuple((t.data_ptr(), t._version) for t in
-                     list(self.parameters()) + list(self.buffers()))
+        if self.conv_math not in ops.MATH_MODES:
+            raise ValueError("conv_math must be one of %s" % sorted(ops.MATH_MODES))
+        return (self.conv_math,) + tuple((t.data_ptr(), t._version) for t in
+                                         list(self.parameters()) + list(self.buffers()))
 
     def _build_plan(self):
         enc, dec = self.u_encoder, self.decoder
         P = {}
+        math = ops.MATH_MODES[self.conv_math]
+
+        def _Layer(*args, **kw):          # every conv of the plan uses the model's math mode
+            return _ConvLayer(*args, math=math, **kw)
+
         for name, _, _, stride in _ENC_CONVS:
             conv = getattr(enc, name)
             P[name] = _Layer(name, conv.weight, conv.bias, getattr(enc, _bn_name(name)), 3, stride)

@@ -87,8 +87,11 @@ def scatter_dense(indices, offsets, n_images, dims):
 # ---------------------------------------------------------------------------
 # K2/K3/K7
 # ---------------------------------------------------------------------------
+MATH_MODES = {"f32": 0, "f16x3": 1}
+
+
 def conv_desc(n_images, h_in, w_in, c0, c_out, ksize, stride=1, relu=True, c1=0, up0=False,
-              ld0=None, ld1=None, ldo=None):
+              ld0=None, ld1=None, ldo=None, math=0):
     d = ConvDesc()
     d.n_images, d.h_in, d.w_in = n_images, h_in, w_in
     d.c0, d.c1, d.up0 = c0, c1, int(bool(up0))
@@ -96,6 +99,7 @@ def conv_desc(n_images, h_in, w_in, c0, c_out, ksize, stride=1, relu=True, c1=0,
     d.ld0 = c0 if ld0 is None else ld0
     d.ld1 = c1 if ld1 is None else ld1
     d.ldo = c_out if ldo is None else ldo
+    d.math = MATH_MODES.get(math, math)
     return d
 
 

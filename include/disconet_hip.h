@@ -90,6 +90,9 @@ typedef struct dn_conv_desc {
   int32_t stride;        /* 1 or 2 */
   int32_t relu;          /* apply ReLU after the affine */
   int32_t ld0, ld1, ldo; /* floats per pixel of src0 / src1 / out (>= channels) */
+  int32_t math;          /* 0 = exact fp32 MFMA; 1 = split-f16 (x = hi + lo halves, hi*hi + hi*lo +
+                            lo*hi on the f16 MFMA, fp32 accumulate, ~2^-22 per product).  The
+                            packed weights are math-specific: pack and run with the same value. */
 } dn_conv_desc;
 
 /* floats needed for the packed weights of this conv */

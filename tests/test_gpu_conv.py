@@ -8,7 +8,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _run(n, h, w, c0, c_out, k, stride=1, relu=True, c1=0, up0=False, bn=True, seed=0):
+MATHS = ["f32", "f16x3"]
+
+
+def _run(n, h, w, c0, c_out, k, stride=1, relu=True, c1=0, up0=False, bn=True, seed=0, math="f32"):
     from disconet_amd import ops
     g = torch.Generator().manual_seed(seed)
     cin = c0 + c1
@@ -32,7 +35,7 @@ def _run(n, h, w, c0, c_out, k, stride=1, relu=True, c1=0, up0=False, bn=True, s
             y = bn_mod(y)
     if relu:
         y = F.relu(y)
-    d = ops.conv_desc(n, h, w, c0, c_out, k, stride, relu, c1=c1, up0=up0)
+    d = ops.conv_desc(n, h, w, c0, c_out, k, stride, relu, c1=c1, up0=up0, math=math)
     packed = ops.pack_conv_weights(d, wgt.cuda())
     scale, shift = ops.fold_bn(bias.cuda(), bn_mod.cuda() if bn_mod else None, c_out)
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
@@ -45,37 +48,68 @@ def _run(n, h, w, c0, c_out, k, stride=1, relu=True, c1=0, up0=False, bn=True, s
     return err
 
 
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("c0,c_out", [(13, 32), (32, 32), (32, 64), (64, 64), (64, 128),
                                       (128, 256), (256, 512)])
-def test_conv3x3_stride1(c0, c_out):
-    _run(2, 32, 32, c0, c_out, 3)
+def test_conv3x3_stride1(c0, c_out, math):
+    _run(2, 32, 32, c0, c_out, 3, math=math)
 
 
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("c0,c_out", [(32, 64), (64, 128), (128, 256), (256, 512)])
-def test_conv3x3_stride2(c0, c_out):
-    _run(2, 32, 32, c0, c_out, 3, stride=2)
+def test_conv3x3_stride2(c0, c_out, math):
+    _run(2, 32, 32, c0, c_out, 3, stride=2, math=math)
 
 
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("c0,c1,c_out", [(512, 256, 256), (256, 128, 128), (128, 64, 64),
                                          (64, 32, 32)])
-def test_conv3x3_upsample_concat(c0, c1, c_out):
-    _run(2, 32, 32, c0, c_out, 3, c1=c1, up0=True)
+def test_conv3x3_upsample_concat(c0, c1, c_out, math):
+    _run(2, 32, 32, c0, c_out, 3, c1=c1, up0=True, math=math)
 
 
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("c0,c_out,relu,bn", [(32, 12, False, False), (32, 36, False, False),
                                               (64, 64, True, True), (128, 128, True, True),
                                               (256, 256, False, False), (256, 128, False, False)])
-def test_conv1x1(c0, c_out, relu, bn):
-    _run(2, 32, 32, c0, c_out, 1, relu=relu, bn=bn)
+def test_conv1x1(c0, c_out, relu, bn, math):
+    _run(2, 32, 32, c0, c_out, 1, relu=relu, bn=bn, math=math)
 
 
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("h,w", [(8, 8), (20, 44), (17, 33), (256, 256)])
-def test_conv3x3_ragged_and_full_size_tiles(h, w):
+def test_conv3x3_ragged_and_full_size_tiles(h, w, math):
     # sizes that do not divide the 8x32 / 8x16 tiles exercise the edge guards;
     # 256x256 is the BASELINE plane size
-    _run(1, h, w, 32, 32, 3)
+    _run(1, h, w, 32, 32, 3, math=math)
     if h % 2 == 0 and h < 256:
-        _run(1, h, w, 32, 64, 3, stride=2)
+        _run(1, h, w, 32, 64, 3, stride=2, math=math)
+
+
+@pytest.mark.parametrize("math", MATHS)
+def test_conv_many_tiles_per_workgroup(math):
+    """enough tiles that the persistent workgroups each walk several items, with a
+    ragged right/bottom edge"""
+    _run(24, 250, 252, 32, 32, 3, math=math)
+    _run(24, 124, 120, 64, 64, 3, math=math)
+
+
+def test_split_f16_extremes():
+    """split-f16 keeps small magnitudes (fp16-subnormal lo parts) and large ones"""
+    from disconet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 32, 16, 16, generator=g)
+    x[:, :8] *= 1e-4
+    x[:, 8:16] *= 300.0
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.05
+    y = F.conv2d(x.double(), w.double(), None, padding=1).float()
+    d = ops.conv_desc(1, 16, 16, 32, 32, 3, 1, False, math="f16x3")
+    packed = ops.pack_conv_weights(d, w.cuda())
+    scale, shift = ops.fold_bn(torch.zeros(32).cuda(), None, 32)
+    out = ops.conv2d(d, x.permute(0, 2, 3, 1).contiguous().cuda(), packed, scale, shift)
+    got = out.cpu().permute(0, 3, 1, 2)
+    rel = ((got - y).abs().max() / y.abs().max()).item()
+    assert rel <= 2e-6, rel
 
 
 def test_conv_rejects_bad_arguments():

@@ -13,9 +13,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _product(ref, map_hw, agents, kd_flag=1, **kw):
+MATHS = ["f32", "f16x3"]
+
+
+def _product(ref, map_hw, agents, kd_flag=1, math="f32", **kw):
     from disconet_amd import Config, DiscoNet
     m = DiscoNet(Config(map_hw=map_hw), kd_flag=kd_flag, num_agent=agents, **kw).eval()
+    m.conv_math = math
     m.load_state_dict({"module." + k: v for k, v in ref.state_dict().items()})
     return m.cuda()
 
@@ -28,12 +32,13 @@ def _gpu_outputs(m, bevs, trans, na, batch):
             "fused": fused.cpu()}
 
 
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("case", list(cases.MODEL_CASES))
-def test_model_vs_oracle_and_golden(case, golden_dir):
+def test_model_vs_oracle_and_golden(case, math, golden_dir):
     c = cases.MODEL_CASES[case]
     ref = cases.ref_model(c["map_hw"], c["agents"])
     want = cases.run_ref(case, ref)
-    m = _product(ref, c["map_hw"], c["agents"])
+    m = _product(ref, c["map_hw"], c["agents"], math=math)
     bevs, trans, na = cases.model_inputs(case)
     got = _gpu_outputs(m, bevs, trans, na, c["batch"])
     g = np.load(os.path.join(golden_dir, "model_cases.npz"))
@@ -45,14 +50,15 @@ def test_model_vs_oracle_and_golden(case, golden_dir):
         assert gerr <= TOL, "%s/%s golden err %.3e" % (case, name, gerr)
 
 
-def test_model_256_five_agents_default_init():
+@pytest.mark.parametrize("math", MATHS)
+def test_model_256_five_agents_default_init(math):
     """BASELINE plane size, torch default init (the bench's weights), batch 1."""
     from disconet_amd.synthetic import make_scene_batch
     ref = cases.ref_model(256, 5, init="torch")
     bevs, trans, na = make_scene_batch(1, 5, 256)
     with torch.no_grad():
         res, x8, x7, x6, x5, fused = ref(bevs, trans, na, 1)
-    m = _product(ref, 256, 5)
+    m = _product(ref, 256, 5, math=math)
     got = _gpu_outputs(m, bevs, trans, na, 1)
     for name, w in (("cls", res["cls"]), ("loc", res["loc"]), ("x8", x8), ("fused", fused)):
         err = (got[name] - w).abs().max().item()
@@ -73,7 +79,8 @@ def test_kd_flag_zero_returns_dict_and_only_v2i():
         assert (got[k].cpu() - want[k]).abs().max().item() <= TOL
 
 
-def test_batch_position_independence_at_baseline_size():
+@pytest.mark.parametrize("math", MATHS)
+def test_batch_position_independence_at_baseline_size(math):
     """configs[1] size (5 agents, batch 4, 256x256x13): a scene's result must not
     depend on which batch slot it sits in -- bitwise (fixed summation order)."""
     from disconet_amd import Config, DiscoNet
@@ -81,6 +88,7 @@ def test_batch_position_independence_at_baseline_size():
     torch.manual_seed(0)
     A, B = 5, 4
     m = DiscoNet(Config(), kd_flag=0, num_agent=A).eval().cuda()
+    m.conv_math = math
     bevs, trans, na = make_scene_batch(B, A, 256, jitter_seed=3)
     with torch.no_grad():
         full = m(bevs.cuda(), trans.cuda(), na.cuda(), B)

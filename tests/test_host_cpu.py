@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from disconet_amd import _lib
-    assert ctypes.sizeof(_lib.ConvDesc) == 13 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 14 * 4
     assert ctypes.sizeof(_lib.MlpTailParams) == 10 * ctypes.sizeof(ctypes.c_void_p)
 
 
