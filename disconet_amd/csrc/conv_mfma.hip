@@ -528,13 +528,11 @@ int g_persist = 1;
 // tile menu and per-launch selection
 // ---------------------------------------------------------------------------
 enum CfgId {
-  T3_256x32,   // 8x32 px, 32 ch : the 32-channel full-resolution layers
+  T3_256x32,   // 8x32 px, 32 ch
   T3_256x64,   // 8x32 px, 64 ch
-  T3_128x128,  // 8x16 px, 128 ch: most operand reuse, fewest weight re-reads
   T3_128x64,   // 8x16 px, 64 ch
   T3_64x64,    // 8x8 px,  64 ch : small maps -> enough workgroups to fill 256 CUs
-  T3S2_128x64, // stride 2
-  T3S2_64x64,
+  T3S2_64x64,  // stride 2 (KC 8 in fp32, 16 in split-f16)
   T1_256x32, T1_256x64, T1_128x128, T1_64x64,
   CFG_COUNT
 };
@@ -542,13 +540,19 @@ enum CfgId {
 struct Cfg {
   CfgId id;
   int th, tw, bn;
+  float bias[2];   // measured time per unit of tile area relative to 256x32, per math mode
 };
 
+// biases from profiles/r01_conv_tile_sweep.txt (tools/conv_tile_sweep.hip, batch-4
+// layer shapes): in fp32 only the 64x64 tile pays (~10 %, one MFMA tile per wave);
+// in split-f16 the MFMA phase is 5x shorter, so LDS reads per MFMA and weight
+// staging per workgroup decide: the narrow 32-channel tile wins for deep layers.
 const Cfg kCfgs[CFG_COUNT] = {
-    {T3_256x32, 8, 32, 32},  {T3_256x64, 8, 32, 64},   {T3_128x128, 8, 16, 128},
-    {T3_128x64, 8, 16, 64},  {T3_64x64, 8, 8, 64},     {T3S2_128x64, 8, 16, 64},
-    {T3S2_64x64, 8, 8, 64},  {T1_256x32, 8, 32, 32},   {T1_256x64, 8, 32, 64},
-    {T1_128x128, 8, 16, 128}, {T1_64x64, 8, 8, 64},
+    {T3_256x32, 8, 32, 32, {1.00f, 1.00f}},   {T3_256x64, 8, 32, 64, {1.00f, 0.90f}},
+    {T3_128x64, 8, 16, 64, {1.00f, 1.04f}},   {T3_64x64, 8, 8, 64, {1.10f, 1.36f}},
+    {T3S2_64x64, 8, 8, 64, {1.00f, 1.00f}},   {T1_256x32, 8, 32, 32, {1.00f, 1.00f}},
+    {T1_256x64, 8, 32, 64, {1.00f, 1.00f}},   {T1_128x128, 8, 16, 128, {1.00f, 1.00f}},
+    {T1_64x64, 8, 8, 64, {1.00f, 1.00f}},
 };
 
 inline int out_dim(int in, int ksize, int stride) {
@@ -558,19 +562,18 @@ inline int out_dim(int in, int ksize, int stride) {
 
 // MFMA-bound cost model: workgroups are dealt round-robin to the 256 CUs and a
 // CU runs its workgroups' MFMAs on the same 4 SIMDs, so time ~ ceil(blocks/256)
-// x (pixels x channels per tile); ties go to the larger tile (fewer weight and
-// halo re-reads).  Tiles wider than the padded channel count waste MFMAs and
-// are charged for it by construction.
+// x (pixels x channels per tile) x the tile's measured bias; ties go to the
+// earlier candidate.  Tiles wider than the padded channel count or than the map
+// waste MFMAs and are charged for it by construction.
 Cfg select_cfg(const dn_conv_desc& d) {
   const int ho = out_dim(d.h_in, d.ksize, d.stride), wo = out_dim(d.w_in, d.ksize, d.stride);
   const CfgId* cand;
   int ncand;
-  // preference order: ties go to the earlier entry
-  static const CfgId c3[] = {T3_128x128, T3_256x64, T3_128x64, T3_64x64, T3_256x32};
-  static const CfgId c3s2[] = {T3S2_128x64, T3S2_64x64};
+  static const CfgId c3[] = {T3_256x32, T3_256x64, T3_128x64, T3_64x64};
+  static const CfgId c3s2[] = {T3S2_64x64};
   static const CfgId c1[] = {T1_128x128, T1_256x64, T1_64x64, T1_256x32};
-  if (d.ksize == 3 && d.stride == 2) { cand = c3s2; ncand = 2; }
-  else if (d.ksize == 3) { cand = c3; ncand = 5; }
+  if (d.ksize == 3 && d.stride == 2) { cand = c3s2; ncand = 1; }
+  else if (d.ksize == 3) { cand = c3; ncand = 4; }
   else { cand = c1; ncand = 4; }
   Cfg best = kCfgs[cand[0]];
   double best_cost = 1e300;
@@ -579,7 +582,7 @@ Cfg select_cfg(const dn_conv_desc& d) {
     const long tiles = (long)d.n_images * ((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
     const long blocks = tiles * ((d.c_out + c.bn - 1) / c.bn);
     const double rounds = (double)((blocks + 255) / 256);
-    const double cost = rounds * c.th * c.tw * c.bn;
+    const double cost = rounds * c.th * c.tw * c.bn * c.bias[d.math == 1 ? 1 : 0];
     if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
   }
   return best;
@@ -770,11 +773,11 @@ extern "C" int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* 
     //                        KS S  TH TW  BN  KC WM WN WTM WTN
     DN_CONV_CASE(T3_256x32,   3, 1, 8, 32, 32, 16, 4, 1, 2, 1)
     DN_CONV_CASE(T3_256x64,   3, 1, 8, 32, 64, 16, 4, 1, 2, 2)
-    DN_CONV_CASE(T3_128x128,  3, 1, 8, 16, 128, 8, 2, 2, 2, 2)
     DN_CONV_CASE(T3_128x64,   3, 1, 8, 16, 64, 16, 2, 2, 2, 1)
     DN_CONV_CASE(T3_64x64,    3, 1, 8, 8, 64, 16, 2, 2, 1, 1)
-    DN_CONV_CASE(T3S2_128x64, 3, 2, 8, 16, 64, 8, 2, 2, 2, 1)
-    DN_CONV_CASE(T3S2_64x64,  3, 2, 8, 8, 64, 8, 2, 2, 1, 1)
+    case T3S2_64x64:   // 8-channel chunks keep 3 workgroups/CU in fp32; split-f16 wants 16 k per MFMA
+      return d->math == 1 ? launch<3, 2, 8, 8, 64, 16, 2, 2, 1, 1, 0, 1>(a, *d, s)
+                          : launch<3, 2, 8, 8, 64, 8, 2, 2, 1, 1, 0, 0>(a, *d, s);
     DN_CONV_CASE(T1_256x32,   1, 1, 8, 32, 32, 32, 4, 1, 2, 1)
     DN_CONV_CASE(T1_256x64,   1, 1, 8, 32, 64, 32, 4, 1, 2, 2)
     DN_CONV_CASE(T1_128x128,  1, 1, 8, 16, 128, 32, 2, 2, 2, 2)
