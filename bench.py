@@ -30,7 +30,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 AGENTS, BATCH, MAP_HW = 5, 4, 256
-FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+# /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks
+MFMA_PEAK_TFLOPS = {"f32": 157.3,      # v_mfma_f32_32x32x2_f32
+                    "f16x3": 2500.0}   # v_mfma_f32_32x32x16_f16 (the split-f16 path runs 3 per product)
+EXECUTED_FLOP_FACTOR = {"f32": 1, "f16x3": 3}
 
 
 def parse():
@@ -42,8 +45,9 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-launch HIP events in the timed region")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table (stderr)")
-    ap.add_argument("--math", choices=["f32", "f16x3"], default=os.environ.get("DISCONET_CONV_MATH", "f32"),
-                    help="conv arithmetic: exact-fp32 MFMA or split-f16 (3 f16 MFMAs / product)")
+    ap.add_argument("--math", choices=["f32", "f16x3"], default=os.environ.get("DISCONET_CONV_MATH", "f16x3"),
+                    help="conv arithmetic: split-f16 (3 f16 MFMAs / product, default) or exact-fp32 MFMA")
+    ap.add_argument("--no-alt-math", action="store_true", help="skip the other math mode's timed region")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
     ap.add_argument("--cpu-baseline-child", nargs=3, metavar=("STATE", "OUT", "THREADS"),
                     help=argparse.SUPPRESS)
@@ -167,34 +171,81 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(events):
+        """K steps of the hot path.  events=False: nothing but the steps (-> value).
+        events=True: a HIP-event pair around every launch, on the launch stream (->
+        per-kernel durations); kept apart because each event record drains the queue
+        (~30 us per launch), which would understate `value` by ~15 %."""
+        timer = KernelTimer() if events else None
+        fence() if not events else torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if events:
+            with timing(timer):
+                for _ in range(args.steps):
+                    step()
+        else:
+            for _ in range(args.steps):
+                step()
+        fence() if not events else torch.cuda.synchronize()
+        return time.perf_counter() - t0, timer
+
+    def roofline_of(timer, elapsed_events, math):
+        summ = timer.summary()
+        conv = {k: v for k, v in summ.items() if v["kernel"] == "conv_mfma_kernel"}
+        flops = sum(v["flops"] for v in conv.values())
+        ms = sum(v["ms_total"] for v in conv.values())
+        launches = sum(v["calls"] for v in conv.values())
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak, factor = MFMA_PEAK_TFLOPS[math], EXECUTED_FLOP_FACTOR[math]
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per conv launch from the committed rocprofv3 --pmc passes
+            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                          if f.endswith("_pmc_traffic_%s.json" % math))[-1]
+            traffic = json.load(open(os.path.join(ROOT, "profiles", prof)))["hbm_bytes_per_launch"]
+            traffic_src = "profiles/" + prof
+        except (OSError, IndexError, KeyError, ValueError):
+            pass
+        alg_bytes = sum(v["bytes"] for v in conv.values())
+        roof = {
+            "kernel": "conv_mfma_kernel (%s MFMA implicit-GEMM conv, all %d launches/step)"
+                      % ("exact-fp32" if math == "f32" else "split-f16x3", launches // args.steps),
+            "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4),
+            "note": "achieved = algorithmic FLOP (true channel counts) / HIP-event kernel time",
+            "executed_flop_factor": factor, "frac_executed": round(achieved * factor / peak, 4),
+            "hbm_algorithmic_TBps": round(alg_bytes / (ms * 1e-3) / 1e12, 3) if ms > 0 else None,
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": round(alg_bytes / max(launches, 1)),
+            "flop_per_step": flops / args.steps, "kernel_ms_per_step": round(ms / args.steps, 4),
+            "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
+            "ms_per_step_with_events": round(1e3 * elapsed_events / args.steps, 4),
+            "other_kernels_ms_per_step": {k: round(v["ms_total"] / args.steps, 4)
+                                          for k, v in summ.items() if v["kernel"] != "conv_mfma_kernel"},
+        }
+        if args.layers:
+            print("[%s] %-12s %8s %10s %9s %8s" % (math, "layer", "ms/step", "GFLOP/step", "TFLOP/s", "GB/s"),
+                  file=sys.stderr)
+            for k, v in summ.items():
+                m = v["ms_total"] / args.steps
+                print("[%s] %-12s %8.4f %10.3f %9.2f %8.1f" % (
+                    math, k, m, v["flops"] / args.steps / 1e9,
+                    v["flops"] / (v["ms_total"] * 1e-3) / 1e12 if v["ms_total"] else 0,
+                    v["bytes"] / (v["ms_total"] * 1e-3) / 1e9 if v["ms_total"] else 0), file=sys.stderr)
+        return roof
+
     for _ in range(args.warmup):
         step()
-    # ---- timed region #1: exactly K steps, nothing but the hot path -> `value`
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    # ---- timed region #2 (rank 0): the same K steps with a HIP-event pair around
-    # every launch, on the launch stream -> per-kernel durations for the roofline.
-    # Kept apart from region #1 because each event record drains the queue (~30 us
-    # per launch), which would understate `value` by ~15 %.
-    timer = None
+    elapsed, _ = timed(False)                      # timed region #1 -> value
+    timer, elapsed_events = None, 0.0
     if rank == 0 and not args.no_kernel_events:
-        timer = KernelTimer()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        with timing(timer):
-            for _ in range(args.steps):
-                out = step()
-        torch.cuda.synchronize()
-        elapsed_events = time.perf_counter() - t1
+        elapsed_events, timer = timed(True)        # timed region #2 -> roofline
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    dtype_name = {"f32": "f32", "f16x3": "f32 storage; conv products as split-f16 x3 MFMA, f32 accumulate"}
     scenes = world * BATCH * args.steps
     result = {
         "metric": "scenes/sec (5-agent 256x256 BEV)",
@@ -207,55 +258,34 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.math == "f32" else "f32 storage, split-f16x3 MFMA products, f32 accumulate",
+        "dtype": dtype_name[args.math],
         "data": "synthetic",
         "config": {"workload": "DiscoNet det eval forward (--com disco), 5-agent, batch 4 per GPU, "
                                "256x256x13 BEV, no KD, sparse voxel lists -> dense -> enc -> "
                                "DiscoGraph fusion -> dec -> cls/reg heads",
                    "agents": AGENTS, "batch_per_gpu": BATCH, "bev": [MAP_HW, MAP_HW, 13],
+                   "conv_math": args.math,
                    "parallelism": "scene-parallel x%d (no data-path collective)" % world},
     }
 
     if rank == 0:
         if timer is not None:
-            summ = timer.summary()
-            conv = {k: v for k, v in summ.items() if v["kernel"] == "conv_mfma_kernel"}
-            flops = sum(v["flops"] for v in conv.values())
-            ms = sum(v["ms_total"] for v in conv.values())
-            launches = sum(v["calls"] for v in conv.values())
-            achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            traffic, traffic_src = None, None
-            try:   # HBM bytes per conv launch from the committed rocprofv3 --pmc passes
-                prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
-                              if f.endswith("_pmc_traffic.json"))[-1]
-                traffic = json.load(open(os.path.join(ROOT, "profiles", prof)))["hbm_bytes_per_launch"]
-                traffic_src = "profiles/" + prof
-            except (OSError, IndexError, KeyError, ValueError):
-                pass
-            result["roofline"] = {
-                "kernel": "conv_mfma_kernel (fp32 MFMA implicit-GEMM conv, all %d launches/step)"
-                          % (launches // args.steps),
-                "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": round(sum(v["bytes"] for v in conv.values()) / max(launches, 1)),
-                "flop_per_step": flops / args.steps, "kernel_ms_per_step": round(ms / args.steps, 4),
-                "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
-                "ms_per_step_with_events": round(1e3 * elapsed_events / args.steps, 4),
-            }
-            other = {k: round(v["ms_total"] / args.steps, 4) for k, v in summ.items()
-                     if v["kernel"] != "conv_mfma_kernel"}
-            result["roofline"]["other_kernels_ms_per_step"] = other
-            if args.layers:
-                print("%-12s %8s %10s %9s %8s" % ("layer", "ms/step", "GFLOP/step", "TFLOP/s", "GB/s"),
-                      file=sys.stderr)
-                for k, v in summ.items():
-                    m = v["ms_total"] / args.steps
-                    print("%-12s %8.4f %10.3f %9.2f %8.1f" % (
-                        k, m, v["flops"] / args.steps / 1e9,
-                        v["flops"] / (v["ms_total"] * 1e-3) / 1e12 if v["ms_total"] else 0,
-                        v["bytes"] / (v["ms_total"] * 1e-3) / 1e9 if v["ms_total"] else 0), file=sys.stderr)
+            result["roofline"] = roofline_of(timer, elapsed_events, args.math)
+        if world == 1 and not args.no_alt_math:
+            # the other conv arithmetic on the same workload, K steps each way
+            alt = "f32" if args.math == "f16x3" else "f16x3"
+            model.conv_math = alt
+            for _ in range(args.warmup):
+                step()
+            alt_elapsed, _ = timed(False)
+            alt_res = {"conv_math": alt, "dtype": dtype_name[alt],
+                       "value": round(BATCH * args.steps / alt_elapsed, 3),
+                       "ms_per_step": round(1e3 * alt_elapsed / args.steps, 4)}
+            if not args.no_kernel_events:
+                alt_ev, alt_timer = timed(True)
+                alt_res["roofline"] = roofline_of(alt_timer, alt_ev, alt)
+            result["alt_math"] = alt_res
+            model.conv_math = args.math
         if world == 1 and not args.no_cpu_baseline:
             threads = usable_cores()
             base, ref_out = cpu_baseline_bounded(state_dict_cpu, threads, args.cpu_baseline_timeout)

@@ -54,6 +54,7 @@
 // Replaces the conv2d/conv3d(1x1x1)+batch_norm+relu(+interpolate+cat) chains of
 // upstream:coperception/models/det/backbone/Backbone.py.
 #include "dn_internal.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -698,7 +699,12 @@ int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   // persistent grid: as many workgroups as are resident (no inter-workgroup sync
   // depends on the count; an over-estimate only queues the surplus)
   const long resident = (long)occupancy * kNumCUs;
-  const bool persist = g_persist == 2 || (g_persist == 1 && T::BM == 256 && a.nchunks >= 2 && a.nchunks <= 4);
+  static const int persist_env = [] {   // experiments: DN_CONV_PERSIST=0|1|2 overrides the policy
+    const char* e = getenv("DN_CONV_PERSIST");
+    return e ? atoi(e) : -1;
+  }();
+  const int pmode = persist_env >= 0 ? persist_env : g_persist;
+  const bool persist = pmode == 2 || (pmode == 1 && T::BM == 256 && a.nchunks >= 2 && a.nchunks <= 4);
   dim3 grid((unsigned)((persist && total > resident) ? resident : total));
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, stream, a);
   return dn::check_launch("conv_mfma_kernel");

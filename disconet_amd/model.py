@@ -172,10 +172,13 @@ class DiscoNet(nn.Module):
 
         self._plan = None
         self._plan_sig = None
-        # conv arithmetic: "f32" = exact-fp32 MFMA; "f16x3" = split-f16 (hi/lo halves, three f16
-        # MFMAs per product, fp32 accumulate; ~1e-5 max abs deviation over the whole network).
-        # Not a constructor argument so the reference's signature is untouched.
-        self.conv_math = os.environ.get("DISCONET_CONV_MATH", "f32")
+        # conv arithmetic: "f16x3" (default) = split-f16: every fp32 operand as hi + lo halves,
+        # three f16 MFMAs per product, fp32 accumulate -- max abs deviation from the fp32 oracle
+        # ~1e-5 over the whole network (the 1e-4 parity bar; same size as the exact mode's own
+        # summation-order noise); needs |activations|, |weights| < 65504.  "f32" = exact-fp32
+        # MFMA at half the throughput.  Not a constructor argument so the reference's signature
+        # is untouched: set model.conv_math or DISCONET_CONV_MATH before the first forward.
+        self.conv_math = os.environ.get("DISCONET_CONV_MATH", "f16x3")
 
     # ------------------------------------------------------------------
     # checkpoint compatibility
