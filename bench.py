@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--math", choices=["f32", "f16x3"], default=os.environ.get("DISCONET_CONV_MATH", "f16x3"),
                     help="conv arithmetic: split-f16 (3 f16 MFMAs / product, default) or exact-fp32 MFMA")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the other math mode's timed region")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
     ap.add_argument("--cpu-baseline-child", nargs=3, metavar=("STATE", "OUT", "THREADS"),
                     help=argparse.SUPPRESS)
@@ -171,6 +173,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    graphed = {}
+
+    def run_step():
+        """One step for the un-instrumented region: a captured hipGraph of step() (the
+        same launches, replayed without per-launch host work) unless --no-graph."""
+        if args.no_graph:
+            return step()
+        key = model.conv_math
+        if key not in graphed:
+            from disconet_amd.graph import GraphedStep
+            graphed[key] = GraphedStep(step)
+        return graphed[key]()
+
     def timed(events):
         """K steps of the hot path.  events=False: nothing but the steps (-> value).
         events=True: a HIP-event pair around every launch, on the launch stream (->
@@ -185,7 +200,7 @@ def main():
                     step()
         else:
             for _ in range(args.steps):
-                step()
+                run_step()
         fence() if not events else torch.cuda.synchronize()
         return time.perf_counter() - t0, timer
 
@@ -235,7 +250,7 @@ def main():
         return roof
 
     for _ in range(args.warmup):
-        step()
+        run_step()
     elapsed, _ = timed(False)                      # timed region #1 -> value
     timer, elapsed_events = None, 0.0
     if rank == 0 and not args.no_kernel_events:
@@ -264,7 +279,7 @@ def main():
                                "256x256x13 BEV, no KD, sparse voxel lists -> dense -> enc -> "
                                "DiscoGraph fusion -> dec -> cls/reg heads",
                    "agents": AGENTS, "batch_per_gpu": BATCH, "bev": [MAP_HW, MAP_HW, 13],
-                   "conv_math": args.math,
+                   "conv_math": args.math, "launch": "eager" if args.no_graph else "hipGraph replay",
                    "parallelism": "scene-parallel x%d (no data-path collective)" % world},
     }
 
@@ -276,7 +291,7 @@ def main():
             alt = "f32" if args.math == "f16x3" else "f16x3"
             model.conv_math = alt
             for _ in range(args.warmup):
-                step()
+                run_step()
             alt_elapsed, _ = timed(False)
             alt_res = {"conv_math": alt, "dtype": dtype_name[alt],
                        "value": round(BATCH * args.steps / alt_elapsed, 3),
