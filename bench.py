@@ -48,6 +48,11 @@ def parse():
     ap.add_argument("--math", choices=["f32", "f16x3"], default=os.environ.get("DISCONET_CONV_MATH", "f16x3"),
                     help="conv arithmetic: split-f16 (3 f16 MFMAs / product, default) or exact-fp32 MFMA")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the other math mode's timed region")
+    ap.add_argument("--mode", choices=["scene", "agent"], default="scene",
+                    help="multi-GPU partitioning: 'scene' = every rank its own scenes (default, weak "
+                         "scaling, no data-path collective); 'agent' = BASELINE configs[4]: 8-agent "
+                         "scenes, agents sharded across ranks, one RCCL all-gather of the layer-3 maps "
+                         "per step (strong scaling of a fixed batch of scenes)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
@@ -128,6 +133,70 @@ def cpu_baseline_bounded(state_dict, threads, timeout_s):
                 "sample": "1 scene (5 agents, 256x256x13)", "error": type(e).__name__}, None
 
 
+def agent_sharded_bench(args, world, rank, dist):
+    """BASELINE configs[4]: 8-agent scenes, one agent group per GPU, RCCL all-gather of
+    the intermediate maps as the V2X exchange.  Fixed work (batch 4 of 8-agent scenes)
+    for every N -> "scaling": "strong"."""
+    from disconet_amd import Config, DiscoNet, ops, sharded
+    from disconet_amd.synthetic import make_sparse_scene_batch, make_trans_matrices, randomize_bn_stats
+    agents = 8
+    if agents % world:
+        raise SystemExit("--mode agent needs a GPU count that divides 8 agents")
+    if world == 1:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+    torch.manual_seed(0)
+    model = DiscoNet(Config(map_hw=MAP_HW), kd_flag=0, num_agent=agents)
+    randomize_bn_stats(model)
+    model.conv_math = args.math
+    model.eval().cuda()
+    engine = sharded.HipEngine(model)
+    first, count = sharded.agent_range(agents, world, rank)
+    indices, offsets, _ = make_sparse_scene_batch(BATCH, agents, MAP_HW)
+    # this rank's agents: images [first*B, (first+count)*B) of the agent-major stack
+    lo, hi = int(offsets[first * BATCH]), int(offsets[(first + count) * BATCH])
+    my_idx = indices[lo:hi].contiguous().cuda()
+    my_off = (offsets[first * BATCH:(first + count) * BATCH + 1] - lo).to(torch.int32).cuda()
+    trans = make_trans_matrices(BATCH, agents).cuda()
+    na = torch.full((BATCH, agents), agents, dtype=torch.int64).cuda()
+    dims = (MAP_HW, MAP_HW, 13)
+
+    def step():
+        bevs = ops.scatter_dense(my_idx, my_off, count * BATCH, dims)
+        with torch.no_grad():
+            return sharded.forward_agent_sharded(engine, bevs, trans, na, BATCH)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    t = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "scenes/sec (8-agent 256x256 BEV, agents sharded across GPUs)",
+            "value": round(BATCH * args.steps / elapsed, 3), "unit": "scenes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.math == "f32" else "f32 storage; conv products as split-f16 x3 MFMA, f32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": "DiscoNet det eval forward, 8-agent scenes, batch 4, 256x256x13 BEV, "
+                                   "%d agent(s) per GPU, RCCL all-gather of the 256x32x32 maps" % count,
+                       "agents": agents, "batch": BATCH, "conv_math": args.math,
+                       "parallelism": "agent-parallel x%d" % world}}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.cpu_baseline_child:
@@ -142,6 +211,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.mode == "agent":
+        return agent_sharded_bench(args, world, rank, dist)
 
     from disconet_amd import Config, DiscoNet, ops
     from disconet_amd.profiling import KernelTimer, timing
