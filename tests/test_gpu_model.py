@@ -106,3 +106,37 @@ def test_cpu_tensors_fail_loudly():
     bevs, trans, na = make_scene_batch(1, 2, 128)
     with pytest.raises(_lib.DnError):
         m(bevs, trans, na, 1)
+
+
+@pytest.mark.parametrize("kw", [dict(layer=2), dict(layer=4), dict(layer=1), dict(compress_level=1),
+                                dict(compress_level=2, only_v2i=True)])
+def test_other_fusion_layers_and_compression(kw):
+    """the constructor's other knobs: fusion at another pyramid level (C = 64 / 128 / 512
+    maps at 64x64 / 32x32 / 8x8) and the 1x1 compress/decompress of the exchanged map"""
+    c = cases.MODEL_CASES["ragged_a4"]
+    ref = cases.ref_model(c["map_hw"], c["agents"], **kw)
+    bevs, trans, na = cases.model_inputs("ragged_a4")
+    with torch.no_grad():
+        res, x8, x7, x6, x5, fused = ref(bevs, trans, na, c["batch"])
+    m = _product(ref, c["map_hw"], c["agents"], **kw)
+    got = _gpu_outputs(m, bevs, trans, na, c["batch"])
+    for name, w in (("cls", res["cls"]), ("loc", res["loc"]), ("fused", fused), ("x5", x5)):
+        assert got[name].shape == w.shape, (kw, name)
+        err = (got[name] - w).abs().max().item()
+        assert err <= TOL, "%s %s max abs err %.3e" % (kw, name, err)
+
+
+@pytest.mark.parametrize("agents,live", [(1, [1]), (6, [6]), (6, [1]), (5, [2])])
+def test_agent_count_edges(agents, live):
+    """one agent (no neighbours at all), six agents (5 vehicles + RSU), and scenes whose
+    live count is 1 or 2 of the padded slots"""
+    from disconet_amd.synthetic import make_scene_batch
+    ref = cases.ref_model(128, agents)
+    bevs, trans, na = make_scene_batch(1, agents, 128, live=live, jitter_seed=11)
+    with torch.no_grad():
+        res, _, _, _, _, fused = ref(bevs, trans, na, 1)
+    m = _product(ref, 128, agents)
+    got = _gpu_outputs(m, bevs, trans, na, 1)
+    for name, w in (("cls", res["cls"]), ("loc", res["loc"]), ("fused", fused)):
+        err = (got[name] - w).abs().max().item()
+        assert err <= TOL, "A=%d live=%s %s max abs err %.3e" % (agents, live, name, err)
