@@ -23,6 +23,11 @@ class ConvDesc(Structure):
         "ld0", "ld1", "ldo", "math")]
 
 
+class Post1x1Desc(Structure):
+    """struct dn_post1x1_desc"""
+    _fields_ = [(n, c_int32) for n in ("c_out2", "relu2", "split", "ldo_a", "ldo_b")]
+
+
 class MlpTailParams(Structure):
     """struct dn_mlp_tail_params"""
     _fields_ = [(n, c_void_p) for n in (
@@ -46,6 +51,9 @@ SIGNATURES = {
                            c_void_p, c_void_p, c_void_p]),
     "dn_conv2d": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p]),
+    "dn_post1x1_packed_floats": (c_size_t, []),
+    "dn_post1x1_pack_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dn_conv2d_post1x1": (c_int, [POINTER(ConvDesc), POINTER(Post1x1Desc)] + [c_void_p] * 11),
     "dn_warp_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_void_p, c_void_p]),
     "dn_disco_fuse_tail": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -85,6 +85,12 @@ struct ConvArgs {
   int wpk_bytes;  // size of the packed weights (buffer bounds)
   int total_items;     // work items = channel blocks x images x tiles
   int vec_out;    // out / scale / shift allow 16-byte accesses
+  // fused 1x1 stage (POST kernels only): out2 = act2(h . W2^T * scale2 + shift2)
+  const float* w2;      // packed split-f16 rows [64][BN hi halves | BN lo halves]
+  const float* scale2;
+  const float* shift2;
+  float* out_b;         // columns [split2, c_out2) of the fused stage (may be null)
+  int c_out2, relu2, split2, ldo_b;
 };
 
 constexpr int kcp_of(int ksize) { return ksize == 3 ? 16 : 32; }
@@ -125,12 +131,17 @@ struct ConvTile {
 // barriers, 3 = no epilogue stores, 5 = 1 + 3 + MFMA operands from registers
 // (pure MFMA stream).
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int ABL = 0, int MATH = 0>
+          int WTM, int WTN, int ABL = 0, int MATH = 0, int POST = 0>
 __global__ void __launch_bounds__(
     (WAVES_M * WAVES_N * 64),
     (ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>::OCC))
 conv_mfma_kernel(const ConvArgs a) {
   constexpr bool kSplit = MATH == 1;
+  // POST: a 1x1 conv (<= 64 outputs) on this layer's activated output, fused into
+  // the epilogue: the tile never leaves the CU between the two layers (heads:
+  // conv1 + conv2 of cls and reg in one launch; conv*_2 + the 1x1x1 Conv3D).
+  static_assert(POST == 0 || (kSplit && WTN == 1 && BN == 64 && WAVES_N == 2),
+                "fused 1x1 stage: split-f16, 64-channel tile, 2 channel waves");
   constexpr bool kNoStream = ABL == 1 || ABL == 5;
   constexpr bool kNoStore = ABL == 3 || ABL == 5;
   constexpr bool kNoLds = ABL == 5;
@@ -187,6 +198,15 @@ conv_mfma_kernel(const ConvArgs a) {
   f32x16 acc[WTM][WTN];
   const f32x4 abl_const = {li * 1e-3f, 0.5f, -0.25f, lh * 1.f};   // ablation operands only
   f32x4 ra[T::A_IT], rb[T::B_IT];   // the next chunk, in flight from global memory
+  // fused stage's weights: 16 KiB for the whole workgroup, held in registers across
+  // tiles (the LDS region they are staged to is reused by every tile's operands)
+  f32x4 w2r[POST ? 4 : 1];
+  if constexpr (POST != 0) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      w2r[it] = *reinterpret_cast<const f32x4*>(a.w2 + (size_t)(tid + it * NT) * 4);
+  }
+
 
   // ---- staging state.  Buffer loads: per-lane byte offsets are computed once per
   // tile (and once more where a concat layer switches source); a chunk only moves
@@ -412,6 +432,97 @@ conv_mfma_kernel(const ConvArgs a) {
     const int t = opaque_tid();
     const int eli = t & 31, elh = (t >> 5) & 1;
     __syncthreads();   // every wave is done with the last chunk's operands
+    if constexpr (POST != 0) {
+      // ---- stage 1 output h = act(acc * scale + shift), written to LDS as split-f16 rows
+      // [BN hi halves | BN lo halves] (row stride CS floats) = the A-operand image of stage 2
+      _Float16* Hh = reinterpret_cast<_Float16*>(smem);
+      float* W2s = smem + T::BM * CS;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cl = wave_n * 32 + 8 * g + 4 * elh;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cl + e < a.c_out) { sc[e] = a.scale[cl + e]; sh[e] = a.shift[cl + e]; }
+#pragma unroll
+        for (int wm = 0; wm < WTM; ++wm) {
+          const int m = (wave_m * WTM + wm) * 32 + eli;
+          half4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[wm][0][4 * g + e] * sc[e] + sh[e];
+            if (a.relu) v = fmaxf(v, 0.f);
+            v = fminf(fmaxf(v, -65504.f), 65504.f);
+            hi[e] = (_Float16)v;
+            lo[e] = (_Float16)(v - (float)hi[e]);
+          }
+          *reinterpret_cast<half4*>(Hh + (size_t)m * CS * 2 + cl) = hi;
+          *reinterpret_cast<half4*>(Hh + (size_t)m * CS * 2 + BN + cl) = lo;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {   // W2: 64 rows x BN floats, row-linear copy
+        const int idx = tid + it * NT;
+        *reinterpret_cast<f32x4*>(&W2s[(idx / (BN / 4)) * CS + 4 * (idx % (BN / 4))]) = w2r[it];
+      }
+      __syncthreads();
+      // ---- stage 2: out2[pixel][n2] = sum_k h[pixel][k] * W2[n2][k], split-f16 x3
+#pragma unroll
+      for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[wm][0][r] = 0.f;
+      const int n2 = wave_n * 32 + eli;
+#pragma unroll
+      for (int s2 = 0; s2 < BN / 16; ++s2) {
+        const half8 bh = *reinterpret_cast<const half8*>(&W2s[n2 * CS + 8 * s2 + 4 * elh]);
+        const half8 bl = *reinterpret_cast<const half8*>(&W2s[n2 * CS + BN / 2 + 8 * s2 + 4 * elh]);
+#pragma unroll
+        for (int wm = 0; wm < WTM; ++wm) {
+          const int m = (wave_m * WTM + wm) * 32 + eli;
+          const half8 ah = *reinterpret_cast<const half8*>(&smem[m * CS + 8 * s2 + 4 * elh]);
+          const half8 al = *reinterpret_cast<const half8*>(&smem[m * CS + BN / 2 + 8 * s2 + 4 * elh]);
+          acc[wm][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[wm][0], 0, 0, 0);
+          acc[wm][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[wm][0], 0, 0, 0);
+          acc[wm][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[wm][0], 0, 0, 0);
+        }
+      }
+      __syncthreads();   // h and W2 have been read by every wave
+      // ---- stage 2 affine (+ReLU) -> fp32 rows [pixel][64] in LDS
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cl = wave_n * 32 + 8 * g + 4 * elh;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cl + e < a.c_out2) { sc[e] = a.scale2[cl + e]; sh[e] = a.shift2[cl + e]; }
+#pragma unroll
+        for (int wm = 0; wm < WTM; ++wm) {
+          const int m = (wave_m * WTM + wm) * 32 + eli;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[wm][0][4 * g + e] * sc[e] + sh[e];
+            if (a.relu2) v[e] = fmaxf(v[e], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(&smem[m * CS + cl]) = v;
+        }
+      }
+      __syncthreads();
+      // ---- row-major stores; columns [0, split2) -> out (ldo), the rest -> out_b (ldo_b)
+      const int nc4 = a.c_out2 >> 2, sp4 = a.split2 >> 2;
+      const size_t img_px = (size_t)tc.img * a.h_out * a.w_out;
+      for (int idx = t; idx < T::BM * nc4; idx += NT) {
+        const int m = idx / nc4, c4 = idx % nc4;
+        const int oy = tc.oy0 + m / TW, ox = tc.ox0 + m % TW;
+        if (oy < a.h_out && ox < a.w_out) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&smem[m * CS + 4 * c4]);
+          const size_t px = img_px + (size_t)oy * a.w_out + ox;
+          if (c4 < sp4) *reinterpret_cast<f32x4*>(a.out + px * a.ldo + 4 * c4) = v;
+          else *reinterpret_cast<f32x4*>(a.out_b + px * a.ldo_b + 4 * (c4 - sp4)) = v;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int wn = 0; wn < WTN; ++wn) {
 #pragma unroll
@@ -668,10 +779,12 @@ __global__ void fold_bn_kernel(const float* bias, const float* gamma, const floa
 }
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int ABL = 0, int MATH = 0>
+          int WTM, int WTN, int ABL = 0, int MATH = 0, int POST = 0>
 int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   using T = ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>;
-  auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN, ABL, MATH>;
+  auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN, ABL, MATH, POST>;
+  static_assert(POST == 0 || (size_t)(T::BM + 64) * T::CS * sizeof(float) <= T::LDS_BYTES,
+                "fused stage does not fit the tile's LDS");
   static_assert(T::LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   // opt in to > 64 KiB of dynamic LDS once per instantiation (idempotent; a race
   // between two first callers only repeats the same attribute write)
@@ -704,7 +817,9 @@ int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
     return e ? atoi(e) : -1;
   }();
   const int pmode = persist_env >= 0 ? persist_env : g_persist;
-  const bool persist = pmode == 2 || (pmode == 1 && T::BM == 256 && a.nchunks >= 2 && a.nchunks <= 4);
+  // fused-1x1 launches: short tiles with a long epilogue and per-workgroup weight registers
+  const bool persist = pmode == 2 || (pmode == 1 && (POST != 0 || T::BM == 256) && a.nchunks >= 2 &&
+                                      a.nchunks <= 4);
   dim3 grid((unsigned)((persist && total > resident) ? resident : total));
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, stream, a);
   return dn::check_launch("conv_mfma_kernel");
@@ -745,14 +860,71 @@ extern "C" int dn_fold_bn(const float* bias, const float* gamma, const float* be
   return dn::check_launch("fold_bn_kernel");
 }
 
-extern "C" int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* src1,
-                         const float* packed, const float* scale, const float* shift,
-                         float* out, void* stream) {
+namespace {
+
+__global__ void pack_post1x1_kernel(const float* __restrict__ w2, _Float16* __restrict__ out,
+                                    int c_out2, int c_in2) {
+  // [64 rows][64 hi halves | 64 lo halves]; rows >= c_out2 / columns >= c_in2 are zero
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 64 * 64) return;
+  const int n = idx / 64, k = idx % 64;
+  float v = (n < c_out2 && k < c_in2) ? w2[(size_t)n * c_in2 + k] : 0.f;
+  v = fminf(fmaxf(v, -65504.f), 65504.f);
+  const _Float16 hi = (_Float16)v;
+  out[n * 128 + k] = hi;
+  out[n * 128 + 64 + k] = (_Float16)(v - (float)hi);
+}
+
+int fill_args(const dn_conv_desc* d, const float* src0, const float* src1, const float* packed,
+              const float* scale, const float* shift, float* out, ConvArgs& a);
+
+}  // namespace
+
+extern "C" size_t dn_post1x1_packed_floats(void) { return 64 * 64; }
+
+extern "C" int dn_post1x1_pack_weights(const float* w2, int c_out2, int c_in2, float* packed,
+                                       void* stream) {
+  DN_REQUIRE(w2 && packed, "post1x1 pack: null pointer");
+  DN_REQUIRE(c_out2 > 0 && c_out2 <= 64 && c_in2 > 0 && c_in2 <= 64,
+             "post1x1 pack: c_out2 %d / c_in2 %d must be in 1..64", c_out2, c_in2);
+  hipLaunchKernelGGL(pack_post1x1_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, w2,
+                     reinterpret_cast<_Float16*>(packed), c_out2, c_in2);
+  return dn::check_launch("pack_post1x1_kernel");
+}
+
+extern "C" int dn_conv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p,
+                                 const float* src0, const float* src1, const float* packed,
+                                 const float* scale, const float* shift, const float* packed2,
+                                 const float* scale2, const float* shift2, float* out_a,
+                                 float* out_b, void* stream) {
   if (int rc = validate(d)) return rc;
-  DN_REQUIRE(src0 && packed && scale && shift && out, "conv: null pointer");
-  DN_REQUIRE(d->c1 == 0 || src1, "conv: c1 > 0 but src1 is null");
-  const Cfg c = select_cfg(*d);
+  DN_REQUIRE(p && src0 && packed && scale && shift && packed2 && scale2 && shift2 && out_a,
+             "conv+1x1: null pointer");
+  DN_REQUIRE(d->math == 1 && d->ksize == 3 && d->stride == 1 && d->c_out == 64,
+             "conv+1x1: needs the split-f16 3x3 stride-1 path with 64 output channels");
+  DN_REQUIRE(p->c_out2 > 0 && p->c_out2 <= 64 && p->c_out2 % 4 == 0 && p->split % 4 == 0 &&
+                 p->split > 0 && p->split <= p->c_out2,
+             "conv+1x1: c_out2 %d / split %d must be multiples of 4, split in (0, c_out2]",
+             p->c_out2, p->split);
+  DN_REQUIRE(p->ldo_a >= p->split && p->ldo_a % 4 == 0, "conv+1x1: bad ldo_a");
+  DN_REQUIRE(p->split == p->c_out2 || (out_b && p->ldo_b >= p->c_out2 - p->split && p->ldo_b % 4 == 0),
+             "conv+1x1: second output missing or too narrow");
+  auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  DN_REQUIRE(aligned16(out_a) && aligned16(packed2) && (!out_b || aligned16(out_b)),
+             "conv+1x1: outputs / packed2 must be 16-byte aligned");
   ConvArgs a;
+  if (int rc = fill_args(d, src0, src1, packed, scale, shift, out_a, a)) return rc;
+  a.ldo = p->ldo_a;
+  a.w2 = packed2; a.scale2 = scale2; a.shift2 = shift2; a.out_b = out_b;
+  a.c_out2 = p->c_out2; a.relu2 = p->relu2; a.split2 = p->split; a.ldo_b = p->ldo_b;
+  return launch<3, 1, 8, 16, 64, 16, 2, 2, 2, 1, 0, 1, 1>(a, *d, (hipStream_t)stream);
+}
+
+namespace {
+
+// common argument set-up of dn_conv2d / dn_conv2d_post1x1
+int fill_args(const dn_conv_desc* d, const float* src0, const float* src1, const float* packed,
+              const float* scale, const float* shift, float* out, ConvArgs& a) {
   a.src0 = src0; a.src1 = src1; a.wpk = packed; a.scale = scale; a.shift = shift; a.out = out;
   a.n_images = d->n_images; a.h_in = d->h_in; a.w_in = d->w_in;
   a.h_out = out_dim(d->h_in, d->ksize, d->stride);
@@ -761,6 +933,8 @@ extern "C" int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* 
   a.ld0 = d->ld0; a.ld1 = d->ld1; a.ldo = d->ldo;
   a.cout_pad = cout_pad_of(*d);
   a.wpk_bytes = (int)(dn_conv_packed_weight_floats(d) * sizeof(float));
+  a.w2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out_b = nullptr;
+  a.c_out2 = 0; a.relu2 = 0; a.split2 = 0; a.ldo_b = 0;
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec0 = (d->c0 % 4 == 0 && d->ld0 % 4 == 0 && aligned16(src0)) ? 1 : 0;
   a.vec1 = (d->c1 > 0 && d->c1 % 4 == 0 && d->ld1 % 4 == 0 && aligned16(src1)) ? 1 : 0;
@@ -771,6 +945,20 @@ extern "C" int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* 
   DN_REQUIRE(hs0 * ws0 * d->ld0 * 4 < (1ull << 31) &&
                  (size_t)d->h_in * d->w_in * (d->c1 ? d->ld1 : 1) * 4 < (1ull << 31),
              "conv: one image must stay below 2 GiB");
+  return DN_OK;
+}
+
+}  // namespace
+
+extern "C" int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* src1,
+                         const float* packed, const float* scale, const float* shift,
+                         float* out, void* stream) {
+  if (int rc = validate(d)) return rc;
+  DN_REQUIRE(src0 && packed && scale && shift && out, "conv: null pointer");
+  DN_REQUIRE(d->c1 == 0 || src1, "conv: c1 > 0 but src1 is null");
+  const Cfg c = select_cfg(*d);
+  ConvArgs a;
+  if (int rc = fill_args(d, src0, src1, packed, scale, shift, out, a)) return rc;
   hipStream_t s = (hipStream_t)stream;
 #define DN_CONV_CASE(ID, ...)                                                         \
   case ID:                                                                            \

@@ -150,6 +150,40 @@ class _ConvLayer:
             return ops.conv2d(d, src0, self.packed, self.scale, self.shift, src1=src1, out=out)
 
 
+class _ConvPostLayer:
+    """A 3x3 conv (64 channels) + affine + ReLU fused with a following 1x1 stage
+    (dn_conv2d_post1x1): split-f16 math only.  out_a gets columns [0, split) of the
+    1x1 stage, out_b the rest (two-headed use) -- or everything goes to out_a."""
+
+    def __init__(self, name, weight, scale, shift, w2, scale2, shift2, split, relu2):
+        self.name = name
+        self.c_out, self.c_in = weight.shape[0], weight.shape[1]
+        assert self.c_out == 64
+        d = ops.conv_desc(1, 8, 8, self.c_in, 64, 3, 1, True, math=1)
+        self.packed = ops.pack_conv_weights(d, weight)
+        self.scale, self.shift = scale.contiguous(), shift.contiguous()
+        self.c_out2, self.split, self.relu2 = w2.shape[0], split, relu2
+        self.packed2 = ops.pack_post1x1_weights(w2)
+        self.scale2, self.shift2 = scale2.contiguous(), shift2.contiguous()
+
+    def run(self, src0):
+        n, h, w, c0 = src0.shape
+        assert c0 == self.c_in
+        d = ops.conv_desc(n, h, w, c0, 64, 3, 1, True, math=1)
+        out_a = torch.empty((n, h, w, self.split), dtype=torch.float32, device=src0.device)
+        out_b = None
+        if self.split < self.c_out2:
+            out_b = torch.empty((n, h, w, self.c_out2 - self.split), dtype=torch.float32,
+                                device=src0.device)
+        flops = 2.0 * n * h * w * (64 * self.c_in * 9 + self.c_out2 * 64)
+        nbytes = 4.0 * (src0.numel() + n * h * w * self.c_out2)
+        with region(self.name, "conv_mfma_kernel", flops, nbytes):
+            ops.conv2d_post1x1(d, src0, self.packed, self.scale, self.shift, self.packed2,
+                               self.scale2, self.shift2, self.c_out2, self.split, self.relu2,
+                               out_a, out_b)
+        return out_a, out_b
+
+
 class DiscoNet(nn.Module):
     def __init__(self, config, layer=3, in_channels=13, kd_flag=True, num_agent=5,
                  compress_level=0, only_v2i=False):
@@ -179,6 +213,8 @@ class DiscoNet(nn.Module):
         # MFMA at half the throughput.  Not a constructor argument so the reference's signature
         # is untouched: set model.conv_math or DISCONET_CONV_MATH before the first forward.
         self.conv_math = os.environ.get("DISCONET_CONV_MATH", "f16x3")
+        # fold the 1x1 layers that follow a 64-channel 3x3 conv into that conv's launch
+        self.fuse_1x1 = os.environ.get("DISCONET_FUSE_1X1", "1") != "0"
 
     # ------------------------------------------------------------------
     # checkpoint compatibility
@@ -214,7 +250,7 @@ class DiscoNet(nn.Module):
     def _signature(self):
         if self.conv_math not in ops.MATH_MODES:
             raise ValueError("conv_math must be one of %s" % sorted(ops.MATH_MODES))
-        return (self.conv_math,) + tuple((t.data_ptr(), t._version) for t in
+        return (self.conv_math, self.fuse_1x1) + tuple((t.data_ptr(), t._version) for t in
                                          list(self.parameters()) + list(self.buffers()))
 
     def _build_plan(self):
@@ -244,6 +280,26 @@ class DiscoNet(nn.Module):
         P["cls2"] = _Layer("cls2", cls.conv2.weight, cls.conv2.bias, None, 1, relu=False)
         P["reg1"] = _Layer("reg1", reg[0].weight, reg[0].bias, reg[1], 3)
         P["reg2"] = _Layer("reg2", reg[3].weight, reg[3].bias, None, 1, relu=False)
+
+        if math == 1 and self.fuse_1x1:
+            # split-f16 only: 1x1 layers ride in the epilogue of the 3x3 conv before them
+            dev = cls.conv1.weight.device
+            n_cls, n_reg = cls.conv2.weight.shape[0], reg[3].weight.shape[0]
+            if n_cls % 4 == 0 and n_reg % 4 == 0 and n_cls + n_reg <= 64:
+                w1 = torch.cat([cls.conv1.weight, reg[0].weight], 0).detach()
+                w2 = torch.zeros(n_cls + n_reg, 64, device=dev)
+                w2[:n_cls, :32] = cls.conv2.weight.detach().reshape(n_cls, 32)
+                w2[n_cls:, 32:] = reg[3].weight.detach().reshape(n_reg, 32)
+                P["heads_fused"] = _ConvPostLayer(
+                    "heads", w1, torch.cat([P["cls1"].scale, P["reg1"].scale]),
+                    torch.cat([P["cls1"].shift, P["reg1"].shift]), w2,
+                    torch.ones(n_cls + n_reg, device=dev),
+                    torch.cat([cls.conv2.bias, reg[3].bias]).detach().float(), n_cls, False)
+            c3 = enc.conv3d_1
+            s3, t3 = ops.fold_bn(c3.conv3d.bias, c3.bn3d, 64)
+            P["conv1_2_3d"] = _ConvPostLayer(
+                "conv1_2+3d", enc.conv1_2.weight.detach(), P["conv1_2"].scale, P["conv1_2"].shift,
+                c3.conv3d.weight.detach().reshape(64, 64), s3, t3, 64, True)
 
         # attention MLP: layer 1 split W1 = [W1_ego | W1_nbr] (see fuse_tail.hip)
         f = self.pixel_weighted_fusion
@@ -294,7 +350,10 @@ class DiscoNet(nn.Module):
             x = x.float().contiguous()
         x = P["conv_pre_1"].run(x)
         x0 = P["conv_pre_2"].run(x)
-        x1 = P["conv3d_1"].run(P["conv1_2"].run(P["conv1_1"].run(x0)))
+        if "conv1_2_3d" in P:
+            x1 = P["conv1_2_3d"].run(P["conv1_1"].run(x0))[0]
+        else:
+            x1 = P["conv3d_1"].run(P["conv1_2"].run(P["conv1_1"].run(x0)))
         x2 = P["conv3d_2"].run(P["conv2_2"].run(P["conv2_1"].run(x1)))
         x3 = P["conv3_2"].run(P["conv3_1"].run(x2))
         x4 = P["conv4_2"].run(P["conv4_1"].run(x3))
@@ -337,8 +396,11 @@ class DiscoNet(nn.Module):
         return x8, x7, x6, x5
 
     def heads(self, x8, P):
-        cls = P["cls2"].run(P["cls1"].run(x8))          # [N, H, W, A_loc*cat]  (NHWC: the
-        loc = P["reg2"].run(P["reg1"].run(x8))          #  reference's permute(0,2,3,1) is free)
+        if "heads_fused" in P:                          # conv1 of both heads + both conv2, one launch
+            cls, loc = P["heads_fused"].run(x8)
+        else:
+            cls = P["cls2"].run(P["cls1"].run(x8))      # [N, H, W, A_loc*cat]  (NHWC: the
+            loc = P["reg2"].run(P["reg1"].run(x8))      #  reference's permute(0,2,3,1) is free)
         n, h, w = cls.shape[0], cls.shape[1], cls.shape[2]
         cls_preds = cls.view(n, -1, self.category_num)
         loc_preds = loc.view(n, h, w, self.anchor_num_per_loc, self.out_seq_len, self.box_code_size)

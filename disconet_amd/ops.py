@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, MlpTailParams, check
+from ._lib import ConvDesc, MlpTailParams, Post1x1Desc, check
 
 
 def _ptr(t):
@@ -151,6 +151,32 @@ def conv2d(d, src0, packed, scale, shift, src1=None, out=None):
     check(_lib.load().dn_conv2d(ctypes.byref(d), _ptr(src0), _ptr(src1), _ptr(packed), _ptr(scale),
                                 _ptr(shift), _ptr(out), _stream()), "dn_conv2d")
     return out
+
+
+def pack_post1x1_weights(weight):
+    """weight [c_out2, c_in2(, 1, 1)] -> packed split-f16 rows for dn_conv2d_post1x1."""
+    _need_gpu(weight)
+    w = weight.detach().reshape(weight.shape[0], -1).contiguous().float()
+    lib = _lib.load()
+    packed = torch.empty(lib.dn_post1x1_packed_floats(), dtype=torch.float32, device=weight.device)
+    check(lib.dn_post1x1_pack_weights(_ptr(w), w.shape[0], w.shape[1], _ptr(packed), _stream()),
+          "dn_post1x1_pack_weights")
+    return packed
+
+
+def conv2d_post1x1(d, src0, packed, scale, shift, packed2, scale2, shift2, c_out2, split, relu2,
+                   out_a, out_b=None, src1=None):
+    """3x3 conv (64 ch) + affine + ReLU fused with a 1x1 stage; writes out_a (and out_b)."""
+    _need_gpu(src0, packed, packed2, out_a)
+    p = Post1x1Desc()
+    p.c_out2, p.relu2, p.split = c_out2, int(bool(relu2)), split
+    p.ldo_a = out_a.shape[-1]
+    p.ldo_b = out_b.shape[-1] if out_b is not None else 0
+    check(_lib.load().dn_conv2d_post1x1(ctypes.byref(d), ctypes.byref(p), _ptr(src0), _ptr(src1),
+                                        _ptr(packed), _ptr(scale), _ptr(shift), _ptr(packed2),
+                                        _ptr(scale2), _ptr(shift2), _ptr(out_a), _ptr(out_b),
+                                        _stream()), "dn_conv2d_post1x1")
+    return out_a, out_b
 
 
 # ---------------------------------------------------------------------------

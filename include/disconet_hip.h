@@ -111,6 +111,28 @@ int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* src1,
               const float* packed, const float* scale, const float* shift,
               float* out, void* stream);
 
+/* Fused "3x3 conv + affine + ReLU, then 1x1 conv + affine (+ReLU)" in one launch:
+ * the activated 64-channel tile stays in LDS between the two layers.  Used for
+ * the detection heads (conv1 of the cls and reg heads as one 64-channel conv,
+ * their 1x1 conv2 as one block-diagonal second stage with two outputs) and for
+ * conv*_2 + the (1,1,1) Conv3D of the encoder -- upstream ClassificationHead /
+ * SingleRegressionHead / Backbone.encode.  Split-f16 math,
+ * 3x3 stride 1, c_out == 64 only.  Columns [0, split) of the second stage go to
+ * out_a (pixel stride ldo_a), columns [split, c_out2) to out_b (ldo_b). */
+typedef struct dn_post1x1_desc {
+  int32_t c_out2;        /* outputs of the 1x1 stage, multiple of 4, <= 64 */
+  int32_t relu2;
+  int32_t split;         /* multiple of 4; == c_out2 for a single output */
+  int32_t ldo_a, ldo_b;
+} dn_post1x1_desc;
+size_t dn_post1x1_packed_floats(void);
+/* w2: [c_out2][c_in2] float32, c_in2 <= 64 = channels of the first stage */
+int dn_post1x1_pack_weights(const float* w2, int c_out2, int c_in2, float* packed, void* stream);
+int dn_conv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p, const float* src0,
+                      const float* src1, const float* packed, const float* scale,
+                      const float* shift, const float* packed2, const float* scale2,
+                      const float* shift2, float* out_a, float* out_b, void* stream);
+
 /* ------------------------------------------------------------------------
  * K4 -- pose-based two-pass bilinear warp of neighbour feature maps.
  * Replaces upstream:coperception/models/det/base/* :: feature_transformation

@@ -119,3 +119,33 @@ def test_conv_rejects_bad_arguments():
         ops.pack_conv_weights(d, torch.zeros(32, 32, 5, 5, device="cuda"))
     with pytest.raises(_lib.DnError):
         ops.conv2d(ops.conv_desc(1, 8, 8, 32, 32, 3), torch.zeros(1, 8, 8, 32), None, None, None)
+
+
+@pytest.mark.parametrize("c_in,c_out2,split,relu2", [(32, 48, 12, False), (64, 64, 64, True),
+                                                     (96, 8, 4, False)])
+def test_conv3x3_fused_1x1_stage(c_in, c_out2, split, relu2):
+    """dn_conv2d_post1x1: 3x3 conv (64 ch) + affine + ReLU, then 1x1 + affine (+ReLU),
+    one or two outputs, vs the two torch ops"""
+    from disconet_amd import ops
+    g = torch.Generator().manual_seed(4)
+    n, h, w = 3, 40, 24                      # not a multiple of the 8x16 tile
+    x = torch.randn(n, c_in, h, w, generator=g)
+    w1 = torch.randn(64, c_in, 3, 3, generator=g) * (2.0 / (c_in * 9)) ** 0.5
+    s1, t1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    w2 = torch.randn(c_out2, 64, generator=g) * (2.0 / 64) ** 0.5
+    s2, t2 = torch.rand(c_out2, generator=g) + 0.5, torch.randn(c_out2, generator=g) * 0.1
+    hmid = F.relu(F.conv2d(x, w1, None, padding=1) * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1))
+    y = F.conv2d(hmid, w2.view(c_out2, 64, 1, 1)) * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1)
+    if relu2:
+        y = F.relu(y)
+    d = ops.conv_desc(n, h, w, c_in, 64, 3, 1, True, math="f16x3")
+    packed = ops.pack_conv_weights(d, w1.cuda())
+    packed2 = ops.pack_post1x1_weights(w2.cuda())
+    out_a = torch.empty(n, h, w, split, device="cuda")
+    out_b = torch.empty(n, h, w, c_out2 - split, device="cuda") if split < c_out2 else None
+    ops.conv2d_post1x1(d, x.permute(0, 2, 3, 1).contiguous().cuda(), packed, s1.cuda(), t1.cuda(),
+                       packed2, s2.cuda(), t2.cuda(), c_out2, split, relu2, out_a, out_b)
+    torch.cuda.synchronize()
+    got = out_a.cpu() if out_b is None else torch.cat([out_a.cpu(), out_b.cpu()], -1)
+    err = (got.permute(0, 3, 1, 2) - y).abs().max().item()
+    assert err <= TOL, "max abs err %.3e" % err

@@ -140,3 +140,23 @@ def test_agent_count_edges(agents, live):
     for name, w in (("cls", res["cls"]), ("loc", res["loc"]), ("fused", fused)):
         err = (got[name] - w).abs().max().item()
         assert err <= TOL, "A=%d live=%s %s max abs err %.3e" % (agents, live, name, err)
+
+
+def test_fused_1x1_layers_match_unfused():
+    """split-f16: the launches that fold a 1x1 layer into the preceding conv give the
+    same result as the separate launches (same arithmetic up to the order of one sum)"""
+    from disconet_amd import Config, DiscoNet
+    from disconet_amd.synthetic import make_scene_batch
+    ref = cases.ref_model(128, 3)
+    bevs, trans, na = make_scene_batch(2, 3, 128, jitter_seed=2)
+    outs = []
+    for fuse in (True, False):
+        m = DiscoNet(Config(map_hw=128), kd_flag=0, num_agent=3).eval()
+        m.load_state_dict(ref.state_dict())
+        m.fuse_1x1 = fuse
+        m.cuda()
+        with torch.no_grad():
+            outs.append(m(bevs.cuda(), trans.cuda(), na.cuda(), 2))
+        assert ("heads_fused" in m._plan) == fuse
+    for k in ("cls", "loc"):
+        assert (outs[0][k] - outs[1][k]).abs().max().item() <= 2e-5
