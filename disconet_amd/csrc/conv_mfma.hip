@@ -129,7 +129,8 @@ struct ConvTile {
 // ABL != 0 builds ablation variants for tools/conv_ablate.hip only (the product
 // always launches ABL = 0): 1 = no steady-state global loads / LDS stores /
 // barriers, 3 = no epilogue stores, 5 = 1 + 3 + MFMA operands from registers
-// (pure MFMA stream).
+// (pure MFMA stream), 8 = split-f16 staging without the fp32 -> hi/lo conversion
+// (what a pre-split activation format would cost).
 template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int WAVES_N,
           int WTM, int WTN, int ABL = 0, int MATH = 0, int POST = 0>
 __global__ void __launch_bounds__(
@@ -319,7 +320,13 @@ conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < T::A_IT; ++it) {
       const int idx = tid + it * NT;
-      if (kSplit) {
+      if (kSplit && ABL == 8) {   // ablation: staging without the fp32 -> hi/lo split
+        if (idx < T::A_VEC) {
+          float* rowp = &As[(idx / KV) * PS];
+          *reinterpret_cast<f32x2*>(rowp + 2 * (idx % KV)) = f32x2{ra[it][0], ra[it][1]};
+          *reinterpret_cast<f32x2*>(rowp + KC / 2 + 2 * (idx % KV)) = f32x2{ra[it][2], ra[it][3]};
+        }
+      } else if (kSplit) {
         // x = hi + lo, hi = half(x) (clamped to the finite fp16 range), lo = half(x - hi);
         // row layout [KC hi halves | KC lo halves]: slot q owns halves 4q..4q+3 of each part
         half4 hi, lo;
@@ -661,7 +668,7 @@ struct Cfg {
 // staging per workgroup decide: the narrow 32-channel tile wins for deep layers.
 const Cfg kCfgs[CFG_COUNT] = {
     {T3_256x32, 8, 32, 32, {1.00f, 1.00f}},   {T3_256x64, 8, 32, 64, {1.00f, 0.90f}},
-    {T3_128x64, 8, 16, 64, {1.00f, 1.04f}},   {T3_64x64, 8, 8, 64, {1.10f, 1.36f}},
+    {T3_128x64, 8, 16, 64, {1.00f, 1.04f}},   {T3_64x64, 8, 8, 64, {1.10f, 1.45f}},
     {T3S2_64x64, 8, 8, 64, {1.00f, 1.00f}},   {T1_256x32, 8, 32, 32, {1.00f, 1.00f}},
     {T1_256x64, 8, 32, 64, {1.00f, 1.00f}},   {T1_128x128, 8, 16, 128, {1.00f, 1.00f}},
     {T1_64x64, 8, 8, 64, {1.00f, 1.00f}},

@@ -9,14 +9,14 @@
 
 struct Bufs { float *s0, *s1, *wp, *sc, *sh, *out; };
 
-template <int KS, int S, int TH, int TW, int BN, int KC, int WM, int WN, int WTM, int WTN, int MATH>
+template <int KS, int S, int TH, int TW, int BN, int KC, int WM, int WN, int WTM, int WTN, int MATH, int ABL = 0>
 float time_tile(ConvArgs a, const dn_conv_desc& d) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) launch<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 0, MATH>(a, d, 0);
+  for (int i = 0; i < 3; ++i) launch<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, ABL, MATH>(a, d, 0);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
   const int iters = 10;
-  for (int i = 0; i < iters; ++i) launch<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 0, MATH>(a, d, 0);
+  for (int i = 0; i < iters; ++i) launch<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, ABL, MATH>(a, d, 0);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
   return ms / iters * 1e3f;
@@ -40,6 +40,12 @@ void sweep(const char* name, int n, int h, int w, int c0, int c1, int up0, int c
     t = time_tile<3, 1, 8, 16, 128, 8, 2, 2, 2, 2, MATH>(a, d);  printf("  128x128 %6.1f", t);
     t = time_tile<3, 1, 8, 16, 64, 16, 2, 2, 2, 1, MATH>(a, d);  printf("  128x64 %6.1f", t);
     t = time_tile<3, 1, 8, 8, 64, 16, 2, 2, 1, 1, MATH>(a, d);   printf("  64x64 %6.1f", t);
+    if (MATH == 1) {
+      t = time_tile<3, 1, 8, 32, 32, 16, 4, 1, 2, 1, 1, 8>(a, d);  printf("  | no-split-VALU: 256x32 %6.1f", t);
+      t = time_tile<3, 1, 8, 32, 64, 16, 4, 1, 2, 2, 1, 8>(a, d);  printf("  256x64 %6.1f", t);
+      t = time_tile<3, 1, 8, 32, 32, 16, 4, 1, 2, 1, 1, 1>(a, d);  printf("  | no-stream: 256x32 %6.1f", t);
+      t = time_tile<3, 1, 8, 32, 32, 16, 4, 1, 2, 1, 1, 3>(a, d);  printf("  | no-store: 256x32 %6.1f", t);
+    }
   } else {
     float t;
     t = time_tile<3, 2, 8, 16, 64, 8, 2, 2, 2, 1, MATH>(a, d);   printf("  s2 128x64/kc8 %6.1f", t);
