@@ -384,6 +384,23 @@ def main():
                     got = model(bevs1.cuda(), trans1.cuda(), na1.cuda(), 1)
                 base["parity_max_abs_err"] = {k: float((got[k].cpu() - ref_out[k]).abs().max())
                                               for k in ("cls", "loc")}
+                # the metric's accuracy half: mAP of the HIP path's detections scored against
+                # the oracle's detections on the same scene (decode + rotated NMS both ways)
+                try:
+                    from oracle import postprocess_ref as R
+                    from disconet_amd import postprocess
+                    cfg = Config(map_hw=MAP_HW)
+                    anchors_np = R.make_anchors(cfg)
+                    gts = [R.detections_from_logits(ref_out["cls"][i].numpy(), ref_out["loc"][i].numpy(),
+                                                    anchors_np, pre_nms_top_k=200)[0] for i in range(AGENTS)]
+                    dets = postprocess.predict_all(model, postprocess.make_anchors(cfg), bevs1.cuda(),
+                                                   trans1.cuda(), na1.cuda(), 1, pre_nms_top_k=200)
+                    base["map_vs_oracle_detections"] = {
+                        "mAP@0.5": round(R.average_precision([d[0] for d in dets], [d[1] for d in dets], gts, 0.5), 4),
+                        "mAP@0.7": round(R.average_precision([d[0] for d in dets], [d[1] for d in dets], gts, 0.7), 4),
+                        "note": "random-init weights: the oracle's own detections are the ground truth"}
+                except Exception as e:   # never lose the bench line to the accuracy add-on
+                    base["map_vs_oracle_detections"] = {"error": repr(e)}
             result["cpu_baseline"] = base
         print(json.dumps(result), flush=True)
 

@@ -6,7 +6,8 @@ module raises.  The library is built in-tree by disconet_amd/csrc/build.py
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t,
+                    c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdisconet_hip.so")
@@ -54,6 +55,8 @@ SIGNATURES = {
     "dn_post1x1_packed_floats": (c_size_t, []),
     "dn_post1x1_pack_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dn_conv2d_post1x1": (c_int, [POINTER(ConvDesc), POINTER(Post1x1Desc)] + [c_void_p] * 11),
+    "dn_decode_boxes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p,
+                                c_void_p]),
     "dn_warp_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_void_p, c_void_p]),
     "dn_disco_fuse_tail": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -187,6 +187,18 @@ int dn_disco_fuse_tail(const float* feat, const float* warped, const float* g,
                        float* weights_out, /* <- may be NULL; [B][ego_count][A][hw] softmax
                        weights in neighbour-list order */ void* stream);
 
+/* ------------------------------------------------------------------------
+ * Detection decode (first step after the hot path).
+ * Replaces the dense part of upstream:coperception/utils/postprocess.py that
+ * CoDetModule.predict_all runs on the CPU: foreground probability = softmax of
+ * the 2 class logits, box = anchor-relative decode of the 6-value code
+ * (x, y, w, h, sin, cos).  NMS / mAP stay on the CPU as in the reference.
+ *   cls [n_images][anchors_per_image][2], loc [n_images][anchors_per_image][6],
+ *   anchors [anchors_per_image][6] -> scores [n][apl], boxes [n][apl][6]
+ * ------------------------------------------------------------------------ */
+int dn_decode_boxes(const float* cls, const float* loc, const float* anchors, int n_images,
+                    long anchors_per_image, float* scores, float* boxes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
