@@ -146,6 +146,8 @@ conv_mfma_kernel(const ConvArgs a) {
   constexpr bool kNoStream = ABL == 1 || ABL == 5;
   constexpr bool kNoStore = ABL == 3 || ABL == 5;
   constexpr bool kNoLds = ABL == 5;
+  constexpr bool kNoBStage = ABL == 9;    // steady state without weight staging
+  constexpr bool kNoAStage = ABL == 10;   // steady state without activation staging
   using T = ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>;
   constexpr int NT = T::NT, PW = T::PW, PS = T::PS, TAPS = T::TAPS, KV = T::KV, KCP = T::KCP;
   constexpr int ROWS_PER_IT = NT / KV;   // weight rows one staging iteration covers
@@ -289,7 +291,8 @@ conv_mfma_kernel(const ConvArgs a) {
   auto load_chunk = [&](const TileCoord& tc, int ch) {
     const int cbeg = ch * KC;
     if (ch == src_switch) setup_voff_a(tc, true);
-    if (cbeg < a.c0) {
+    if (kNoAStage && ch > 0) {
+    } else if (cbeg < a.c0) {
       const int soff = cbeg * 4;
       if (a.vec0) {
 #pragma unroll
@@ -312,13 +315,15 @@ conv_mfma_kernel(const ConvArgs a) {
     // sub-row (ch % (KCP/KC)) of rows n0..n0+BN
     // sub-chunk inside a packed chunk: KC floats on for fp32 rows, KC halves on for split rows
     const int wsoff = (cbeg / KCP) * TAPS * a.cout_pad * KCP * 4 + (cbeg % KCP) * (kSplit ? 2 : 4);
+    if (!(kNoBStage && ch > 0)) {
 #pragma unroll
-    for (int it = 0; it < T::B_IT; ++it) rb[it] = ld128(rsrcw, voff_b, wsoff + it * b_step);
+      for (int it = 0; it < T::B_IT; ++it) rb[it] = ld128(rsrcw, voff_b, wsoff + it * b_step);
+    }
   };
 
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](bool steady = false) {
 #pragma unroll
-    for (int it = 0; it < T::A_IT; ++it) {
+    for (int it = 0; it < (kNoAStage && steady ? 0 : T::A_IT); ++it) {
       const int idx = tid + it * NT;
       if (kSplit && ABL == 8) {   // ablation: staging without the fp32 -> hi/lo split
         if (idx < T::A_VEC) {
@@ -346,7 +351,7 @@ conv_mfma_kernel(const ConvArgs a) {
       }
     }
 #pragma unroll
-    for (int it = 0; it < T::B_IT; ++it) {
+    for (int it = 0; it < (kNoBStage && steady ? 0 : T::B_IT); ++it) {
       const int idx = tid + it * NT;
       if (idx < T::B_VEC) *reinterpret_cast<f32x4*>(&Bs[(idx / KV) * PS + 4 * (idx % KV)]) = rb[it];
     }
@@ -621,7 +626,7 @@ conv_mfma_kernel(const ConvArgs a) {
       mfma_chunk();
       if (stage && !last) {
         __syncthreads();   // every wave is done reading this chunk from LDS
-        store_chunk();
+        store_chunk(true);
         __syncthreads();
       }
     }

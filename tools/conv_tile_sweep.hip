@@ -45,6 +45,8 @@ void sweep(const char* name, int n, int h, int w, int c0, int c1, int up0, int c
       t = time_tile<3, 1, 8, 32, 64, 16, 4, 1, 2, 2, 1, 8>(a, d);  printf("  256x64 %6.1f", t);
       t = time_tile<3, 1, 8, 32, 32, 16, 4, 1, 2, 1, 1, 1>(a, d);  printf("  | no-stream: 256x32 %6.1f", t);
       t = time_tile<3, 1, 8, 32, 32, 16, 4, 1, 2, 1, 1, 3>(a, d);  printf("  | no-store: 256x32 %6.1f", t);
+      t = time_tile<3, 1, 8, 32, 32, 16, 4, 1, 2, 1, 1, 9>(a, d);  printf("  | no-B-stage: %6.1f", t);
+      t = time_tile<3, 1, 8, 32, 32, 16, 4, 1, 2, 1, 1, 10>(a, d); printf("  | no-A-stage: %6.1f", t);
     }
   } else {
     float t;
