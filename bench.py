@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="create the RCCL process group even for one rank (exercises the N>1 code path)")
     ap.add_argument("--cpu-baseline-child", nargs=3, metavar=("STATE", "OUT", "THREADS"),
                     help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -209,8 +211,12 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
+    use_pg = world > 1 or args.force_process_group
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.force_process_group and args.mode != "agent":
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29518", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank))
 
     if args.mode == "agent":
         return agent_sharded_bench(args, world, rank, dist)
@@ -241,11 +247,12 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
             torch.cuda.synchronize()
 
     graphed = {}
+    launch_mode = {"mode": "eager" if args.no_graph else "hipGraph replay"}
 
     def run_step():
         """One step for the un-instrumented region: a captured hipGraph of step() (the
@@ -255,7 +262,13 @@ def main():
         key = model.conv_math
         if key not in graphed:
             from disconet_amd.graph import GraphedStep
-            graphed[key] = GraphedStep(step)
+            try:
+                graphed[key] = GraphedStep(step)
+            except Exception as e:   # capture refused (driver / collective library state): run eagerly
+                print("bench: hipGraph capture failed (%r); launching eagerly" % (e,), file=sys.stderr)
+                torch.cuda.synchronize()
+                graphed[key] = step
+                launch_mode["mode"] = "eager (graph capture failed)"
         return graphed[key]()
 
     def timed(events):
@@ -327,7 +340,7 @@ def main():
     timer, elapsed_events = None, 0.0
     if rank == 0 and not args.no_kernel_events:
         elapsed_events, timer = timed(True)        # timed region #2 -> roofline
-    if world > 1:
+    if use_pg:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -351,7 +364,7 @@ def main():
                                "256x256x13 BEV, no KD, sparse voxel lists -> dense -> enc -> "
                                "DiscoGraph fusion -> dec -> cls/reg heads",
                    "agents": AGENTS, "batch_per_gpu": BATCH, "bev": [MAP_HW, MAP_HW, 13],
-                   "conv_math": args.math, "launch": "eager" if args.no_graph else "hipGraph replay",
+                   "conv_math": args.math, "launch": launch_mode["mode"],
                    "parallelism": "scene-parallel x%d (no data-path collective)" % world},
     }
 
@@ -404,7 +417,7 @@ def main():
             result["cpu_baseline"] = base
         print(json.dumps(result), flush=True)
 
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -27,7 +27,9 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads of the process (e.g. the RCCL watchdog of an
+        # initialised process group) may keep issuing HIP calls during the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.outputs = fn()
 
     def __call__(self):

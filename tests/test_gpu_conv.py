@@ -149,3 +149,35 @@ def test_conv3x3_fused_1x1_stage(c_in, c_out2, split, relu2):
     got = out_a.cpu() if out_b is None else torch.cat([out_a.cpu(), out_b.cpu()], -1)
     err = (got.permute(0, 3, 1, 2) - y).abs().max().item()
     assert err <= TOL, "max abs err %.3e" % err
+
+
+def test_conv_random_shapes_fuzz():
+    """seeded sweep over odd sizes / channel counts / modes: ragged tiles, channel tails
+    (c_in not a multiple of the chunk, c_out not a multiple of 4 or 32), 1x1 and 3x3,
+    stride 2, upsample+concat, both math modes"""
+    import random
+    rnd = random.Random(1234)
+    fails = []
+    for case in range(48):
+        k = rnd.choice([1, 3, 3])
+        stride = rnd.choice([1, 1, 2]) if k == 3 else 1
+        math = rnd.choice(MATHS)
+        n = rnd.randint(1, 3)
+        up0 = k == 3 and stride == 1 and rnd.random() < 0.3
+        h, w = rnd.randint(3, 40), rnd.randint(3, 70)
+        if up0:
+            h, w = 2 * ((h + 1) // 2), 2 * ((w + 1) // 2)
+        kcp = 16 if k == 3 else 32
+        if up0 or rnd.random() < 0.25:
+            c0 = rnd.choice([kcp, 2 * kcp, 4 * kcp])           # concat: c0 multiple of the packed chunk
+            c1 = rnd.choice([4, 8, 20, 32, 36])
+        else:
+            c0, c1 = rnd.choice([3, 13, 16, 24, 32, 40, 64, 100]), 0
+        c_out = rnd.choice([1, 6, 12, 32, 36, 64, 72, 100, 128])
+        relu, bn = rnd.random() < 0.7, rnd.random() < 0.7
+        try:
+            _run(n, h, w, c0, c_out, k, stride=stride, relu=relu, c1=c1, up0=up0, bn=bn,
+                 seed=100 + case, math=math)
+        except AssertionError as e:
+            fails.append((case, n, h, w, c0, c1, c_out, k, stride, up0, math, str(e)[:80]))
+    assert not fails, fails
