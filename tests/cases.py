@@ -81,3 +81,30 @@ def run_ref(case, model=None):
     with torch.no_grad():
         res, x8, x7, x6, x5, fused = model(bevs, trans, na, c["batch"])
     return {"cls": res["cls"], "loc": res["loc"], "x8": x8, "x5": x5, "fused": fused}
+
+
+# --- fusion block alone at the BASELINE map size: 5 agents x [256, 32, 32] ---------------
+def fusion_inputs(agents=5, c=256, hw=32, seed=21):
+    """post-ReLU-like maps (agent-major, B = 1), the synthetic poses and all agents live"""
+    g = torch.Generator().manual_seed(seed)
+    feat = torch.randn(agents, c, hw, hw, generator=g).clamp_(min=0)
+    from disconet_amd.synthetic import make_trans_matrices
+    return feat, make_trans_matrices(1, agents, jitter_seed=4), torch.full((1, agents), agents)
+
+
+def ref_fuse(model, feat, trans, na):
+    """the oracle's fusion loop on given layer-3 maps (encoder bypassed)"""
+    from oracle.disconet_ref import feature_transformation
+    A = model.agent_num
+    com = model.build_local_communication_matrix(feat, 1)
+    out = com.clone()
+    size = (1,) + tuple(feat.shape[1:])
+    with torch.no_grad():
+        for i in range(int(na[0, 0])):
+            nbrs = [com[0, i]] + [feature_transformation(0, j, com, trans[0, i], size)
+                                   for j in range(int(na[0, 0])) if j != i]
+            e = [torch.exp(torch.squeeze(model.pixel_weighted_fusion(
+                torch.cat([com[0, i], nb], 0).unsqueeze(0)))) for nb in nbrs]
+            ssum = sum(e)
+            out[0, i] = sum((ek / ssum) * nb for ek, nb in zip(e, nbrs))
+    return model.agents_to_batch(out)

@@ -61,6 +61,14 @@ def main():
             store["%s/%s_absmax" % (case, name)] = np.float32(t.abs().max())
         print("model", case, {k: tuple(v.shape) for k, v in outs.items()})
     np.savez_compressed(os.path.join(HERE, "model_cases.npz"), **store)
+
+    # 4. fusion block alone at the BASELINE map size (5 agents x [256, 32, 32])
+    model = cases.ref_model(256, 5)
+    feat, trans, na = cases.fusion_inputs()
+    fused = cases.ref_fuse(model, feat, trans, na)
+    np.savez_compressed(os.path.join(HERE, "fusion_5x256.npz"),
+                        fused=fused.numpy()[:, ::4, ::2, ::2], absmax=np.float32(fused.abs().max()))
+    print("fusion", tuple(fused.shape), float(fused.abs().max()))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

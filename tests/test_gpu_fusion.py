@@ -74,3 +74,21 @@ def test_identical_agents_identity_pose_fuse_to_themselves():
     na = torch.full((B,), A, dtype=torch.int32).cuda()
     fused = m.fuse(x, trans, na, B, m._get_plan())
     assert (fused - x).abs().max().item() <= 1e-5
+
+
+def test_fusion_block_at_baseline_map_size_vs_oracle_and_golden(golden_dir):
+    """5 agents x [256, 32, 32] (SURVEY.md §8(c) golden (3)): warp + attention + softmax +
+    weighted sum through the C ABI vs the oracle's loop and the committed golden"""
+    from disconet_amd import Config, DiscoNet
+    g = np.load(os.path.join(golden_dir, "fusion_5x256.npz"))
+    ref = cases.ref_model(256, 5)
+    feat, trans, na = cases.fusion_inputs()
+    want = cases.ref_fuse(ref, feat, trans, na)
+    m = DiscoNet(Config(), kd_flag=1, num_agent=5).eval()
+    m.load_state_dict(ref.state_dict())
+    m.cuda()
+    fused = m.fuse(_nhwc(feat).cuda(), trans.cuda().contiguous(), na[:, 0].to(torch.int32).cuda(), 1,
+                   m._get_plan())
+    got = fused.cpu().permute(0, 3, 1, 2)
+    assert (got - want).abs().max().item() <= TOL
+    assert np.abs(got.numpy()[:, ::4, ::2, ::2] - g["fused"]).max() <= TOL
