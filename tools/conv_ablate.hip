@@ -41,16 +41,13 @@ int run_shape(const char* name, int n, int h, int w, int c0, int c1, int up0, in
   };
   CK(fill(s0, n0, 1.f)); CK(fill(s1, n1, 1.f)); CK(fill(wp, nw, 0.05f)); CK(fill(sc, cout, 1.f)); CK(fill(sh, cout, 0.1f));
   ConvArgs a;
-  a.src0 = s0; a.src1 = c1 ? s1 : nullptr; a.wpk = wp; a.scale = sc; a.shift = sh; a.out = out;
-  a.n_images = n; a.h_in = h; a.w_in = w; a.h_out = ho; a.w_out = wo;
-  a.c0 = c0; a.c1 = c1; a.up0 = up0; a.c_out = cout; a.relu = 1; a.ld0 = c0; a.ld1 = c1; a.ldo = cout;
-  a.cout_pad = cout_pad_of(d); a.vec0 = 1; a.vec1 = c1 ? 1 : 0;
+  if (fill_args(&d, s0, c1 ? s1 : nullptr, wp, sc, sh, out, a) != DN_OK) { printf("%s\n", dn_last_error()); return 1; }
   const double flop = 2.0 * n * ho * wo * cout * (c0 + c1) * KS * KS;
   const int iters = 20;
   float t[8];
   g_persist = 0;
   const float t_np = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 0>(a, d, iters);
-  g_persist = 2;
+  g_persist = 2;   // persistent workgroups for every variant below
   t[0] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 0>(a, d, iters);
   t[1] = time_variant<KS, S, TH, TW, BN, KC, WM, WN, WTM, WTN, 1>(a, d, iters);
   t[2] = 0;
