@@ -386,6 +386,27 @@ def main():
                 alt_res["roofline"] = roofline_of(alt_timer, alt_ev, alt)
             result["alt_math"] = alt_res
             model.conv_math = args.math
+        if world == 1:
+            # K1 from raw points (not part of the step: the reference voxelizes offline and
+            # ships sparse lists): one 60k-point cloud -> dense grid -> sorted index list
+            try:
+                from disconet_amd.synthetic import make_point_cloud
+                pts = torch.from_numpy(make_point_cloud(60000, seed=1)).cuda()
+                cfgv = Config(map_hw=MAP_HW)
+                for _ in range(3):
+                    dense = ops.voxelize_occupy(pts, cfgv.voxel_size, cfgv.area_extents, dims)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    dense = ops.voxelize_occupy(pts, cfgv.voxel_size, cfgv.area_extents, dims)
+                e1.record()
+                torch.cuda.synchronize()
+                result["voxelize"] = {"points": int(pts.shape[0]), "us_per_cloud": round(50 * e0.elapsed_time(e1), 2),
+                                      "occupied": int(dense.sum().item()),
+                                      "note": "dn_voxelize_occupy (memset + scatter), HIP events, not in `value`"}
+            except Exception as e:
+                result["voxelize"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             threads = usable_cores()
             base, ref_out = cpu_baseline_bounded(state_dict_cpu, threads, args.cpu_baseline_timeout)
