@@ -1,4 +1,4 @@
-"""ctypes binding of libdisconet_hip.so (include/disconet_hip.h).
+"""ctypes binding of libdisconet_hip.so (include/disconet_hip.h, include/disconet_train.h).
 
 There is no fallback: if the shared object is missing or a call fails, this
 module raises.  The library is built in-tree by disconet_amd/csrc/build.py
@@ -35,7 +35,7 @@ class MlpTailParams(Structure):
         "bn1_scale", "bn1_shift", "w2", "s2", "t2", "w3", "s3", "t3", "w4", "b4")]
 
 
-# name -> (restype, argtypes); must list every symbol include/disconet_hip.h declares
+# name -> (restype, argtypes); must list every symbol include/*.h declares
 SIGNATURES = {
     "dn_version": (c_int, []),
     "dn_last_error": (c_char_p, []),
@@ -62,6 +62,39 @@ SIGNATURES = {
     "dn_disco_fuse_tail": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    POINTER(MlpTailParams), c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    # ---- include/disconet_train.h ----
+    "dn_conv_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
+    "dn_conv_wgrad": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_int, c_int, c_void_p]),
+    "dn_conv_dgrad_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                      c_void_p]),
+    "dn_bn_train_stats": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    "dn_bn_train_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                  c_int, c_long, c_int, c_int, c_void_p, c_void_p]),
+    "dn_bn_update_running": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_void_p, c_float,
+                                     c_void_p, c_void_p, c_void_p]),
+    "dn_bn_train_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_void_p]),
+    "dn_channel_sum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "dn_add_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_void_p]),
+    "dn_pair_add_ego": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dn_pair_sum_ego": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                c_void_p]),
+    "dn_fuse_combine": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dn_fuse_combine_backward": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_int, c_int,
+                                                                             c_void_p, c_void_p,
+                                                                             c_void_p]),
+    "dn_warp_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                 c_void_p, c_void_p]),
+    "dn_warp_list": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                             c_void_p]),
+    "dn_det_loss": (c_int, [c_void_p] * 5 + [c_long, c_int, c_float, c_float, c_float, c_float,
+                                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dn_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float,
+                             c_float, c_float, c_float, c_int, c_void_p]),
 }
 
 _lib = None

@@ -266,7 +266,9 @@ conv_mfma_kernel(const ConvArgs a) {
       const int idx = t + it * NT;
       const int p = idx / KV, q = idx % KV;
       const int iy = iy0 + p / PW, ix = ix0 + p % PW;
-      const bool ok = idx < T::A_VEC && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+      bool ok = idx < T::A_VEC && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+      // up0 == 2: source 0 is read zero-stuffed (data gradient of a stride-2 layer)
+      if (!from1 && a.up0 == 2) ok = ok && !((iy | ix) & 1);
       unsigned off;
       if (from1) {
         off = (unsigned)(((iy * a.w_in + ix) * a.ld1 + 4 * q) * 4);

@@ -1,0 +1,349 @@
+// Weight gradient of the conv layers (training step).
+//
+// Replaces the autograd backward of every nn.Conv2d / Conv3d(1,1,1) on the path
+// (upstream:coperception/models/det/backbone/Backbone.py, base/*: conv layers trained
+// through loss.backward() in upstream:coperception/utils/CoDetModule.py :: step).
+//
+//   dW[co][ci][ky][kx] = sum over (image, oy, ox) of
+//                        dz[img, oy, ox, co] * x[img, oy*s + ky - pad, ox*s + kx - pad, ci]
+//
+// A GEMM per tap with K = pixels: D[co][ci] += dz^T . x_shifted on the exact-fp32
+// MFMA (v_mfma_f32_32x32x2_f32; K = 2 pixels per instruction).  A workgroup owns a
+// 32 x 32 (co, ci) block for all taps and a slice of the pixel tiles: it stages the
+// dz tile and the halo patch of x (the same gather as the forward kernel: nearest
+// x2 upsample of source 0, channel concat of two sources, stride 2) in LDS, every
+// wave takes a quarter of the tile's pixels through all taps (9 independent
+// accumulators, no dependent MFMA chain), the four waves meet in an LDS reduction
+// and the slice's partial block goes to the workspace.  A second kernel sums the
+// slices in a fixed order (deterministic, no float atomics in HBM) into OIHW.
+#include <hip/hip_runtime.h>
+
+#include "disconet_train.h"
+#include "dn_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+  const float* src0;
+  const float* src1;
+  const float* dz;
+  float* partial;
+  int n_images, h_in, w_in, h_out, w_out;
+  int c0, c1, up0, c_out;
+  int ld0, ld1, ldz;
+  int tiles_x, tiles_y, n_tiles;   // pixel tiles per image row / column, total
+  int n_cot, n_cit, n_slices;
+  int vec0, vec1, vecz;
+};
+
+template <int KS, int STRIDE>
+struct WgradTile {
+  static constexpr int TH = STRIDE == 1 ? 8 : 4;
+  static constexpr int TW = 16;
+  static constexpr int BM = TH * TW;
+  static constexpr int PAD = KS / 2;
+  static constexpr int PH = (TH - 1) * STRIDE + KS;
+  static constexpr int PW = (TW - 1) * STRIDE + KS;
+  static constexpr int TAPS = KS * KS;
+  static constexpr int X_VEC = PH * PW * 8;            // float4 slots of the x patch (32 channels)
+  static constexpr int X_IT = (X_VEC + 255) / 256;
+  static constexpr int D_IT = BM * 8 / 256;
+  static constexpr int X_FLOATS = PH * PW * 32;
+  static constexpr int D_FLOATS = BM * 32;
+  static constexpr int R_FLOATS = TAPS * 1024;         // the block's reduction buffer
+  static constexpr int LDS_FLOATS = (X_FLOATS + D_FLOATS) > R_FLOATS ? (X_FLOATS + D_FLOATS) : R_FLOATS;
+};
+
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
+  using T = WgradTile<KS, STRIDE>;
+  constexpr int TH = T::TH, TW = T::TW, PW = T::PW, TAPS = T::TAPS;
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;
+  float* Ds = smem + T::X_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // work item -> (co block, ci block, slice); slices of one (co, ci) block are adjacent
+  int item = blockIdx.x;
+  const int slice = item % a.n_slices;
+  item /= a.n_slices;
+  const int cit = item % a.n_cit;
+  const int cot = item / a.n_cit;
+  const int co0 = cot * 32, ci0 = cit * 32;
+  const bool from1 = ci0 >= a.c0;                       // the ci block lies in the concat source
+  const int cs0 = from1 ? ci0 - a.c0 : ci0;             // first channel inside that source
+  const int csrc = from1 ? a.c1 : a.c0;                 // channels of that source
+  const int ld = from1 ? a.ld1 : a.ld0;
+  const bool up = !from1 && a.up0;
+  const int hs = up ? a.h_in >> 1 : a.h_in, ws = up ? a.w_in >> 1 : a.w_in;
+  const float* src = from1 ? a.src1 : a.src0;
+  const bool vecx = from1 ? a.vec1 : a.vec0;
+  const size_t img_x = (size_t)hs * ws * ld, img_z = (size_t)a.h_out * a.w_out * a.ldz;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  f32x4 rx[T::X_IT], rd[T::D_IT];
+
+  auto ld128 = [](auto rsrc, unsigned voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+  };
+  // channel tails / unaligned rows: dword loads, each with its own bound
+  auto ld32x4 = [](auto rsrc, unsigned voff, int nvalid) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                           rsrc, (voff == 0xFFFFFFFFu || e >= nvalid) ? 0xFFFFFFFFu : voff + 4 * e, 0, 0));
+    return v;
+  };
+
+  auto load_tile = [&](int tile) {
+    int sp = tile;
+    const int ox0 = (sp % a.tiles_x) * TW;
+    sp /= a.tiles_x;
+    const int oy0 = (sp % a.tiles_y) * TH;
+    const int img = sp / a.tiles_y;
+    const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + img * img_x), 0,
+                                                       (int)(img_x * 4), 0x00020000);
+    const auto rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz + img * img_z), 0,
+                                                       (int)(img_z * 4), 0x00020000);
+    const int iy0 = oy0 * STRIDE - T::PAD, ix0 = ox0 * STRIDE - T::PAD;
+#pragma unroll
+    for (int it = 0; it < T::X_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int p = idx >> 3, q = idx & 7;
+      const int iy = iy0 + p / PW, ix = ix0 + p % PW;
+      const int c = cs0 + 4 * q;
+      const bool ok = idx < T::X_VEC && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in && c < csrc;
+      const int sy = up ? iy >> 1 : iy, sx = up ? ix >> 1 : ix;
+      const unsigned off = ok ? (unsigned)(((sy * ws + sx) * ld + c) * 4) : OOB;
+      rx[it] = vecx ? ld128(rsx, off) : ld32x4(rsx, off, csrc - c);
+    }
+#pragma unroll
+    for (int it = 0; it < T::D_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int m = idx >> 3, q = idx & 7;
+      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+      const int c = co0 + 4 * q;
+      const bool ok = oy < a.h_out && ox < a.w_out && c < a.c_out;
+      const unsigned off = ok ? (unsigned)(((oy * a.w_out + ox) * a.ldz + c) * 4) : OOB;
+      rd[it] = a.vecz ? ld128(rsz, off) : ld32x4(rsz, off, a.c_out - c);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < T::X_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < T::X_VEC) *reinterpret_cast<f32x4*>(&Xs[idx * 4]) = rx[it];
+    }
+#pragma unroll
+    for (int it = 0; it < T::D_IT; ++it)
+      *reinterpret_cast<f32x4*>(&Ds[(tid + it * 256) * 4]) = rd[it];
+  };
+
+  int tile = slice;
+  if (tile < a.n_tiles) {
+    load_tile(tile);
+    store_tile();
+  }
+  __syncthreads();
+  for (; tile < a.n_tiles; tile += a.n_slices) {
+    const bool more = tile + a.n_slices < a.n_tiles;
+    if (more) load_tile(tile + a.n_slices);
+    // this wave's pixels: rows wave*TH/4 .. of the tile, pairs (x, x + 1) are one K = 2 step
+#pragma unroll
+    for (int rr = 0; rr < TH / 4; ++rr) {
+      const int row = wave * (TH / 4) + rr;
+#pragma unroll 2
+      for (int kp = 0; kp < TW / 2; ++kp) {
+        const int col = 2 * kp + lh;
+        const float av = Ds[(row * TW + col) * 32 + li];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int ty = t / KS, tx = t % KS;
+          const float bv = Xs[((row * STRIDE + ty) * PW + col * STRIDE + tx) * 32 + li];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (more) store_tile();
+    __syncthreads();
+  }
+
+  // four waves -> one block: LDS reduction, then the slice's partial goes out row-major
+  float* R = smem;
+  for (int i = tid; i < T::R_FLOATS; i += 256) R[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = lh * 4 + (r & 3) + 8 * (r >> 2);
+      atomicAdd(&R[t * 1024 + i * 32 + li], acc[t][r]);
+    }
+  __syncthreads();
+  float* out = a.partial + ((size_t)(slice * a.n_cot + cot) * a.n_cit + cit) * T::R_FLOATS;
+  for (int i = tid * 4; i < T::R_FLOATS; i += 1024)
+    *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(&R[i]);
+}
+
+// partial [slice][cot][cit][tap][32 co][32 ci] -> dW [c_out][c_in][taps] (OIHW), slices summed in order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                    int n_slices, int n_cot, int n_cit, int taps, int c_out, int c_in,
+                                    int cin_total, int accumulate) {
+  const long per_slice = (long)n_cot * n_cit * taps * 1024;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < per_slice;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int j = idx & 31, i = (idx >> 5) & 31;
+    long r = idx >> 10;
+    const int t = r % taps;
+    r /= taps;
+    const int cit = r % n_cit, cot = (int)(r / n_cit);
+    const int co = cot * 32 + i, ci = cit * 32 + j;
+    if (co >= c_out || ci >= c_in) continue;
+    float s = 0.f;
+    for (int sl = 0; sl < n_slices; ++sl) s += partial[sl * per_slice + idx];
+    float* dst = dw + ((size_t)co * cin_total + ci) * taps + t;
+    *dst = accumulate ? *dst + s : s;
+  }
+}
+
+int out_dim(int in, int k, int stride) { return (in + 2 * (k / 2) - k) / stride + 1; }
+
+int validate(const dn_conv_desc* d) {
+  DN_REQUIRE(d != nullptr, "wgrad: null descriptor");
+  DN_REQUIRE(d->n_images > 0 && d->h_in > 0 && d->w_in > 0 && d->c0 > 0 && d->c1 >= 0 && d->c_out > 0,
+             "wgrad: non-positive dimension");
+  DN_REQUIRE((d->ksize == 3 && (d->stride == 1 || d->stride == 2)) || (d->ksize == 1 && d->stride == 1),
+             "wgrad: ksize %d stride %d unsupported (3x3 s1/s2, 1x1 s1)", d->ksize, d->stride);
+  DN_REQUIRE(d->up0 == 0 || (d->up0 == 1 && d->h_in % 2 == 0 && d->w_in % 2 == 0),
+             "wgrad: up0 needs even input dims");
+  DN_REQUIRE(d->c1 == 0 || d->c0 % 32 == 0, "wgrad: concat needs c0 %% 32 == 0 (got %d)", d->c0);
+  DN_REQUIRE(d->ld0 >= d->c0 && d->ld1 >= d->c1 && d->ldo >= d->c_out, "wgrad: row stride < channels");
+  return DN_OK;
+}
+
+struct Plan {
+  int h_out, w_out, tiles_x, tiles_y, n_tiles, n_cot, n_cit, n_slices, taps;
+};
+
+Plan make_plan(const dn_conv_desc& d) {
+  Plan p;
+  const int th = d.stride == 1 ? 8 : 4, tw = 16;
+  p.h_out = out_dim(d.h_in, d.ksize, d.stride);
+  p.w_out = out_dim(d.w_in, d.ksize, d.stride);
+  p.tiles_x = (p.w_out + tw - 1) / tw;
+  p.tiles_y = (p.h_out + th - 1) / th;
+  p.n_tiles = d.n_images * p.tiles_x * p.tiles_y;
+  p.n_cot = (d.c_out + 31) / 32;
+  // a concat layer's ci blocks never straddle the sources (c0 % 32 == 0)
+  p.n_cit = (d.c0 + 31) / 32 + (d.c1 + 31) / 32;
+  p.taps = d.ksize * d.ksize;
+  // ~4 workgroups per CU in flight, every slice at least 4 pixel tiles long
+  int s = 1024 / (p.n_cot * p.n_cit);
+  if (s > p.n_tiles / 4) s = p.n_tiles / 4;
+  if (s < 1) s = 1;
+  p.n_slices = s;
+  return p;
+}
+
+template <int KS, int STRIDE>
+int launch(const WgradArgs& a, const Plan& p, hipStream_t stream) {
+  using T = WgradTile<KS, STRIDE>;
+  auto kern = conv_wgrad_kernel<KS, STRIDE>;
+  static bool ready = false;
+  if (!ready) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_FLOATS * 4);
+    if (e != hipSuccess)
+      return dn::fail(DN_ERR_LAUNCH, "wgrad: cannot reserve %d B of LDS: %s", T::LDS_FLOATS * 4,
+                      hipGetErrorString(e));
+    ready = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.n_cot * p.n_cit * p.n_slices), dim3(256), T::LDS_FLOATS * 4, stream, a);
+  return dn::check_launch("conv_wgrad_kernel");
+}
+
+}  // namespace
+
+extern "C" size_t dn_conv_wgrad_workspace(const dn_conv_desc* d) {
+  if (validate(d) != DN_OK) return 0;
+  const Plan p = make_plan(*d);
+  return (size_t)p.n_slices * p.n_cot * p.n_cit * p.taps * 1024 * sizeof(float);
+}
+
+extern "C" int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz,
+                             void* workspace, float* dw_oihw, int dw_cin_total, int accumulate,
+                             void* stream) {
+  if (int rc = validate(d)) return rc;
+  DN_REQUIRE(src0 && dz && workspace && dw_oihw, "wgrad: null pointer");
+  DN_REQUIRE(dw_cin_total == 0 || dw_cin_total >= d->c0 + d->c1, "wgrad: dw_cin_total %d < c_in",
+             dw_cin_total);
+  DN_REQUIRE(d->c1 == 0 || src1, "wgrad: c1 > 0 needs src1");
+  const Plan p = make_plan(*d);
+  WgradArgs a;
+  a.src0 = src0; a.src1 = src1; a.dz = dz; a.partial = static_cast<float*>(workspace);
+  a.n_images = d->n_images; a.h_in = d->h_in; a.w_in = d->w_in; a.h_out = p.h_out; a.w_out = p.w_out;
+  a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0; a.c_out = d->c_out;
+  a.ld0 = d->ld0; a.ld1 = d->ld1; a.ldz = d->ldo;
+  a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles;
+  a.n_cot = p.n_cot; a.n_cit = p.n_cit; a.n_slices = p.n_slices;
+  auto aligned = [](const void* ptr, int c, int ldv) {
+    return c % 4 == 0 && ldv % 4 == 0 && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0;
+  };
+  a.vec0 = aligned(src0, d->c0, d->ld0);
+  a.vec1 = d->c1 ? aligned(src1, d->c1, d->ld1) : 1;
+  a.vecz = aligned(dz, d->c_out, d->ldo);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (d->ksize == 3 && d->stride == 1) rc = launch<3, 1>(a, p, s);
+  else if (d->ksize == 3) rc = launch<3, 2>(a, p, s);
+  else rc = launch<1, 1>(a, p, s);
+  if (rc) return rc;
+  const long per_slice = (long)p.n_cot * p.n_cit * p.taps * 1024;
+  const int blocks = (int)((per_slice + 255) / 256 < 2048 ? (per_slice + 255) / 256 : 2048);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, dw_oihw, p.n_slices,
+                     p.n_cot, p.n_cit, p.taps, d->c_out, d->c0 + d->c1,
+                     dw_cin_total ? dw_cin_total : d->c0 + d->c1, accumulate);
+  return dn::check_launch("wgrad_reduce_kernel");
+}
+
+namespace {
+// wt[ci][co][kk - 1 - t] = w[co][ci_first + ci][t]
+__global__ void dgrad_weights_kernel(const float* __restrict__ w, int c_out, int cin_total, int ci_first,
+                                     int c_in, int taps, float* __restrict__ wt) {
+  const long total = (long)c_in * c_out * taps;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(idx % taps);
+    const long r = idx / taps;
+    const int co = (int)(r % c_out), ci = (int)(r / c_out);
+    wt[idx] = w[((size_t)co * cin_total + ci_first + ci) * taps + (taps - 1 - t)];
+  }
+}
+}  // namespace
+
+extern "C" int dn_conv_dgrad_weights(const float* w_oihw, int c_out, int cin_total, int ci_first,
+                                     int c_in, int ksize, float* wt_oihw, void* stream) {
+  DN_REQUIRE(w_oihw && wt_oihw, "dgrad weights: null pointer");
+  DN_REQUIRE(c_out > 0 && c_in > 0 && ci_first >= 0 && ci_first + c_in <= cin_total &&
+                 (ksize == 1 || ksize == 3),
+             "dgrad weights: bad shape");
+  const long total = (long)c_in * c_out * ksize * ksize;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(dgrad_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, c_out,
+                     cin_total, ci_first, c_in, ksize * ksize, wt_oihw);
+  return dn::check_launch("dgrad_weights_kernel");
+}

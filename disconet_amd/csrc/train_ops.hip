@@ -1,0 +1,583 @@
+// Training-step kernels around the convs (include/disconet_train.h): batch-norm in
+// training mode and its backward, bias / channel sums, the training form of the
+// DiscoGraph fusion tail, the detection loss and Adam.  All HBM-bound row-major
+// streaming over NHWC maps: lanes run along the channel axis (coalesced rows),
+// per-channel sums are kept in double (the batch variance is E[z^2] - mean^2 over
+// up to 1.3 M pixels) in LDS per workgroup and merged with one double atomic per
+// (workgroup, channel).
+//
+// Replaces the autograd graph of upstream:coperception/utils/CoDetModule.py :: step
+// (nn.BatchNorm2d / BatchNorm3d in train(), F.relu, torch.exp / div / mul of the fusion
+// loop in upstream:.../det/DiscoNet.py :: forward, loss.py's focal / smooth-L1 losses,
+// torch.optim.Adam).
+#include <hip/hip_runtime.h>
+
+#include "disconet_train.h"
+#include "dn_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMaxC = 512;      // channels of the widest map on the path (conv4_*)
+
+__device__ inline int lanes_for(int c) {   // power-of-two channel lanes per row, <= 64
+  int t = 1;
+  while (t < c && t < 64) t <<= 1;
+  return t;
+}
+
+__device__ inline void atomic_add_f64(double* p, double v) { atomicAdd(p, v); }
+
+// ---------------------------------------------------------------------------------
+// per-(group, channel) sums of up to two quantities over the rows of a group
+// ---------------------------------------------------------------------------------
+// F(row_in_group, c, &q0, &q1) yields the two addends; grid = (blocks per group, groups)
+template <int NQ, class F>
+__device__ inline void group_channel_sums(int c, long rows_per_group, double* sums_g, F f) {
+  __shared__ double acc[2][kMaxC];
+  for (int i = threadIdx.x; i < NQ * kMaxC; i += blockDim.x) acc[i / kMaxC][i % kMaxC] = 0.0;
+  __syncthreads();
+  const int tx_n = lanes_for(c), ty_n = blockDim.x / tx_n;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const long chunk = (rows_per_group + gridDim.x - 1) / gridDim.x;
+  const long r0 = blockIdx.x * chunk;
+  const long r1 = r0 + chunk < rows_per_group ? r0 + chunk : rows_per_group;
+  for (int cc = tx; cc < c; cc += tx_n) {
+    double s0 = 0.0, s1 = 0.0;
+    for (long r = r0 + ty; r < r1; r += ty_n) {
+      float q0 = 0.f, q1 = 0.f;
+      f(r, cc, q0, q1);
+      s0 += q0;
+      if (NQ > 1) s1 += q1;
+    }
+    atomic_add_f64(&acc[0][cc], s0);
+    if (NQ > 1) atomic_add_f64(&acc[1][cc], s1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * c; i += blockDim.x)
+    atomic_add_f64(&sums_g[i], acc[i / c][i % c]);
+}
+
+__global__ void __launch_bounds__(256)
+bn_stats_kernel(const float* __restrict__ z, long rows_per_group, int c, int ldz,
+                double* __restrict__ sums) {
+  const int g = blockIdx.y;
+  const float* zg = z + (size_t)g * rows_per_group * ldz;
+  group_channel_sums<2>(c, rows_per_group, sums + (size_t)g * 2 * c,
+                        [&](long r, int cc, float& q0, float& q1) {
+                          const float v = zg[r * ldz + cc];
+                          q0 = v;
+                          q1 = v * v;
+                        });
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ sums, int n, int c, long rows,
+                                         float* __restrict__ mean, float* __restrict__ var) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (group, channel)
+  if (i >= n) return;
+  const int g = i / c, cc = i % c;
+  const double m = sums[(size_t)g * 2 * c + cc] / rows;
+  const double v = sums[(size_t)g * 2 * c + c + cc] / rows - m * m;
+  mean[i] = (float)m;
+  var[i] = (float)(v > 0.0 ? v : 0.0);
+}
+
+__global__ void __launch_bounds__(256)
+bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                const float* __restrict__ var, const float* __restrict__ gamma,
+                const float* __restrict__ beta, float eps, int relu, long rows_per_group, int c,
+                int ldz, long total, float* __restrict__ y) {
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / c;
+    const int cc = (int)(idx % c);
+    const int g = (int)(row / rows_per_group);
+    const float rstd = 1.f / sqrtf(var[g * c + cc] + eps);
+    float v = (z[row * ldz + cc] - mean[g * c + cc]) * rstd * gamma[cc] + beta[cc];
+    if (relu) v = fmaxf(v, 0.f);
+    y[idx] = v;
+  }
+}
+
+__global__ void bn_update_running_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                         int n_groups, long rows, int c, const int* __restrict__ order,
+                                         float momentum, float* __restrict__ rmean,
+                                         float* __restrict__ rvar) {
+  const int cc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cc >= c) return;
+  float rm = rmean[cc], rv = rvar[cc];
+  const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+  for (int k = 0; k < n_groups; ++k) {
+    const int g = order ? order[k] : k;
+    rm = (1.f - momentum) * rm + momentum * mean[g * c + cc];
+    rv = (1.f - momentum) * rv + momentum * (var[g * c + cc] * unbias);
+  }
+  rmean[cc] = rm;
+  rvar[cc] = rv;
+}
+
+// incoming gradient of one element: dy_a (optionally the 2 x 2 block sum of a map at twice
+// the resolution) + dy_b, gated by the ReLU
+struct GradSrc {
+  const float* dy_a;
+  const float* dy_b;
+  const float* y;
+  int ld_a, up_a, ld_b, relu, h, w, c;
+  __device__ inline float operator()(long row, int cc) const {
+    float g;
+    if (up_a) {
+      const long img = row / ((long)h * w);
+      const int p = (int)(row % ((long)h * w));
+      const int py = p / w, px = p % w;
+      const float* b = dy_a + ((img * 2 * h + 2 * py) * (2L * w) + 2 * px) * ld_a + cc;
+      g = (b[0] + b[ld_a]) + (b[2L * w * ld_a] + b[(2L * w + 1) * ld_a]);
+    } else {
+      g = dy_a[row * ld_a + cc];
+    }
+    if (dy_b) g += dy_b[row * ld_b + cc];
+    if (relu && !(y[row * c + cc] > 0.f)) g = 0.f;
+    return g;
+  }
+};
+
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_kernel(GradSrc src, const float* __restrict__ z, const float* __restrict__ mean,
+                     const float* __restrict__ var, float eps, long rows_per_group,
+                     double* __restrict__ sums) {
+  const int g = blockIdx.y, c = src.c;
+  const long base = (long)g * rows_per_group;
+  group_channel_sums<2>(c, rows_per_group, sums + (size_t)g * 2 * c,
+                        [&](long r, int cc, float& q0, float& q1) {
+                          const float gr = src(base + r, cc);
+                          const float rstd = 1.f / sqrtf(var[g * c + cc] + eps);
+                          q0 = gr;
+                          q1 = gr * ((z[(base + r) * c + cc] - mean[g * c + cc]) * rstd);
+                        });
+}
+
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(GradSrc src, const float* __restrict__ z, const float* __restrict__ mean,
+                    const float* __restrict__ var, const float* __restrict__ gamma, float eps,
+                    long rows_per_group, const double* __restrict__ sums, long total,
+                    float* __restrict__ dz) {
+  const int c = src.c;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / c;
+    const int cc = (int)(idx % c);
+    const int g = (int)(row / rows_per_group);
+    const float rstd = 1.f / sqrtf(var[g * c + cc] + eps);
+    const float zh = (z[idx] - mean[g * c + cc]) * rstd;
+    const float m1 = (float)(sums[(size_t)g * 2 * c + cc] / rows_per_group);
+    const float m2 = (float)(sums[(size_t)g * 2 * c + c + cc] / rows_per_group);
+    dz[idx] = gamma[cc] * rstd * (src(row, cc) - m1 - zh * m2);
+  }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ sums, int n_groups, int c,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     int accumulate) {
+  const int cc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cc >= c) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int g = 0; g < n_groups; ++g) {
+    s1 += sums[(size_t)g * 2 * c + cc];
+    s2 += sums[(size_t)g * 2 * c + c + cc];
+  }
+  dbeta[cc] = (accumulate ? dbeta[cc] : 0.f) + (float)s1;
+  dgamma[cc] = (accumulate ? dgamma[cc] : 0.f) + (float)s2;
+}
+
+__global__ void __launch_bounds__(256)
+channel_sum_kernel(const float* __restrict__ x, long rows, int c, int ld, double* __restrict__ sums) {
+  group_channel_sums<1>(c, rows, sums, [&](long r, int cc, float& q0, float& q1) {
+    q0 = x[r * ld + cc];
+    (void)q1;
+  });
+}
+
+__global__ void channel_sum_finalize_kernel(const double* __restrict__ sums, int c,
+                                            float* __restrict__ out, int accumulate) {
+  const int cc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cc < c) out[cc] = (accumulate ? out[cc] : 0.f) + (float)sums[cc];
+}
+
+__global__ void add_rows_kernel(float* __restrict__ a, int ld_a, const float* __restrict__ b, int ld_b,
+                                int c, long total) {
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / c;
+    const int cc = (int)(idx % c);
+    a[row * ld_a + cc] += b[row * ld_b + cc];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// fusion, training form
+// ---------------------------------------------------------------------------------
+__global__ void pair_add_ego_kernel(float* __restrict__ z1, const float* __restrict__ e,
+                                    const int* __restrict__ ego_image, long per_image, long total) {
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(idx / per_image);
+    z1[idx] += e[(size_t)ego_image[p] * per_image + idx % per_image];
+  }
+}
+
+__global__ void pair_sum_ego_kernel(const float* __restrict__ dz1, const int* __restrict__ first,
+                                    const int* __restrict__ pairs, long per_image, long total,
+                                    float* __restrict__ de) {
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int img = (int)(idx / per_image);
+    const long off = idx % per_image;
+    float s = 0.f;
+    for (int k = first[img]; k < first[img + 1]; ++k) s += dz1[(size_t)pairs[k] * per_image + off];
+    de[idx] = s;
+  }
+}
+
+constexpr int kMaxNbr = 16;
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one wavefront per (ego, pixel); lanes carry float4s of channels
+__global__ void __launch_bounds__(256)
+fuse_combine_kernel(const float* __restrict__ z4, const float* __restrict__ maps,
+                    const int* __restrict__ first, const int* __restrict__ pair_index,
+                    const int* __restrict__ map_image, const int* __restrict__ ego_out, int n_egos,
+                    int hw, int c, float* __restrict__ weights, float* __restrict__ fused) {
+  const int lane = threadIdx.x & 63;
+  const long item = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (item >= (long)n_egos * hw) return;
+  const int e = (int)(item / hw), px = (int)(item % hw);
+  const int k0 = first[e], kn = first[e + 1] - k0;
+  float wk[kMaxNbr];
+  float sum = 0.f;
+  for (int k = 0; k < kn; ++k) {
+    const int p = pair_index[k0 + k];
+    const float s = p >= 0 ? fmaxf(z4[(size_t)p * hw + px], 0.f) : 0.f;
+    wk[k] = expf(s);
+    sum += wk[k];
+  }
+  for (int k = 0; k < kn; ++k) {
+    wk[k] = wk[k] / sum;
+    const int p = pair_index[k0 + k];
+    if (lane == 0 && p >= 0) weights[(size_t)p * hw + px] = wk[k];
+  }
+  float* out = fused + ((size_t)ego_out[e] * hw + px) * c;
+  for (int c4 = lane; c4 < (c >> 2); c4 += 64) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < kn; ++k)
+      acc += *reinterpret_cast<const f32x4*>(maps + ((size_t)map_image[k0 + k] * hw + px) * c + 4 * c4) * wk[k];
+    *reinterpret_cast<f32x4*>(out + 4 * c4) = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+fuse_combine_bwd_kernel(const float* __restrict__ dfused, int ld_df, const float* __restrict__ z4,
+                        const float* __restrict__ weights, const float* __restrict__ maps,
+                        const int* __restrict__ first, const int* __restrict__ pair_index,
+                        const int* __restrict__ map_image, const int* __restrict__ ego_out, int n_egos,
+                        int hw, int c, float* __restrict__ dmaps, float* __restrict__ dz4) {
+  const int lane = threadIdx.x & 63;
+  const long item = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (item >= (long)n_egos * hw) return;
+  const int e = (int)(item / hw), px = (int)(item % hw);
+  const int k0 = first[e], kn = first[e + 1] - k0;
+  const float* df = dfused + ((size_t)ego_out[e] * hw + px) * ld_df;
+  float wk[kMaxNbr], dot[kMaxNbr];
+  for (int k = 0; k < kn; ++k) {
+    const int p = pair_index[k0 + k];
+    wk[k] = p >= 0 ? weights[(size_t)p * hw + px] : 1.f;
+    dot[k] = 0.f;
+  }
+  for (int c4 = lane; c4 < (c >> 2); c4 += 64) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(df + 4 * c4);
+    for (int k = 0; k < kn; ++k) {
+      const size_t off = ((size_t)map_image[k0 + k] * hw + px) * c + 4 * c4;
+      const f32x4 m = *reinterpret_cast<const f32x4*>(maps + off);
+      dot[k] += (g[0] * m[0] + g[1] * m[1]) + (g[2] * m[2] + g[3] * m[3]);
+      *reinterpret_cast<f32x4*>(dmaps + off) = g * wk[k];
+    }
+  }
+  float mean = 0.f;
+  for (int k = 0; k < kn; ++k) {
+    dot[k] = wave_sum(dot[k]);
+    mean += wk[k] * dot[k];
+  }
+  if (lane == 0)
+    for (int k = 0; k < kn; ++k) {
+      const int p = pair_index[k0 + k];
+      if (p >= 0) {
+        const size_t i = (size_t)p * hw + px;
+        dz4[i] = z4[i] > 0.f ? wk[k] * (dot[k] - mean) : 0.f;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// loss and optimiser
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+det_loss_kernel(const float* __restrict__ cls, const float* __restrict__ labels,
+                const float* __restrict__ loc, const float* __restrict__ targets,
+                const float* __restrict__ mask, long n, int code, float alpha, float gamma,
+                float sigma, float inv_norm, double* __restrict__ losses, float* __restrict__ dcls,
+                float* __restrict__ dloc) {
+  double l_cls = 0.0, l_loc = 0.0;
+  const float s2 = sigma * sigma;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    // two-class softmax, target = the one-hot column
+    const float z0 = cls[2 * i], z1 = cls[2 * i + 1];
+    const float mx = fmaxf(z0, z1);
+    const float e0 = expf(z0 - mx), e1 = expf(z1 - mx);
+    const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+    const bool fg = labels[2 * i + 1] > 0.5f;
+    const bool any = fg || labels[2 * i] > 0.5f;      // an all-zero row is "don't care"
+    float d0 = 0.f, d1 = 0.f;
+    if (any) {
+      const float q = fg ? p1 : p0;
+      const float a = fg ? alpha : 1.f - alpha;
+      const float lq = logf(fmaxf(q, 1e-30f));
+      const float om = 1.f - q;
+      const float mod = powf(om, gamma);
+      l_cls += (double)(-a * mod * lq);
+      // dL/dq, then dq/dz_c = q (delta_ct - p_c)
+      const float dmod = gamma == 0.f ? 0.f : gamma * powf(om, gamma - 1.f);
+      const float dl_dq = a * (dmod * lq - mod / fmaxf(q, 1e-30f));
+      const float t0 = fg ? 0.f : 1.f, t1 = fg ? 1.f : 0.f;
+      d0 = dl_dq * q * (t0 - p0) * inv_norm;
+      d1 = dl_dq * q * (t1 - p1) * inv_norm;
+    }
+    dcls[2 * i] = d0;
+    dcls[2 * i + 1] = d1;
+    const float mk = mask[i];
+    for (int k = 0; k < code; ++k) {
+      const float d = loc[i * code + k] - targets[i * code + k];
+      const float ad = fabsf(d);
+      float l, g;
+      if (ad <= 1.f / s2) {
+        l = 0.5f * s2 * d * d;
+        g = s2 * d;
+      } else {
+        l = ad - 0.5f / s2;
+        g = d > 0.f ? 1.f : -1.f;
+      }
+      l_loc += (double)(mk * l);
+      dloc[i * code + k] = mk * g * inv_norm;
+    }
+  }
+  // workgroup reduction, one atomic per workgroup and loss
+  __shared__ double red[2][256];
+  red[0][threadIdx.x] = l_cls;
+  red[1][threadIdx.x] = l_loc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomic_add_f64(&losses[0], red[0][0] * inv_norm);
+    atomic_add_f64(&losses[1], red[1][0] * inv_norm);
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                            float wd, float bc1, float bc2_sqrt) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    if (wd != 0.f) gi += wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    // torch: denom = sqrt(v) / sqrt(bias_correction2) + eps; p -= (lr / bias_correction1) * m / denom
+    p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+
+int grid_for(long total, int cap = 4096) {
+  const long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+int blocks_per_group(long rows_per_group, int n_groups) {
+  // ~2048 workgroups over all groups, at least 64 rows each
+  long b = 2048 / n_groups;
+  if (b > rows_per_group / 64) b = rows_per_group / 64;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" int dn_bn_train_stats(const float* z, int n_groups, long rows_per_group, int c, int ldz,
+                                 double* sums, float* mean, float* var, void* stream) {
+  DN_REQUIRE(z && sums && mean && var, "bn stats: null pointer");
+  DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0 && c <= kMaxC && ldz >= c,
+             "bn stats: bad shape (groups %d rows %ld c %d ld %d)", n_groups, rows_per_group, c, ldz);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * c * n_groups, s) != hipSuccess)
+    return dn::fail(DN_ERR_LAUNCH, "bn stats: memset failed");
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
+                     dim3(256), 0, s, z, rows_per_group, c, ldz, sums);
+  const int n = n_groups * c;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sums, n, c,
+                     rows_per_group, mean, var);
+  return dn::check_launch("bn_stats_kernel");
+}
+
+extern "C" int dn_bn_train_apply(const float* z, const float* mean, const float* var,
+                                 const float* gamma, const float* beta, float eps, int relu,
+                                 int n_groups, long rows_per_group, int c, int ldz, float* y,
+                                 void* stream) {
+  DN_REQUIRE(z && mean && var && gamma && beta && y, "bn apply: null pointer");
+  DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0 && ldz >= c, "bn apply: bad shape");
+  const long total = (long)n_groups * rows_per_group * c;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, z,
+                     mean, var, gamma, beta, eps, relu, rows_per_group, c, ldz, total, y);
+  return dn::check_launch("bn_apply_kernel");
+}
+
+extern "C" int dn_bn_update_running(const float* mean, const float* var, int n_groups,
+                                    long rows_per_group, int c, const int* order, float momentum,
+                                    float* running_mean, float* running_var, void* stream) {
+  DN_REQUIRE(mean && var && running_mean && running_var, "bn running: null pointer");
+  DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0, "bn running: bad shape");
+  hipLaunchKernelGGL(bn_update_running_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                     mean, var, n_groups, rows_per_group, c, order, momentum, running_mean, running_var);
+  return dn::check_launch("bn_update_running_kernel");
+}
+
+extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
+                                    const float* y, const float* z, const float* mean,
+                                    const float* var, const float* gamma, float eps, int relu,
+                                    int n_groups, int h, int w, int images_per_group, int c,
+                                    double* sums, float* dz, float* dgamma, float* dbeta,
+                                    int accumulate, void* stream) {
+  DN_REQUIRE(dy_a && z && mean && var && gamma && sums && dz && dgamma && dbeta,
+             "bn backward: null pointer");
+  DN_REQUIRE(!relu || y, "bn backward: relu needs y");
+  DN_REQUIRE(n_groups > 0 && h > 0 && w > 0 && images_per_group > 0 && c > 0 && c <= kMaxC &&
+                 ld_a >= c && (!dy_b || ld_b >= c),
+             "bn backward: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const long rows_per_group = (long)images_per_group * h * w;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * c * n_groups, s) != hipSuccess)
+    return dn::fail(DN_ERR_LAUNCH, "bn backward: memset failed");
+  GradSrc src{dy_a, dy_b, y, ld_a, up_a, ld_b, relu, h, w, c};
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
+                     dim3(256), 0, s, src, z, mean, var, eps, rows_per_group, sums);
+  const long total = (long)n_groups * rows_per_group * c;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, src, z, mean,
+                     var, gamma, eps, rows_per_group, sums, total, dz);
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((c + 63) / 64), dim3(64), 0, s, sums, n_groups, c,
+                     dgamma, dbeta, accumulate);
+  return dn::check_launch("bn_backward kernels");
+}
+
+extern "C" int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, float* out,
+                              int accumulate, void* stream) {
+  DN_REQUIRE(x && sums && out, "channel sum: null pointer");
+  DN_REQUIRE(rows > 0 && c > 0 && c <= kMaxC && ld >= c, "channel sum: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * c, s) != hipSuccess)
+    return dn::fail(DN_ERR_LAUNCH, "channel sum: memset failed");
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(blocks_per_group(rows, 1)), dim3(256), 0, s, x, rows, c,
+                     ld, sums);
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, s, sums, c, out,
+                     accumulate);
+  return dn::check_launch("channel_sum_kernel");
+}
+
+extern "C" int dn_add_rows(float* a, int ld_a, const float* b, int ld_b, long rows, int c,
+                           void* stream) {
+  DN_REQUIRE(a && b && rows > 0 && c > 0 && ld_a >= c && ld_b >= c, "add rows: bad arguments");
+  const long total = rows * c;
+  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, a,
+                     ld_a, b, ld_b, c, total);
+  return dn::check_launch("add_rows_kernel");
+}
+
+extern "C" int dn_pair_add_ego(float* z1, const float* e, const int* ego_image, int n_pairs,
+                               int rows_per_image, int c, void* stream) {
+  DN_REQUIRE(z1 && e && ego_image && n_pairs > 0 && rows_per_image > 0 && c > 0,
+             "pair add: bad arguments");
+  const long per_image = (long)rows_per_image * c, total = per_image * n_pairs;
+  hipLaunchKernelGGL(pair_add_ego_kernel, dim3(grid_for(total, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, z1, e, ego_image, per_image, total);
+  return dn::check_launch("pair_add_ego_kernel");
+}
+
+extern "C" int dn_pair_sum_ego(const float* dz1, const int* first, const int* pairs, int n_images,
+                               int rows_per_image, int c, float* de, void* stream) {
+  DN_REQUIRE(dz1 && first && pairs && de && n_images > 0 && rows_per_image > 0 && c > 0,
+             "pair sum: bad arguments");
+  const long per_image = (long)rows_per_image * c, total = per_image * n_images;
+  hipLaunchKernelGGL(pair_sum_ego_kernel, dim3(grid_for(total, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, dz1, first, pairs, per_image, total, de);
+  return dn::check_launch("pair_sum_ego_kernel");
+}
+
+extern "C" int dn_fuse_combine(const float* z4, const float* maps, const int* first,
+                               const int* pair_index, const int* map_image, const int* ego_out,
+                               int n_egos, int hw, int c, float* weights, float* fused, void* stream) {
+  DN_REQUIRE(z4 && maps && first && pair_index && map_image && ego_out && weights && fused,
+             "fuse combine: null pointer");
+  DN_REQUIRE(n_egos > 0 && hw > 0 && c > 0 && c % 4 == 0, "fuse combine: bad shape");
+  const long items = (long)n_egos * hw;
+  hipLaunchKernelGGL(fuse_combine_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, z4, maps, first, pair_index, map_image, ego_out, n_egos, hw, c,
+                     weights, fused);
+  return dn::check_launch("fuse_combine_kernel");
+}
+
+extern "C" int dn_fuse_combine_backward(const float* dfused, int ld_df, const float* z4,
+                                        const float* weights, const float* maps, const int* first,
+                                        const int* pair_index, const int* map_image,
+                                        const int* ego_out, int n_egos, int hw, int c, float* dmaps,
+                                        float* dz4, void* stream) {
+  DN_REQUIRE(dfused && z4 && weights && maps && first && pair_index && map_image && ego_out && dmaps &&
+                 dz4,
+             "fuse combine backward: null pointer");
+  DN_REQUIRE(n_egos > 0 && hw > 0 && c > 0 && c % 4 == 0 && ld_df >= c && ld_df % 4 == 0,
+             "fuse combine backward: bad shape");
+  const long items = (long)n_egos * hw;
+  hipLaunchKernelGGL(fuse_combine_bwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, dfused, ld_df, z4, weights, maps, first, pair_index, map_image,
+                     ego_out, n_egos, hw, c, dmaps, dz4);
+  return dn::check_launch("fuse_combine_bwd_kernel");
+}
+
+extern "C" int dn_det_loss(const float* cls, const float* labels, const float* loc,
+                           const float* targets, const float* mask, long n, int code, float alpha,
+                           float gamma, float sigma, float norm, double* losses, float* dcls,
+                           float* dloc, void* stream) {
+  DN_REQUIRE(cls && labels && loc && targets && mask && losses && dcls && dloc, "det loss: null pointer");
+  DN_REQUIRE(n > 0 && code > 0 && norm > 0.f && sigma > 0.f, "det loss: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(losses, 0, 2 * sizeof(double), s) != hipSuccess)
+    return dn::fail(DN_ERR_LAUNCH, "det loss: memset failed");
+  hipLaunchKernelGGL(det_loss_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, cls, labels, loc, targets,
+                     mask, n, code, alpha, gamma, sigma, 1.f / norm, losses, dcls, dloc);
+  return dn::check_launch("det_loss_kernel");
+}
+
+extern "C" int dn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int step,
+                            void* stream) {
+  DN_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+  return dn::check_launch("adam_kernel");
+}

@@ -16,6 +16,9 @@
 //
 // Replaces upstream:coperception/models/det/base/* :: feature_transformation
 // (SURVEY.md §8 a5).
+#include <hip/hip_runtime.h>
+
+#include "disconet_train.h"
 #include "dn_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -128,7 +131,116 @@ warp_neighbors_kernel(const float* __restrict__ feat, const float* __restrict__ 
   }
 }
 
+// ---- training form: an explicit list of warps, and the backward scatter ------------------
+struct PoseTerms {
+  float r00, r01, r10, r11, x_trans, y_trans;
+};
+__device__ inline PoseTerms pose_terms(const float* m) {
+  return PoseTerms{m[0], m[1], m[4], m[5], (4.f * m[3]) / 128.f, -(4.f * m[7]) / 128.f};
+}
+__device__ inline Bilinear pass2_taps(const PoseTerms& t, int px, int py, int w, int h) {
+  const float bx = (2.f * px + 1.f) / w - 1.f;
+  const float by = (2.f * py + 1.f) / h - 1.f;
+  return bilinear_taps(bx + t.x_trans, by + t.y_trans, w, h);
+}
+__device__ inline Bilinear pass1_taps(const PoseTerms& t, int qx, int qy, int w, int h) {
+  const float qbx = (2.f * qx + 1.f) / w - 1.f;
+  const float qby = (2.f * qy + 1.f) / h - 1.f;
+  return bilinear_taps(t.r00 * qbx + t.r01 * qby, t.r10 * qbx + t.r11 * qby, w, h);
+}
+
+__global__ void __launch_bounds__(256)
+warp_list_kernel(const float* __restrict__ src_maps, const float* __restrict__ poses,
+                 const int32_t* __restrict__ src_image, int h, int w, int c,
+                 float* __restrict__ warped) {
+  const int wi = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4n = c >> 2, hw = h * w;
+  const float* src = src_maps + (size_t)src_image[wi] * hw * c;
+  const PoseTerms t = pose_terms(poses + 16 * (size_t)wi);
+  for (int pp = wave; pp < PIX_PER_BLOCK; pp += 4) {
+    const int p = blockIdx.x * PIX_PER_BLOCK + pp;
+    if (p >= hw) break;
+    const Bilinear t2 = pass2_taps(t, p % w, p / w, w, h);
+    Bilinear t1[4];
+    bool qok[4];
+    float qw[4] = {t2.w_nw, t2.w_ne, t2.w_sw, t2.w_se};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int qx = t2.x0 + (k & 1), qy = t2.y0 + (k >> 1);
+      qok[k] = qx >= 0 && qx < w && qy >= 0 && qy < h;
+      t1[k] = pass1_taps(t, qx, qy, w, h);
+    }
+    float* out = warped + ((size_t)wi * hw + p) * c;
+    for (int c4 = lane; c4 < c4n; c4 += 64) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc += sample_src(src, t1[k], w, h, c, c4) * (qok[k] ? qw[k] : 0.f);
+      *reinterpret_cast<f32x4*>(out + 4 * c4) = acc;
+    }
+  }
+}
+
+// Transposes of the two gathers, in reverse order.  PASS = 2: gradient of the translated map
+// -> gradient of the rotated map (scratch, per warp).  PASS = 1: rotated-map gradient ->
+// the source agent's map.  Several outputs share a tap: hardware float atomics (L2).
+template <int PASS>
+__global__ void __launch_bounds__(256)
+warp_scatter_kernel(const float* __restrict__ grad_in, const float* __restrict__ poses,
+                    const int32_t* __restrict__ src_image, int h, int w, int c,
+                    float* __restrict__ grad_out) {
+  const int wi = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4n = c >> 2, hw = h * w;
+  const PoseTerms t = pose_terms(poses + 16 * (size_t)wi);
+  float* dst = grad_out + (size_t)(PASS == 2 ? wi : src_image[wi]) * hw * c;
+  for (int pp = wave; pp < PIX_PER_BLOCK; pp += 4) {
+    const int p = blockIdx.x * PIX_PER_BLOCK + pp;
+    if (p >= hw) break;
+    const Bilinear b = PASS == 2 ? pass2_taps(t, p % w, p / w, w, h) : pass1_taps(t, p % w, p / w, w, h);
+    const float wt[4] = {b.w_nw, b.w_ne, b.w_sw, b.w_se};
+    const float* gin = grad_in + ((size_t)wi * hw + p) * c;
+    for (int c4 = lane; c4 < c4n; c4 += 64) {
+      const f32x4 g = ld4(gin + 4 * c4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x = b.x0 + (k & 1), y = b.y0 + (k >> 1);
+        if (x < 0 || x >= w || y < 0 || y >= h) continue;   // wave-uniform
+        float* o = dst + ((size_t)y * w + x) * c + 4 * c4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, g[e] * wt[k]);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int dn_warp_list(const float* src, const float* poses, const int32_t* src_image,
+                            int n_warps, int h, int w, int c, float* warped, void* stream) {
+  DN_REQUIRE(src && poses && src_image && warped, "warp list: null pointer");
+  DN_REQUIRE(n_warps > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "warp list: bad shape");
+  dim3 grid((h * w + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, n_warps);
+  hipLaunchKernelGGL(warp_list_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, poses, src_image, h,
+                     w, c, warped);
+  return dn::check_launch("warp_list_kernel");
+}
+
+extern "C" int dn_warp_backward(const float* d_warped, const float* poses, const int32_t* src_image,
+                                int n_warps, int h, int w, int c, float* scratch, float* d_src,
+                                void* stream) {
+  DN_REQUIRE(d_warped && poses && src_image && scratch && d_src, "warp backward: null pointer");
+  DN_REQUIRE(n_warps > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "warp backward: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)n_warps * h * w * c, s) != hipSuccess)
+    return dn::fail(DN_ERR_LAUNCH, "warp backward: memset failed");
+  dim3 grid((h * w + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, n_warps);
+  hipLaunchKernelGGL(warp_scatter_kernel<2>, grid, dim3(256), 0, s, d_warped, poses, src_image, h, w, c,
+                     scratch);
+  hipLaunchKernelGGL(warp_scatter_kernel<1>, grid, dim3(256), 0, s, scratch, poses, src_image, h, w, c,
+                     d_src);
+  return dn::check_launch("warp_scatter_kernel");
+}
 
 extern "C" int dn_warp_neighbors(const float* feat, const float* trans, const int32_t* num_agent,
                                  int batch, int agents, int h, int w, int c, int only_v2i,

@@ -94,7 +94,7 @@ def conv_desc(n_images, h_in, w_in, c0, c_out, ksize, stride=1, relu=True, c1=0,
               ld0=None, ld1=None, ldo=None, math=0):
     d = ConvDesc()
     d.n_images, d.h_in, d.w_in = n_images, h_in, w_in
-    d.c0, d.c1, d.up0 = c0, c1, int(bool(up0))
+    d.c0, d.c1, d.up0 = c0, c1, int(up0)   # 1: nearest x2 upsample, 2: zero-stuffed (dgrad)
     d.c_out, d.ksize, d.stride, d.relu = c_out, ksize, stride, int(bool(relu))
     d.ld0 = c0 if ld0 is None else ld0
     d.ld1 = c1 if ld1 is None else ld1

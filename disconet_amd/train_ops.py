@@ -1,0 +1,210 @@
+"""Tensor-level wrappers over the training C ABI (include/disconet_train.h).
+
+Same rules as ops.py: float32 HIP tensors, torch's current stream, no CPU path.
+Maps are NHWC; a tensor argument that is a channel slice of a wider map is passed
+as (tensor_view, ld) with the view's data_ptr at the first channel.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .ops import _need_gpu, _ptr, _stream, conv_desc
+
+
+def _ws(device, nbytes, cache={}):
+    """grow-only scratch buffer per device (doubles / floats reinterpret it)"""
+    key = str(device)
+    buf = cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        cache[key] = buf
+    return buf
+
+
+def _ld(t):
+    """row stride (floats) of an NHWC map or a channel slice of one"""
+    assert t.stride(-1) == 1, "channel axis must be contiguous"
+    return t.stride(-2)
+
+
+# ---- conv backward ------------------------------------------------------------------------
+def conv_wgrad(desc, src0, src1, dz, dw, dw_cin_total=0, accumulate=False):
+    """dw [c_out, c_in(, k, k)] (a column block of a [c_out, dw_cin_total, k, k] tensor when
+    dw_cin_total is given) = weight gradient of the layer `desc` (desc.ldo = row stride of dz)."""
+    _need_gpu(src0, src1, dz, dw)
+    lib = _lib.load()
+    nbytes = lib.dn_conv_wgrad_workspace(ctypes.byref(desc))
+    if nbytes == 0:
+        check(-1, "dn_conv_wgrad_workspace")
+    ws = _ws(dz.device, nbytes)
+    check(lib.dn_conv_wgrad(ctypes.byref(desc), _ptr(src0), _ptr(src1), _ptr(dz), _ptr(ws), _ptr(dw),
+                            int(dw_cin_total), int(bool(accumulate)), _stream()), "dn_conv_wgrad")
+    return dw
+
+
+def dgrad_weights(w, ci_first=0, c_in=None):
+    """w [c_out, cin_total, k, k] -> wt [c_in, c_out, k, k], taps flipped (weights of the
+    data-gradient conv for input columns ci_first .. ci_first + c_in)."""
+    _need_gpu(w)
+    c_out, cin_total, k = w.shape[0], w.shape[1], w.shape[-1] if w.dim() == 4 else 1
+    c_in = cin_total - ci_first if c_in is None else c_in
+    wt = torch.empty((c_in, c_out, k, k), dtype=torch.float32, device=w.device)
+    check(_lib.load().dn_conv_dgrad_weights(_ptr(w), c_out, cin_total, ci_first, c_in, k, _ptr(wt),
+                                            _stream()), "dn_conv_dgrad_weights")
+    return wt
+
+
+# ---- batch norm, training mode ------------------------------------------------------------
+def bn_stats(z, n_groups=1):
+    """z [..., c] dense NHWC rows -> (mean, biased var) each [n_groups, c]"""
+    _need_gpu(z)
+    c = z.shape[-1]
+    rows = z.numel() // c
+    assert rows % n_groups == 0
+    mean = torch.empty((n_groups, c), dtype=torch.float32, device=z.device)
+    var = torch.empty_like(mean)
+    sums = _ws(z.device, 16 * c * n_groups)
+    check(_lib.load().dn_bn_train_stats(_ptr(z), n_groups, rows // n_groups, c, c, _ptr(sums),
+                                        _ptr(mean), _ptr(var), _stream()), "dn_bn_train_stats")
+    return mean, var
+
+
+def bn_apply(z, mean, var, gamma, beta, eps, relu=True, out=None):
+    _need_gpu(z, mean, var, gamma, beta)
+    c = z.shape[-1]
+    n_groups = mean.shape[0]
+    rows = z.numel() // c
+    y = torch.empty_like(z) if out is None else out
+    check(_lib.load().dn_bn_train_apply(_ptr(z), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta),
+                                        float(eps), int(relu), n_groups, rows // n_groups, c, c,
+                                        _ptr(y), _stream()), "dn_bn_train_apply")
+    return y
+
+
+def bn_update_running(mean, var, rows_per_group, running_mean, running_var, momentum=0.1, order=None):
+    n_groups, c = mean.shape
+    check(_lib.load().dn_bn_update_running(_ptr(mean), _ptr(var), n_groups, int(rows_per_group), c,
+                                           _ptr(order), float(momentum), _ptr(running_mean),
+                                           _ptr(running_var), _stream()), "dn_bn_update_running")
+
+
+def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_b=None, up_a=False,
+                accumulate=False, out=None):
+    """z, y [n, h, w, c] dense.  dy_a: [n, h, w, c'] view (or [n, 2h, 2w, c'] when up_a), dy_b
+    optional second gradient (same resolution as y).  Returns dz; fills dgamma / dbeta."""
+    _need_gpu(dy_a, dy_b, y, z, mean, var, gamma)
+    n, h, w, c = z.shape
+    n_groups = mean.shape[0]
+    assert n % n_groups == 0
+    dz = torch.empty_like(z) if out is None else out
+    sums = _ws(z.device, 16 * c * n_groups)
+    check(_lib.load().dn_bn_train_backward(
+        _ptr(dy_a), _ld(dy_a), int(bool(up_a)), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0,
+        _ptr(y), _ptr(z), _ptr(mean), _ptr(var), _ptr(gamma), float(eps), int(relu), n_groups, h, w,
+        n // n_groups, c, _ptr(sums), _ptr(dz), _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)),
+        _stream()), "dn_bn_train_backward")
+    return dz
+
+
+def channel_sum(x, out, accumulate=False):
+    """out[c] (+)= sum over all rows of x [..., c] (x may be a channel slice)"""
+    _need_gpu(x, out)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    sums = _ws(x.device, 8 * c)
+    check(_lib.load().dn_channel_sum(_ptr(x), rows, c, _ld(x), _ptr(sums), _ptr(out),
+                                     int(bool(accumulate)), _stream()), "dn_channel_sum")
+    return out
+
+
+def add_rows(a, b):
+    """a += b for NHWC maps / channel slices of equal shape"""
+    _need_gpu(a, b)
+    c = a.shape[-1]
+    rows = a.numel() // c
+    check(_lib.load().dn_add_rows(_ptr(a), _ld(a), _ptr(b), _ld(b), rows, c, _stream()), "dn_add_rows")
+    return a
+
+
+# ---- fusion, training form ----------------------------------------------------------------
+def pair_add_ego(z1, e, ego_image):
+    n_pairs, rows, c = z1.shape[0], z1[0].numel() // z1.shape[-1], z1.shape[-1]
+    check(_lib.load().dn_pair_add_ego(_ptr(z1), _ptr(e), _ptr(ego_image), n_pairs, rows, c, _stream()),
+          "dn_pair_add_ego")
+    return z1
+
+
+def pair_sum_ego(dz1, first, pairs, n_images):
+    rows, c = dz1[0].numel() // dz1.shape[-1], dz1.shape[-1]
+    de = torch.empty((n_images,) + tuple(dz1.shape[1:]), dtype=torch.float32, device=dz1.device)
+    check(_lib.load().dn_pair_sum_ego(_ptr(dz1), _ptr(first), _ptr(pairs), n_images, rows, c, _ptr(de),
+                                      _stream()), "dn_pair_sum_ego")
+    return de
+
+
+def fuse_combine(z4, maps, first, pair_index, map_image, ego_out, fused):
+    """z4 [P, h, w, 1]; maps [M, h, w, c]; lists per ego; writes fused[ego_out[e]]; returns weights"""
+    _need_gpu(z4, maps, fused)
+    hw, c = maps.shape[1] * maps.shape[2], maps.shape[3]
+    weights = torch.empty_like(z4)
+    check(_lib.load().dn_fuse_combine(_ptr(z4), _ptr(maps), _ptr(first), _ptr(pair_index),
+                                      _ptr(map_image), _ptr(ego_out), ego_out.numel(), hw, c,
+                                      _ptr(weights), _ptr(fused), _stream()), "dn_fuse_combine")
+    return weights
+
+
+def fuse_combine_backward(dfused, z4, weights, maps, first, pair_index, map_image, ego_out, dmaps):
+    hw, c = maps.shape[1] * maps.shape[2], maps.shape[3]
+    dz4 = torch.zeros_like(z4)
+    check(_lib.load().dn_fuse_combine_backward(
+        _ptr(dfused), _ld(dfused), _ptr(z4), _ptr(weights), _ptr(maps), _ptr(first), _ptr(pair_index),
+        _ptr(map_image), _ptr(ego_out), ego_out.numel(), hw, c, _ptr(dmaps), _ptr(dz4), _stream()),
+        "dn_fuse_combine_backward")
+    return dz4
+
+
+def warp_list(src, poses, src_image, out=None):
+    """src [M, h, w, c]; poses [n, 4, 4]; src_image [n] int32 -> warped [n, h, w, c]"""
+    _need_gpu(src, poses, src_image)
+    n = src_image.numel()
+    _, h, w, c = src.shape
+    warped = torch.empty((n, h, w, c), dtype=torch.float32, device=src.device) if out is None else out
+    check(_lib.load().dn_warp_list(_ptr(src), _ptr(poses), _ptr(src_image), n, h, w, c, _ptr(warped),
+                                   _stream()), "dn_warp_list")
+    return warped
+
+
+def warp_backward(d_warped, poses, src_image, d_src):
+    """scatter-adds into d_src [M, h, w, c]"""
+    n, h, w, c = d_warped.shape
+    scratch = _ws(d_warped.device, 4 * d_warped.numel())
+    check(_lib.load().dn_warp_backward(_ptr(d_warped), _ptr(poses), _ptr(src_image), n, h, w, c,
+                                       _ptr(scratch), _ptr(d_src), _stream()), "dn_warp_backward")
+    return d_src
+
+
+# ---- loss / optimiser ---------------------------------------------------------------------
+def det_loss(cls, labels, loc, targets, mask, norm, alpha=0.25, gamma=2.0, sigma=3.0):
+    """-> (losses [2] float64 = (cls, loc), dcls, dloc)"""
+    _need_gpu(cls, labels, loc, targets, mask)
+    code = loc.shape[-1]
+    n = loc.numel() // code
+    assert cls.numel() == 2 * n and mask.numel() == n
+    losses = torch.empty(2, dtype=torch.float64, device=cls.device)
+    dcls, dloc = torch.empty_like(cls), torch.empty_like(loc)
+    check(_lib.load().dn_det_loss(_ptr(cls), _ptr(labels), _ptr(loc), _ptr(targets), _ptr(mask), n,
+                                  code, float(alpha), float(gamma), float(sigma), float(norm),
+                                  _ptr(losses), _ptr(dcls), _ptr(dloc), _stream()), "dn_det_loss")
+    return losses, dcls, dloc
+
+
+def adam_step(p, g, m, v, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    _need_gpu(p, g, m, v)
+    check(_lib.load().dn_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr),
+                                   float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                   int(step), _stream()), "dn_adam_step")
+
+
+__all__ = [n for n in dir() if not n.startswith("_")] + ["conv_desc"]

@@ -1,0 +1,137 @@
+/*
+ * disconet_train.h -- C ABI of the training-step kernels (same library,
+ * libdisconet_hip.so).  SURVEY.md §8(f) "next" row 1.
+ *
+ * Replaces what autograd + torch.optim run under
+ *   upstream:coperception/utils/CoDetModule.py :: CoDetModule.step
+ *     (model(...) in train() mode; loss_calculator; loss.backward(); optimizer.step())
+ *   upstream:coperception/utils/loss.py :: SoftmaxFocalClassificationLoss,
+ *     WeightedSmoothL1LocalizationLoss
+ * (invoked by the `python train_codet.py ... --com disco` line, /root/reference/README.md:54-63;
+ * the sources are in the un-vendored submodule, /root/reference/.gitmodules:1-3, so there
+ * are no line numbers to cite).
+ *
+ * Same conventions as disconet_hip.h: device pointers, fp32 NHWC maps with an explicit
+ * row stride ("ld", in floats) where a tensor may be a channel slice of a wider one,
+ * caller-owned buffers and workspaces, everything enqueued on `stream`, int status +
+ * dn_last_error().
+ */
+#ifndef DISCONET_TRAIN_H
+#define DISCONET_TRAIN_H
+
+#include "disconet_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- conv backward ------------------------------------------------------------------- */
+
+/* dW of the layer `d` describes (the same descriptor its forward dn_conv2d used; d->ldo is
+ * the row stride of dz).  dw[co][ci][ky][kx] with ci running over c0 + c1; `dw_cin_total`
+ * (0 = c0 + c1) is the ci extent of the tensor dw points into, so a column block of a wider
+ * weight (the attention MLP's [W_ego | W_nbr]) can be written in place.  Slices are summed
+ * in a fixed order: deterministic.  accumulate != 0 adds to dw. */
+size_t dn_conv_wgrad_workspace(const dn_conv_desc* d);
+int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz,
+                  void* workspace, float* dw, int dw_cin_total, int accumulate, void* stream);
+
+/* Weights of the data-gradient conv: wt[ci][co][2-ky][2-kx] = w[co][ci][ky][kx] for the
+ * c_in columns starting at `ci_first` of a [c_out][cin_total][k][k] tensor.  dx is then
+ * dn_conv2d(dz; pack(wt)) with stride 1 -- for a stride-2 layer with src0 read zero-stuffed
+ * (dn_conv_desc.up0 = 2: source pixel (y/2, x/2) where y and x are even, 0 elsewhere). */
+int dn_conv_dgrad_weights(const float* w_oihw, int c_out, int cin_total, int ci_first, int c_in,
+                          int ksize, float* wt_oihw, void* stream);
+
+/* ---- batch norm in training mode (+ ReLU) ---------------------------------------------- */
+
+/* Statistics over `rows_per_group` pixels for each of `n_groups` consecutive groups of rows
+ * (n_groups = 1: nn.BatchNorm2d over the batch; n_groups = calls: the attention MLP's BN
+ * layers, which see one (ego, neighbour) pair of 1 x C x 32 x 32 per call).
+ * sums: workspace of n_groups * 2 * c doubles.  var is the biased variance. */
+int dn_bn_train_stats(const float* z, int n_groups, long rows_per_group, int c, int ldz,
+                      double* sums, float* mean, float* var, void* stream);
+
+/* y = act((z - mean) * rsqrt(var + eps) * gamma + beta), act = ReLU if relu */
+int dn_bn_train_apply(const float* z, const float* mean, const float* var, const float* gamma,
+                      const float* beta, float eps, int relu, int n_groups, long rows_per_group,
+                      int c, int ldz, float* y, void* stream);
+
+/* running = (1 - momentum) * running + momentum * batch stat, group after group in the order
+ * `order` lists them (null = 0..n_groups-1); running_var takes the unbiased variance. */
+int dn_bn_update_running(const float* mean, const float* var, int n_groups, long rows_per_group,
+                         int c, const int* order, float momentum, float* running_mean,
+                         float* running_var, void* stream);
+
+/* Backward of y = act(bn(z)).  The incoming gradient is dy_a (+ dy_b if not null); each has
+ * its own row stride, and dy_a may live at twice the resolution (up_a != 0: the 2 x 2 block
+ * sum, i.e. the backward of the decoder's nearest upsample; h, w are then y's dims).
+ *   g = (dy_a + dy_b) * (y > 0)      dbeta = sum g      dgamma = sum g * zhat
+ *   dz = gamma * rstd * (g - mean(g) - zhat * mean(g * zhat))       (means per group)
+ * dgamma / dbeta are summed over groups and ADDED when accumulate != 0.
+ * sums: workspace of n_groups * 2 * c doubles. */
+int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
+                         const float* y, const float* z, const float* mean, const float* var,
+                         const float* gamma, float eps, int relu, int n_groups, int h, int w,
+                         int images_per_group, int c, double* sums, float* dz, float* dgamma,
+                         float* dbeta, int accumulate, void* stream);
+
+/* out[c] (+)= sum over rows of x[row][c] (bias gradients); sums: c doubles */
+int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, float* out,
+                   int accumulate, void* stream);
+
+/* a[row][0..c) += b[row][0..c) */
+int dn_add_rows(float* a, int ld_a, const float* b, int ld_b, long rows, int c, void* stream);
+
+/* ---- DiscoGraph fusion, training mode ------------------------------------------------------ */
+
+/* z1[p] += e[ego_image[p]] for every pair p (rows_per_image pixels of c channels each) */
+int dn_pair_add_ego(float* z1, const float* e, const int* ego_image, int n_pairs,
+                    int rows_per_image, int c, void* stream);
+/* de[img] = sum of dz1[p] over the pairs listed for img: pairs[first[img] .. first[img + 1]) */
+int dn_pair_sum_ego(const float* dz1, const int* first, const int* pairs, int n_images,
+                    int rows_per_image, int c, float* de, void* stream);
+
+/* Softmax over a scene-agent's neighbour list and the weighted sum (forward), per pixel:
+ *   s_k = relu(z4[pair_k]);  w_k = exp(s_k) / sum_j exp(s_j);  fused = sum_k w_k * maps[nbr_k]
+ * lists: for ego e in [0, n_egos): entries first[e] .. first[e+1) of (pair_index, map_image);
+ * ego_out[e] = image of `fused` to write.  maps holds own and warped maps in one buffer. */
+int dn_fuse_combine(const float* z4, const float* maps, const int* first, const int* pair_index,
+                    const int* map_image, const int* ego_out, int n_egos, int hw, int c,
+                    float* weights, float* fused, void* stream);
+/* backward: dmaps[map_image_k] = w_k * dfused (assignment: every map is in one list),
+ * dz4[pair_k] = w_k * (<dfused, map_k> - sum_j w_j <dfused, map_j>) * (z4 > 0) */
+int dn_fuse_combine_backward(const float* dfused, int ld_df, const float* z4, const float* weights,
+                             const float* maps, const int* first, const int* pair_index,
+                             const int* map_image, const int* ego_out, int n_egos, int hw, int c,
+                             float* dmaps, float* dz4, void* stream);
+
+/* Backward of dn_warp_neighbors for a list of warps: the gradient of warp w (source image
+ * src_image[w], 4x4 pose at poses + 16 * w, row-major, neighbour -> ego) is scattered through
+ * both bilinear passes into d_src[src_image[w]] with float atomics.  scratch: n_warps maps. */
+int dn_warp_backward(const float* d_warped, const float* poses, const int* src_image, int n_warps,
+                     int h, int w, int c, float* scratch, float* d_src, void* stream);
+/* forward over the same list (training keeps every warp, in list order) */
+int dn_warp_list(const float* src, const float* poses, const int* src_image, int n_warps, int h,
+                 int w, int c, float* warped, void* stream);
+
+/* ---- loss and optimiser --------------------------------------------------------------------- */
+
+/* Focal softmax classification loss + masked smooth-L1 localisation loss, forward and the
+ * gradient w.r.t. the logits / box codes in one pass:
+ *   cls [n, 2] logits, labels [n, 2] one-hot;  loc, targets [n, code] ; mask [n] (0/1 floats)
+ *   loss_cls = sum_n alpha_t (1 - p_t)^gamma (-log p_t) / norm
+ *   loss_loc = sum_n mask * sum_code smoothL1_sigma(loc - target) / norm
+ * losses: 2 doubles (cls, loc), zeroed by the call. */
+int dn_det_loss(const float* cls, const float* labels, const float* loc, const float* targets,
+                const float* mask, long n, int code, float alpha, float gamma, float sigma,
+                float norm, double* losses, float* dcls, float* dloc, void* stream);
+
+/* torch.optim.Adam (no amsgrad) on a flat parameter buffer; step counts from 1 */
+int dn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

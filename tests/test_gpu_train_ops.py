@@ -1,0 +1,332 @@
+"""Training-step kernels (include/disconet_train.h) against torch-CPU autograd of the same
+op in float64 (these are floating-point kernels; the reference is the op's own definition,
+the whole-step parity against the oracle model is tests/test_gpu_train_step.py).
+
+Tolerances are relative to the largest reference magnitude of each tensor: 2e-5 for the
+exact-fp32 kernels (fp32 accumulation over up to 1e5 terms), 1e-4 where the split-f16
+conv engine takes part."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(got, ref):
+    ref = ref.double()
+    return float((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+WGRAD_CASES = [
+    # n, h, w, c0, c1, up0, c_out, k, stride
+    (2, 32, 32, 32, 0, 0, 32, 3, 1),
+    (2, 20, 24, 13, 0, 0, 32, 3, 1),        # voxel input: 13 channels, ragged tiles
+    (3, 32, 32, 64, 0, 0, 128, 3, 2),
+    (2, 18, 22, 32, 0, 0, 64, 3, 2),
+    (2, 32, 32, 64, 32, 1, 32, 3, 1),       # decoder: up(64) || skip(32)
+    (2, 16, 16, 512, 256, 1, 256, 3, 1),    # conv5_1's channel structure
+    (2, 32, 32, 64, 0, 0, 64, 1, 1),        # Conv3D(1,1,1)
+    (2, 32, 32, 32, 0, 0, 12, 1, 1),        # cls head conv2
+    (4, 32, 32, 8, 0, 0, 1, 1, 1),          # attention MLP's last layer
+    (1, 256, 256, 32, 0, 0, 32, 3, 1),      # full-resolution layer, many slices
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_wgrad_matches_autograd(case):
+    from disconet_amd import ops, train_ops
+    n, h, w, c0, c1, up0, c_out, k, stride = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    hs, ws = (h // 2, w // 2) if up0 else (h, w)
+    x0 = torch.randn(n, c0, hs, ws, generator=g)
+    x1 = torch.randn(n, c1, h, w, generator=g) if c1 else None
+    wgt = (torch.randn(c_out, c0 + c1, k, k, generator=g) * 0.1).double().requires_grad_(True)
+    xin = F.interpolate(x0, scale_factor=2) if up0 else x0
+    if c1:
+        xin = torch.cat([xin, x1], 1)
+    z = F.conv2d(xin.double(), wgt, None, stride, k // 2)
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz.double())
+
+    d = ops.conv_desc(n, h, w, c0, c_out, ksize=k, stride=stride, c1=c1, up0=up0, relu=False)
+    dw = torch.full((c_out, c0 + c1, k, k), 7.0, device=_dev())
+    train_ops.conv_wgrad(d, nhwc(x0).to(_dev()), nhwc(x1).to(_dev()) if c1 else None,
+                         nhwc(dz).to(_dev()), dw)
+    assert rel_err(dw, wgt.grad) < 2e-5
+    # accumulate adds to what is there
+    train_ops.conv_wgrad(d, nhwc(x0).to(_dev()), nhwc(x1).to(_dev()) if c1 else None,
+                         nhwc(dz).to(_dev()), dw, accumulate=True)
+    assert rel_err(dw, 2 * wgt.grad) < 2e-5
+
+
+def test_conv_wgrad_column_block_and_strided_dz():
+    """the attention MLP's W1 = [W_ego | W_nbr]: dW written into a column block; dz as a
+    channel slice of a wider tensor"""
+    from disconet_amd import ops, train_ops
+    g = torch.Generator().manual_seed(3)
+    n, h, w, c_in, c_out = 3, 32, 32, 256, 128
+    x = torch.randn(n, h, w, c_in, generator=g)
+    dz_wide = torch.randn(n, h, w, c_out + 32, generator=g)
+    dz = dz_wide[..., 16:16 + c_out]
+    ref = torch.einsum("nhwo,nhwi->oi", dz.double(), x.double())
+    dw = torch.zeros(c_out, 2 * c_in, 1, 1, device=_dev())
+    d = ops.conv_desc(n, h, w, c_in, c_out, ksize=1, relu=False, ldo=c_out + 32)
+    dzg = dz_wide.to(_dev())
+    train_ops.conv_wgrad(d, x.to(_dev()), None, dzg[..., 16:16 + c_out], dw[:, c_in:], dw_cin_total=2 * c_in)
+    assert rel_err(dw[:, c_in:, 0, 0], ref) < 2e-5
+    assert float(dw[:, :c_in].abs().max()) == 0.0
+
+
+DGRAD_CASES = [
+    (2, 32, 32, 64, 64, 3, 1), (2, 32, 32, 32, 64, 3, 2), (2, 20, 24, 128, 256, 3, 2),
+    (2, 32, 32, 96, 32, 3, 1), (2, 32, 32, 64, 64, 1, 1), (2, 32, 32, 32, 36, 1, 1),
+]
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+@pytest.mark.parametrize("case", DGRAD_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_dgrad_through_the_forward_engine(case, math):
+    """dx = conv(dz, flipped / transposed weights), stride-2 layers read dz zero-stuffed"""
+    from disconet_amd import ops, train_ops
+    n, h, w, c_in, c_out, k, stride = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, c_in, h, w, generator=g).double().requires_grad_(True)
+    wgt = torch.randn(c_out, c_in, k, k, generator=g) * 0.1
+    z = F.conv2d(x, wgt.double(), None, stride, k // 2)
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz.double())
+
+    wt = train_ops.dgrad_weights(wgt.to(_dev()))
+    d = ops.conv_desc(n, h, w, c_out, c_in, ksize=k, stride=1, up0=2 if stride == 2 else 0,
+                      relu=False, math=math)
+    packed = ops.pack_conv_weights(d, wt)
+    one = torch.ones(c_in, device=_dev())
+    zero = torch.zeros(c_in, device=_dev())
+    dx = ops.conv2d(d, nhwc(dz).to(_dev()), packed, one, zero)
+    assert rel_err(dx, nhwc(x.grad)) < (2e-5 if math == "f32" else 1e-4)
+
+
+@pytest.mark.parametrize("shape,groups", [((4, 32, 32, 64), 1), ((6, 16, 16, 128), 6),
+                                          ((2, 64, 64, 13), 1), ((5, 32, 32, 8), 5),
+                                          ((3, 32, 32, 1), 3), ((2, 16, 16, 512), 1)])
+def test_bn_train_forward_and_backward(shape, groups):
+    from disconet_amd import train_ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(shape, generator=g) * 2 + 0.5
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.2
+    eps = 1e-5
+    zd = z.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    # per group: F.batch_norm over that group's images (training mode)
+    ys = []
+    for k in range(groups):
+        zg = zd[k * (n // groups):(k + 1) * (n // groups)].permute(0, 3, 1, 2)
+        ys.append(F.relu(F.batch_norm(zg, None, None, gd, bd, True, 0.1, eps)).permute(0, 2, 3, 1))
+    y_ref = torch.cat(ys, 0)
+    dy = torch.randn(shape, generator=g)
+    dy2 = torch.randn(shape, generator=g)
+    y_ref.backward((dy + dy2).double())
+
+    zg_, gm, bt = z.to(_dev()), gamma.to(_dev()), beta.to(_dev())
+    mean, var = train_ops.bn_stats(zg_, groups)
+    y = train_ops.bn_apply(zg_, mean, var, gm, bt, eps, relu=True)
+    assert rel_err(y, y_ref.detach()) < 2e-5
+    dgamma, dbeta = torch.empty(c, device=_dev()), torch.empty(c, device=_dev())
+    # second gradient as a channel slice of a wider tensor
+    wide = torch.zeros(n, h, w, c + 8, device=_dev())
+    wide[..., 8:] = dy2.to(_dev())
+    dz = train_ops.bn_backward(dy.to(_dev()), y, zg_, mean, var, gm, eps, dgamma, dbeta,
+                               dy_b=wide[..., 8:])
+    assert rel_err(dz, zd.grad) < 5e-5
+    assert rel_err(dgamma, gd.grad) < 2e-5
+    assert rel_err(dbeta, bd.grad) < 2e-5
+
+
+def test_bn_backward_of_upsampled_gradient_and_running_stats():
+    from disconet_amd import train_ops
+    n, h, w, c = 2, 16, 16, 64
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn(n, h, w, c, generator=g)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    zd = z.double().requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(c).double()
+    bn.weight.data, bn.bias.data = gamma.double(), beta.double()
+    bn.running_mean.data = torch.randn(c, generator=g).double()
+    rm0, rv0 = bn.running_mean.clone().float(), bn.running_var.clone().float()
+    y_ref = F.relu(bn(zd.permute(0, 3, 1, 2)))
+    up = F.interpolate(y_ref, scale_factor=2)                       # decoder's nearest upsample
+    cat = torch.cat([up, torch.zeros(n, 32, 2 * h, 2 * w, dtype=torch.float64)], 1)
+    dcat = torch.randn(n, 2 * h, 2 * w, c + 32, generator=g)        # NHWC gradient of the concat
+    cat.backward(dcat.permute(0, 3, 1, 2).double())
+
+    zg_, gm = z.to(_dev()), gamma.to(_dev())
+    mean, var = train_ops.bn_stats(zg_)
+    y = train_ops.bn_apply(zg_, mean, var, gm, beta.to(_dev()), bn.eps)
+    dgamma, dbeta = torch.zeros(c, device=_dev()), torch.zeros(c, device=_dev())
+    dz = train_ops.bn_backward(dcat.to(_dev())[..., :c], y, zg_, mean, var, gm, bn.eps, dgamma, dbeta,
+                               up_a=True)
+    assert rel_err(dz, zd.grad) < 5e-5
+    assert rel_err(dgamma, bn.weight.grad) < 2e-5
+    rm, rv = rm0.to(_dev()), rv0.to(_dev())
+    train_ops.bn_update_running(mean, var, n * h * w, rm, rv, 0.1)
+    assert rel_err(rm, bn.running_mean) < 1e-6 and rel_err(rv, bn.running_var) < 1e-6
+
+
+def test_channel_sum_add_rows_and_pair_kernels():
+    from disconet_amd import train_ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 32, 32, 48, generator=g)
+    xg = x.to(_dev())
+    out = torch.ones(36, device=_dev())
+    train_ops.channel_sum(xg[..., 4:40], out, accumulate=True)
+    assert rel_err(out, 1 + x[..., 4:40].double().sum((0, 1, 2))) < 1e-6
+    a = torch.randn(3, 32, 32, 36, generator=g)
+    ag = a.to(_dev())
+    train_ops.add_rows(ag, xg[..., 4:40])
+    assert rel_err(ag, a + x[..., 4:40]) < 1e-6
+    # pairs: z1[p] += e[ego[p]];  de[img] = sum of dz1 over the image's pairs
+    e = torch.randn(4, 8, 8, 16, generator=g)
+    z1 = torch.randn(7, 8, 8, 16, generator=g)
+    ego = torch.tensor([0, 1, 1, 3, 3, 3, 2], dtype=torch.int32)
+    got = train_ops.pair_add_ego(z1.to(_dev()), e.to(_dev()), ego.to(_dev()))
+    assert rel_err(got, z1 + e[ego.long()]) < 1e-6
+    first = torch.tensor([0, 1, 3, 4, 7], dtype=torch.int32)
+    pairs = torch.tensor([0, 1, 2, 6, 3, 4, 5], dtype=torch.int32)
+    de = train_ops.pair_sum_ego(z1.to(_dev()), first.to(_dev()), pairs.to(_dev()), 4)
+    ref = torch.stack([z1[pairs[first[i]:first[i + 1]].long()].sum(0) for i in range(4)])
+    assert rel_err(de, ref) < 1e-6
+
+
+def _poses(n, seed=4):
+    rng = np.random.RandomState(seed)
+    out = np.zeros((n, 4, 4), dtype=np.float32)
+    for k in range(n):
+        yaw, tx, ty = rng.uniform(-0.6, 0.6), rng.uniform(-12, 12), rng.uniform(-12, 12)
+        out[k] = np.eye(4)
+        out[k, 0, 0], out[k, 0, 1], out[k, 1, 0], out[k, 1, 1] = math.cos(yaw), -math.sin(yaw), math.sin(yaw), math.cos(yaw)
+        out[k, 0, 3], out[k, 1, 3] = tx, ty
+    out[0] = np.eye(4)
+    out[1, 0, 3], out[1, 1, 3] = 500.0, 500.0          # out of frame
+    return torch.from_numpy(out)
+
+
+def _warp_ref(nb, pose):
+    """the two-pass warp of the oracle (upstream feature_transformation), differentiable"""
+    theta_rot = torch.tensor([[pose[0, 0], pose[0, 1], 0.0], [pose[1, 0], pose[1, 1], 0.0]],
+                             dtype=nb.dtype).unsqueeze(0)
+    theta_trans = torch.tensor([[1.0, 0.0, 4 * pose[0, 3] / 128], [0.0, 1.0, -4 * pose[1, 3] / 128]],
+                               dtype=nb.dtype).unsqueeze(0)
+    size = (1,) + tuple(nb.shape)
+    r = F.grid_sample(nb.unsqueeze(0), F.affine_grid(theta_rot, size, align_corners=False),
+                      align_corners=False)
+    return F.grid_sample(r, F.affine_grid(theta_trans, size, align_corners=False),
+                         align_corners=False)[0]
+
+
+def test_warp_list_and_backward_match_autograd():
+    from disconet_amd import train_ops
+    g = torch.Generator().manual_seed(9)
+    m, c, hw, n = 4, 64, 32, 7
+    maps = torch.randn(m, c, hw, hw, generator=g).double().requires_grad_(True)
+    poses = _poses(n)
+    src = torch.tensor([0, 1, 2, 3, 1, 1, 0], dtype=torch.int32)
+    ref = torch.stack([_warp_ref(maps[int(src[k])], poses[k].double()) for k in range(n)])
+    dwarp = torch.randn(ref.shape, generator=g)
+    ref.backward(dwarp.double())
+
+    mg = nhwc(maps.detach().float()).to(_dev())
+    warped = train_ops.warp_list(mg, poses.to(_dev()), src.to(_dev()))
+    assert rel_err(warped, nhwc(ref.detach())) < 1e-5
+    d_src = torch.ones(m, hw, hw, c, device=_dev())      # accumulates on top of what is there
+    train_ops.warp_backward(nhwc(dwarp).to(_dev()), poses.to(_dev()), src.to(_dev()), d_src)
+    assert rel_err(d_src - 1, nhwc(maps.grad)) < 2e-5
+
+
+def test_fuse_combine_forward_backward():
+    from disconet_amd import train_ops
+    g = torch.Generator().manual_seed(12)
+    hw, c = 16, 256
+    n_maps, n_pairs = 7, 6
+    maps = torch.randn(n_maps, hw, hw, c, generator=g).double().requires_grad_(True)
+    z4 = (torch.randn(n_pairs, hw, hw, 1, generator=g) * 2).double().requires_grad_(True)
+    # ego 0: pairs 0,1,2 over maps 0,4,5; ego 1: pairs 3,4,5 over maps 1,6,2; ego 2 not live: itself
+    lists = [[(0, 0), (1, 4), (2, 5)], [(3, 1), (4, 6), (5, 2)], [(-1, 3)]]
+    ego_out = [0, 1, 3]
+    fused_ref = torch.zeros(4, hw, hw, c, dtype=torch.float64)
+    outs = []
+    for lst in lists:
+        s = [F.relu(z4[p, ..., 0]) if p >= 0 else torch.zeros(hw, hw, dtype=torch.float64) for p, _ in lst]
+        e = [torch.exp(v) for v in s]
+        tot = sum(e)
+        outs.append(sum((ek / tot).unsqueeze(-1) * maps[mi] for ek, (_, mi) in zip(e, lst)))
+    dfused = torch.randn(4, hw, hw, c + 64, generator=g)
+    loss = sum((o * dfused[eo, ..., 64:].double()).sum() for o, eo in zip(outs, ego_out))
+    loss.backward()
+
+    first = torch.tensor([0, 3, 6, 7], dtype=torch.int32).to(_dev())
+    pair_index = torch.tensor([p for l in lists for p, _ in l], dtype=torch.int32).to(_dev())
+    map_image = torch.tensor([m for l in lists for _, m in l], dtype=torch.int32).to(_dev())
+    eo = torch.tensor(ego_out, dtype=torch.int32).to(_dev())
+    mg, zg = maps.detach().float().to(_dev()), z4.detach().float().to(_dev())
+    fused = torch.zeros(4, hw, hw, c, device=_dev())
+    wts = train_ops.fuse_combine(zg, mg, first, pair_index, map_image, eo, fused)
+    for o, e_ in zip(outs, ego_out):
+        assert rel_err(fused[e_], o.detach()) < 1e-5
+    dmaps = torch.zeros_like(mg)
+    dz4 = train_ops.fuse_combine_backward(dfused.to(_dev())[..., 64:], zg, wts, mg, first, pair_index,
+                                          map_image, eo, dmaps)
+    assert rel_err(dmaps, maps.grad) < 1e-5
+    assert rel_err(dz4, z4.grad) < 2e-5
+
+
+def test_det_loss_and_gradients_match_the_oracle():
+    from disconet_amd import train_ops
+    from oracle.train_ref import det_loss
+    g = torch.Generator().manual_seed(6)
+    n_img, hw, a, code = 2, 16, 6, 6
+    n = n_img * hw * hw * a
+    cls = (torch.randn(n_img, hw * hw * a, 2, generator=g) * 3).double().requires_grad_(True)
+    loc = torch.randn(n_img, hw, hw, a, 1, code, generator=g).double().requires_grad_(True)
+    fg = torch.rand(n, generator=g) < 0.05
+    ignore = torch.rand(n, generator=g) < 0.02
+    labels = torch.stack([(~fg).float(), fg.float()], -1)
+    labels[ignore] = 0
+    targets = torch.randn(n, code, generator=g) * 0.5
+    mask = fg.float()
+    l_cls, l_loc = det_loss({"cls": cls, "loc": loc}, labels, targets, mask, norm=n_img)
+    (l_cls + l_loc).backward()
+    losses, dcls, dloc = train_ops.det_loss(
+        cls.detach().float().reshape(-1, 2).to(_dev()), labels.to(_dev()),
+        loc.detach().float().reshape(-1, code).to(_dev()), targets.to(_dev()), mask.to(_dev()), norm=n_img)
+    assert abs(float(losses[0]) - float(l_cls)) < 1e-5 * abs(float(l_cls))
+    assert abs(float(losses[1]) - float(l_loc)) < 1e-5 * abs(float(l_loc))
+    assert rel_err(dcls, cls.grad.reshape(-1, 2)) < 2e-5
+    assert rel_err(dloc, loc.grad.reshape(-1, code)) < 2e-5
+
+
+def test_adam_matches_torch_optim():
+    from disconet_amd import train_ops
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(10007, generator=g)
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p_ref], lr=1e-3)
+    p, m, v = p0.to(_dev()), torch.zeros(10007, device=_dev()), torch.zeros(10007, device=_dev())
+    for step in range(1, 4):
+        grad = torch.randn(10007, generator=g) * (10.0 ** (step - 2))
+        p_ref.grad = grad.clone()
+        opt.step()
+        train_ops.adam_step(p, grad.to(_dev()), m, v, step, lr=1e-3)
+    assert float((p.cpu() - p_ref.detach()).abs().max()) < 2e-6

@@ -13,7 +13,8 @@ from tests.conftest import ROOT
 
 
 def _header_functions():
-    text = open(os.path.join(ROOT, "include", "disconet_hip.h")).read()
+    text = "".join(open(os.path.join(ROOT, "include", f)).read()
+                   for f in ("disconet_hip.h", "disconet_train.h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(dn_[a-z0-9_]+)\s*\(", text)))
 
