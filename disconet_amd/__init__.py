@@ -6,5 +6,6 @@ include/disconet_hip.h).  See DESIGN.md.
 """
 from .config import Config
 from .model import DiscoNet
+from .train import CoDetModule, TrainEngine
 
-__all__ = ["Config", "DiscoNet"]
+__all__ = ["Config", "DiscoNet", "CoDetModule", "TrainEngine"]

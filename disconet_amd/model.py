@@ -238,10 +238,9 @@ class DiscoNet(nn.Module):
         return super().load_state_dict(cleaned, strict=strict, **kw)
 
     def train(self, mode=True):
-        if mode:
-            raise NotImplementedError(
-                "disconet_amd.DiscoNet: only the eval-mode forward is built on the HIP path so "
-                "far (training step = SURVEY.md §8(f) next #1); call .eval()")
+        """train(): forward() runs the training-mode graph of disconet_amd/train.py (batch
+        statistics, explicit HIP backward); eval(): the fused inference plan."""
+        self._plan = None
         return super().train(mode)
 
     # ------------------------------------------------------------------
@@ -407,10 +406,11 @@ class DiscoNet(nn.Module):
         return {"loc": loc_preds, "cls": cls_preds}
 
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size=1):
-        if self.training:
-            raise NotImplementedError("eval-mode forward only (call .eval())")
         if not bevs.is_cuda:
             raise ops._lib.DnError("DiscoNet.forward needs GPU tensors; there is no CPU path")
+        if self.training:
+            from .train import train_forward
+            return train_forward(self, bevs, trans_matrices, num_agent_tensor, batch_size)
         P = self._get_plan()
         A = self.agent_num
         if bevs.shape[0] != A * batch_size:

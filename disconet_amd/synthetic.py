@@ -127,3 +127,20 @@ def make_sparse_scene_batch(batch_size=4, num_agent=5, map_hw=256, z=13, p=0.02)
         lists.append(idx)
         offsets.append(offsets[-1] + idx.shape[0])
     return torch.cat(lists, 0).contiguous(), torch.tensor(offsets, dtype=torch.int32), bevs
+
+
+def make_train_targets(n_images, map_hw=256, anchors=6, code=6, seed=17, p_fg=0.01, p_ignore=0.005):
+    """Seeded stand-ins for what V2XSimDet yields next to the voxels (upstream
+    V2XSimDet.__getitem__: labels, reg_targets, reg_loss_mask): one-hot (bg, vehicle) labels per
+    anchor [N, H*W*A, 2] (an all-zero row = don't care), box-code regression targets
+    [N, H, W, A, 1, code] and the positive-anchor mask [N, H, W, A, 1]."""
+    g = torch.Generator().manual_seed(seed)
+    n = n_images * map_hw * map_hw * anchors
+    fg = torch.rand(n, generator=g) < p_fg
+    ignore = torch.rand(n, generator=g) < p_ignore
+    labels = torch.stack([(~fg).float(), fg.float()], -1)
+    labels[ignore & ~fg] = 0
+    reg_targets = (torch.randn(n, code, generator=g) * 0.5) * fg[:, None]
+    return (labels.view(n_images, -1, 2),
+            reg_targets.view(n_images, map_hw, map_hw, anchors, 1, code),
+            fg.view(n_images, map_hw, map_hw, anchors, 1))

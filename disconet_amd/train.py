@@ -1,0 +1,523 @@
+"""Training step of the `--com disco` detector on the HIP path.
+
+Mirrors upstream:coperception/utils/CoDetModule.py :: CoDetModule.step for the no-KD
+configuration (`python train_codet.py ... --com disco`, /root/reference/README.md:54-63):
+
+    model.train();  result = model(bev_seq, trans_matrices, num_agent, batch_size)
+    loss = focal(cls, labels) / N + smooth_l1(loc, reg_targets)[reg_loss_mask] / N
+    optimizer.zero_grad();  loss.backward();  optimizer.step()
+
+Nothing here runs through autograd or ATen math: the forward is the conv engine with
+batch-statistics BatchNorm kernels, the backward is an explicit reverse pass over the
+(static) layer graph -- data gradients through the same MFMA conv engine with flipped /
+transposed weights, weight gradients on the fp32 MFMA split-K kernel, BN / ReLU / upsample /
+concat / warp / softmax backward kernels -- and Adam is one launch over a flat parameter
+buffer (the module's nn.Parameters are views into it, so state_dict() / checkpoints keep
+working and a DDP-style gradient all-reduce is ONE RCCL collective over 31.5 MB).
+
+Two ways in:
+  * `CoDetModule(model, ...).step(data, batch_size)` -- native loss + backward + Adam.
+  * `model.train(); out = model(...); loss.backward()` -- the reference's own step code:
+    DiscoNet.forward returns tensors attached to one autograd node whose backward is the
+    explicit reverse pass (torch only routes d(loss)/d(cls, loc) in and parameter grads out).
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops, train_ops as T
+from .model import LAYER_CHANNEL, _bn_name
+
+_EPS = 1e-5          # nn.BatchNorm default
+_MOMENTUM = 0.1
+
+
+class _Layer:
+    """conv (+ BatchNorm in training mode + ReLU) of the graph and what its backward needs"""
+
+    def __init__(self, name, conv_w, conv_b, bn, ksize, stride=1):
+        self.name, self.w, self.b, self.bn = name, conv_w, conv_b, bn
+        self.ksize, self.stride = ksize, stride
+        self.c_out, self.c_in = conv_w.shape[0], conv_w.shape[1]
+        self.ctx = None
+
+
+def _param_order(model):
+    """flat-buffer order: the two heads' first convs / BNs adjacent (they run as one 64-channel
+    layer), then everything else in module order"""
+    cls, reg = model.classification, model.regression.box_prediction
+    first = [cls.conv1.weight, reg[0].weight, cls.conv1.bias, reg[0].bias,
+             cls.bn1.weight, reg[1].weight, cls.bn1.bias, reg[1].bias]
+    seen = {id(p) for p in first}
+    return first + [p for p in model.parameters() if id(p) not in seen]
+
+
+class TrainEngine:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if model.u_encoder.compress_level > 0:
+            raise NotImplementedError("training with compress_level > 0 is not built yet")
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        params = _param_order(model)
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise ops._lib.DnError("TrainEngine needs the model on the GPU; there is no CPU path")
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]      # 16-byte aligned views
+        total = sum(sizes)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad_of = {}
+        off = 0
+        for p, n in zip(params, sizes):
+            view = self.flat_p[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            self.grad_of[id(p)] = (off, p.numel(), p.shape)
+            off += n
+        self.params = params
+        self._graph()
+
+    # ------------------------------------------------------------------
+    def g(self, p, flat=None):
+        off, n, shape = self.grad_of[id(p)]
+        return (self.flat_g if flat is None else flat)[off:off + n].view(shape)
+
+    def _graph(self):
+        m = self.model
+        enc, dec = m.u_encoder, m.decoder
+        L = {}
+        for name in ("conv_pre_1", "conv_pre_2", "conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1",
+                     "conv3_2", "conv4_1", "conv4_2"):
+            conv = getattr(enc, name)
+            L[name] = _Layer(name, conv.weight, conv.bias, getattr(enc, _bn_name(name)), 3, conv.stride[0])
+        for name in ("conv3d_1", "conv3d_2"):
+            mod = getattr(enc, name)
+            L[name] = _Layer(name, mod.conv3d.weight, mod.conv3d.bias, mod.bn3d, 1)
+        for name in ("conv5_1", "conv5_2", "conv6_1", "conv6_2", "conv7_1", "conv7_2", "conv8_1", "conv8_2"):
+            conv = getattr(dec, name)
+            L[name] = _Layer(name, conv.weight, conv.bias, getattr(dec, _bn_name(name)), 3)
+        f = m.pixel_weighted_fusion
+        for i, (cname, bname) in enumerate((("conv1_2", "bn1_2"), ("conv1_3", "bn1_3")), 2):
+            conv = getattr(f, cname)
+            L["mlp%d" % i] = _Layer("mlp%d" % i, conv.weight, conv.bias, getattr(f, bname), 1)
+        self.L = L
+
+    # ------------------------------------------------------------------
+    # one conv + BN(train) + ReLU
+    # ------------------------------------------------------------------
+    def _math(self):
+        return ops.MATH_MODES[self.model.conv_math]
+
+    def _conv(self, w, bias, src0, src1=None, up0=0, stride=1, ksize=3, out=None, h_in=None, w_in=None):
+        """raw conv + bias through the forward engine (weights packed on the fly)"""
+        n, h0, w0 = src0.shape[0], src0.shape[1], src0.shape[2]
+        c0 = src0.shape[3]
+        if h_in is None:
+            h_in, w_in = (h0 * 2, w0 * 2) if up0 else (h0, w0)
+        c1 = src1.shape[3] if src1 is not None else 0
+        c_out = w.shape[0]
+        d = ops.conv_desc(n, h_in, w_in, c0, c_out, ksize, stride, False, c1=c1, up0=up0,
+                          ld0=src0.stride(2), ld1=src1.stride(2) if src1 is not None else None,
+                          ldo=out.stride(2) if out is not None else None, math=self._math())
+        packed = ops.pack_conv_weights(d, w)
+        dev = src0.device
+        one = self._const(dev, c_out, 1.0)
+        shift = bias if bias is not None else self._const(dev, c_out, 0.0)
+        if out is None:
+            ho, wo = ops.conv_out_hw(d)
+            out = torch.empty((n, ho, wo, c_out), dtype=torch.float32, device=dev)
+        ops.conv2d(d, src0, packed, one, shift, src1=src1, out=out)
+        return out, d
+
+    def _const(self, dev, n, val, cache={}):
+        key = (str(dev), n, val)
+        if key not in cache:
+            cache[key] = torch.full((n,), val, dtype=torch.float32, device=dev)
+        return cache[key]
+
+    def _layer_fwd(self, lay, src0, src1=None, up0=0, groups=1, w=None, b=None, gamma=None, beta=None,
+                   y_out=None):
+        w = lay.w if w is None else w
+        b = lay.b if b is None else b
+        z, d = self._conv(w, b, src0, src1, up0, lay.stride, lay.ksize)
+        mean, var = T.bn_stats(z, groups)
+        gamma = lay.bn.weight if gamma is None else gamma
+        beta = lay.bn.bias if beta is None else beta
+        y = T.bn_apply(z, mean, var, gamma, beta, _EPS, relu=True, out=y_out)
+        lay.ctx = dict(src0=src0, src1=src1, up0=up0, z=z, y=y, mean=mean, var=var, desc=d,
+                       groups=groups, w=w, gamma=gamma)
+        return y
+
+    def _update_running(self, bn, mean, var, rows, order=None, calls=1):
+        T.bn_update_running(mean, var, rows, bn.running_mean, bn.running_var, _MOMENTUM, order)
+        bn.num_batches_tracked += calls
+
+    def _layer_bwd(self, lay, dy_a, G, dy_b=None, up_a=False, need_dx=True, gw=None, gb=None,
+                   ggamma=None, gbeta=None):
+        """-> gradient w.r.t. the layer's (concatenated) input, [n, h_in, w_in, c_in]"""
+        c = lay.ctx
+        gw = self.g(lay.w, G) if gw is None else gw
+        gb = self.g(lay.b, G) if gb is None else gb
+        ggamma = self.g(lay.bn.weight, G) if ggamma is None else ggamma
+        gbeta = self.g(lay.bn.bias, G) if gbeta is None else gbeta
+        dz = T.bn_backward(dy_a, c["y"], c["z"], c["mean"], c["var"], c["gamma"], _EPS, ggamma, gbeta,
+                           relu=True, dy_b=dy_b, up_a=up_a)
+        return self._conv_bwd(c["desc"], c["w"], c["src0"], c["src1"], dz, gw, gb, need_dx)
+
+    def _conv_bwd(self, d, w, src0, src1, dz, gw, gb, need_dx=True, dw_cin_total=0, w_ci_first=0,
+                  w_c_in=None, dx_out=None):
+        T.conv_wgrad(d, src0, src1, dz, gw, dw_cin_total=dw_cin_total)
+        if gb is not None:
+            T.channel_sum(dz, gb)
+        if not need_dx:
+            return None
+        return self._dgrad(d, w, dz, w_ci_first, w_c_in, dx_out)
+
+    def _dgrad(self, d, w, dz, ci_first=0, c_in=None, dx_out=None):
+        """data gradient = forward engine on dz with flipped / transposed weights.  Always the
+        exact-fp32 MFMA mode: gradients span many orders of magnitude, and the split-f16 mode's
+        absolute floor (fp16 subnormals, 6e-8) would need per-tensor loss scaling (measured: 3.6 %
+        error on conv5_1.weight's gradient against 1 % for fp32)."""
+        wt = T.dgrad_weights(w.reshape(w.shape[0], w.shape[1], d.ksize, d.ksize), ci_first, c_in)
+        c_in = wt.shape[0]
+        dd = ops.conv_desc(d.n_images, d.h_in, d.w_in, d.c_out, c_in, d.ksize, 1, False,
+                           up0=2 if d.stride == 2 else 0, ld0=dz.stride(2),
+                           ldo=dx_out.stride(2) if dx_out is not None else None, math=0)
+        packed = ops.pack_conv_weights(dd, wt)
+        dev = dz.device
+        if dx_out is None:
+            dx_out = torch.empty((d.n_images, d.h_in, d.w_in, c_in), dtype=torch.float32, device=dev)
+        ops.conv2d(dd, dz, packed, self._const(dev, c_in, 1.0), self._const(dev, c_in, 0.0), out=dx_out)
+        return dx_out
+
+    # ------------------------------------------------------------------
+    # fusion lists (host side, from num_agent / only_v2i)
+    # ------------------------------------------------------------------
+    def _fusion_lists(self, trans, num_agent_cpu, B, dev):
+        A = self.model.agent_num
+        NI = A * B
+        img = lambda a, b: a * B + b
+        src_image, poses_idx, warp_ego = [], [], []
+        first, pair_index, map_image, ego_out = [0], [], [], []
+        order = []
+        for b in range(B):
+            n = int(num_agent_cpu[b])
+            for i in range(A):
+                ego_out.append(img(i, b))
+                if i >= n:
+                    pair_index.append(-1)
+                    map_image.append(img(i, b))
+                    first.append(len(pair_index))
+                    continue
+                pair_index.append(img(i, b))
+                map_image.append(img(i, b))
+                order.append(img(i, b))
+                for j in range(n):
+                    if j == i or (self.model.only_v2i and i != 0 and j != 0):
+                        continue
+                    wi = len(src_image)
+                    src_image.append(img(j, b))
+                    poses_idx.append((b, i, j))
+                    warp_ego.append(img(i, b))
+                    pair_index.append(NI + wi)
+                    map_image.append(NI + wi)
+                    order.append(NI + wi)
+                first.append(len(pair_index))
+        nw = len(src_image)
+        ego_image = list(range(NI)) + warp_ego
+        # pairs per ego image, for dE = sum over the ego's pairs
+        per = [[] for _ in range(NI)]
+        for p, e in enumerate(ego_image):
+            per[e].append(p)
+        efirst = [0]
+        for lst in per:
+            efirst.append(efirst[-1] + len(lst))
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+        if nw:
+            bi = torch.tensor(poses_idx, dtype=torch.long, device=dev)
+            poses = trans[bi[:, 0], bi[:, 1], bi[:, 2]].contiguous()
+        else:
+            poses = torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
+        return dict(n_warps=nw, src_image=i32(src_image), poses=poses, first=i32(first),
+                    pair_index=i32(pair_index), map_image=i32(map_image), ego_out=i32(ego_out),
+                    ego_image=i32(ego_image), efirst=i32(efirst), epairs=i32([p for l in per for p in l]),
+                    order=i32(order), n_calls=len(order))
+
+    # ------------------------------------------------------------------
+    # forward (training mode)
+    # ------------------------------------------------------------------
+    def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size):
+        m, L = self.model, self.L
+        A, B = m.agent_num, batch_size
+        if m.layer != 3:
+            raise NotImplementedError("training is built for layer = 3 (the reference default)")
+        n = bevs.shape[0] * bevs.shape[1]
+        if n != A * B:
+            raise ValueError("bevs has %d images, expected num_agent*batch_size = %d" % (n, A * B))
+        dev = bevs.device
+        x = bevs.reshape(n, bevs.shape[2], bevs.shape[3], bevs.shape[4])
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        trans = trans_matrices.to(device=dev, dtype=torch.float32).contiguous()
+        F = self._fusion_lists(trans, num_agent_tensor[:, 0].cpu(), B, dev)
+        self.F = F
+
+        a = self._layer_fwd(L["conv_pre_1"], x)
+        x0 = self._layer_fwd(L["conv_pre_2"], a)
+        a = self._layer_fwd(L["conv1_1"], x0)
+        a = self._layer_fwd(L["conv1_2"], a)
+        x1 = self._layer_fwd(L["conv3d_1"], a)
+        a = self._layer_fwd(L["conv2_1"], x1)
+        a = self._layer_fwd(L["conv2_2"], a)
+        x2 = self._layer_fwd(L["conv3d_2"], a)
+        a = self._layer_fwd(L["conv3_1"], x2)
+        h3, w3 = a.shape[1], a.shape[2]
+        C = LAYER_CHANNEL[3]
+        NI, NW = n, F["n_warps"]
+        maps = torch.empty((NI + NW, h3, w3, C), dtype=torch.float32, device=dev)
+        x3 = self._layer_fwd(L["conv3_2"], a, y_out=maps[:NI])        # own maps land in the pair buffer
+        a = self._layer_fwd(L["conv4_1"], x3)
+        x4 = self._layer_fwd(L["conv4_2"], a)
+
+        x3f = self._fusion_fwd(maps, NI, NW, F)
+
+        a = self._layer_fwd(L["conv5_1"], x4, x3f, up0=1)
+        x5 = self._layer_fwd(L["conv5_2"], a)
+        a = self._layer_fwd(L["conv6_1"], x5, x2, up0=1)
+        x6 = self._layer_fwd(L["conv6_2"], a)
+        a = self._layer_fwd(L["conv7_1"], x6, x1, up0=1)
+        x7 = self._layer_fwd(L["conv7_2"], a)
+        a = self._layer_fwd(L["conv8_1"], x7, x0, up0=1)
+        x8 = self._layer_fwd(L["conv8_2"], a)
+
+        # heads: both first convs as one 64-channel layer (their parameters are adjacent in the
+        # flat buffer), then the two 1x1 prediction convs on the halves
+        cls, reg = m.classification, m.regression.box_prediction
+        po, _, _ = self.grad_of[id(cls.conv1.weight)]
+        w1 = self.flat_p[po:po + 2 * cls.conv1.weight.numel()].view(64, 32, 3, 3)
+        bo, _, _ = self.grad_of[id(cls.conv1.bias)]
+        b1 = self.flat_p[bo:bo + 64]
+        go, _, _ = self.grad_of[id(cls.bn1.weight)]
+        gamma = self.flat_p[go:go + 64]
+        beo, _, _ = self.grad_of[id(cls.bn1.bias)]
+        beta = self.flat_p[beo:beo + 64]
+        self.head1 = _Layer("heads1", w1, b1, None, 3)
+        h1 = self._layer_fwd(self.head1, x8, w=w1, b=b1, gamma=gamma, beta=beta)
+        cls_out, dc = self._conv(cls.conv2.weight, cls.conv2.bias, h1[..., :32], ksize=1)
+        loc_out, dr = self._conv(reg[3].weight, reg[3].bias, h1[..., 32:], ksize=1)
+        self.head_ctx = dict(h1=h1, dc=dc, dr=dr)
+
+        # running statistics (momentum updates in the reference's call order)
+        for lay in L.values():
+            if lay.name.startswith("mlp"):
+                continue
+            c = lay.ctx
+            self._update_running(lay.bn, c["mean"], c["var"], c["z"].numel() // c["z"].shape[-1])
+        hc = self.head1.ctx
+        rows = hc["z"].numel() // 64
+        T.bn_update_running(hc["mean"][:, :32], hc["var"][:, :32], rows, cls.bn1.running_mean,
+                            cls.bn1.running_var, _MOMENTUM)
+        T.bn_update_running(hc["mean"][:, 32:], hc["var"][:, 32:], rows, reg[1].running_mean,
+                            reg[1].running_var, _MOMENTUM)
+        cls.bn1.num_batches_tracked += 1
+        reg[1].num_batches_tracked += 1
+
+        nI, h, w = cls_out.shape[0], cls_out.shape[1], cls_out.shape[2]
+        self.outs = dict(x5=x5, x6=x6, x7=x7, x8=x8, fused=x3f)
+        return {"loc": loc_out.view(nI, h, w, m.anchor_num_per_loc, m.out_seq_len, m.box_code_size),
+                "cls": cls_out.view(nI, -1, m.category_num)}
+
+    def _fusion_fwd(self, maps, NI, NW, F):
+        m, L = self.model, self.L
+        f = m.pixel_weighted_fusion
+        C = maps.shape[-1]
+        P = NI + NW
+        hw = maps.shape[1] * maps.shape[2]
+        if NW:
+            T.warp_list(maps, F["poses"], F["src_image"], out=maps[NI:])
+        w1 = f.conv1_1.weight.reshape(128, 2 * C)
+        w_ego, w_nbr = w1[:, :C].contiguous(), w1[:, C:].contiguous()
+        E, d_e = self._conv(w_ego.view(128, C, 1, 1), None, maps[:NI], ksize=1)
+        z1, d_f = self._conv(w_nbr.view(128, C, 1, 1), f.conv1_1.bias, maps, ksize=1)
+        T.pair_add_ego(z1, E, F["ego_image"])
+        mean1, var1 = T.bn_stats(z1, P)
+        h1 = T.bn_apply(z1, mean1, var1, f.bn1_1.weight, f.bn1_1.bias, _EPS, relu=True)
+        h2 = self._layer_fwd(L["mlp2"], h1, groups=P)
+        h3 = self._layer_fwd(L["mlp3"], h2, groups=P)
+        z4, d4 = self._conv(f.conv1_4.weight, f.conv1_4.bias, h3, ksize=1)
+        fused = torch.empty((NI,) + tuple(maps.shape[1:]), dtype=torch.float32, device=maps.device)
+        weights = T.fuse_combine(z4, maps, F["first"], F["pair_index"], F["map_image"], F["ego_out"], fused)
+        self.fctx = dict(maps=maps, NI=NI, NW=NW, z1=z1, mean1=mean1, var1=var1, h1=h1, d_e=d_e, d_f=d_f,
+                         w_ego=w_ego, w_nbr=w_nbr, h3=h3, z4=z4, d4=d4, weights=weights)
+        if F["n_calls"]:
+            for bn, mean, var in ((f.bn1_1, mean1, var1),
+                                  (f.bn1_2, L["mlp2"].ctx["mean"], L["mlp2"].ctx["var"]),
+                                  (f.bn1_3, L["mlp3"].ctx["mean"], L["mlp3"].ctx["var"])):
+                T.bn_update_running(mean, var, hw, bn.running_mean, bn.running_var, _MOMENTUM,
+                                    F["order"][:F["n_calls"]].contiguous())
+                bn.num_batches_tracked += F["n_calls"]
+        return fused
+
+    # ------------------------------------------------------------------
+    # backward: d(loss)/d(cls), d(loss)/d(loc) -> every parameter's gradient (into flat G)
+    # ------------------------------------------------------------------
+    def backward(self, dcls, dloc, G=None):
+        m, L = self.model, self.L
+        G = self.flat_g if G is None else G
+        cls, reg = m.classification, m.regression.box_prediction
+        hc = self.head_ctx
+        h1 = hc["h1"]
+        n, h, w = h1.shape[0], h1.shape[1], h1.shape[2]
+        dcls = dcls.reshape(n, h, w, -1)
+        dloc = dloc.reshape(n, h, w, -1)
+        if not dcls.is_contiguous():
+            dcls = dcls.contiguous()
+        if not dloc.is_contiguous():
+            dloc = dloc.contiguous()
+        dh1 = torch.empty_like(h1)
+        self._conv_bwd(hc["dc"], cls.conv2.weight, h1[..., :32], None, dcls, self.g(cls.conv2.weight, G),
+                       self.g(cls.conv2.bias, G), dx_out=dh1[..., :32])
+        self._conv_bwd(hc["dr"], reg[3].weight, h1[..., 32:], None, dloc, self.g(reg[3].weight, G),
+                       self.g(reg[3].bias, G), dx_out=dh1[..., 32:])
+
+        def merged(p, count):
+            off, _, _ = self.grad_of[id(p)]
+            return G[off:off + count]
+        dx8 = self._layer_bwd(self.head1, dh1, G, gw=merged(cls.conv1.weight, 64 * 32 * 9).view(64, 32, 3, 3),
+                              gb=merged(cls.conv1.bias, 64), ggamma=merged(cls.bn1.weight, 64),
+                              gbeta=merged(cls.bn1.bias, 64))
+
+        d = self._layer_bwd(L["conv8_2"], dx8, G)
+        dcat8 = self._layer_bwd(L["conv8_1"], d, G)                     # [.., 64 (up x7) | 32 (x0)]
+        d = self._layer_bwd(L["conv7_2"], dcat8[..., :64], G, up_a=True)
+        dcat7 = self._layer_bwd(L["conv7_1"], d, G)                     # [.., 128 (up x6) | 64 (x1)]
+        d = self._layer_bwd(L["conv6_2"], dcat7[..., :128], G, up_a=True)
+        dcat6 = self._layer_bwd(L["conv6_1"], d, G)                     # [.., 256 (up x5) | 128 (x2)]
+        d = self._layer_bwd(L["conv5_2"], dcat6[..., :256], G, up_a=True)
+        dcat5 = self._layer_bwd(L["conv5_1"], d, G)                     # [.., 512 (up x4) | 256 (fused)]
+
+        d_x3 = self._fusion_bwd(dcat5[..., 512:], G)
+
+        d = self._layer_bwd(L["conv4_2"], dcat5[..., :512], G, up_a=True)
+        d = self._layer_bwd(L["conv4_1"], d, G)
+        d = self._layer_bwd(L["conv3_2"], d, G, dy_b=d_x3)
+        d = self._layer_bwd(L["conv3_1"], d, G)
+        d = self._layer_bwd(L["conv3d_2"], d, G, dy_b=dcat6[..., 256:])
+        d = self._layer_bwd(L["conv2_2"], d, G)
+        d = self._layer_bwd(L["conv2_1"], d, G)
+        d = self._layer_bwd(L["conv3d_1"], d, G, dy_b=dcat7[..., 128:])
+        d = self._layer_bwd(L["conv1_2"], d, G)
+        d = self._layer_bwd(L["conv1_1"], d, G)
+        d = self._layer_bwd(L["conv_pre_2"], d, G, dy_b=dcat8[..., 64:])
+        self._layer_bwd(L["conv_pre_1"], d, G, need_dx=False)
+        return G
+
+    def _fusion_bwd(self, dfused, G):
+        m, L, F, c = self.model, self.L, self.F, self.fctx
+        f = m.pixel_weighted_fusion
+        maps, NI, NW = c["maps"], c["NI"], c["NW"]
+        C = maps.shape[-1]
+        P = NI + NW
+        dmaps = torch.empty_like(maps)
+        dz4 = T.fuse_combine_backward(dfused, c["z4"], c["weights"], maps, F["first"], F["pair_index"],
+                                      F["map_image"], F["ego_out"], dmaps)
+        dh3 = self._conv_bwd(c["d4"], f.conv1_4.weight, c["h3"], None, dz4, self.g(f.conv1_4.weight, G),
+                             self.g(f.conv1_4.bias, G))
+        dh2 = self._layer_bwd(L["mlp3"], dh3, G)
+        dh1 = self._layer_bwd(L["mlp2"], dh2, G)
+        dz1 = T.bn_backward(dh1, c["h1"], c["z1"], c["mean1"], c["var1"], f.bn1_1.weight, _EPS,
+                            self.g(f.bn1_1.weight, G), self.g(f.bn1_1.bias, G), relu=True)
+        T.channel_sum(dz1, self.g(f.conv1_1.bias, G))
+        dE = T.pair_sum_ego(dz1, F["efirst"], F["epairs"], NI)
+        gw1 = self.g(f.conv1_1.weight, G).view(128, 2 * C)
+        T.conv_wgrad(c["d_e"], maps[:NI], None, dE, gw1[:, :C], dw_cin_total=2 * C)
+        T.conv_wgrad(c["d_f"], maps, None, dz1, gw1[:, C:], dw_cin_total=2 * C)
+        T.add_rows(dmaps, self._dgrad(c["d_f"], c["w_nbr"].view(128, C, 1, 1), dz1))
+        T.add_rows(dmaps[:NI], self._dgrad(c["d_e"], c["w_ego"].view(128, C, 1, 1), dE))
+        if NW:
+            T.warp_backward(dmaps[NI:], F["poses"], F["src_image"], dmaps[:NI])
+        return dmaps[:NI]
+
+    # ------------------------------------------------------------------
+    def optimizer_step(self):
+        self.step_count += 1
+        T.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.lr,
+                    self.betas, self.eps, self.weight_decay)
+        self.model._plan = None          # eval-mode packed weights are stale now
+
+    def allreduce_grads(self):
+        """DDP's gradient averaging as ONE collective over the flat buffer (RCCL over xGMI)"""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_g)
+            self.flat_g.div_(dist.get_world_size())
+
+
+class _TrainFn(torch.autograd.Function):
+    """The whole forward as one autograd node: lets the reference's own
+    `loss.backward(); optimizer.step()` drive the explicit reverse pass."""
+
+    @staticmethod
+    def forward(ctx, engine, bevs, trans, num_agent, batch_size, *params):
+        res = engine.forward(bevs, trans, num_agent, batch_size)
+        ctx.engine = engine
+        return res["cls"], res["loc"]
+
+    @staticmethod
+    def backward(ctx, dcls, dloc):
+        eng = ctx.engine
+        G = torch.zeros_like(eng.flat_g)
+        eng.backward(dcls.contiguous(), dloc.contiguous(), G)
+        return (None, None, None, None, None) + tuple(eng.g(p, G) for p in eng.params)
+
+
+def train_forward(model, bevs, trans_matrices, num_agent_tensor, batch_size):
+    """DiscoNet.forward in train() mode"""
+    if model.kd_flag == 1:
+        raise NotImplementedError("training with kd_flag = 1 (teacher distillation) is the next scope "
+                                  "row (SURVEY.md §8(f) #2); build the student with kd_flag=0")
+    eng = model.__dict__.get("_train_engine")
+    if eng is None:
+        eng = TrainEngine(model)
+        model.__dict__["_train_engine"] = eng
+    if torch.is_grad_enabled():
+        cls, loc = _TrainFn.apply(eng, bevs, trans_matrices, num_agent_tensor, batch_size, *eng.params)
+        return {"loc": loc, "cls": cls}
+    return eng.forward(bevs, trans_matrices, num_agent_tensor, batch_size)
+
+
+class CoDetModule:
+    """upstream:coperception/utils/CoDetModule.py :: CoDetModule, the no-KD training surface:
+    step(data, batch_size) -> loss values, with the loss, backward and Adam on the HIP path."""
+
+    def __init__(self, model, teacher=None, config=None, optimizer=None, kd_flag=0, lr=1e-3,
+                 alpha=0.25, gamma=2.0, sigma=3.0):
+        if kd_flag or teacher is not None:
+            raise NotImplementedError("KD training (kd_flag = 1) is not built yet")
+        self.model = model
+        if optimizer is not None:      # take the hyper-parameters of the torch optimizer handed in
+            grp = optimizer.param_groups[0]
+            lr = grp["lr"]
+        self.engine = TrainEngine(model, lr=lr)
+        model.__dict__["_train_engine"] = self.engine
+        self.alpha, self.gamma, self.sigma = alpha, gamma, sigma
+
+    def step(self, data, batch_size):
+        bev_seq = data["bev_seq"]
+        eng = self.engine
+        self.model.train()
+        with torch.no_grad():
+            res = eng.forward(bev_seq, data["trans_matrices"], data["num_agent"], batch_size)
+            code = res["loc"].shape[-1]
+            dev = bev_seq.device
+            f32 = lambda t, shape: t.to(device=dev, dtype=torch.float32).reshape(shape).contiguous()
+            losses, dcls, dloc = T.det_loss(
+                res["cls"].reshape(-1, 2), f32(data["labels"], (-1, 2)), res["loc"].reshape(-1, code),
+                f32(data["reg_targets"], (-1, code)), f32(data["reg_loss_mask"], (-1,)),
+                norm=bev_seq.shape[0], alpha=self.alpha, gamma=self.gamma, sigma=self.sigma)
+            eng.backward(dcls, dloc)
+            eng.allreduce_grads()
+            eng.optimizer_step()
+        l = losses.tolist()
+        return {"loss": l[0] + l[1], "cls_loss": l[0], "loc_loss": l[1]}

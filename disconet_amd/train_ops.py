@@ -85,6 +85,8 @@ def bn_apply(z, mean, var, gamma, beta, eps, relu=True, out=None):
 
 def bn_update_running(mean, var, rows_per_group, running_mean, running_var, momentum=0.1, order=None):
     n_groups, c = mean.shape
+    if order is not None:            # only the listed groups, in that order
+        n_groups = order.numel()
     check(_lib.load().dn_bn_update_running(_ptr(mean), _ptr(var), n_groups, int(rows_per_group), c,
                                            _ptr(order), float(momentum), _ptr(running_mean),
                                            _ptr(running_var), _stream()), "dn_bn_update_running")

@@ -61,4 +61,4 @@ def train_step(model, optimizer, bevs, trans, num_agent, batch_size, labels, reg
     optimizer.zero_grad()
     (l_cls + l_loc).backward()
     optimizer.step()
-    return float(l_cls), float(l_loc)
+    return float(l_cls.detach()), float(l_loc.detach())

@@ -104,8 +104,10 @@ def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch):
     with pytest.raises(_lib.DnError):
         ops.voxelize_occupy(torch.zeros(4, 4), (0.25, 0.25, 0.4), np.array([[-32, 32]] * 2 + [[-3, 2]]),
                             (256, 256, 13))
-    with pytest.raises(NotImplementedError):
-        m.train()
+    m.train()                                  # training mode: same rule, no CPU path
+    with pytest.raises(_lib.DnError):
+        m(bevs, trans, na, 1)
+    m.eval()
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdisconet_hip.so")
     with pytest.raises(_lib.DnError, match="not built"):
