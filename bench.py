@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
+    ap.add_argument("--train-steps", type=int, default=4,
+                    help="also time this many training steps (forward + loss + backward + Adam) of the "
+                         "same batch; 0 = skip (reported next to the headline value, never in it)")
     ap.add_argument("--force-process-group", action="store_true",
                     help="create the RCCL process group even for one rank (exercises the N>1 code path)")
     ap.add_argument("--cpu-baseline-child", nargs=3, metavar=("STATE", "OUT", "THREADS"),
@@ -436,6 +439,34 @@ def main():
                 except Exception as e:   # never lose the bench line to the accuracy add-on
                     base["map_vs_oracle_detections"] = {"error": repr(e)}
             result["cpu_baseline"] = base
+        if world == 1 and args.train_steps > 0:
+            # CoDetModule.step on the same batch (train() mode, batch statistics)
+            try:
+                from disconet_amd import CoDetModule
+                from disconet_amd.synthetic import make_train_targets
+                tmodel = DiscoNet(Config(map_hw=MAP_HW), kd_flag=0, num_agent=AGENTS)
+                tmodel.conv_math = args.math
+                tmodel.cuda()
+                labels, targets, mask = make_train_targets(n_img, MAP_HW)
+                data = {"bev_seq": ops.scatter_dense(indices, offsets, n_img, dims),
+                        "trans_matrices": trans, "num_agent": na, "labels": labels.cuda(),
+                        "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda()}
+                mod = CoDetModule(tmodel, lr=1e-3)
+                first = mod.step(data, BATCH)          # warm-up (allocator, LDS attributes)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.train_steps):
+                    last = mod.step(data, BATCH)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / args.train_steps
+                result["train_step"] = {
+                    "ms_per_step": round(1e3 * dt, 3), "scenes_per_s": round(BATCH / dt, 2),
+                    "steps": args.train_steps, "batch_per_gpu": BATCH, "loss_first": round(first["loss"], 4),
+                    "loss_last": round(last["loss"], 4),
+                    "note": "train() forward (batch-stat BN) + focal/smooth-L1 loss + explicit HIP backward "
+                            "(dgrad/wgrad on the fp32 MFMA) + Adam, eager launches, wall clock"}
+            except Exception as e:
+                result["train_step"] = {"error": repr(e)}
         print(json.dumps(result), flush=True)
 
     if use_pg:

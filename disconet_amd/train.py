@@ -22,7 +22,6 @@ Two ways in:
     explicit reverse pass (torch only routes d(loss)/d(cls, loc) in and parameter grads out).
 """
 import torch
-import torch.distributed as dist
 
 from . import ops, train_ops as T
 from .model import LAYER_CHANNEL, _bn_name
@@ -449,9 +448,8 @@ class TrainEngine:
 
     def allreduce_grads(self):
         """DDP's gradient averaging as ONE collective over the flat buffer (RCCL over xGMI)"""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_g)
-            self.flat_g.div_(dist.get_world_size())
+        from .sharded import average_gradients_
+        average_gradients_(self.flat_g)
 
 
 class _TrainFn(torch.autograd.Function):

@@ -73,3 +73,39 @@ def test_agent_range_and_layout_helpers():
         sharded.agent_range(5, 2, 0)
     x = torch.arange(12).view(6, 2)             # A=3, B=2 agent-major
     assert torch.equal(sharded.local_bevs(x, 3, 2, 3, 1), x[2:4])
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disconet_amd import sharded
+        g = torch.Generator().manual_seed(100 + rank)
+        flat = torch.randn(7919, generator=g)          # each rank's own gradient
+        out = sharded.average_gradients_(flat)
+        assert out.data_ptr() == flat.data_ptr()       # in place, one buffer, one collective
+        q.put((rank, flat.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_gradient_average_is_the_mean_over_ranks():
+    """the training step's data-parallel exchange (TrainEngine.allreduce_grads)"""
+    from disconet_amd import sharded
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = sum(torch.randn(7919, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
+    for r in range(world):
+        assert abs(got[r] - want.numpy()).max() < 1e-6
+    t = torch.ones(5)
+    assert sharded.average_gradients_(t) is t and float(t.sum()) == 5.0     # no process group: no-op
