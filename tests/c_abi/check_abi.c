@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include "disconet_hip.h"
+#include "disconet_train.h"
 
 #define CHECK(cond, ...) do { if (!(cond)) { printf("FAIL line %d: ", __LINE__); printf(__VA_ARGS__); printf("\n"); return 1; } } while (0)
 #define HIP(x) CHECK((x) == hipSuccess, "%s", #x)
@@ -33,6 +34,13 @@ static int errors_only(void) {
   int dims[3] = {256, 256, 13};
   CHECK(dn_voxel_compact_workspace(dims) == ((256 * 256 * 13 + 1023) / 1024) * sizeof(int), "workspace");
   CHECK(dn_post1x1_packed_floats() == 64 * 64, "post1x1 size");
+  /* training header: plain C as well, same error convention */
+  d.math = 0;
+  CHECK(dn_conv_wgrad_workspace(&d) > 0, "wgrad workspace");
+  CHECK(dn_conv_wgrad(&d, NULL, NULL, NULL, NULL, NULL, 0, 0, NULL) == DN_ERR_ARG, "wgrad null");
+  CHECK(dn_adam_step(NULL, NULL, NULL, NULL, 10, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 1, NULL) == DN_ERR_ARG,
+        "adam null");
+  CHECK(dn_bn_train_stats(NULL, 1, 10, 600, 600, NULL, NULL, NULL, NULL) == DN_ERR_ARG, "bn null");
   printf("C ABI error behaviour: ok\n");
   return 0;
 }
