@@ -465,8 +465,29 @@ def main():
                     "loss_last": round(last["loss"], 4),
                     "note": "train() forward (batch-stat BN) + focal/smooth-L1 loss + explicit HIP backward "
                             "(dgrad/wgrad on the fp32 MFMA) + Adam, eager launches, wall clock"}
+                # BASELINE configs[2]'s per-GPU step: + frozen teacher forward and the KD KL terms
+                from disconet_amd import TeacherNet
+                from disconet_amd.synthetic import make_bevs
+                teacher = TeacherNet(Config(map_hw=MAP_HW)).cuda().eval()
+                teacher.conv_math = args.math
+                kmodel = DiscoNet(Config(map_hw=MAP_HW), kd_flag=1, num_agent=AGENTS)
+                kmodel.conv_math = args.math
+                kmodel.cuda()
+                data["bev_seq_teacher"] = make_bevs(BATCH, AGENTS, MAP_HW, p=0.05).cuda()
+                data["kd_weight"] = 1e5
+                kmod = CoDetModule(kmodel, teacher, None, None, kd_flag=1, lr=1e-3)
+                kmod.step(data, BATCH)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.train_steps):
+                    klast = kmod.step(data, BATCH)
+                torch.cuda.synchronize()
+                dtk = (time.perf_counter() - t0) / args.train_steps
+                result["train_step"]["with_kd"] = {"ms_per_step": round(1e3 * dtk, 3),
+                                                   "scenes_per_s": round(BATCH / dtk, 2),
+                                                   "kd_loss": round(klast["kd_loss"], 4)}
             except Exception as e:
-                result["train_step"] = {"error": repr(e)}
+                result.setdefault("train_step", {})["error"] = repr(e)
         print(json.dumps(result), flush=True)
 
     if use_pg:

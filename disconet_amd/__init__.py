@@ -6,6 +6,7 @@ include/disconet_hip.h).  See DESIGN.md.
 """
 from .config import Config
 from .model import DiscoNet
+from .teacher import TeacherNet
 from .train import CoDetModule, TrainEngine
 
-__all__ = ["Config", "DiscoNet", "CoDetModule", "TrainEngine"]
+__all__ = ["Config", "DiscoNet", "TeacherNet", "CoDetModule", "TrainEngine"]

@@ -93,6 +93,8 @@ SIGNATURES = {
                              c_void_p]),
     "dn_det_loss": (c_int, [c_void_p] * 5 + [c_long, c_int, c_float, c_float, c_float, c_float,
                                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dn_kd_kl_loss": (c_int, [c_void_p, c_void_p, c_long, c_int, c_float, c_void_p, c_void_p, c_int,
+                              c_void_p]),
     "dn_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float,
                              c_float, c_float, c_float, c_int, c_void_p]),
 }

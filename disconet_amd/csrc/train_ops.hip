@@ -581,3 +581,67 @@ extern "C" int dn_adam_step(float* p, const float* g, float* m, float* v, long n
                      n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
   return dn::check_launch("adam_kernel");
 }
+
+// ---------------------------------------------------------------------------------
+// knowledge distillation: KLDivLoss(log_softmax(student), softmax(teacher)) over channels
+// ---------------------------------------------------------------------------------
+namespace {
+
+// one wavefront per row (= pixel of an NHWC map); mean over ALL elements (the reference's
+// nn.KLDivLoss(size_average=True, reduce=True)), times `scale` = kd_weight / (rows * c)
+__global__ void __launch_bounds__(256)
+kd_kl_kernel(const float* __restrict__ student, const float* __restrict__ teacher, long rows, int c,
+             float scale, double* __restrict__ loss, float* __restrict__ dstudent) {
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (long row = blockIdx.x * 4L + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4L) {
+    const float* s = student + row * c;
+    const float* t = teacher + row * c;
+    float ms = -INFINITY, mt = -INFINITY;
+    for (int k = lane; k < c; k += 64) {
+      ms = fmaxf(ms, s[k]);
+      mt = fmaxf(mt, t[k]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ms = fmaxf(ms, __shfl_xor(ms, o, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, o, 64));
+    }
+    float es = 0.f, et = 0.f;
+    for (int k = lane; k < c; k += 64) {
+      es += expf(s[k] - ms);
+      et += expf(t[k] - mt);
+    }
+    es = wave_sum(es);
+    et = wave_sum(et);
+    const float lse_s = ms + logf(es), lse_t = mt + logf(et);
+    float part = 0.f;
+    for (int k = lane; k < c; k += 64) {
+      const float ls = s[k] - lse_s;              // log_softmax(student)
+      const float lt = t[k] - lse_t;              // log softmax(teacher)
+      const float pt = expf(lt);
+      if (pt > 0.f) part += pt * (lt - ls);
+      dstudent[row * c + k] = (expf(ls) - pt) * scale;
+    }
+    acc += (double)wave_sum(part);
+  }
+  __shared__ double red[4];
+  if (lane == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomic_add_f64(loss, (red[0] + red[1] + red[2] + red[3]) * (double)scale);
+}
+
+}  // namespace
+
+extern "C" int dn_kd_kl_loss(const float* student, const float* teacher, long rows, int c, float scale,
+                             double* loss, float* dstudent, int zero_loss, void* stream) {
+  DN_REQUIRE(student && teacher && loss && dstudent, "kd loss: null pointer");
+  DN_REQUIRE(rows > 0 && c > 0, "kd loss: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (zero_loss && hipMemsetAsync(loss, 0, sizeof(double), s) != hipSuccess)
+    return dn::fail(DN_ERR_LAUNCH, "kd loss: memset failed");
+  const long blocks = (rows + 3) / 4;
+  hipLaunchKernelGGL(kd_kl_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s,
+                     student, teacher, rows, c, scale, loss, dstudent);
+  return dn::check_launch("kd_kl_kernel");
+}

@@ -325,8 +325,9 @@ class TrainEngine:
 
         nI, h, w = cls_out.shape[0], cls_out.shape[1], cls_out.shape[2]
         self.outs = dict(x5=x5, x6=x6, x7=x7, x8=x8, fused=x3f)
-        return {"loc": loc_out.view(nI, h, w, m.anchor_num_per_loc, m.out_seq_len, m.box_code_size),
-                "cls": cls_out.view(nI, -1, m.category_num)}
+        self.last_result = {"loc": loc_out.view(nI, h, w, m.anchor_num_per_loc, m.out_seq_len, m.box_code_size),
+                            "cls": cls_out.view(nI, -1, m.category_num)}
+        return self.last_result
 
     def _fusion_fwd(self, maps, NI, NW, F):
         m, L = self.model, self.L
@@ -362,9 +363,13 @@ class TrainEngine:
     # ------------------------------------------------------------------
     # backward: d(loss)/d(cls), d(loss)/d(loc) -> every parameter's gradient (into flat G)
     # ------------------------------------------------------------------
-    def backward(self, dcls, dloc, G=None):
+    def backward(self, dcls, dloc, G=None, dkd=None):
+        """dkd (knowledge distillation): optional dict of dense NHWC gradients w.r.t. the student's
+        x5 / x6 / x7 / fused maps; each is a second consumer of that map, added in the BN backward
+        that already reads the decoder's gradient."""
         m, L = self.model, self.L
         G = self.flat_g if G is None else G
+        dkd = dkd or {}
         cls, reg = m.classification, m.regression.box_prediction
         hc = self.head_ctx
         h1 = hc["h1"]
@@ -390,14 +395,17 @@ class TrainEngine:
 
         d = self._layer_bwd(L["conv8_2"], dx8, G)
         dcat8 = self._layer_bwd(L["conv8_1"], d, G)                     # [.., 64 (up x7) | 32 (x0)]
-        d = self._layer_bwd(L["conv7_2"], dcat8[..., :64], G, up_a=True)
+        d = self._layer_bwd(L["conv7_2"], dcat8[..., :64], G, up_a=True, dy_b=dkd.get("x7"))
         dcat7 = self._layer_bwd(L["conv7_1"], d, G)                     # [.., 128 (up x6) | 64 (x1)]
-        d = self._layer_bwd(L["conv6_2"], dcat7[..., :128], G, up_a=True)
+        d = self._layer_bwd(L["conv6_2"], dcat7[..., :128], G, up_a=True, dy_b=dkd.get("x6"))
         dcat6 = self._layer_bwd(L["conv6_1"], d, G)                     # [.., 256 (up x5) | 128 (x2)]
-        d = self._layer_bwd(L["conv5_2"], dcat6[..., :256], G, up_a=True)
+        d = self._layer_bwd(L["conv5_2"], dcat6[..., :256], G, up_a=True, dy_b=dkd.get("x5"))
         dcat5 = self._layer_bwd(L["conv5_1"], d, G)                     # [.., 512 (up x4) | 256 (fused)]
 
-        d_x3 = self._fusion_bwd(dcat5[..., 512:], G)
+        dfused = dcat5[..., 512:]
+        if dkd.get("fused") is not None:
+            dfused = T.add_rows(dkd["fused"], dfused)      # in place on the KD gradient buffer
+        d_x3 = self._fusion_bwd(dfused, G)
 
         d = self._layer_bwd(L["conv4_2"], dcat5[..., :512], G, up_a=True)
         d = self._layer_bwd(L["conv4_1"], d, G)
@@ -454,46 +462,65 @@ class TrainEngine:
 
 class _TrainFn(torch.autograd.Function):
     """The whole forward as one autograd node: lets the reference's own
-    `loss.backward(); optimizer.step()` drive the explicit reverse pass."""
+    `loss.backward(); optimizer.step()` drive the explicit reverse pass.  Outputs: cls, loc and
+    (for the KD loss of kd_flag = 1) NCHW-shaped views of x8, x7, x6, x5 and the fused map."""
 
     @staticmethod
     def forward(ctx, engine, bevs, trans, num_agent, batch_size, *params):
         res = engine.forward(bevs, trans, num_agent, batch_size)
         ctx.engine = engine
-        return res["cls"], res["loc"]
+        ctx.set_materialize_grads(False)      # outputs the loss does not touch come back as None
+        o = engine.outs
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        return (res["cls"], res["loc"], nchw(o["x8"]), nchw(o["x7"]), nchw(o["x6"]), nchw(o["x5"]),
+                nchw(o["fused"]))
 
     @staticmethod
-    def backward(ctx, dcls, dloc):
+    def backward(ctx, dcls, dloc, dx8, dx7, dx6, dx5, dfused):
         eng = ctx.engine
+        if dx8 is not None:
+            raise NotImplementedError("a loss on x8 itself is not part of the reference's KD term")
+        nhwc = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous()
+        dkd = {"x7": nhwc(dx7), "x6": nhwc(dx6), "x5": nhwc(dx5), "fused": nhwc(dfused)}
+        zeros = lambda t, ref: torch.zeros_like(ref) if t is None else t.contiguous()
         G = torch.zeros_like(eng.flat_g)
-        eng.backward(dcls.contiguous(), dloc.contiguous(), G)
+        eng.backward(zeros(dcls, eng.last_result["cls"]), zeros(dloc, eng.last_result["loc"]), G, dkd)
         return (None, None, None, None, None) + tuple(eng.g(p, G) for p in eng.params)
 
 
 def train_forward(model, bevs, trans_matrices, num_agent_tensor, batch_size):
     """DiscoNet.forward in train() mode"""
-    if model.kd_flag == 1:
-        raise NotImplementedError("training with kd_flag = 1 (teacher distillation) is the next scope "
-                                  "row (SURVEY.md §8(f) #2); build the student with kd_flag=0")
     eng = model.__dict__.get("_train_engine")
     if eng is None:
         eng = TrainEngine(model)
         model.__dict__["_train_engine"] = eng
     if torch.is_grad_enabled():
-        cls, loc = _TrainFn.apply(eng, bevs, trans_matrices, num_agent_tensor, batch_size, *eng.params)
-        return {"loc": loc, "cls": cls}
-    return eng.forward(bevs, trans_matrices, num_agent_tensor, batch_size)
+        cls, loc, x8, x7, x6, x5, fused = _TrainFn.apply(eng, bevs, trans_matrices, num_agent_tensor,
+                                                         batch_size, *eng.params)
+        result = {"loc": loc, "cls": cls}
+    else:
+        result = eng.forward(bevs, trans_matrices, num_agent_tensor, batch_size)
+        o = eng.outs
+        x8, x7, x6, x5, fused = (o[k].permute(0, 3, 1, 2) for k in ("x8", "x7", "x6", "x5", "fused"))
+    if model.kd_flag == 1:
+        return (result, x8, x7, x6, x5, fused)
+    return result
 
 
 class CoDetModule:
-    """upstream:coperception/utils/CoDetModule.py :: CoDetModule, the no-KD training surface:
-    step(data, batch_size) -> loss values, with the loss, backward and Adam on the HIP path."""
+    """upstream:coperception/utils/CoDetModule.py :: CoDetModule, the training surface:
+    step(data, batch_size) -> loss values, with the losses, the backward and Adam on the HIP path.
+    kd_flag = 1: `teacher` (disconet_amd.TeacherNet, frozen, eval) sees data["bev_seq_teacher"] and
+    kd_weight * sum of KLDiv(log_softmax(student), softmax(teacher)) over x5, x6, x7 and the fused
+    layer-3 map (vs the teacher's x3) joins the loss."""
 
     def __init__(self, model, teacher=None, config=None, optimizer=None, kd_flag=0, lr=1e-3,
                  alpha=0.25, gamma=2.0, sigma=3.0):
-        if kd_flag or teacher is not None:
-            raise NotImplementedError("KD training (kd_flag = 1) is not built yet")
-        self.model = model
+        if kd_flag and teacher is None:
+            raise ValueError("kd_flag = 1 needs the teacher network")
+        self.model, self.teacher, self.kd_flag = model, teacher, int(bool(kd_flag))
+        if self.kd_flag:
+            teacher.eval()
         if optimizer is not None:      # take the hyper-parameters of the torch optimizer handed in
             grp = optimizer.param_groups[0]
             lr = grp["lr"]
@@ -514,8 +541,20 @@ class CoDetModule:
                 res["cls"].reshape(-1, 2), f32(data["labels"], (-1, 2)), res["loc"].reshape(-1, code),
                 f32(data["reg_targets"], (-1, code)), f32(data["reg_loss_mask"], (-1,)),
                 norm=bev_seq.shape[0], alpha=self.alpha, gamma=self.gamma, sigma=self.sigma)
-            eng.backward(dcls, dloc)
+            dkd, kd = None, None
+            if self.kd_flag:
+                kd_weight = float(data["kd_weight"]) if "kd_weight" in data else 1e5
+                t8, t7, t6, t5, t3, t2 = self.teacher.forward_nhwc(data["bev_seq_teacher"])
+                kd = torch.zeros(1, dtype=torch.float64, device=dev)
+                o = eng.outs
+                dkd = {k: T.kd_kl_loss(o[k], t, kd_weight, kd)
+                       for k, t in (("x5", t5), ("x6", t6), ("x7", t7), ("fused", t3))}
+            eng.backward(dcls, dloc, dkd=dkd)
             eng.allreduce_grads()
             eng.optimizer_step()
         l = losses.tolist()
-        return {"loss": l[0] + l[1], "cls_loss": l[0], "loc_loss": l[1]}
+        out = {"loss": l[0] + l[1], "cls_loss": l[0], "loc_loss": l[1]}
+        if kd is not None:
+            out["kd_loss"] = float(kd)
+            out["loss"] += out["kd_loss"]
+        return out

@@ -202,6 +202,20 @@ def det_loss(cls, labels, loc, targets, mask, norm, alpha=0.25, gamma=2.0, sigma
     return losses, dcls, dloc
 
 
+def kd_kl_loss(student, teacher, kd_weight, loss, zero=False):
+    """student, teacher [..., c] dense NHWC maps of equal shape; adds kd_weight * KLDiv (mean over
+    all elements) to loss[0] (float64, zeroed first if zero) and returns d(term)/d(student)."""
+    _need_gpu(student, teacher, loss)
+    assert student.shape == teacher.shape and student.is_contiguous() and teacher.is_contiguous()
+    c = student.shape[-1]
+    rows = student.numel() // c
+    d = torch.empty_like(student)
+    check(_lib.load().dn_kd_kl_loss(_ptr(student), _ptr(teacher), rows, c,
+                                    float(kd_weight) / float(rows * c), _ptr(loss), _ptr(d), int(zero),
+                                    _stream()), "dn_kd_kl_loss")
+    return d
+
+
 def adam_step(p, g, m, v, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
     _need_gpu(p, g, m, v)
     check(_lib.load().dn_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr),

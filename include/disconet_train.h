@@ -127,6 +127,13 @@ int dn_det_loss(const float* cls, const float* labels, const float* loc, const f
                 const float* mask, long n, int code, float alpha, float gamma, float sigma,
                 float norm, double* losses, float* dcls, float* dloc, void* stream);
 
+/* Knowledge distillation term of CoDetModule.step (kd_flag = 1): for NHWC maps viewed as
+ * [rows, c], nn.KLDivLoss(size_average=True)(log_softmax(student, 1), softmax(teacher, 1)) -- the
+ * mean over ALL rows * c elements -- times kd_weight: pass scale = kd_weight / (rows * c).
+ * *loss (double) is zeroed first if zero_loss, then the term is added; dstudent = d(term)/d(student). */
+int dn_kd_kl_loss(const float* student, const float* teacher, long rows, int c, float scale,
+                  double* loss, float* dstudent, int zero_loss, void* stream);
+
 /* torch.optim.Adam (no amsgrad) on a flat parameter buffer; step counts from 1 */
 int dn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int step, void* stream);

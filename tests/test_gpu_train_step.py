@@ -169,3 +169,128 @@ def test_reference_style_step_through_autograd():
             assert float(a.abs().max()) < 1e-4 * gmax, name
             continue
         assert float((a - b).abs().max()) < 1e-3 * float(b.abs().max()), name
+
+
+def _teacher_pair(c):
+    """oracle teacher + the HIP TeacherNet with the same weights, and holistic-view voxels"""
+    from disconet_amd import Config, TeacherNet
+    from disconet_amd.synthetic import make_bevs
+    from oracle.disconet_ref import RefConfig
+    from oracle.teacher_ref import build_teacher
+    t_ref = build_teacher(RefConfig(c["map_hw"]))
+    t_hip = TeacherNet(Config(map_hw=c["map_hw"]))
+    t_hip.load_state_dict(t_ref.state_dict())
+    t_hip = t_hip.cuda().eval()
+    bevs_t = make_bevs(c["batch"], c["agents"], c["map_hw"], p=0.05)      # denser: everyone's points
+    return t_ref, t_hip, bevs_t
+
+
+def test_teacher_forward_matches_oracle():
+    c = STEP_CASES["cfg1"]
+    t_ref, t_hip, bevs_t = _teacher_pair(c)
+    with torch.no_grad():
+        want = t_ref(bevs_t)
+    got = t_hip(bevs_t.cuda())
+    assert len(got) == 6
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        assert float((g.cpu() - w).abs().max()) < 1e-4
+
+
+def test_kd_kernel_matches_torch_kl_div():
+    from disconet_amd import train_ops
+    g = torch.Generator().manual_seed(4)
+    for c_ in (64, 128, 256):
+        s = (torch.randn(3, 16, 16, c_, generator=g) * 3).double().requires_grad_(True)
+        t = torch.randn(3, 16, 16, c_, generator=g) * 3
+        ref = 1e5 * F.kl_div(F.log_softmax(s.reshape(-1, c_), 1), F.softmax(t.double().reshape(-1, c_), 1),
+                             reduction="mean")
+        ref.backward()
+        loss = torch.full((1,), 5.0, dtype=torch.float64, device="cuda")
+        d = train_ops.kd_kl_loss(s.detach().float().cuda(), t.cuda(), 1e5, loss)
+        assert abs(float(loss) - 5.0 - float(ref)) < 2e-5 * abs(float(ref))
+        assert float((d.cpu().double() - s.grad).abs().max()) < 2e-5 * float(s.grad.abs().max())
+
+
+@pytest.mark.parametrize("case", ["cfg1", "ragged_a4"])
+def test_kd_train_step_matches_oracle(case, monkeypatch):
+    """kd_flag = 1: detection losses + kd_weight * KL(student || teacher) on x5, x6, x7, fused"""
+    from disconet_amd import CoDetModule
+    from oracle.train_ref import det_loss
+    from oracle.teacher_ref import kd_loss
+    c, ref, model, (bevs, trans, na), (labels, targets, mask) = _setup(case, "f16x3")
+    ref.kd_flag = model.kd_flag = 1
+    t_ref, t_hip, bevs_t = _teacher_pair(c)
+    kd_weight = 1e5
+
+    def oracle_step(m, tm, dt):
+        m.train()
+        res, x8, x7, x6, x5, fused = m(bevs, trans, na, c["batch"])
+        with torch.no_grad():
+            t8, t7, t6, t5, t3, t2 = tm(bevs_t.to(dt))
+        l_cls, l_loc = det_loss(res, labels, targets, mask, norm=bevs.shape[0])
+        l_kd = kd_loss((x5, x6, x7, fused), (t5, t6, t7, t3), kd_weight)
+        (l_cls + l_loc + l_kd).backward()
+        return float(l_cls.detach()), float(l_loc.detach()), float(l_kd.detach())
+
+    orig = F.grid_sample
+    monkeypatch.setattr(F, "grid_sample", lambda inp, grid, **kw: orig(inp, grid.to(inp.dtype), **kw))
+    ref64, t64 = copy.deepcopy(ref).double(), copy.deepcopy(t_ref).double()
+    for m_ in (ref64.u_encoder, t64.stpn):
+        m_.conv_pre_1.register_forward_pre_hook(lambda m, inp: (inp[0].double(),))
+    oracle_step(ref64, t64, torch.float64)
+    monkeypatch.undo()
+    g64 = {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
+    l_ref = oracle_step(ref, t_ref, torch.float32)
+
+    mod = CoDetModule(model, t_hip, None, None, kd_flag=1, lr=1e-3)
+    data = {"bev_seq": bevs.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(),
+            "labels": labels.cuda(), "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda(),
+            "bev_seq_teacher": bevs_t.cuda(), "kd_weight": kd_weight}
+    out = mod.step(data, c["batch"])
+    assert abs(out["cls_loss"] - l_ref[0]) < 2e-5 * abs(l_ref[0])
+    assert abs(out["loc_loss"] - l_ref[1]) < 2e-5 * abs(l_ref[1])
+    assert abs(out["kd_loss"] - l_ref[2]) < 1e-4 * abs(l_ref[2]), (out, l_ref)
+    rows = _grad_report(g64, ref, mod.engine, model)
+    bad = {k: v for k, v in rows.items() if v[0] > max(5 * v[1], 2e-3) or (v[3] and v[2] < 0.9995)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
+
+
+def test_kd_through_autograd_node():
+    """the reference's own KD step: loss on (result, x8, x7, x6, x5, fused) from model(...)"""
+    from oracle.train_ref import det_loss
+    from oracle.teacher_ref import kd_loss
+    c, ref, model, (bevs, trans, na), (labels, targets, mask) = _setup("cfg1", "f16x3")
+    model.kd_flag = 1
+    t_ref, t_hip, bevs_t = _teacher_pair(c)
+    model.train()
+    res, x8, x7, x6, x5, fused = model(bevs.cuda(), trans.cuda(), na.cuda(), c["batch"])
+    t8, t7, t6, t5, t3, t2 = t_hip(bevs_t.cuda())
+    l_cls, l_loc = det_loss(res, labels.cuda(), targets.cuda(), mask.cuda(), norm=bevs.shape[0])
+    l_kd = kd_loss((x5, x6, x7, fused), (t5, t6, t7, t3), 1e5)
+    (l_cls + l_loc + l_kd).backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    from disconet_amd import CoDetModule, train_ops
+    c2, ref2, model2, _, _ = _setup("cfg1", "f16x3")
+    model2.kd_flag = 1
+    mod = CoDetModule(model2, t_hip, kd_flag=1)
+    eng = mod.engine
+    with torch.no_grad():
+        r = eng.forward(bevs.cuda(), trans.cuda(), na.cuda(), c["batch"])
+        _, dcls, dloc = train_ops.det_loss(r["cls"].reshape(-1, 2), labels.cuda().reshape(-1, 2).float(),
+                                           r["loc"].reshape(-1, 6), targets.cuda().reshape(-1, 6).float(),
+                                           mask.cuda().reshape(-1).float(), norm=bevs.shape[0])
+        kd = torch.zeros(1, dtype=torch.float64, device="cuda")
+        tn = t_hip.forward_nhwc(bevs_t.cuda())
+        dkd = {k: train_ops.kd_kl_loss(eng.outs[k], t, 1e5, kd)
+               for k, t in (("x5", tn[3]), ("x6", tn[2]), ("x7", tn[1]), ("fused", tn[4]))}
+        eng.backward(dcls, dloc, dkd=dkd)
+    assert abs(float(kd) - float(l_kd)) < 1e-4 * abs(float(l_kd))
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    for name, p in model2.named_parameters():
+        a, b = grads[name], eng.g(p)
+        if float(b.abs().max()) < 1e-4 * gmax:
+            assert float(a.abs().max()) < 1e-4 * gmax, name
+            continue
+        assert float((a - b).abs().max()) < 1e-3 * float(b.abs().max()), name
