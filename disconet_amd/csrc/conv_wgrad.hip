@@ -251,8 +251,9 @@ Plan make_plan(const dn_conv_desc& d) {
   // a concat layer's ci blocks never straddle the sources (c0 % 32 == 0)
   p.n_cit = (d.c0 + 31) / 32 + (d.c1 + 31) / 32;
   p.taps = d.ksize * d.ksize;
-  // ~4 workgroups per CU in flight, every slice at least 4 pixel tiles long
-  int s = 1024 / (p.n_cot * p.n_cit);
+  // one resident generation (2 workgroups per CU), every slice at least 4 pixel tiles long;
+  // fewer, longer slices also mean fewer partial blocks for the reduction to read back
+  int s = 512 / (p.n_cot * p.n_cit);
   if (s > p.n_tiles / 4) s = p.n_tiles / 4;
   if (s < 1) s = 1;
   p.n_slices = s;

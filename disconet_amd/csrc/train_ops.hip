@@ -12,6 +12,8 @@
 // torch.optim.Adam).
 #include <hip/hip_runtime.h>
 
+#include <initializer_list>
+
 #include "disconet_train.h"
 #include "dn_internal.h"
 
@@ -56,6 +58,78 @@ __device__ inline void group_channel_sums(int c, long rows_per_group, double* su
   __syncthreads();
   for (int i = threadIdx.x; i < NQ * c; i += blockDim.x)
     atomic_add_f64(&sums_g[i], acc[i / c][i % c]);
+}
+
+// float4 form: lanes over groups of 4 channels (c % 4 == 0, 16-byte aligned rows)
+template <int NQ, class F>
+__device__ inline void group_channel_sums_v4(int c, long rows_per_group, double* sums_g, F f) {
+  __shared__ double acc[2][kMaxC];
+  for (int i = threadIdx.x; i < NQ * kMaxC; i += blockDim.x) acc[i / kMaxC][i % kMaxC] = 0.0;
+  __syncthreads();
+  const int c4n = c >> 2;
+  const int tx_n = lanes_for(c4n), ty_n = blockDim.x / tx_n;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const long chunk = (rows_per_group + gridDim.x - 1) / gridDim.x;
+  const long r0 = blockIdx.x * chunk;
+  const long r1 = r0 + chunk < rows_per_group ? r0 + chunk : rows_per_group;
+  for (int c4 = tx; c4 < c4n; c4 += tx_n) {
+    double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long r = r0 + ty; r < r1; r += ty_n) {
+      f32x4 q0, q1 = {0.f, 0.f, 0.f, 0.f};
+      f(r, c4, q0, q1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s0[e] += q0[e];
+        if (NQ > 1) s1[e] += q1[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomic_add_f64(&acc[0][4 * c4 + e], s0[e]);
+      if (NQ > 1) atomic_add_f64(&acc[1][4 * c4 + e], s1[e]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * c; i += blockDim.x)
+    atomic_add_f64(&sums_g[i], acc[i / c][i % c]);
+}
+
+__device__ inline f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ inline f32x4 rstd4(const float* var, float eps) {
+  const f32x4 v = ldv4(var);
+  return f32x4{1.f / sqrtf(v[0] + eps), 1.f / sqrtf(v[1] + eps), 1.f / sqrtf(v[2] + eps),
+               1.f / sqrtf(v[3] + eps)};
+}
+
+__global__ void __launch_bounds__(256)
+bn_stats_v4_kernel(const float* __restrict__ z, long rows_per_group, int c, int ldz,
+                   double* __restrict__ sums) {
+  const int g = blockIdx.y;
+  const float* zg = z + (size_t)g * rows_per_group * ldz;
+  group_channel_sums_v4<2>(c, rows_per_group, sums + (size_t)g * 2 * c,
+                           [&](long r, int c4, f32x4& q0, f32x4& q1) {
+                             q0 = ldv4(zg + r * ldz + 4 * c4);
+                             q1 = q0 * q0;
+                           });
+}
+
+__global__ void __launch_bounds__(256)
+bn_apply_v4_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                   const float* __restrict__ var, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, float eps, int relu, long rows_per_group, int c,
+                   int ldz, long total4, float* __restrict__ y) {
+  const int c4n = c >> 2;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total4;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / c4n;
+    const int c4 = (int)(idx % c4n);
+    const int g = (int)(row / rows_per_group);
+    const f32x4 rs = rstd4(var + g * c + 4 * c4, eps);
+    f32x4 v = (ldv4(z + row * ldz + 4 * c4) - ldv4(mean + g * c + 4 * c4)) * rs * ldv4(gamma + 4 * c4) +
+              ldv4(beta + 4 * c4);
+    if (relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+    *reinterpret_cast<f32x4*>(y + row * (long)c + 4 * c4) = v;
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -138,7 +212,67 @@ struct GradSrc {
     if (relu && !(y[row * c + cc] > 0.f)) g = 0.f;
     return g;
   }
+  __device__ inline f32x4 v4(long row, int c4) const {
+    f32x4 g;
+    if (up_a) {
+      const long img = row / ((long)h * w);
+      const int p = (int)(row % ((long)h * w));
+      const int py = p / w, px = p % w;
+      const float* b = dy_a + ((img * 2 * h + 2 * py) * (2L * w) + 2 * px) * ld_a + 4 * c4;
+      g = (ldv4(b) + ldv4(b + ld_a)) + (ldv4(b + 2L * w * ld_a) + ldv4(b + (2L * w + 1) * ld_a));
+    } else {
+      g = ldv4(dy_a + row * ld_a + 4 * c4);
+    }
+    if (dy_b) g += ldv4(dy_b + row * ld_b + 4 * c4);
+    if (relu) {
+      const f32x4 yv = ldv4(y + row * (long)c + 4 * c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!(yv[e] > 0.f)) g[e] = 0.f;
+    }
+    return g;
+  }
 };
+
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_v4_kernel(GradSrc src, const float* __restrict__ z, const float* __restrict__ mean,
+                        const float* __restrict__ var, float eps, long rows_per_group,
+                        double* __restrict__ sums) {
+  const int g = blockIdx.y, c = src.c;
+  const long base = (long)g * rows_per_group;
+  group_channel_sums_v4<2>(c, rows_per_group, sums + (size_t)g * 2 * c,
+                           [&](long r, int c4, f32x4& q0, f32x4& q1) {
+                             q0 = src.v4(base + r, c4);
+                             const f32x4 zh = (ldv4(z + (base + r) * c + 4 * c4) - ldv4(mean + g * c + 4 * c4)) *
+                                              rstd4(var + g * c + 4 * c4, eps);
+                             q1 = q0 * zh;
+                           });
+}
+
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_v4_kernel(GradSrc src, const float* __restrict__ z, const float* __restrict__ mean,
+                       const float* __restrict__ var, const float* __restrict__ gamma, float eps,
+                       long rows_per_group, const double* __restrict__ sums, long total4,
+                       float* __restrict__ dz) {
+  const int c = src.c, c4n = c >> 2;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total4;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / c4n;
+    const int c4 = (int)(idx % c4n);
+    const int g = (int)(row / rows_per_group);
+    const f32x4 rs = rstd4(var + g * c + 4 * c4, eps);
+    const f32x4 zh = (ldv4(z + row * c + 4 * c4) - ldv4(mean + g * c + 4 * c4)) * rs;
+    const double* sg = sums + (size_t)g * 2 * c + 4 * c4;
+    f32x4 m1, m2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      m1[e] = (float)(sg[e] / rows_per_group);
+      m2[e] = (float)(sg[c + e] / rows_per_group);
+    }
+    *reinterpret_cast<f32x4*>(dz + row * c + 4 * c4) =
+        ldv4(gamma + 4 * c4) * rs * (src.v4(row, c4) - m1 - zh * m2);
+  }
+}
 
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(GradSrc src, const float* __restrict__ z, const float* __restrict__ mean,
@@ -192,6 +326,14 @@ __global__ void __launch_bounds__(256)
 channel_sum_kernel(const float* __restrict__ x, long rows, int c, int ld, double* __restrict__ sums) {
   group_channel_sums<1>(c, rows, sums, [&](long r, int cc, float& q0, float& q1) {
     q0 = x[r * ld + cc];
+    (void)q1;
+  });
+}
+
+__global__ void __launch_bounds__(256)
+channel_sum_v4_kernel(const float* __restrict__ x, long rows, int c, int ld, double* __restrict__ sums) {
+  group_channel_sums_v4<1>(c, rows, sums, [&](long r, int c4, f32x4& q0, f32x4& q1) {
+    q0 = ldv4(x + r * ld + 4 * c4);
     (void)q1;
   });
 }
@@ -410,6 +552,15 @@ int grid_for(long total, int cap = 4096) {
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+bool vec4_ok(int c, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+  if (c % 4) return false;
+  for (int ld : lds)
+    if (ld % 4) return false;
+  for (const void* p : ptrs)
+    if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return false;
+  return true;
+}
+
 int blocks_per_group(long rows_per_group, int n_groups) {
   // ~2048 workgroups over all groups, at least 64 rows each
   long b = 2048 / n_groups;
@@ -427,8 +578,12 @@ extern "C" int dn_bn_train_stats(const float* z, int n_groups, long rows_per_gro
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * c * n_groups, s) != hipSuccess)
     return dn::fail(DN_ERR_LAUNCH, "bn stats: memset failed");
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
-                     dim3(256), 0, s, z, rows_per_group, c, ldz, sums);
+  if (vec4_ok(c, {ldz}, {z}))
+    hipLaunchKernelGGL(bn_stats_v4_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
+                       dim3(256), 0, s, z, rows_per_group, c, ldz, sums);
+  else
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
+                       dim3(256), 0, s, z, rows_per_group, c, ldz, sums);
   const int n = n_groups * c;
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sums, n, c,
                      rows_per_group, mean, var);
@@ -442,8 +597,13 @@ extern "C" int dn_bn_train_apply(const float* z, const float* mean, const float*
   DN_REQUIRE(z && mean && var && gamma && beta && y, "bn apply: null pointer");
   DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0 && ldz >= c, "bn apply: bad shape");
   const long total = (long)n_groups * rows_per_group * c;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, z,
-                     mean, var, gamma, beta, eps, relu, rows_per_group, c, ldz, total, y);
+  if (vec4_ok(c, {ldz}, {z, y, mean, var, gamma, beta}))
+    hipLaunchKernelGGL(bn_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, z, mean, var, gamma, beta, eps, relu, rows_per_group, c, ldz,
+                       total / 4, y);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, z,
+                       mean, var, gamma, beta, eps, relu, rows_per_group, c, ldz, total, y);
   return dn::check_launch("bn_apply_kernel");
 }
 
@@ -474,11 +634,18 @@ extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const
   if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * c * n_groups, s) != hipSuccess)
     return dn::fail(DN_ERR_LAUNCH, "bn backward: memset failed");
   GradSrc src{dy_a, dy_b, y, ld_a, up_a, ld_b, relu, h, w, c};
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
-                     dim3(256), 0, s, src, z, mean, var, eps, rows_per_group, sums);
   const long total = (long)n_groups * rows_per_group * c;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, src, z, mean,
-                     var, gamma, eps, rows_per_group, sums, total, dz);
+  if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz})) {
+    hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
+                       dim3(256), 0, s, src, z, mean, var, eps, rows_per_group, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z,
+                       mean, var, gamma, eps, rows_per_group, sums, total / 4, dz);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
+                       dim3(256), 0, s, src, z, mean, var, eps, rows_per_group, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, src, z, mean,
+                       var, gamma, eps, rows_per_group, sums, total, dz);
+  }
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((c + 63) / 64), dim3(64), 0, s, sums, n_groups, c,
                      dgamma, dbeta, accumulate);
   return dn::check_launch("bn_backward kernels");
@@ -491,8 +658,12 @@ extern "C" int dn_channel_sum(const float* x, long rows, int c, int ld, double* 
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, sizeof(double) * c, s) != hipSuccess)
     return dn::fail(DN_ERR_LAUNCH, "channel sum: memset failed");
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(blocks_per_group(rows, 1)), dim3(256), 0, s, x, rows, c,
-                     ld, sums);
+  if (vec4_ok(c, {ld}, {x}))
+    hipLaunchKernelGGL(channel_sum_v4_kernel, dim3(blocks_per_group(rows, 1)), dim3(256), 0, s, x, rows,
+                       c, ld, sums);
+  else
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(blocks_per_group(rows, 1)), dim3(256), 0, s, x, rows, c,
+                       ld, sums);
   hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, s, sums, c, out,
                      accumulate);
   return dn::check_launch("channel_sum_kernel");

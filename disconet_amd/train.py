@@ -454,6 +454,24 @@ class TrainEngine:
                     self.betas, self.eps, self.weight_decay)
         self.model._plan = None          # eval-mode packed weights are stale now
 
+    # -- what the reference's epoch loop saves / resumes (optimizer_state_dict, scheduler) ------
+    def state_dict(self):
+        """Adam moments per parameter NAME (independent of the flat layout) + step count + lr"""
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        view = lambda flat, p: flat[self.grad_of[id(p)][0]:self.grad_of[id(p)][0] + p.numel()].view(p.shape)
+        return {"step": self.step_count, "lr": self.lr, "betas": self.betas, "eps": self.eps,
+                "weight_decay": self.weight_decay,
+                "exp_avg": {names[id(p)]: view(self.flat_m, p).clone() for p in self.params},
+                "exp_avg_sq": {names[id(p)]: view(self.flat_v, p).clone() for p in self.params}}
+
+    def load_state_dict(self, sd):
+        self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
+        self.betas, self.eps, self.weight_decay = tuple(sd["betas"]), float(sd["eps"]), float(sd["weight_decay"])
+        for n, p in self.model.named_parameters():
+            off = self.grad_of[id(p)][0]
+            self.flat_m[off:off + p.numel()].view(p.shape).copy_(sd["exp_avg"][n])
+            self.flat_v[off:off + p.numel()].view(p.shape).copy_(sd["exp_avg_sq"][n])
+
     def allreduce_grads(self):
         """DDP's gradient averaging as ONE collective over the flat buffer (RCCL over xGMI)"""
         from .sharded import average_gradients_
@@ -527,6 +545,13 @@ class CoDetModule:
         self.engine = TrainEngine(model, lr=lr)
         model.__dict__["_train_engine"] = self.engine
         self.alpha, self.gamma, self.sigma = alpha, gamma, sigma
+
+    def scheduler_step(self, epoch, milestones=(50, 100), gamma=0.5):
+        """torch.optim.lr_scheduler.MultiStepLR as the reference's epoch loop steps it: call once
+        per finished epoch (1-based count of finished epochs)"""
+        if epoch in milestones:
+            self.engine.lr *= gamma
+        return self.engine.lr
 
     def step(self, data, batch_size):
         bev_seq = data["bev_seq"]
