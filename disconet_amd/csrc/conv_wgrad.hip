@@ -199,22 +199,160 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(&R[i]);
 }
 
-// partial [slice][cot][cit][tap][32 co][32 ci] -> dW [c_out][c_in][taps] (OIHW), slices summed in order
+// 3x3 stride-1 layers with >= 64 channels on both sides: a 64 x 64 (co, ci) block per workgroup.
+// Wave (wm, wn) owns one 32 x 32 quadrant over ALL pixels of the (4 x 16) tile, so the dz tile and
+// the x patch are staged once for four times the MFMA work of the 32 x 32 form (half the global
+// re-reads, no cross-wave reduction).  LDS rows are 64 floats = all 64 banks: the second half-wave
+// (the other pixel of the K = 2 pair) would hit the first one's banks, so odd pixels store their two
+// 32-channel halves swapped (c ^ 32) -- conflict-free without padding.
+__global__ __launch_bounds__(256, 2) void conv_wgrad64_kernel(const WgradArgs a) {
+  constexpr int TH = 4, TW = 16, BM = TH * TW, PH = TH + 2, PW = TW + 2, TAPS = 9;
+  constexpr int X_VEC = PH * PW * 16, X_IT = (X_VEC + 255) / 256, D_IT = BM * 16 / 256;
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;
+  float* Ds = smem + PH * PW * 64;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int item = blockIdx.x;
+  const int slice = item % a.n_slices;
+  item /= a.n_slices;
+  const int cit = item % a.n_cit;
+  const int cot = item / a.n_cit;
+  const int co0 = cot * 64, ci0 = cit * 64;
+  const bool from1 = ci0 >= a.c0;
+  const int cs0 = from1 ? ci0 - a.c0 : ci0;
+  const int csrc = from1 ? a.c1 : a.c0;
+  const int ld = from1 ? a.ld1 : a.ld0;
+  const bool up = !from1 && a.up0;
+  const int hs = up ? a.h_in >> 1 : a.h_in, ws = up ? a.w_in >> 1 : a.w_in;
+  const float* src = from1 ? a.src1 : a.src0;
+  const size_t img_x = (size_t)hs * ws * ld, img_z = (size_t)a.h_out * a.w_out * a.ldz;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  f32x4 rx[X_IT], rd[D_IT];
+
+  auto ld128 = [](auto rsrc, unsigned voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+  };
+  auto load_tile = [&](int tile) {
+    int sp = tile;
+    const int ox0 = (sp % a.tiles_x) * TW;
+    sp /= a.tiles_x;
+    const int oy0 = (sp % a.tiles_y) * TH;
+    const int img = sp / a.tiles_y;
+    const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + img * img_x), 0,
+                                                       (int)(img_x * 4), 0x00020000);
+    const auto rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz + img * img_z), 0,
+                                                       (int)(img_z * 4), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int p = idx >> 4, q = idx & 15;
+      const int iy = oy0 - 1 + p / PW, ix = ox0 - 1 + p % PW;
+      const int c = cs0 + 4 * q;
+      const bool ok = idx < X_VEC && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in && c < csrc;
+      const int sy = up ? iy >> 1 : iy, sx = up ? ix >> 1 : ix;
+      rx[it] = ld128(rsx, ok ? (unsigned)(((sy * ws + sx) * ld + c) * 4) : OOB);
+    }
+#pragma unroll
+    for (int it = 0; it < D_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int m = idx >> 4, q = idx & 15;
+      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+      const int c = co0 + 4 * q;
+      const bool ok = oy < a.h_out && ox < a.w_out && c < a.c_out;
+      rd[it] = ld128(rsz, ok ? (unsigned)(((oy * a.w_out + ox) * a.ldz + c) * 4) : OOB);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int p = idx >> 4, q = idx & 15;
+      if (idx < X_VEC) *reinterpret_cast<f32x4*>(&Xs[p * 64 + ((4 * q) ^ (((p % PW) & 1) << 5))]) = rx[it];
+    }
+#pragma unroll
+    for (int it = 0; it < D_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int m = idx >> 4, q = idx & 15;
+      *reinterpret_cast<f32x4*>(&Ds[m * 64 + ((4 * q) ^ ((m & 1) << 5))]) = rd[it];
+    }
+  };
+
+  int tile = slice;
+  if (tile < a.n_tiles) {
+    load_tile(tile);
+    store_tile();
+  }
+  __syncthreads();
+  const int a_col = (wm * 32 + li) ^ (lh << 5);            // dz column of this lane (pixel parity = lh)
+  for (; tile < a.n_tiles; tile += a.n_slices) {
+    const bool more = tile + a.n_slices < a.n_tiles;
+    if (more) load_tile(tile + a.n_slices);
+#pragma unroll
+    for (int row = 0; row < TH; ++row) {
+#pragma unroll 1   // 9 independent MFMAs per step already fill the pipe; more unrolling spills
+      for (int kp = 0; kp < TW / 2; ++kp) {
+        const int col = 2 * kp + lh;
+        const float av = Ds[(row * TW + col) * 64 + a_col];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int ty = t / 3, tx = t % 3;
+          const int xx = col + tx;
+          const float bv = Xs[((row + ty) * PW + xx) * 64 + ((wn * 32 + li) ^ ((xx & 1) << 5))];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (more) store_tile();
+    __syncthreads();
+  }
+
+  float* out = a.partial + ((size_t)(slice * a.n_cot + cot) * a.n_cit + cit) * (TAPS * 4096);
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = lh * 4 + (r & 3) + 8 * (r >> 2);
+      out[t * 4096 + (wm * 32 + i) * 64 + wn * 32 + li] = acc[t][r];
+    }
+}
+
+// partial [slice][cot][cit][tap][ct co][ct ci] -> dW [c_out][c_in][taps] (OIHW), slices summed in order
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                     int n_slices, int n_cot, int n_cit, int taps, int c_out, int c_in,
-                                    int cin_total, int accumulate) {
-  const long per_slice = (long)n_cot * n_cit * taps * 1024;
+                                    int cin_total, int accumulate, int ct) {
+  const long per_slice = (long)n_cot * n_cit * taps * ct * ct;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < per_slice;
        idx += (long)gridDim.x * blockDim.x) {
-    const int j = idx & 31, i = (idx >> 5) & 31;
-    long r = idx >> 10;
+    const int j = (int)(idx % ct), i = (int)((idx / ct) % ct);
+    long r = idx / (ct * ct);
     const int t = r % taps;
     r /= taps;
     const int cit = r % n_cit, cot = (int)(r / n_cit);
-    const int co = cot * 32 + i, ci = cit * 32 + j;
+    const int co = cot * ct + i, ci = cit * ct + j;
     if (co >= c_out || ci >= c_in) continue;
-    float s = 0.f;
-    for (int sl = 0; sl < n_slices; ++sl) s += partial[sl * per_slice + idx];
+    // four independent chains keep the loads in flight; the order is fixed, so still deterministic
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sl = 0;
+    for (; sl + 4 <= n_slices; sl += 4) {
+      s0 += partial[(sl + 0) * per_slice + idx];
+      s1 += partial[(sl + 1) * per_slice + idx];
+      s2 += partial[(sl + 2) * per_slice + idx];
+      s3 += partial[(sl + 3) * per_slice + idx];
+    }
+    for (; sl < n_slices; ++sl) s0 += partial[sl * per_slice + idx];
+    const float s = (s0 + s1) + (s2 + s3);
     float* dst = dw + ((size_t)co * cin_total + ci) * taps + t;
     *dst = accumulate ? *dst + s : s;
   }
@@ -231,25 +369,30 @@ int validate(const dn_conv_desc* d) {
   DN_REQUIRE(d->up0 == 0 || (d->up0 == 1 && d->h_in % 2 == 0 && d->w_in % 2 == 0),
              "wgrad: up0 needs even input dims");
   DN_REQUIRE(d->c1 == 0 || d->c0 % 32 == 0, "wgrad: concat needs c0 %% 32 == 0 (got %d)", d->c0);
+  DN_REQUIRE(d->c0 + d->c1 <= 4096 && d->c_out <= 4096, "wgrad: channel count out of range");
   DN_REQUIRE(d->ld0 >= d->c0 && d->ld1 >= d->c1 && d->ldo >= d->c_out, "wgrad: row stride < channels");
   return DN_OK;
 }
 
 struct Plan {
-  int h_out, w_out, tiles_x, tiles_y, n_tiles, n_cot, n_cit, n_slices, taps;
+  int h_out, w_out, tiles_x, tiles_y, n_tiles, n_cot, n_cit, n_slices, taps, ct;
 };
 
 Plan make_plan(const dn_conv_desc& d) {
   Plan p;
-  const int th = d.stride == 1 ? 8 : 4, tw = 16;
+  // 64 x 64 channel blocks where both sides have them (and every source is 16-byte loadable)
+  p.ct = (d.ksize == 3 && d.stride == 1 && d.c_out >= 64 && d.c_out % 4 == 0 && d.c0 % 64 == 0 &&
+          d.c1 % 64 == 0 && d.ld0 % 4 == 0 && d.ld1 % 4 == 0 && d.ldo % 4 == 0)
+             ? 64 : 32;
+  const int th = (d.stride == 1 && p.ct == 32) ? 8 : 4, tw = 16;
   p.h_out = out_dim(d.h_in, d.ksize, d.stride);
   p.w_out = out_dim(d.w_in, d.ksize, d.stride);
   p.tiles_x = (p.w_out + tw - 1) / tw;
   p.tiles_y = (p.h_out + th - 1) / th;
   p.n_tiles = d.n_images * p.tiles_x * p.tiles_y;
-  p.n_cot = (d.c_out + 31) / 32;
-  // a concat layer's ci blocks never straddle the sources (c0 % 32 == 0)
-  p.n_cit = (d.c0 + 31) / 32 + (d.c1 + 31) / 32;
+  p.n_cot = (d.c_out + p.ct - 1) / p.ct;
+  // a concat layer's ci blocks never straddle the sources (c0 % ct == 0)
+  p.n_cit = (d.c0 + p.ct - 1) / p.ct + (d.c1 + p.ct - 1) / p.ct;
   p.taps = d.ksize * d.ksize;
   // one resident generation (2 workgroups per CU), every slice at least 4 pixel tiles long;
   // fewer, longer slices also mean fewer partial blocks for the reduction to read back
@@ -282,7 +425,7 @@ int launch(const WgradArgs& a, const Plan& p, hipStream_t stream) {
 extern "C" size_t dn_conv_wgrad_workspace(const dn_conv_desc* d) {
   if (validate(d) != DN_OK) return 0;
   const Plan p = make_plan(*d);
-  return (size_t)p.n_slices * p.n_cot * p.n_cit * p.taps * 1024 * sizeof(float);
+  return (size_t)p.n_slices * p.n_cot * p.n_cit * p.taps * p.ct * p.ct * sizeof(float);
 }
 
 extern "C" int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz,
@@ -309,15 +452,29 @@ extern "C" int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const flo
   a.vecz = aligned(dz, d->c_out, d->ldo);
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (d->ksize == 3 && d->stride == 1) rc = launch<3, 1>(a, p, s);
+  if (p.ct == 64) {
+    // the vector path also needs 16-byte aligned bases
+    DN_REQUIRE(a.vec0 && a.vec1 && a.vecz, "wgrad: 64-channel blocks need 16-byte aligned sources");
+    constexpr int lds = (6 * 18 * 64 + 64 * 64) * 4;
+    static bool ready = false;
+    if (!ready) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad64_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess)
+        return dn::fail(DN_ERR_LAUNCH, "wgrad: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+      ready = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad64_kernel, dim3(p.n_cot * p.n_cit * p.n_slices), dim3(256), lds, s, a);
+    rc = dn::check_launch("conv_wgrad64_kernel");
+  } else if (d->ksize == 3 && d->stride == 1) rc = launch<3, 1>(a, p, s);
   else if (d->ksize == 3) rc = launch<3, 2>(a, p, s);
   else rc = launch<1, 1>(a, p, s);
   if (rc) return rc;
-  const long per_slice = (long)p.n_cot * p.n_cit * p.taps * 1024;
+  const long per_slice = (long)p.n_cot * p.n_cit * p.taps * p.ct * p.ct;
   const int blocks = (int)((per_slice + 255) / 256 < 2048 ? (per_slice + 255) / 256 : 2048);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, dw_oihw, p.n_slices,
                      p.n_cot, p.n_cit, p.taps, d->c_out, d->c0 + d->c1,
-                     dw_cin_total ? dw_cin_total : d->c0 + d->c1, accumulate);
+                     dw_cin_total ? dw_cin_total : d->c0 + d->c1, accumulate, p.ct);
   return dn::check_launch("wgrad_reduce_kernel");
 }
 

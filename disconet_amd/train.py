@@ -176,9 +176,10 @@ class TrainEngine:
 
     def _dgrad(self, d, w, dz, ci_first=0, c_in=None, dx_out=None):
         """data gradient = forward engine on dz with flipped / transposed weights.  Always the
-        exact-fp32 MFMA mode: gradients span many orders of magnitude, and the split-f16 mode's
-        absolute floor (fp16 subnormals, 6e-8) would need per-tensor loss scaling (measured: 3.6 %
-        error on conv5_1.weight's gradient against 1 % for fp32)."""
+        exact-fp32 MFMA mode: a split-f16 product carries 22 mantissa bits against fp32's 24, and
+        this backward amplifies relative error by ~1e5 (BatchNorm's mean subtraction, see
+        tests/test_gpu_train_step.py) -- measured 3.6 % error on conv5_1.weight's gradient with
+        split-f16 dgrad against 1 % with fp32 (= ATen's own fp32 autograd)."""
         wt = T.dgrad_weights(w.reshape(w.shape[0], w.shape[1], d.ksize, d.ksize), ci_first, c_in)
         c_in = wt.shape[0]
         dd = ops.conv_desc(d.n_images, d.h_in, d.w_in, d.c_out, c_in, d.ksize, 1, False,

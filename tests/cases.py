@@ -108,3 +108,73 @@ def ref_fuse(model, feat, trans, na):
             ssum = sum(e)
             out[0, i] = sum((ek / ssum) * nb for ek, nb in zip(e, nbrs))
     return model.agents_to_batch(out)
+
+
+# --- training step ------------------------------------------------
+TRAIN_CASES = {
+    "cfg1": dict(map_hw=128, agents=2, batch=1, live=None, jitter=101),
+    "ragged_a4": dict(map_hw=128, agents=4, batch=2, live=[3, 2], jitter=7),
+}
+KD_WEIGHT = 1e5
+# parameters whose float64 gradients (strided slices) are kept in tests/golden/train_step.npz
+GOLDEN_GRAD_TENSORS = [
+    "u_encoder.conv_pre_1.weight", "u_encoder.bn2_1.weight", "u_encoder.conv3d_1.conv3d.weight",
+    "u_encoder.conv4_2.weight", "decoder.conv5_1.weight", "decoder.bn7_2.bias",
+    "pixel_weighted_fusion.conv1_1.weight", "pixel_weighted_fusion.bn1_3.weight",
+    "classification.conv2.weight", "regression.box_prediction.3.bias",
+]
+
+
+def train_inputs(case):
+    from disconet_amd.synthetic import make_train_targets
+    c = TRAIN_CASES[case]
+    inputs = make_scene_batch(c["batch"], c["agents"], c["map_hw"], live=c["live"], jitter_seed=c["jitter"])
+    targets = make_train_targets(inputs[0].shape[0], c["map_hw"], p_fg=0.02)
+    return inputs, targets
+
+
+def teacher_bevs(case):
+    from disconet_amd.synthetic import make_bevs
+    c = TRAIN_CASES[case]
+    return make_bevs(c["batch"], c["agents"], c["map_hw"], p=0.05)     # denser: everyone's points
+
+
+def grad_slice(t):
+    flat = t.detach().reshape(-1)
+    return flat[::max(1, flat.numel() // 64)][:64].double().numpy()
+
+
+def oracle_train_fp64(case, ref, kd_teacher=None):
+    """The oracle's training forward / backward in float64 (same parameters, inputs and fp32
+    warp grids as the fp32 run): the reference point for gradient comparisons, because the
+    fp32 backward is ill-conditioned (tests/test_gpu_train_step.py).  Returns (losses, grads)."""
+    import copy
+    import torch.nn.functional as F
+    from oracle.train_ref import det_loss
+    c = TRAIN_CASES[case]
+    (bevs, trans, na), (labels, targets, mask) = train_inputs(case)
+    ref64 = copy.deepcopy(ref).double().train()
+    ref64.u_encoder.conv_pre_1.register_forward_pre_hook(lambda m, inp: (inp[0].double(),))
+    orig = F.grid_sample
+    F.grid_sample = lambda inp, grid, **kw: orig(inp, grid.to(inp.dtype), **kw)
+    try:
+        if kd_teacher is None:
+            out = ref64(bevs, trans, na, c["batch"])
+            res = out[0] if isinstance(out, tuple) else out
+            l_kd = None
+        else:
+            from oracle.teacher_ref import kd_loss
+            t64 = copy.deepcopy(kd_teacher).double().eval()
+            t64.stpn.conv_pre_1.register_forward_pre_hook(lambda m, inp: (inp[0].double(),))
+            ref64.kd_flag = 1
+            res, x8, x7, x6, x5, fused = ref64(bevs, trans, na, c["batch"])
+            with torch.no_grad():
+                t8, t7, t6, t5, t3, t2 = t64(teacher_bevs(case))
+            l_kd = kd_loss((x5, x6, x7, fused), (t5, t6, t7, t3), KD_WEIGHT)
+        l_cls, l_loc = det_loss(res, labels, targets, mask, norm=bevs.shape[0])
+        total = l_cls + l_loc + (l_kd if l_kd is not None else 0.0)
+        total.backward()
+    finally:
+        F.grid_sample = orig
+    losses = [float(l_cls.detach()), float(l_loc.detach())] + ([float(l_kd.detach())] if l_kd is not None else [])
+    return losses, {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}

@@ -69,6 +69,22 @@ def main():
     np.savez_compressed(os.path.join(HERE, "fusion_5x256.npz"),
                         fused=fused.numpy()[:, ::4, ::2, ::2], absmax=np.float32(fused.abs().max()))
     print("fusion", tuple(fused.shape), float(fused.abs().max()))
+    # 5. training step (float64 oracle): losses and strided gradient slices, with and without KD
+    from oracle.disconet_ref import RefConfig
+    from oracle.teacher_ref import build_teacher
+    store = {}
+    for case, c in cases.TRAIN_CASES.items():
+        ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=0)
+        teacher = build_teacher(RefConfig(c["map_hw"]))
+        for tag, t in (("det", None), ("kd", teacher)):
+            losses, grads = cases.oracle_train_fp64(case, ref, t)
+            store["%s/%s/losses" % (case, tag)] = np.asarray(losses)
+            for n in cases.GOLDEN_GRAD_TENSORS:
+                store["%s/%s/%s" % (case, tag, n)] = cases.grad_slice(grads[n])
+                store["%s/%s/%s/absmax" % (case, tag, n)] = np.float64(grads[n].abs().max())
+            print("train", case, tag, losses)
+    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **store)
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

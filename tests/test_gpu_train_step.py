@@ -21,10 +21,7 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 
-STEP_CASES = {
-    "cfg1": dict(map_hw=128, agents=2, batch=1, live=None, jitter=101),
-    "ragged_a4": dict(map_hw=128, agents=4, batch=2, live=[3, 2], jitter=7),
-}
+STEP_CASES = cases.TRAIN_CASES
 
 
 def _setup(case, math):
@@ -89,6 +86,15 @@ def test_train_step_matches_oracle(case, math, monkeypatch):
     out = mod.step(data, c["batch"])
     assert abs(out["cls_loss"] - l_ref[0]) < 2e-5 * abs(l_ref[0]), (out, l_ref)
     assert abs(out["loc_loss"] - l_ref[1]) < 2e-5 * abs(l_ref[1]), (out, l_ref)
+    # and the committed float64 golden (tests/golden/train_step.npz): losses and gradient slices
+    import os
+    import numpy as np
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_step.npz"))
+    assert np.allclose([out["cls_loss"], out["loc_loss"]], gold["%s/det/losses" % case], rtol=2e-5)
+    for n in cases.GOLDEN_GRAD_TENSORS:
+        got = cases.grad_slice(mod.engine.g(dict(model.named_parameters())[n]).cpu())
+        scale = float(gold["%s/det/%s/absmax" % (case, n)])
+        assert abs(got - gold["%s/det/%s" % (case, n)]).max() < 0.05 * scale, n    # ~1 % fp32 noise floor
 
     rows = _grad_report(g64, ref, mod.engine, model)
     bad = {k: v for k, v in rows.items() if v[0] > max(5 * v[1], 2e-3) or (v[3] and v[2] < 0.9995)}

@@ -109,3 +109,23 @@ def test_fusion_block_golden(golden_dir):
     assert np.abs(fused[:, ::4, ::2, ::2] - g["fused"]).max() <= 2e-5
     # and the helper agrees with the oracle's own forward loop: warped neighbours matter
     assert np.abs(fused - feat.numpy()).max() > 0.1
+
+
+@pytest.mark.parametrize("case,tag", [("cfg1", "det"), ("cfg1", "kd"), ("ragged_a4", "kd")])
+def test_training_step_golden(golden_dir, case, tag):
+    """the oracle's float64 training forward / backward (oracle/train_ref.py, oracle/teacher_ref.py)
+    against tests/golden/train_step.npz: losses and strided slices of ten parameters' gradients.
+    float64 on purpose -- in float32 this backward moves by ~1 % with the summation order
+    (thread count) alone, see tests/test_gpu_train_step.py."""
+    from oracle.disconet_ref import RefConfig
+    from oracle.teacher_ref import build_teacher
+    g = np.load(os.path.join(golden_dir, "train_step.npz"))
+    c = cases.TRAIN_CASES[case]
+    ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=0)
+    teacher = build_teacher(RefConfig(c["map_hw"])) if tag == "kd" else None
+    losses, grads = cases.oracle_train_fp64(case, ref, teacher)
+    assert np.allclose(losses, g["%s/%s/losses" % (case, tag)], rtol=1e-9)
+    for n in cases.GOLDEN_GRAD_TENSORS:
+        want = g["%s/%s/%s" % (case, tag, n)]
+        scale = float(g["%s/%s/%s/absmax" % (case, tag, n)])
+        assert abs(cases.grad_slice(grads[n]) - want).max() <= 1e-7 * scale, n
