@@ -223,13 +223,17 @@ conv_mfma_kernel(const ConvArgs a) {
   f32x16 acc[WTM][WTN];
   const f32x4 abl_const = {li * 1e-3f, 0.5f, -0.25f, lh * 1.f};   // ablation operands only
   f32x4 ra[T::A_IT], rb[T::B_IT];   // the next chunk, in flight from global memory
-  // fused stage's weights: 16 KiB for the whole workgroup, held in registers across
-  // tiles (the LDS region they are staged to is reused by every tile's operands)
-  f32x4 w2r[POST ? 4 : 1];
+  // fused stage's weights: this lane's B-operand fragments of W2 (row n2 = wave_n * 32 + lane % 32,
+  // k-slices by lane / 32) do not depend on the tile -- 32 VGPRs held for the whole launch instead
+  // of an LDS image rewritten every tile
+  half8 w2h[POST ? BN / 16 : 1], w2l[POST ? BN / 16 : 1];
   if constexpr (POST != 0) {
+    const float* row = a.w2 + (size_t)(wave_n * 32 + li) * BN;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-      w2r[it] = *reinterpret_cast<const f32x4*>(a.w2 + (size_t)(tid + it * NT) * 4);
+    for (int s2 = 0; s2 < BN / 16; ++s2) {
+      w2h[s2] = *reinterpret_cast<const half8*>(row + 8 * s2 + 4 * lh);
+      w2l[s2] = *reinterpret_cast<const half8*>(row + BN / 2 + 8 * s2 + 4 * lh);
+    }
   }
 
 
@@ -472,7 +476,6 @@ conv_mfma_kernel(const ConvArgs a) {
       // ---- stage 1 output h = act(acc * scale + shift), written to LDS as split-f16 rows
       // [BN hi halves | BN lo halves] (row stride CS floats) = the A-operand image of stage 2
       _Float16* Hh = reinterpret_cast<_Float16*>(smem);
-      float* W2s = smem + T::BM * CS;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int cl = wave_n * 32 + 8 * g + 4 * elh;
@@ -496,33 +499,25 @@ conv_mfma_kernel(const ConvArgs a) {
           *reinterpret_cast<half4*>(Hh + (size_t)m * CS * 2 + BN + cl) = lo;
         }
       }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {   // W2: 64 rows x BN floats, row-linear copy
-        const int idx = tid + it * NT;
-        *reinterpret_cast<f32x4*>(&W2s[(idx / (BN / 4)) * CS + 4 * (idx % (BN / 4))]) = w2r[it];
-      }
       __syncthreads();
       // ---- stage 2: out2[pixel][n2] = sum_k h[pixel][k] * W2[n2][k], split-f16 x3
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[wm][0][r] = 0.f;
-      const int n2 = wave_n * 32 + eli;
 #pragma unroll
       for (int s2 = 0; s2 < BN / 16; ++s2) {
-        const half8 bh = *reinterpret_cast<const half8*>(&W2s[n2 * CS + 8 * s2 + 4 * elh]);
-        const half8 bl = *reinterpret_cast<const half8*>(&W2s[n2 * CS + BN / 2 + 8 * s2 + 4 * elh]);
 #pragma unroll
         for (int wm = 0; wm < WTM; ++wm) {
           const int m = (wave_m * WTM + wm) * 32 + eli;
           const half8 ah = *reinterpret_cast<const half8*>(&smem[m * CS + 8 * s2 + 4 * elh]);
           const half8 al = *reinterpret_cast<const half8*>(&smem[m * CS + BN / 2 + 8 * s2 + 4 * elh]);
-          acc[wm][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[wm][0], 0, 0, 0);
-          acc[wm][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[wm][0], 0, 0, 0);
-          acc[wm][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[wm][0], 0, 0, 0);
+          acc[wm][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[s2], ah, acc[wm][0], 0, 0, 0);
+          acc[wm][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[s2], al, acc[wm][0], 0, 0, 0);
+          acc[wm][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[s2], ah, acc[wm][0], 0, 0, 0);
         }
       }
-      __syncthreads();   // h and W2 have been read by every wave
+      __syncthreads();   // h has been read by every wave
       // ---- stage 2 affine (+ReLU) -> fp32 rows [pixel][64] in LDS
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -717,6 +712,8 @@ Cfg select_cfg(const dn_conv_desc& d) {
   const int ho = out_dim(d.h_in, d.ksize, d.stride), wo = out_dim(d.w_in, d.ksize, d.stride);
   const CfgId* cand;
   int ncand;
+  // (a 16x32-pixel, 32-channel tile for the full-resolution layers was measured 3.4 % slower
+  // per step than 8x32: fewer, longer workgroups hide less of the HBM latency)
   static const CfgId c3[] = {T3_256x32, T3_256x64, T3_128x64, T3_64x64};
   static const CfgId c3s2[] = {T3S2_64x64};
   static const CfgId c1[] = {T1_128x128, T1_256x64, T1_64x64, T1_256x32};
@@ -819,7 +816,7 @@ template <int KS, int STRIDE, int TH, int TW, int BN, int KC, int WAVES_M, int W
 int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   using T = ConvTile<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN>;
   auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, BN, KC, WAVES_M, WAVES_N, WTM, WTN, ABL, MATH, POST>;
-  static_assert(POST == 0 || (size_t)(T::BM + 64) * T::CS * sizeof(float) <= T::LDS_BYTES,
+  static_assert(POST == 0 || (size_t)T::BM * T::CS * sizeof(float) <= T::LDS_BYTES,
                 "fused stage does not fit the tile's LDS");
   static_assert(T::LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   // opt in to > 64 KiB of dynamic LDS once per instantiation (idempotent; a race
@@ -862,7 +859,7 @@ int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   }();
   const int pmode = persist_env >= 0 ? persist_env : g_persist;
   // fused-1x1 launches: short tiles with a long epilogue and per-workgroup weight registers
-  const bool persist = pmode == 2 || (pmode == 1 && (POST != 0 || T::BM == 256) && a.nchunks >= 2 &&
+  const bool persist = pmode == 2 || (pmode == 1 && (POST != 0 || T::BM >= 256) && a.nchunks >= 2 &&
                                       a.nchunks <= 4);
   dim3 grid((unsigned)((persist && total > resident) ? resident : total));
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, stream, a);
@@ -961,6 +958,13 @@ extern "C" int dn_conv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p
   a.ldo = p->ldo_a;
   a.w2 = packed2; a.scale2 = scale2; a.shift2 = shift2; a.out_b = out_b;
   a.c_out2 = p->c_out2; a.relu2 = p->relu2; a.split2 = p->split; a.ldo_b = p->ldo_b;
+  // 8x32-pixel workgroups (4 MFMA tiles per wave): +2.9 % per step over 8x16 (weights staged and
+  // barriers paid half as often per pixel); DN_POST_TILE=128 selects the smaller tile
+  static const int tile_env = [] {
+    const char* e = getenv("DN_POST_TILE");
+    return e ? atoi(e) : 256;
+  }();
+  if (tile_env == 256) return launch<3, 1, 8, 32, 64, 16, 2, 2, 4, 1, 0, 1, 1>(a, *d, (hipStream_t)stream);
   return launch<3, 1, 8, 16, 64, 16, 2, 2, 2, 1, 0, 1, 1>(a, *d, (hipStream_t)stream);
 }
 
