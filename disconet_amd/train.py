@@ -26,6 +26,8 @@ import torch
 from . import ops, train_ops as T
 from .model import LAYER_CHANNEL, _bn_name
 
+_ENC_GROUPS = (("conv_pre_1", "conv_pre_2"), ("conv1_1", "conv1_2", "conv3d_1"),
+               ("conv2_1", "conv2_2", "conv3d_2"), ("conv3_1", "conv3_2"), ("conv4_1", "conv4_2"))
 _EPS = 1e-5          # nn.BatchNorm default
 _MOMENTUM = 0.1
 
@@ -52,8 +54,6 @@ def _param_order(model):
 
 class TrainEngine:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        if model.u_encoder.compress_level > 0:
-            raise NotImplementedError("training with compress_level > 0 is not built yet")
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
@@ -97,6 +97,11 @@ class TrainEngine:
         for name in ("conv5_1", "conv5_2", "conv6_1", "conv6_2", "conv7_1", "conv7_2", "conv8_1", "conv8_2"):
             conv = getattr(dec, name)
             L[name] = _Layer(name, conv.weight, conv.bias, getattr(dec, _bn_name(name)), 3)
+        if enc.compress_level > 0:       # 1x1 compress / decompress of the exchanged map
+            L["compress"] = _Layer("compress", enc.com_compresser.weight, enc.com_compresser.bias,
+                                   enc.bn_compress, 1)
+            L["decompress"] = _Layer("decompress", enc.com_decompresser.weight, enc.com_decompresser.bias,
+                                     enc.bn_decompress, 1)
         f = m.pixel_weighted_fusion
         for i, (cname, bname) in enumerate((("conv1_2", "bn1_2"), ("conv1_3", "bn1_3")), 2):
             conv = getattr(f, cname)
@@ -251,8 +256,10 @@ class TrainEngine:
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size):
         m, L = self.model, self.L
         A, B = m.agent_num, batch_size
-        if m.layer != 3:
-            raise NotImplementedError("training is built for layer = 3 (the reference default)")
+        if m.layer == 4:
+            raise NotImplementedError("training with the fusion on layer 4 is not built (layers 0-3 are)")
+        if m.layer != 3 and m.u_encoder.compress_level > 0:
+            raise NotImplementedError("compress_level > 0 in training needs layer = 3")
         n = bevs.shape[0] * bevs.shape[1]
         if n != A * B:
             raise ValueError("bevs has %d images, expected num_agent*batch_size = %d" % (n, A * B))
@@ -264,33 +271,36 @@ class TrainEngine:
         F = self._fusion_lists(trans, num_agent_tensor[:, 0].cpu(), B, dev)
         self.F = F
 
-        a = self._layer_fwd(L["conv_pre_1"], x)
-        x0 = self._layer_fwd(L["conv_pre_2"], a)
-        a = self._layer_fwd(L["conv1_1"], x0)
-        a = self._layer_fwd(L["conv1_2"], a)
-        x1 = self._layer_fwd(L["conv3d_1"], a)
-        a = self._layer_fwd(L["conv2_1"], x1)
-        a = self._layer_fwd(L["conv2_2"], a)
-        x2 = self._layer_fwd(L["conv3d_2"], a)
-        a = self._layer_fwd(L["conv3_1"], x2)
-        h3, w3 = a.shape[1], a.shape[2]
-        C = LAYER_CHANNEL[3]
+        # encoder: groups of layers, the last one of group k yields e[k]; the maps of the fusion layer
+        # are written straight into the pair buffer [own maps | warped maps]
+        lay_k = m.layer
+        C = LAYER_CHANNEL[lay_k]
+        hk, wk = x.shape[1] >> lay_k, x.shape[2] >> lay_k
         NI, NW = n, F["n_warps"]
-        maps = torch.empty((NI + NW, h3, w3, C), dtype=torch.float32, device=dev)
-        x3 = self._layer_fwd(L["conv3_2"], a, y_out=maps[:NI])        # own maps land in the pair buffer
-        a = self._layer_fwd(L["conv4_1"], x3)
-        x4 = self._layer_fwd(L["conv4_2"], a)
+        maps = torch.empty((NI + NW, hk, wk, C), dtype=torch.float32, device=dev)
+        e, a = [], x
+        for k, names in enumerate(_ENC_GROUPS):
+            for name in names:
+                into = maps[:NI] if (name == names[-1] and k == lay_k and "compress" not in L) else None
+                a = self._layer_fwd(L[name], a, y_out=into)
+            e.append(a)
+        if "compress" in L:
+            # the encoder went on from the uncompressed x3; what is exchanged (and what the decoder's
+            # skip sees) goes through the 1x1 compress / decompress pair
+            self._layer_fwd(L["decompress"], self._layer_fwd(L["compress"], e[3]), y_out=maps[:NI])
 
-        x3f = self._fusion_fwd(maps, NI, NW, F)
-
-        a = self._layer_fwd(L["conv5_1"], x4, x3f, up0=1)
+        fused = self._fusion_fwd(maps, NI, NW, F)
+        sk = list(e)
+        sk[lay_k] = fused                                     # the decoder sees the fused map
+        a = self._layer_fwd(L["conv5_1"], sk[4], sk[3], up0=1)
         x5 = self._layer_fwd(L["conv5_2"], a)
-        a = self._layer_fwd(L["conv6_1"], x5, x2, up0=1)
+        a = self._layer_fwd(L["conv6_1"], x5, sk[2], up0=1)
         x6 = self._layer_fwd(L["conv6_2"], a)
-        a = self._layer_fwd(L["conv7_1"], x6, x1, up0=1)
+        a = self._layer_fwd(L["conv7_1"], x6, sk[1], up0=1)
         x7 = self._layer_fwd(L["conv7_2"], a)
-        a = self._layer_fwd(L["conv8_1"], x7, x0, up0=1)
+        a = self._layer_fwd(L["conv8_1"], x7, sk[0], up0=1)
         x8 = self._layer_fwd(L["conv8_2"], a)
+        x3f = fused
 
         # heads: both first convs as one 64-channel layer (their parameters are adjacent in the
         # flat buffer), then the two 1x1 prediction convs on the halves
@@ -403,23 +413,29 @@ class TrainEngine:
         d = self._layer_bwd(L["conv5_2"], dcat6[..., :256], G, up_a=True, dy_b=dkd.get("x5"))
         dcat5 = self._layer_bwd(L["conv5_1"], d, G)                     # [.., 512 (up x4) | 256 (fused)]
 
-        dfused = dcat5[..., 512:]
+        # decoder-side gradient of each encoder output e[k] (k = 4 arrives at twice its resolution)
+        d_dec = [dcat8[..., 64:], dcat7[..., 128:], dcat6[..., 256:], dcat5[..., 512:], dcat5[..., :512]]
+        lay_k = m.layer
+        dfused = d_dec[lay_k]
         if dkd.get("fused") is not None:
             dfused = T.add_rows(dkd["fused"], dfused)      # in place on the KD gradient buffer
-        d_x3 = self._fusion_bwd(dfused, G)
+        d_fus = self._fusion_bwd(dfused, G)                # gradient w.r.t. the own maps of the fusion layer
+        if "compress" in L:
+            d_fus = self._layer_bwd(L["compress"], self._layer_bwd(L["decompress"], d_fus, G), G)
+        d_dec[lay_k] = d_fus
 
-        d = self._layer_bwd(L["conv4_2"], dcat5[..., :512], G, up_a=True)
-        d = self._layer_bwd(L["conv4_1"], d, G)
-        d = self._layer_bwd(L["conv3_2"], d, G, dy_b=d_x3)
-        d = self._layer_bwd(L["conv3_1"], d, G)
-        d = self._layer_bwd(L["conv3d_2"], d, G, dy_b=dcat6[..., 256:])
-        d = self._layer_bwd(L["conv2_2"], d, G)
-        d = self._layer_bwd(L["conv2_1"], d, G)
-        d = self._layer_bwd(L["conv3d_1"], d, G, dy_b=dcat7[..., 128:])
-        d = self._layer_bwd(L["conv1_2"], d, G)
-        d = self._layer_bwd(L["conv1_1"], d, G)
-        d = self._layer_bwd(L["conv_pre_2"], d, G, dy_b=dcat8[..., 64:])
-        self._layer_bwd(L["conv_pre_1"], d, G, need_dx=False)
+        # encoder, top down: e[k] feeds conv{k+1}_1 (gradient d) and the decoder / the fusion (d_dec[k])
+        d = None
+        for k in range(4, -1, -1):
+            names = _ENC_GROUPS[k]
+            for name in reversed(names):
+                last = name == names[-1]
+                if last and d is None:                     # e[4]: one consumer, the decoder's upsample
+                    d = self._layer_bwd(L[name], d_dec[4], G, up_a=True)
+                elif last:
+                    d = self._layer_bwd(L[name], d, G, dy_b=d_dec[k])
+                else:
+                    d = self._layer_bwd(L[name], d, G, need_dx=name != "conv_pre_1")
         return G
 
     def _fusion_bwd(self, dfused, G):

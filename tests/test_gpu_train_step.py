@@ -24,13 +24,15 @@ pytestmark = pytest.mark.gpu
 STEP_CASES = cases.TRAIN_CASES
 
 
-def _setup(case, math):
+def _setup(case, math, only_v2i=False, compress_level=0, layer=3):
     from disconet_amd import Config, DiscoNet
     from disconet_amd.synthetic import make_scene_batch, make_train_targets
     c = STEP_CASES[case]
-    ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=0)
+    ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=0, only_v2i=only_v2i,
+                          compress_level=compress_level, layer=layer)
     cfg = Config(map_hw=c["map_hw"])
-    model = DiscoNet(cfg, kd_flag=0, num_agent=c["agents"])
+    model = DiscoNet(cfg, kd_flag=0, num_agent=c["agents"], only_v2i=only_v2i,
+                     compress_level=compress_level, layer=layer)
     model.load_state_dict(ref.state_dict())
     model = model.cuda()
     model.conv_math = math
@@ -326,3 +328,64 @@ def test_checkpoint_resume_reproduces_the_next_step(tmp_path):
     for (n, a), (_, b) in zip(model.named_parameters(), model2.named_parameters()):
         assert float((a - b).abs().max()) < 2.1e-3, n      # at most one lr-sized sign flip of a noise gradient
     assert mod.scheduler_step(50) == 0.5e-3 and mod.scheduler_step(51) == 0.5e-3
+
+
+def test_train_step_only_v2i(monkeypatch):
+    """--only_v2i: vehicles exchange with the RSU (agent 0) only -- fewer warps / pairs per scene"""
+    from disconet_amd import CoDetModule
+    from oracle.train_ref import train_step
+    c, ref, model, (bevs, trans, na), (labels, targets, mask) = _setup("ragged_a4", "f16x3", only_v2i=True)
+    g64 = _fp64_grads(ref, (bevs, trans, na), (labels, targets, mask), c["batch"], monkeypatch)
+    l_ref = train_step(ref, torch.optim.Adam(ref.parameters(), lr=1e-3), bevs, trans, na, c["batch"],
+                       labels, targets, mask)
+    mod = CoDetModule(model, lr=1e-3)
+    assert mod.engine is model.__dict__["_train_engine"]
+    out = mod.step({"bev_seq": bevs.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(),
+                    "labels": labels.cuda(), "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda()},
+                   c["batch"])
+    assert mod.engine.F["n_warps"] == 2 * 2 + 2 * 1          # scene 0: 3 live -> 4 warps, scene 1: 2 live -> 2
+    assert abs(out["cls_loss"] - l_ref[0]) < 2e-5 * abs(l_ref[0])
+    assert abs(out["loc_loss"] - l_ref[1]) < 2e-5 * abs(l_ref[1])
+    rows = _grad_report(g64, ref, mod.engine, model)
+    bad = {k: v for k, v in rows.items() if v[0] > max(5 * v[1], 2e-3) or (v[3] and v[2] < 0.9995)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
+
+
+def test_train_step_with_compression(monkeypatch):
+    """--compress_level 2: the exchanged map goes through 1x1 compress (256 -> 64) / decompress"""
+    from disconet_amd import CoDetModule
+    from oracle.train_ref import train_step
+    c, ref, model, (bevs, trans, na), (labels, targets, mask) = _setup("cfg1", "f16x3", compress_level=2)
+    g64 = _fp64_grads(ref, (bevs, trans, na), (labels, targets, mask), c["batch"], monkeypatch)
+    l_ref = train_step(ref, torch.optim.Adam(ref.parameters(), lr=1e-3), bevs, trans, na, c["batch"],
+                       labels, targets, mask)
+    mod = CoDetModule(model, lr=1e-3)
+    out = mod.step({"bev_seq": bevs.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(),
+                    "labels": labels.cuda(), "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda()},
+                   c["batch"])
+    assert abs(out["cls_loss"] - l_ref[0]) < 2e-5 * abs(l_ref[0])
+    assert abs(out["loc_loss"] - l_ref[1]) < 2e-5 * abs(l_ref[1])
+    rows = _grad_report(g64, ref, mod.engine, model)
+    assert "u_encoder.com_compresser.weight" in rows and "u_encoder.bn_decompress.bias" in rows
+    bad = {k: v for k, v in rows.items() if v[0] > max(5 * v[1], 2e-3) or (v[3] and v[2] < 0.9995)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
+
+
+@pytest.mark.parametrize("layer", [2, 1])
+def test_train_step_fusion_on_another_layer(layer, monkeypatch):
+    """--layer 2 / 1: the exchange and the DiscoGraph fusion sit on x2 (128 ch) / x1 (64 ch)"""
+    from disconet_amd import CoDetModule
+    from oracle.train_ref import train_step
+    c, ref, model, (bevs, trans, na), (labels, targets, mask) = _setup("cfg1", "f16x3", layer=layer)
+    g64 = _fp64_grads(ref, (bevs, trans, na), (labels, targets, mask), c["batch"], monkeypatch)
+    l_ref = train_step(ref, torch.optim.Adam(ref.parameters(), lr=1e-3), bevs, trans, na, c["batch"],
+                       labels, targets, mask)
+    mod = CoDetModule(model, lr=1e-3)
+    out = mod.step({"bev_seq": bevs.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(),
+                    "labels": labels.cuda(), "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda()},
+                   c["batch"])
+    assert abs(out["cls_loss"] - l_ref[0]) < 2e-5 * abs(l_ref[0])
+    assert abs(out["loc_loss"] - l_ref[1]) < 2e-5 * abs(l_ref[1])
+    rows = _grad_report(g64, ref, mod.engine, model)
+    bad = {k: v for k, v in rows.items() if v[0] > max(5 * v[1], 2e-3) or (v[3] and v[2] < 0.9995)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
