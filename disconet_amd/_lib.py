@@ -79,6 +79,7 @@ SIGNATURES = {
                                      c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_void_p]),
     "dn_channel_sum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "dn_upsample2_sum": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dn_add_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_void_p]),
     "dn_pair_add_ego": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dn_pair_sum_ego": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,

@@ -354,6 +354,23 @@ __global__ void add_rows_kernel(float* __restrict__ a, int ld_a, const float* __
   }
 }
 
+// backward of F.interpolate(scale_factor=2, nearest) on its own: out[n, y, x, c] = sum of the 2 x 2
+// block of the double-resolution gradient (a channel slice with row stride ld)
+__global__ void upsample2_sum_kernel(const float* __restrict__ g, int ld, int h, int w, int c,
+                                     long total, float* __restrict__ out) {
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(idx % c);
+    long r = idx / c;
+    const int px = (int)(r % w);
+    r /= w;
+    const int py = (int)(r % h);
+    const long img = r / h;
+    const float* b = g + ((img * 2 * h + 2 * py) * (2L * w) + 2 * px) * ld + cc;
+    out[idx] = (b[0] + b[ld]) + (b[2L * w * ld] + b[(2L * w + 1) * ld]);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // fusion, training form
 // ---------------------------------------------------------------------------------
@@ -676,6 +693,15 @@ extern "C" int dn_add_rows(float* a, int ld_a, const float* b, int ld_b, long ro
   hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, a,
                      ld_a, b, ld_b, c, total);
   return dn::check_launch("add_rows_kernel");
+}
+
+extern "C" int dn_upsample2_sum(const float* g, int ld, int n_images, int h, int w, int c, float* out,
+                                void* stream) {
+  DN_REQUIRE(g && out && n_images > 0 && h > 0 && w > 0 && c > 0 && ld >= c, "upsample sum: bad arguments");
+  const long total = (long)n_images * h * w * c;
+  hipLaunchKernelGGL(upsample2_sum_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     g, ld, h, w, c, total, out);
+  return dn::check_launch("upsample2_sum_kernel");
 }
 
 extern "C" int dn_pair_add_ego(float* z1, const float* e, const int* ego_image, int n_pairs,

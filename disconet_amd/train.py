@@ -256,8 +256,6 @@ class TrainEngine:
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size):
         m, L = self.model, self.L
         A, B = m.agent_num, batch_size
-        if m.layer == 4:
-            raise NotImplementedError("training with the fusion on layer 4 is not built (layers 0-3 are)")
         if m.layer != 3 and m.u_encoder.compress_level > 0:
             raise NotImplementedError("compress_level > 0 in training needs layer = 3")
         n = bevs.shape[0] * bevs.shape[1]
@@ -416,7 +414,8 @@ class TrainEngine:
         # decoder-side gradient of each encoder output e[k] (k = 4 arrives at twice its resolution)
         d_dec = [dcat8[..., 64:], dcat7[..., 128:], dcat6[..., 256:], dcat5[..., 512:], dcat5[..., :512]]
         lay_k = m.layer
-        dfused = d_dec[lay_k]
+        # (layer 4: the fused map reaches conv5_1 through the upsample -- undo it before the fusion)
+        dfused = T.upsample2_sum(d_dec[4]) if lay_k == 4 else d_dec[lay_k]
         if dkd.get("fused") is not None:
             dfused = T.add_rows(dkd["fused"], dfused)      # in place on the KD gradient buffer
         d_fus = self._fusion_bwd(dfused, G)                # gradient w.r.t. the own maps of the fusion layer
@@ -431,7 +430,7 @@ class TrainEngine:
             for name in reversed(names):
                 last = name == names[-1]
                 if last and d is None:                     # e[4]: one consumer, the decoder's upsample
-                    d = self._layer_bwd(L[name], d_dec[4], G, up_a=True)
+                    d = self._layer_bwd(L[name], d_dec[4], G, up_a=lay_k != 4)
                 elif last:
                     d = self._layer_bwd(L[name], d, G, dy_b=d_dec[k])
                 else:

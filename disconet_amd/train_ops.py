@@ -121,6 +121,16 @@ def channel_sum(x, out, accumulate=False):
     return out
 
 
+def upsample2_sum(g):
+    """g [n, 2h, 2w, c] (may be a channel slice) -> dense [n, h, w, c] of 2 x 2 block sums"""
+    _need_gpu(g)
+    n, h2, w2, c = g.shape
+    out = torch.empty((n, h2 // 2, w2 // 2, c), dtype=torch.float32, device=g.device)
+    check(_lib.load().dn_upsample2_sum(_ptr(g), _ld(g), n, h2 // 2, w2 // 2, c, _ptr(out), _stream()),
+          "dn_upsample2_sum")
+    return out
+
+
 def add_rows(a, b):
     """a += b for NHWC maps / channel slices of equal shape"""
     _need_gpu(a, b)

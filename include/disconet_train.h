@@ -80,6 +80,12 @@ int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const float* dy_
 int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, float* out,
                    int accumulate, void* stream);
 
+/* Backward of the decoder's nearest x2 upsample as a pass of its own (only needed where no
+ * BatchNorm backward follows directly: the fusion on layer 4): out [n, h, w, c] dense = 2 x 2
+ * block sums of g [n, 2h, 2w, c'] read with row stride ld. */
+int dn_upsample2_sum(const float* g, int ld, int n_images, int h, int w, int c, float* out,
+                     void* stream);
+
 /* a[row][0..c) += b[row][0..c) */
 int dn_add_rows(float* a, int ld_a, const float* b, int ld_b, long rows, int c, void* stream);
 
