@@ -215,6 +215,9 @@ class DiscoNet(nn.Module):
         self.conv_math = os.environ.get("DISCONET_CONV_MATH", "f16x3")
         # fold the 1x1 layers that follow a 64-channel 3x3 conv into that conv's launch
         self.fuse_1x1 = os.environ.get("DISCONET_FUSE_1X1", "1") != "0"
+        # run the encoder levels above the exchanged one beside the fusion block (second HIP stream)
+        self.overlap_streams = os.environ.get("DISCONET_OVERLAP", "1") != "0"
+        self._side = {}
 
     # ------------------------------------------------------------------
     # checkpoint compatibility
@@ -236,6 +239,12 @@ class DiscoNet(nn.Module):
                 cleaned[k] = v         # let torch report genuinely unexpected keys
         self._plan = None
         return super().load_state_dict(cleaned, strict=strict, **kw)
+
+    def _side_stream(self, device):
+        key = str(device)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=device)
+        return self._side[key]
 
     def train(self, mode=True):
         """train(): forward() runs the training-mode graph of disconet_amd/train.py (batch
@@ -339,7 +348,7 @@ class DiscoNet(nn.Module):
     # ------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------
-    def encode(self, bevs, P):
+    def _enc_input(self, bevs):
         n = bevs.shape[0] * bevs.shape[1]
         h, w, z = bevs.shape[2], bevs.shape[3], bevs.shape[4]
         # [A*B, 1, H, W, Z] is already NHWC with Z as the channel: the reference's
@@ -347,18 +356,29 @@ class DiscoNet(nn.Module):
         x = bevs.reshape(n, h, w, z)
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
-        x = P["conv_pre_1"].run(x)
-        x0 = P["conv_pre_2"].run(x)
-        if "conv1_2_3d" in P:
-            x1 = P["conv1_2_3d"].run(P["conv1_1"].run(x0))[0]
-        else:
-            x1 = P["conv3d_1"].run(P["conv1_2"].run(P["conv1_1"].run(x0)))
-        x2 = P["conv3d_2"].run(P["conv2_2"].run(P["conv2_1"].run(x1)))
-        x3 = P["conv3_2"].run(P["conv3_1"].run(x2))
-        x4 = P["conv4_2"].run(P["conv4_1"].run(x3))
+        return x
+
+    def _enc_group(self, k, x, P):
+        """encoder group k: its last layer's output is the pyramid level e[k]"""
+        if k == 0:
+            return P["conv_pre_2"].run(P["conv_pre_1"].run(x))
+        if k == 1:
+            if "conv1_2_3d" in P:
+                return P["conv1_2_3d"].run(P["conv1_1"].run(x))[0]
+            return P["conv3d_1"].run(P["conv1_2"].run(P["conv1_1"].run(x)))
+        if k == 2:
+            return P["conv3d_2"].run(P["conv2_2"].run(P["conv2_1"].run(x)))
+        return P["conv%d_2" % k].run(P["conv%d_1" % k].run(x))
+
+    def encode(self, bevs, P):
+        x = self._enc_input(bevs)
+        enc = []
+        for k in range(5):
+            x = self._enc_group(k, x, P)
+            enc.append(x)
         if "compress" in P:
-            x3 = P["decompress"].run(P["compress"].run(x3))
-        return [x0, x1, x2, x3, x4]
+            enc[3] = P["decompress"].run(P["compress"].run(enc[3]))
+        return enc
 
     def fuse(self, feat, trans_matrices, num_agent, batch_size, P, want_weights=False,
              ego_first=0, ego_count=None):
@@ -419,9 +439,39 @@ class DiscoNet(nn.Module):
         trans = trans_matrices.to(device=bevs.device, dtype=torch.float32).contiguous()
         num_agent = num_agent_tensor[:, 0].to(device=bevs.device, dtype=torch.int32).contiguous()
 
-        enc = self.encode(bevs, P)
-        fused = self.fuse(enc[self.layer], trans, num_agent, batch_size, P)
-        enc[self.layer] = fused
+        if self.overlap_streams and self.layer < 4:
+            # The encoder groups above the exchanged level do not depend on the fusion: they run on a
+            # second HIP stream next to the warp / attention kernels (small-grid, MFMA-bound convs
+            # beside L2/HBM-bound gathers) and join before the decoder.  Inside a hipGraph capture the
+            # fork / join become parallel branches of the graph.
+            x = self._enc_input(bevs)
+            enc = []
+            for k in range(self.layer + 1):
+                x = self._enc_group(k, x, P)
+                enc.append(x)
+            main = torch.cuda.current_stream()
+            side = self._side_stream(bevs.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                up = x
+                for k in range(self.layer + 1, 5):
+                    up = self._enc_group(k, up, P)
+                    enc.append(up)
+            feat = enc[self.layer]
+            if "compress" in P and self.layer != 3:
+                with torch.cuda.stream(side):                       # x3 is on the side branch then
+                    enc[3] = P["decompress"].run(P["compress"].run(enc[3]))
+            elif "compress" in P:
+                feat = P["decompress"].run(P["compress"].run(feat))
+            fused = self.fuse(feat, trans, num_agent, batch_size, P)
+            main.wait_stream(side)
+            for t in enc[self.layer + 1:]:
+                t.record_stream(main)
+            enc[self.layer] = fused
+        else:
+            enc = self.encode(bevs, P)
+            fused = self.fuse(enc[self.layer], trans, num_agent, batch_size, P)
+            enc[self.layer] = fused
         x8, x7, x6, x5 = self.decode(enc, P)
 
         result = self.heads(x8, P)
