@@ -79,6 +79,11 @@ class TrainEngine:
         self._graph()
 
     # ------------------------------------------------------------------
+    def _side_stream(self, dev):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
+
     def g(self, p, flat=None):
         off, n, shape = self.grad_of[id(p)]
         return (self.flat_g if flat is None else flat)[off:off + n].view(shape)
@@ -276,18 +281,32 @@ class TrainEngine:
         hk, wk = x.shape[1] >> lay_k, x.shape[2] >> lay_k
         NI, NW = n, F["n_warps"]
         maps = torch.empty((NI + NW, hk, wk, C), dtype=torch.float32, device=dev)
-        e, a = [], x
-        for k, names in enumerate(_ENC_GROUPS):
-            for name in names:
-                into = maps[:NI] if (name == names[-1] and k == lay_k and "compress" not in L) else None
+        def group(k, a):
+            for name in _ENC_GROUPS[k]:
+                into = maps[:NI] if (name == _ENC_GROUPS[k][-1] and k == lay_k and "compress" not in L) else None
                 a = self._layer_fwd(L[name], a, y_out=into)
+            return a
+
+        e, a = [], x
+        for k in range(lay_k + 1):
+            a = group(k, a)
             e.append(a)
+        # the encoder levels above the exchanged one run beside the fusion block on a second stream
+        main, side = torch.cuda.current_stream(dev), self._side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            up = a
+            for k in range(lay_k + 1, 5):
+                up = group(k, up)
+                e.append(up)
         if "compress" in L:
-            # the encoder went on from the uncompressed x3; what is exchanged (and what the decoder's
+            # the encoder goes on from the uncompressed x3; what is exchanged (and what the decoder's
             # skip sees) goes through the 1x1 compress / decompress pair
             self._layer_fwd(L["decompress"], self._layer_fwd(L["compress"], e[3]), y_out=maps[:NI])
-
         fused = self._fusion_fwd(maps, NI, NW, F)
+        main.wait_stream(side)
+        for t in e[lay_k + 1:]:
+            t.record_stream(main)
         sk = list(e)
         sk[lay_k] = fused                                     # the decoder sees the fused map
         a = self._layer_fwd(L["conv5_1"], sk[4], sk[3], up0=1)
@@ -418,14 +437,8 @@ class TrainEngine:
         dfused = T.upsample2_sum(d_dec[4]) if lay_k == 4 else d_dec[lay_k]
         if dkd.get("fused") is not None:
             dfused = T.add_rows(dkd["fused"], dfused)      # in place on the KD gradient buffer
-        d_fus = self._fusion_bwd(dfused, G)                # gradient w.r.t. the own maps of the fusion layer
-        if "compress" in L:
-            d_fus = self._layer_bwd(L["compress"], self._layer_bwd(L["decompress"], d_fus, G), G)
-        d_dec[lay_k] = d_fus
-
         # encoder, top down: e[k] feeds conv{k+1}_1 (gradient d) and the decoder / the fusion (d_dec[k])
-        d = None
-        for k in range(4, -1, -1):
+        def group_bwd(k, d):
             names = _ENC_GROUPS[k]
             for name in reversed(names):
                 last = name == names[-1]
@@ -435,6 +448,25 @@ class TrainEngine:
                     d = self._layer_bwd(L[name], d, G, dy_b=d_dec[k])
                 else:
                     d = self._layer_bwd(L[name], d, G, need_dx=name != "conv_pre_1")
+            return d
+
+        # the levels above the exchanged one do not wait for the fusion's backward: second stream
+        dev = dcls.device
+        main, side = torch.cuda.current_stream(dev), self._side_stream(dev)
+        d = None
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for k in range(4, lay_k, -1):
+                d = group_bwd(k, d)
+        d_fus = self._fusion_bwd(dfused, G)                # gradient w.r.t. the own maps of the fusion layer
+        if "compress" in L:
+            d_fus = self._layer_bwd(L["compress"], self._layer_bwd(L["decompress"], d_fus, G), G)
+        d_dec[lay_k] = d_fus
+        main.wait_stream(side)
+        if d is not None:
+            d.record_stream(main)
+        for k in range(lay_k, -1, -1):
+            d = group_bwd(k, d)
         return G
 
     def _fusion_bwd(self, dfused, G):

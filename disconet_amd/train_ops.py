@@ -14,8 +14,9 @@ from .ops import _need_gpu, _ptr, _stream, conv_desc
 
 
 def _ws(device, nbytes, cache={}):
-    """grow-only scratch buffer per device (doubles / floats reinterpret it)"""
-    key = str(device)
+    """grow-only scratch buffer per (device, stream): two streams may run backward kernels side by
+    side (train.py), each needs its own partial-sum space"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     buf = cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
