@@ -55,6 +55,10 @@ def parse():
                          "per step (strong scaling of a fixed batch of scenes)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from Python instead of replaying a captured hipGraph")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="steps in flight: consecutive steps are replayed on this many alternating HIP "
+                         "streams (each with its own captured graph and buffers), so one batch's small-grid "
+                         "/ launch-bound phases overlap the next batch's; 1 = strictly one step at a time")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
     ap.add_argument("--train-steps", type=int, default=4,
                     help="also time this many training steps (forward + loss + backward + Adam) of the "
@@ -257,24 +261,33 @@ def main():
     graphed = {}
     launch_mode = {"mode": "eager" if args.no_graph else "hipGraph replay"}
 
-    def run_step():
+    def run_step(i=0, depth=None):
         """One step for the un-instrumented region: a captured hipGraph of step() (the
-        same launches, replayed without per-launch host work) unless --no-graph."""
+        same launches, replayed without per-launch host work) unless --no-graph.  With
+        --in-flight N, step i is replayed from graph i % N on stream i % N."""
         if args.no_graph:
             return step()
+        depth = max(1, args.in_flight) if depth is None else depth
         key = model.conv_math
         if key not in graphed:
             from disconet_amd.graph import GraphedStep
             try:
-                graphed[key] = GraphedStep(step)
+                graphed[key] = [(GraphedStep(step), torch.cuda.Stream()) for _ in range(max(1, args.in_flight))]
             except Exception as e:   # capture refused (driver / collective library state): run eagerly
                 print("bench: hipGraph capture failed (%r); launching eagerly" % (e,), file=sys.stderr)
                 torch.cuda.synchronize()
-                graphed[key] = step
+                graphed[key] = None
                 launch_mode["mode"] = "eager (graph capture failed)"
-        return graphed[key]()
+        slots = graphed[key]
+        if slots is None:
+            return step()
+        if depth == 1:
+            return slots[0][0]()
+        g, st = slots[i % depth]
+        with torch.cuda.stream(st):
+            return g()
 
-    def timed(events):
+    def timed(events, depth=None):
         """K steps of the hot path.  events=False: nothing but the steps (-> value).
         events=True: a HIP-event pair around every launch, on the launch stream (->
         per-kernel durations); kept apart because each event record drains the queue
@@ -287,8 +300,8 @@ def main():
                 for _ in range(args.steps):
                     step()
         else:
-            for _ in range(args.steps):
-                run_step()
+            for i in range(args.steps):
+                run_step(i, depth)
         fence() if not events else torch.cuda.synchronize()
         return time.perf_counter() - t0, timer
 
@@ -337,9 +350,10 @@ def main():
                     v["bytes"] / (v["ms_total"] * 1e-3) / 1e9 if v["ms_total"] else 0), file=sys.stderr)
         return roof
 
-    for _ in range(args.warmup):
-        run_step()
+    for i in range(args.warmup):
+        run_step(i)
     elapsed, _ = timed(False)                      # timed region #1 -> value
+    elapsed_serial = timed(False, depth=1)[0] if (args.in_flight > 1 and not args.no_graph) else None
     timer, elapsed_events = None, 0.0
     if rank == 0 and not args.no_kernel_events:
         elapsed_events, timer = timed(True)        # timed region #2 -> roofline
@@ -367,19 +381,34 @@ def main():
                                "256x256x13 BEV, no KD, sparse voxel lists -> dense -> enc -> "
                                "DiscoGraph fusion -> dec -> cls/reg heads",
                    "agents": AGENTS, "batch_per_gpu": BATCH, "bev": [MAP_HW, MAP_HW, 13],
-                   "conv_math": args.math, "launch": launch_mode["mode"],
+                   "conv_math": args.math,
+                   "launch": launch_mode["mode"] + (
+                       ", %d steps in flight (alternating streams, one captured graph + buffers each)"
+                       % args.in_flight if (args.in_flight > 1 and launch_mode["mode"] == "hipGraph replay") else ""),
                    "parallelism": "scene-parallel x%d (no data-path collective)" % world},
     }
 
     if rank == 0:
+        if elapsed_serial is not None:
+            slots = graphed.get(model.conv_math)
+            if slots:      # the overlapped replays wrote the same results as the serial one
+                outs = [g.outputs for g, _ in slots]
+                result["in_flight_outputs_identical"] = all(
+                    torch.equal(o["cls"], outs[0]["cls"]) and torch.equal(o["loc"], outs[0]["loc"])
+                    for o in outs[1:])
+            result["one_step_at_a_time"] = {
+                "value": round(BATCH * args.steps / elapsed_serial, 3),
+                "ms_per_step": round(1e3 * elapsed_serial / args.steps, 4),
+                "note": "same K steps replayed back to back on ONE stream (rank 0's own clock): the "
+                        "latency of a step; `value` overlaps consecutive, independent batches"}
         if timer is not None:
             result["roofline"] = roofline_of(timer, elapsed_events, args.math)
         if world == 1 and not args.no_alt_math:
             # the other conv arithmetic on the same workload, K steps each way
             alt = "f32" if args.math == "f16x3" else "f16x3"
             model.conv_math = alt
-            for _ in range(args.warmup):
-                run_step()
+            for i in range(args.warmup):
+                run_step(i)
             alt_elapsed, _ = timed(False)
             alt_res = {"conv_math": alt, "dtype": dtype_name[alt],
                        "value": round(BATCH * args.steps / alt_elapsed, 3),
