@@ -59,6 +59,7 @@ def parse():
                     help="steps in flight: consecutive steps are replayed on this many alternating HIP "
                          "streams (each with its own captured graph and buffers), so one batch's small-grid "
                          "/ launch-bound phases overlap the next batch's; 1 = strictly one step at a time")
+    ap.add_argument("--no-voxelize", action="store_true", help="skip the K1 (raw points) timing extra")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
     ap.add_argument("--train-steps", type=int, default=4,
                     help="also time this many training steps (forward + loss + backward + Adam) of the "
@@ -418,7 +419,7 @@ def main():
                 alt_res["roofline"] = roofline_of(alt_timer, alt_ev, alt)
             result["alt_math"] = alt_res
             model.conv_math = args.math
-        if world == 1:
+        if world == 1 and not args.no_voxelize:
             # K1 from raw points (not part of the step: the reference voxelizes offline and
             # ships sparse lists): one 60k-point cloud -> dense grid -> sorted index list
             try:

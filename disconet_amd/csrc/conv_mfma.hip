@@ -659,13 +659,13 @@ conv_mfma_kernel(const ConvArgs a) {
   }
 }
 
-// Persistent-workgroup policy: 0 = never, 1 = measured policy, 2 = always
-// (tools/conv_ablate.hip flips it for A/B runs).  Measured on MI355X, batch 4:
-// persistence gains 4-13 % on the 256-pixel tiles with 2-4 chunks (the 32- and
-// 64-channel full/half-resolution layers, whose workgroups are short and many)
-// and loses 2-20 % on the stride-2 and long-K launches, whose tile-end barriers
-// cost more than the hidden prologue is worth.
-int g_persist = 1;
+// Persistent-workgroup policy: 0 = never, 1 = only the 256-pixel / fused tiles with 2-4 chunks,
+// 2 = always (default).  History on MI355X, batch 4: with one step at a time and the first
+// (channel-block-major) work-item order, policy 1 measured best (persistence +4-13 % on the short
+// 32- and 64-channel full/half-resolution layers, -2-20 % on stride-2 and long-K launches).  With
+// the XCD-aware order and two batches in flight, interleaved A/B runs put "always" 1.7-2 % ahead
+// of policy 1 (split-f16) and 3.4 % (exact fp32); "never" lands within 0.5 % of "always".
+int g_persist = 2;
 
 // ---------------------------------------------------------------------------
 // tile menu and per-launch selection
