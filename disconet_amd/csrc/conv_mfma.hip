@@ -663,8 +663,8 @@ conv_mfma_kernel(const ConvArgs a) {
 // 2 = always (default).  History on MI355X, batch 4: with one step at a time and the first
 // (channel-block-major) work-item order, policy 1 measured best (persistence +4-13 % on the short
 // 32- and 64-channel full/half-resolution layers, -2-20 % on stride-2 and long-K launches).  With
-// the XCD-aware order and two batches in flight, interleaved A/B runs put "always" 1.7-2 % ahead
-// of policy 1 (split-f16) and 3.4 % (exact fp32); "never" lands within 0.5 % of "always".
+// the XCD-aware order, interleaved A/B runs put "always" 1.5-2 % ahead of policy 1 (split-f16)
+// and 3.4 % (exact fp32); "never" lands within 0.5 % of "always".
 int g_persist = 2;
 
 // ---------------------------------------------------------------------------

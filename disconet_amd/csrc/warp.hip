@@ -48,21 +48,34 @@ __device__ inline Bilinear bilinear_taps(float gx, float gy, int w, int h) {
 
 __device__ inline f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// One source image as a buffer resource: every tap load is `buffer_load_dwordx4` with a 32-bit
+// byte offset, like the conv engine's operand loads (no 64-bit address arithmetic per tap).
+struct SrcImage {
+  __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ inline SrcImage make_src_image(const float* base, size_t bytes) {
+  return SrcImage{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000)};
+}
+__device__ inline f32x4 ldb4(const SrcImage& s, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, byte_off, 0, 0));
+}
+
 // bilinear sample of src (one image, [h][w][c]) at taps b, channels c4*4..+3.
 // Branch-free: every tap is loaded from a clamped in-frame address and its weight
 // is zeroed when the tap is outside, so the 4 loads (16 per output pixel) issue
 // back to back instead of draining vmcnt at every divergent join.  A zero weight
 // times a finite in-frame value is exactly the zero padding.
-__device__ inline f32x4 sample_src(const float* src, const Bilinear& b, int w, int h, int c,
+__device__ inline f32x4 sample_src(const SrcImage& src, const Bilinear& b, int w, int h, int c,
                                    int c4) {
   const bool x0ok = b.x0 >= 0 && b.x0 < w, x1ok = b.x0 + 1 >= 0 && b.x0 + 1 < w;
   const bool y0ok = b.y0 >= 0 && b.y0 < h, y1ok = b.y0 + 1 >= 0 && b.y0 + 1 < h;
   const int x0 = min(max(b.x0, 0), w - 1), x1 = min(max(b.x0 + 1, 0), w - 1);
   const int y0 = min(max(b.y0, 0), h - 1), y1 = min(max(b.y0 + 1, 0), h - 1);
-  const f32x4 v_nw = ld4(src + ((size_t)y0 * w + x0) * c + 4 * c4);
-  const f32x4 v_ne = ld4(src + ((size_t)y0 * w + x1) * c + 4 * c4);
-  const f32x4 v_sw = ld4(src + ((size_t)y1 * w + x0) * c + 4 * c4);
-  const f32x4 v_se = ld4(src + ((size_t)y1 * w + x1) * c + 4 * c4);
+  const unsigned lane_off = 16u * c4;
+  const f32x4 v_nw = ldb4(src, (unsigned)((y0 * w + x0) * c) * 4u + lane_off);
+  const f32x4 v_ne = ldb4(src, (unsigned)((y0 * w + x1) * c) * 4u + lane_off);
+  const f32x4 v_sw = ldb4(src, (unsigned)((y1 * w + x0) * c) * 4u + lane_off);
+  const f32x4 v_se = ldb4(src, (unsigned)((y1 * w + x1) * c) * 4u + lane_off);
   // order matches torch's CPU kernel: nw, ne, sw, se
   f32x4 acc = v_nw * ((y0ok && x0ok) ? b.w_nw : 0.f);
   acc += v_ne * ((y0ok && x1ok) ? b.w_ne : 0.f);
@@ -89,7 +102,7 @@ warp_neighbors_kernel(const float* __restrict__ feat, const float* __restrict__ 
   float* dst = warped + ((size_t)bi * (agents - 1) + jj) * hw * c;
 
   const bool live = i < n_live && j < n_live && !(only_v2i && i != 0 && j != 0);
-  const float* src = feat + ((size_t)j * batch + b) * hw * c;   // agent-major image j*B+b
+  const SrcImage src = make_src_image(feat + ((size_t)j * batch + b) * hw * c, (size_t)hw * c * 4);   // image j*B+b
 
   const float* m = trans + (((size_t)b * agents + i) * agents + j) * 16;
   const float r00 = m[0], r01 = m[1], r10 = m[4], r11 = m[5];
@@ -156,7 +169,7 @@ warp_list_kernel(const float* __restrict__ src_maps, const float* __restrict__ p
   const int wi = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c4n = c >> 2, hw = h * w;
-  const float* src = src_maps + (size_t)src_image[wi] * hw * c;
+  const SrcImage src = make_src_image(src_maps + (size_t)src_image[wi] * hw * c, (size_t)hw * c * 4);
   const PoseTerms t = pose_terms(poses + 16 * (size_t)wi);
   for (int pp = wave; pp < PIX_PER_BLOCK; pp += 4) {
     const int p = blockIdx.x * PIX_PER_BLOCK + pp;

@@ -291,8 +291,10 @@ class TrainEngine:
         for k in range(lay_k + 1):
             a = group(k, a)
             e.append(a)
-        # the encoder levels above the exchanged one run beside the fusion block on a second stream
-        main, side = torch.cuda.current_stream(dev), self._side_stream(dev)
+        # the encoder levels above the exchanged one: beside the fusion block on a second stream if
+        # model.overlap_streams (experiment, default off -- DESIGN.md 3.6), else in stream order
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if m.overlap_streams else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
             up = a
@@ -452,7 +454,8 @@ class TrainEngine:
 
         # the levels above the exchanged one do not wait for the fusion's backward: second stream
         dev = dcls.device
-        main, side = torch.cuda.current_stream(dev), self._side_stream(dev)
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if m.overlap_streams else main
         d = None
         side.wait_stream(main)
         with torch.cuda.stream(side):
