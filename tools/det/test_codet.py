@@ -47,7 +47,7 @@ def main():
     model = DiscoNet(config, layer=args.layer, kd_flag=args.kd_flag, num_agent=num_agent,
                      compress_level=args.compress_level, only_v2i=bool(args.only_v2i))
     if args.resume:
-        checkpoint = torch.load(args.resume, map_location="cpu")
+        checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
         model.load_state_dict(checkpoint["model_state_dict"])
         print("loaded", args.resume, "epoch", checkpoint.get("epoch"))
     else:

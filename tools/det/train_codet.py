@@ -1,11 +1,118 @@
 #!/usr/bin/env python
-"""Placeholder for the reference's training entry point (flags at
-/root/reference/README.md:54-63).  The training step (losses, backward kernels,
-DDP gradient all-reduce) is SURVEY.md §8(f) next #1 and is not built yet: the
-MI355X path currently covers the eval-mode forward only, and says so instead of
-silently training on a fallback."""
+"""Thin re-hosting of the reference's training entry point for `--com disco`
+(flag names from /root/reference/README.md:54-63).  The reference's tool body -- V2X-Sim
+loading, anchor / target assembly, logging -- is out of scope; this shim
+builds the student (and, with --kd_flag 1, the teacher) the way the reference's tool does,
+resumes from `--resume` / `--resume_teacher` if given, and runs CoDetModule.step on synthetic
+scenes and targets (there is no V2X-Sim data in this environment) through the MI355X path,
+writing `epoch_N.pth` with the reference's checkpoint keys.
+
+    python tools/det/train_codet.py --com disco [--batch 4] [--nepoch 2] [--steps_per_epoch 8] \
+        [--kd_flag 1 --resume_teacher teacher.pth --kd_weight 100000] [--resume epoch_1.pth] \
+        [--logpath logs/] [--num_agent 5] [--layer 3] [--compress_level 0] [--only_v2i 0]
+
+Data-parallel: one process per GPU under torch.distributed.run; every rank trains its own
+scenes and the flat gradient buffer is averaged by one RCCL all-reduce per step.
+"""
+import argparse
+import os
 import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+from disconet_amd import CoDetModule, Config, DiscoNet, TeacherNet  # noqa: E402
+from disconet_amd.synthetic import make_bevs, make_scene_batch, make_train_targets  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-d", "--data", default=None, help="(unused here: synthetic scenes)")
+    ap.add_argument("--com", default="disco")
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--nepoch", type=int, default=2)
+    ap.add_argument("--steps_per_epoch", type=int, default=8)
+    ap.add_argument("--lr", type=float, default=0.001)
+    ap.add_argument("--nworker", type=int, default=0)
+    ap.add_argument("--log", action="store_true")
+    ap.add_argument("--logpath", default="")
+    ap.add_argument("--resume", default="")
+    ap.add_argument("--resume_teacher", default="")
+    ap.add_argument("--layer", type=int, default=3)
+    ap.add_argument("--kd_flag", type=int, default=0)
+    ap.add_argument("--kd_weight", type=float, default=100000.0)
+    ap.add_argument("--num_agent", type=int, default=5)
+    ap.add_argument("--rsu", type=int, default=0)
+    ap.add_argument("--compress_level", type=int, default=0)
+    ap.add_argument("--only_v2i", type=int, default=0)
+    args = ap.parse_args()
+    if args.com != "disco":
+        raise SystemExit("only --com disco is built on the MI355X path (SURVEY.md §2.1 #8)")
+    num_agent = args.num_agent + (1 if args.rsu else 0)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+
+    config = Config("train", binary=True, only_det=True)
+    hw = config.map_dims[0]
+    torch.manual_seed(0)
+    model = DiscoNet(config, layer=args.layer, kd_flag=args.kd_flag, num_agent=num_agent,
+                     compress_level=args.compress_level, only_v2i=bool(args.only_v2i)).cuda()
+    teacher = None
+    if args.kd_flag:
+        teacher = TeacherNet(config).cuda()
+        if args.resume_teacher:
+            teacher.load_state_dict(torch.load(args.resume_teacher, map_location="cpu")["model_state_dict"])
+        teacher.eval()
+    start_epoch = 1
+    optimizer_state = None
+    if args.resume:
+        ck = torch.load(args.resume, map_location="cpu", weights_only=False)
+        model.load_state_dict(ck["model_state_dict"])
+        optimizer_state = ck.get("optimizer_state_dict")
+        start_epoch = int(ck.get("epoch", 0)) + 1
+        print("resumed", args.resume, "-> epoch", start_epoch)
+    fafmodule = CoDetModule(model, teacher, config, None, kd_flag=args.kd_flag, lr=args.lr)
+    if optimizer_state is not None:
+        fafmodule.engine.load_state_dict(optimizer_state)
+
+    n_img = num_agent * args.batch
+    for epoch in range(start_epoch, start_epoch + args.nepoch):
+        t0, running = time.perf_counter(), 0.0
+        for it in range(args.steps_per_epoch):
+            seed = (epoch * 1000 + it) * world + rank
+            bevs, trans, na = make_scene_batch(args.batch, num_agent, hw, jitter_seed=seed)
+            labels, targets, mask = make_train_targets(n_img, hw, seed=seed)
+            data = {"bev_seq": bevs.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(),
+                    "labels": labels.cuda(), "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda()}
+            if args.kd_flag:
+                data["bev_seq_teacher"] = make_bevs(args.batch, num_agent, hw, p=0.05).cuda()
+                data["kd_weight"] = args.kd_weight
+            out = fafmodule.step(data, args.batch)
+            running += out["loss"]
+        torch.cuda.synchronize()
+        lr = fafmodule.scheduler_step(epoch)
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print("epoch %d: mean loss %.4f  (%s)  %.1f scenes/s  lr %.2e" % (
+                epoch, running / args.steps_per_epoch,
+                ", ".join("%s %.4f" % (k, v) for k, v in out.items() if k != "loss"),
+                world * args.batch * args.steps_per_epoch / dt, lr))
+            if args.logpath:
+                os.makedirs(args.logpath, exist_ok=True)
+                torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
+                            "optimizer_state_dict": fafmodule.engine.state_dict(),
+                            "scheduler_state_dict": {"lr": lr}, "loss": running / args.steps_per_epoch},
+                           os.path.join(args.logpath, "epoch_%d.pth" % epoch))
+    if world > 1:
+        dist.destroy_process_group()
+
 
 if __name__ == "__main__":
-    sys.exit("train_codet.py: the --com disco training step is not built on the MI355X path yet "
-             "(SURVEY.md §8(f) next #1); use tools/det/test_codet.py for the forward path.")
+    main()
