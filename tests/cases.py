@@ -114,6 +114,8 @@ def ref_fuse(model, feat, trans, na):
 TRAIN_CASES = {
     "cfg1": dict(map_hw=128, agents=2, batch=1, live=None, jitter=101),
     "ragged_a4": dict(map_hw=128, agents=4, batch=2, live=[3, 2], jitter=7),
+    # a scene with a single live agent (no neighbour to warp) next to a two-agent one
+    "lonely_a3": dict(map_hw=128, agents=3, batch=2, live=[1, 2], jitter=9),
 }
 KD_WEIGHT = 1e5
 # parameters whose float64 gradients (strided slices) are kept in tests/golden/train_step.npz

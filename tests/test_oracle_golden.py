@@ -111,7 +111,7 @@ def test_fusion_block_golden(golden_dir):
     assert np.abs(fused - feat.numpy()).max() > 0.1
 
 
-@pytest.mark.parametrize("case,tag", [("cfg1", "det"), ("cfg1", "kd"), ("ragged_a4", "kd")])
+@pytest.mark.parametrize("case,tag", [("cfg1", "det"), ("cfg1", "kd"), ("ragged_a4", "kd"), ("lonely_a3", "det")])
 def test_training_step_golden(golden_dir, case, tag):
     """the oracle's float64 training forward / backward (oracle/train_ref.py, oracle/teacher_ref.py)
     against tests/golden/train_step.npz: losses and strided slices of ten parameters' gradients.
