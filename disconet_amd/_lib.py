@@ -10,7 +10,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
                     c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdisconet_hip.so")
+# DISCONET_HIP_LIB: load another build of the same library (A/B runs of a kernel variant)
+LIB_PATH = os.environ.get("DISCONET_HIP_LIB") or os.path.join(_HERE, "libdisconet_hip.so")
 
 
 class DnError(RuntimeError):
