@@ -52,6 +52,61 @@ def _param_order(model):
     return first + [p for p in model.parameters() if id(p) not in seen]
 
 
+def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev):
+    """Index lists of the DiscoGraph fusion for one batch, in the reference's loop order
+    (upstream DiscoNet.forward: for b, for ego i < n_b: [ego] + [warp(j -> i) for j < n_b, j != i],
+    honouring only_v2i).  Images are agent-major (agent * B + b); maps / pairs = own maps then warps.
+    Host-side logic only (runs on CPU tensors too)."""
+    A = agents
+    NI = A * B
+    img = lambda a, b: a * B + b
+    src_image, poses_idx, warp_ego = [], [], []
+    first, pair_index, map_image, ego_out = [0], [], [], []
+    order = []
+    for b in range(B):
+        n = int(num_agent_cpu[b])
+        for i in range(A):
+            ego_out.append(img(i, b))
+            if i >= n:
+                pair_index.append(-1)
+                map_image.append(img(i, b))
+                first.append(len(pair_index))
+                continue
+            pair_index.append(img(i, b))
+            map_image.append(img(i, b))
+            order.append(img(i, b))
+            for j in range(n):
+                if j == i or (only_v2i and i != 0 and j != 0):
+                    continue
+                wi = len(src_image)
+                src_image.append(img(j, b))
+                poses_idx.append((b, i, j))
+                warp_ego.append(img(i, b))
+                pair_index.append(NI + wi)
+                map_image.append(NI + wi)
+                order.append(NI + wi)
+            first.append(len(pair_index))
+    nw = len(src_image)
+    ego_image = list(range(NI)) + warp_ego
+    # pairs per ego image, for dE = sum over the ego's pairs
+    per = [[] for _ in range(NI)]
+    for p, e in enumerate(ego_image):
+        per[e].append(p)
+    efirst = [0]
+    for lst in per:
+        efirst.append(efirst[-1] + len(lst))
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    if nw:
+        bi = torch.tensor(poses_idx, dtype=torch.long, device=dev)
+        poses = trans[bi[:, 0], bi[:, 1], bi[:, 2]].contiguous()
+    else:
+        poses = torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
+    return dict(n_warps=nw, src_image=i32(src_image), poses=poses, first=i32(first),
+                pair_index=i32(pair_index), map_image=i32(map_image), ego_out=i32(ego_out),
+                ego_image=i32(ego_image), efirst=i32(efirst), epairs=i32([p for l in per for p in l]),
+                order=i32(order), n_calls=len(order))
+
+
 class TrainEngine:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.model = model
@@ -206,54 +261,7 @@ class TrainEngine:
     # fusion lists (host side, from num_agent / only_v2i)
     # ------------------------------------------------------------------
     def _fusion_lists(self, trans, num_agent_cpu, B, dev):
-        A = self.model.agent_num
-        NI = A * B
-        img = lambda a, b: a * B + b
-        src_image, poses_idx, warp_ego = [], [], []
-        first, pair_index, map_image, ego_out = [0], [], [], []
-        order = []
-        for b in range(B):
-            n = int(num_agent_cpu[b])
-            for i in range(A):
-                ego_out.append(img(i, b))
-                if i >= n:
-                    pair_index.append(-1)
-                    map_image.append(img(i, b))
-                    first.append(len(pair_index))
-                    continue
-                pair_index.append(img(i, b))
-                map_image.append(img(i, b))
-                order.append(img(i, b))
-                for j in range(n):
-                    if j == i or (self.model.only_v2i and i != 0 and j != 0):
-                        continue
-                    wi = len(src_image)
-                    src_image.append(img(j, b))
-                    poses_idx.append((b, i, j))
-                    warp_ego.append(img(i, b))
-                    pair_index.append(NI + wi)
-                    map_image.append(NI + wi)
-                    order.append(NI + wi)
-                first.append(len(pair_index))
-        nw = len(src_image)
-        ego_image = list(range(NI)) + warp_ego
-        # pairs per ego image, for dE = sum over the ego's pairs
-        per = [[] for _ in range(NI)]
-        for p, e in enumerate(ego_image):
-            per[e].append(p)
-        efirst = [0]
-        for lst in per:
-            efirst.append(efirst[-1] + len(lst))
-        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
-        if nw:
-            bi = torch.tensor(poses_idx, dtype=torch.long, device=dev)
-            poses = trans[bi[:, 0], bi[:, 1], bi[:, 2]].contiguous()
-        else:
-            poses = torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
-        return dict(n_warps=nw, src_image=i32(src_image), poses=poses, first=i32(first),
-                    pair_index=i32(pair_index), map_image=i32(map_image), ego_out=i32(ego_out),
-                    ego_image=i32(ego_image), efirst=i32(efirst), epairs=i32([p for l in per for p in l]),
-                    order=i32(order), n_calls=len(order))
+        return fusion_lists(self.model.agent_num, self.model.only_v2i, trans, num_agent_cpu, B, dev)
 
     # ------------------------------------------------------------------
     # forward (training mode)
