@@ -89,8 +89,8 @@ SIGNATURES = {
     "dn_fuse_combine_backward": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_int, c_int,
                                                                              c_void_p, c_void_p,
                                                                              c_void_p]),
-    "dn_warp_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
-                                 c_void_p, c_void_p]),
+    "dn_warp_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p]),
     "dn_warp_list": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                              c_void_p]),
     "dn_det_loss": (c_int, [c_void_p] * 5 + [c_long, c_int, c_float, c_float, c_float, c_float,

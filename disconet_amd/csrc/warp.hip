@@ -227,6 +227,101 @@ warp_scatter_kernel(const float* __restrict__ grad_in, const float* __restrict__
   }
 }
 
+// Gather forms of the same two transposes for RIGID poses (rotation + translation) on square
+// maps: deterministic, no atomics, no zero-filled scratch.  Every output pixel looks at the few
+// input pixels whose bilinear footprint can reach it and re-derives their taps with exactly the
+// forward's arithmetic, so the result is the scatter's sum in a fixed order.
+//   pass 2 (translation): out1_grad[q] = sum over p with q in taps2(p): the taps of p sit at
+//     p + floor(shift) (+1), so p lies within [-2, +1] of q - floor(shift) per axis (float fuzz incl.);
+//   pass 1 (rotation):    src_grad[r] += sum over warps w of source image m, over q with r in
+//     taps1(q): for an orthonormal R the footprint of q reaches r only if q is within sqrt(2) of
+//     R^-1 r, i.e. within +-2 of its rounding.
+__global__ void __launch_bounds__(256)
+warp_gather2_kernel(const float* __restrict__ d_warped, const float* __restrict__ poses, int h, int w,
+                    int c, float* __restrict__ d_out1) {
+  const int wi = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4n = c >> 2, hw = h * w;
+  const PoseTerms t = pose_terms(poses + 16 * (size_t)wi);
+  const int fsx = (int)floorf(t.x_trans * w * 0.5f), fsy = (int)floorf(t.y_trans * h * 0.5f);
+  const float* gin = d_warped + (size_t)wi * hw * c;
+  for (int pp = wave; pp < PIX_PER_BLOCK; pp += 4) {
+    const int q = blockIdx.x * PIX_PER_BLOCK + pp;
+    if (q >= hw) break;
+    const int qx = q % w, qy = q / w;
+    f32x4 acc[4];                                  // c <= 1024
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dy = -2; dy <= 1; ++dy) {
+      const int py = qy - fsy + dy;
+      if (py < 0 || py >= h) continue;
+      for (int dx = -2; dx <= 1; ++dx) {
+        const int px = qx - fsx + dx;
+        if (px < 0 || px >= w) continue;
+        const Bilinear b = pass2_taps(t, px, py, w, h);
+        const int ox = qx - b.x0, oy = qy - b.y0;
+        if (ox < 0 || ox > 1 || oy < 0 || oy > 1) continue;   // wave-uniform
+        const float wt = oy ? (ox ? b.w_se : b.w_sw) : (ox ? b.w_ne : b.w_nw);
+        const float* g = gin + (size_t)(py * w + px) * c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (lane + 64 * i < c4n) acc[i] += ld4(g + 4 * (lane + 64 * i)) * wt;
+      }
+    }
+    float* out = d_out1 + ((size_t)wi * hw + q) * c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < c4n) *reinterpret_cast<f32x4*>(out + 4 * (lane + 64 * i)) = acc[i];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+warp_gather1_kernel(const float* __restrict__ d_out1, const float* __restrict__ poses,
+                    const int32_t* __restrict__ src_image, int n_warps, int h, int w, int c,
+                    float* __restrict__ d_src) {
+  const int m = blockIdx.y;                       // source image
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4n = c >> 2, hw = h * w;
+  for (int pp = wave; pp < PIX_PER_BLOCK; pp += 4) {
+    const int r = blockIdx.x * PIX_PER_BLOCK + pp;
+    if (r >= hw) break;
+    const int rx = r % w, ry = r / w;
+    const float rbx = (2.f * rx + 1.f) / w - 1.f, rby = (2.f * ry + 1.f) / h - 1.f;
+    float* out = d_src + ((size_t)m * hw + r) * c;
+    f32x4 acc[4];                                  // c <= 1024
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[i] = (lane + 64 * i < c4n) ? ld4(out + 4 * (lane + 64 * i)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int wi = 0; wi < n_warps; ++wi) {
+      if (src_image[wi] != m) continue;            // wave-uniform
+      const PoseTerms t = pose_terms(poses + 16 * (size_t)wi);
+      const float det = t.r00 * t.r11 - t.r01 * t.r10;
+      const float qbx = (t.r11 * rbx - t.r01 * rby) / det, qby = (-t.r10 * rbx + t.r00 * rby) / det;
+      const int cx = (int)rintf(((qbx + 1.f) * w - 1.f) * 0.5f), cy = (int)rintf(((qby + 1.f) * h - 1.f) * 0.5f);
+      const float* gin = d_out1 + (size_t)wi * hw * c;
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int qy = cy + dy;
+        if (qy < 0 || qy >= h) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+          const int qx = cx + dx;
+          if (qx < 0 || qx >= w) continue;
+          const Bilinear b = pass1_taps(t, qx, qy, w, h);
+          const int ox = rx - b.x0, oy = ry - b.y0;
+          if (ox < 0 || ox > 1 || oy < 0 || oy > 1) continue;
+          const float wt = oy ? (ox ? b.w_se : b.w_sw) : (ox ? b.w_ne : b.w_nw);
+          const float* g = gin + (size_t)(qy * w + qx) * c;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < c4n) acc[i] += ld4(g + 4 * (lane + 64 * i)) * wt;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < c4n) *reinterpret_cast<f32x4*>(out + 4 * (lane + 64 * i)) = acc[i];
+  }
+}
+
 }  // namespace
 
 extern "C" int dn_warp_list(const float* src, const float* poses, const int32_t* src_image,
@@ -240,14 +335,21 @@ extern "C" int dn_warp_list(const float* src, const float* poses, const int32_t*
 }
 
 extern "C" int dn_warp_backward(const float* d_warped, const float* poses, const int32_t* src_image,
-                                int n_warps, int h, int w, int c, float* scratch, float* d_src,
-                                void* stream) {
+                                int n_warps, int n_src_images, int h, int w, int c, int rigid,
+                                float* scratch, float* d_src, void* stream) {
   DN_REQUIRE(d_warped && poses && src_image && scratch && d_src, "warp backward: null pointer");
-  DN_REQUIRE(n_warps > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "warp backward: bad shape");
+  DN_REQUIRE(n_warps > 0 && n_src_images > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && c <= 1024,
+             "warp backward: bad shape");
   hipStream_t s = (hipStream_t)stream;
+  dim3 grid((h * w + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, n_warps);
+  if (rigid && h == w) {
+    hipLaunchKernelGGL(warp_gather2_kernel, grid, dim3(256), 0, s, d_warped, poses, h, w, c, scratch);
+    hipLaunchKernelGGL(warp_gather1_kernel, dim3(grid.x, n_src_images), dim3(256), 0, s, scratch, poses,
+                       src_image, n_warps, h, w, c, d_src);
+    return dn::check_launch("warp_gather kernels");
+  }
   if (hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)n_warps * h * w * c, s) != hipSuccess)
     return dn::fail(DN_ERR_LAUNCH, "warp backward: memset failed");
-  dim3 grid((h * w + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, n_warps);
   hipLaunchKernelGGL(warp_scatter_kernel<2>, grid, dim3(256), 0, s, d_warped, poses, src_image, h, w, c,
                      scratch);
   hipLaunchKernelGGL(warp_scatter_kernel<1>, grid, dim3(256), 0, s, scratch, poses, src_image, h, w, c,

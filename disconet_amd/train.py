@@ -101,7 +101,14 @@ def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev):
         poses = trans[bi[:, 0], bi[:, 1], bi[:, 2]].contiguous()
     else:
         poses = torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
-    return dict(n_warps=nw, src_image=i32(src_image), poses=poses, first=i32(first),
+    # rigid poses (rotation + translation: what V2X agents' relative poses are) take the deterministic
+    # gather form of the warp backward
+    rigid = True
+    if nw:
+        R = poses[:, :2, :2].double()
+        eye = torch.eye(2, dtype=torch.float64, device=R.device)
+        rigid = bool(((R @ R.transpose(1, 2) - eye).abs().max() < 1e-3).item())
+    return dict(n_warps=nw, rigid=rigid, src_image=i32(src_image), poses=poses, first=i32(first),
                 pair_index=i32(pair_index), map_image=i32(map_image), ego_out=i32(ego_out),
                 ego_image=i32(ego_image), efirst=i32(efirst), epairs=i32([p for l in per for p in l]),
                 order=i32(order), n_calls=len(order))
@@ -503,7 +510,7 @@ class TrainEngine:
         T.add_rows(dmaps, self._dgrad(c["d_f"], c["w_nbr"].view(128, C, 1, 1), dz1))
         T.add_rows(dmaps[:NI], self._dgrad(c["d_e"], c["w_ego"].view(128, C, 1, 1), dE))
         if NW:
-            T.warp_backward(dmaps[NI:], F["poses"], F["src_image"], dmaps[:NI])
+            T.warp_backward(dmaps[NI:], F["poses"], F["src_image"], dmaps[:NI], rigid=F["rigid"])
         return dmaps[:NI]
 
     # ------------------------------------------------------------------

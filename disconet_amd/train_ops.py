@@ -189,12 +189,13 @@ def warp_list(src, poses, src_image, out=None):
     return warped
 
 
-def warp_backward(d_warped, poses, src_image, d_src):
-    """scatter-adds into d_src [M, h, w, c]"""
+def warp_backward(d_warped, poses, src_image, d_src, rigid=False):
+    """adds into d_src [M, h, w, c]; rigid=True (all poses rotation + translation): gather form"""
     n, h, w, c = d_warped.shape
     scratch = _ws(d_warped.device, 4 * d_warped.numel())
-    check(_lib.load().dn_warp_backward(_ptr(d_warped), _ptr(poses), _ptr(src_image), n, h, w, c,
-                                       _ptr(scratch), _ptr(d_src), _stream()), "dn_warp_backward")
+    check(_lib.load().dn_warp_backward(_ptr(d_warped), _ptr(poses), _ptr(src_image), n, d_src.shape[0], h,
+                                       w, c, int(bool(rigid)), _ptr(scratch), _ptr(d_src), _stream()),
+          "dn_warp_backward")
     return d_src
 
 

@@ -113,10 +113,13 @@ int dn_fuse_combine_backward(const float* dfused, int ld_df, const float* z4, co
                              float* dmaps, float* dz4, void* stream);
 
 /* Backward of dn_warp_neighbors for a list of warps: the gradient of warp w (source image
- * src_image[w], 4x4 pose at poses + 16 * w, row-major, neighbour -> ego) is scattered through
- * both bilinear passes into d_src[src_image[w]] with float atomics.  scratch: n_warps maps. */
+ * src_image[w] in [0, n_src_images), 4x4 pose at poses + 16 * w, row-major, neighbour -> ego) goes
+ * back through both bilinear passes and is ADDED to d_src[src_image[w]].  scratch: n_warps maps.
+ * rigid != 0 (every pose a rotation + translation, which V2X poses are) on square maps: gather
+ * form, deterministic, no atomics.  Otherwise: scatter with float atomics. */
 int dn_warp_backward(const float* d_warped, const float* poses, const int* src_image, int n_warps,
-                     int h, int w, int c, float* scratch, float* d_src, void* stream);
+                     int n_src_images, int h, int w, int c, int rigid, float* scratch, float* d_src,
+                     void* stream);
 /* forward over the same list (training keeps every warp, in list order) */
 int dn_warp_list(const float* src, const float* poses, const int* src_image, int n_warps, int h,
                  int w, int c, float* warped, void* stream);

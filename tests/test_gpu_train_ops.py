@@ -236,10 +236,12 @@ def _warp_ref(nb, pose):
                          align_corners=False)[0]
 
 
-def test_warp_list_and_backward_match_autograd():
+@pytest.mark.parametrize("rigid,c", [(False, 64), (True, 64), (True, 512)])
+def test_warp_list_and_backward_match_autograd(rigid, c):
+    """rigid=False: scatter with float atomics (any pose); True: the deterministic gather form"""
     from disconet_amd import train_ops
     g = torch.Generator().manual_seed(9)
-    m, c, hw, n = 4, 64, 32, 7
+    m, hw, n = 4, 32, 7
     maps = torch.randn(m, c, hw, hw, generator=g).double().requires_grad_(True)
     poses = _poses(n)
     src = torch.tensor([0, 1, 2, 3, 1, 1, 0], dtype=torch.int32)
@@ -251,8 +253,12 @@ def test_warp_list_and_backward_match_autograd():
     warped = train_ops.warp_list(mg, poses.to(_dev()), src.to(_dev()))
     assert rel_err(warped, nhwc(ref.detach())) < 1e-5
     d_src = torch.ones(m, hw, hw, c, device=_dev())      # accumulates on top of what is there
-    train_ops.warp_backward(nhwc(dwarp).to(_dev()), poses.to(_dev()), src.to(_dev()), d_src)
+    train_ops.warp_backward(nhwc(dwarp).to(_dev()), poses.to(_dev()), src.to(_dev()), d_src, rigid=rigid)
     assert rel_err(d_src - 1, nhwc(maps.grad)) < 2e-5
+    if rigid:      # deterministic: a second run gives the same bits
+        again = torch.ones(m, hw, hw, c, device=_dev())
+        train_ops.warp_backward(nhwc(dwarp).to(_dev()), poses.to(_dev()), src.to(_dev()), again, rigid=True)
+        assert torch.equal(again, d_src)
 
 
 def test_fuse_combine_forward_backward():
