@@ -55,9 +55,12 @@ disco_fuse_tail_kernel(const TailArgs a) {
 
   if (i >= n_live) {
     // padded agent: its map passes through un-fused
-    for (int idx = tid; idx < PIX * a.c; idx += 256) {
+    // wave-uniform trip counts, per-lane `if` inside: no lane-dependent loop exits
+    const int n_it = (PIX * a.c + 255) / 256;
+    for (int it = 0; it < n_it; ++it) {
+      const int idx = tid + 256 * it;
       const int p = p0 + idx / a.c;
-      if (p < a.hw) out[(size_t)p * a.c + idx % a.c] = ego[(size_t)p * a.c + idx % a.c];
+      if (idx < PIX * a.c && p < a.hw) out[(size_t)p * a.c + idx % a.c] = ego[(size_t)p * a.c + idx % a.c];
     }
     return;
   }
@@ -146,7 +149,9 @@ disco_fuse_tail_kernel(const TailArgs a) {
   for (int p = 0; p < PIX; ++p) {
     const int pix = p0 + p;
     if (pix >= a.hw) break;
-    for (int ch = tid; ch < a.c; ch += 256) {
+    for (int it = 0; it < (a.c + 255) / 256; ++it) {
+      const int ch = tid + 256 * it;
+      if (ch >= a.c) continue;
       float acc = es[0][p] * ego[(size_t)pix * a.c + ch];
       for (int k = 1; k < nk; ++k) {
         const int j = nbr_of[k];
