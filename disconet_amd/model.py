@@ -215,9 +215,12 @@ class DiscoNet(nn.Module):
         self.conv_math = os.environ.get("DISCONET_CONV_MATH", "f16x3")
         # fold the 1x1 layers that follow a 64-channel 3x3 conv into that conv's launch
         self.fuse_1x1 = os.environ.get("DISCONET_FUSE_1X1", "1") != "0"
-        # run the encoder levels above the exchanged one beside the fusion block (second HIP stream,
-        # +2.2 % per step; bit-exact against the serial order, tools/det_check.py)
-        self.overlap_streams = os.environ.get("DISCONET_OVERLAP", "1") != "0"
+        # run the encoder levels above the exchanged one beside the fusion block on a second HIP stream
+        # (+2.2 % per step, bit-exact against the serial order in tools/det_check.py).  Opt-in
+        # (DISCONET_OVERLAP=1 or model.overlap_streams = True; bench.py switches it on and guards its
+        # figure with an output-identity check): kernels running side by side exposed a mask hazard
+        # once, so the library default stays strictly in stream order.
+        self.overlap_streams = os.environ.get("DISCONET_OVERLAP", "0") == "1"
         self._side = {}
 
     # ------------------------------------------------------------------
