@@ -361,10 +361,21 @@ def main():
     timer, elapsed_events = None, 0.0
     if rank == 0 and not args.no_kernel_events:
         elapsed_events, timer = timed(True)        # timed region #2 -> roofline
+    # every rank checks that its graphs in flight wrote the same bits as the serial replay
+    outputs_same = None
+    if elapsed_serial is not None and graphed.get(model.conv_math):
+        outs = [g.outputs for g, _ in graphed[model.conv_math]]
+        outputs_same = all(torch.equal(o["cls"], outs[0]["cls"]) and torch.equal(o["loc"], outs[0]["loc"])
+                           for o in outs[1:])
     if use_pg:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, elapsed_serial or 0.0, -float(outputs_same is not False)], device="cuda",
+                         dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)      # max time over ranks; "any rank differed" as max of -same
+        elapsed = float(t[0].item())
+        if elapsed_serial is not None:
+            elapsed_serial = float(t[1].item())
+        if outputs_same is not None:
+            outputs_same = bool(t[2].item() <= -1.0)
 
     dtype_name = {"f32": "f32", "f16x3": "f32 storage; conv products as split-f16 x3 MFMA, f32 accumulate"}
     scenes = world * BATCH * args.steps
@@ -394,20 +405,16 @@ def main():
 
     if rank == 0:
         if elapsed_serial is not None:
-            slots = graphed.get(model.conv_math)
-            if slots:      # the overlapped replays wrote the same results as the serial one
-                outs = [g.outputs for g, _ in slots]
-                same = all(torch.equal(o["cls"], outs[0]["cls"]) and torch.equal(o["loc"], outs[0]["loc"])
-                           for o in outs[1:])
-                result["in_flight_outputs_identical"] = same
-                if not same:          # never report a throughput whose results are not the serial ones
-                    result["value"] = round(BATCH * args.steps / elapsed_serial, 3)
+            if outputs_same is not None:
+                result["in_flight_outputs_identical"] = outputs_same
+                if not outputs_same:  # never report a throughput whose results are not the serial ones
+                    result["value"] = round(scenes / elapsed_serial, 3)
                     result["ms_per_step"] = round(1e3 * elapsed_serial / args.steps, 4)
                     result["config"]["launch"] = "hipGraph replay (in-flight outputs differed: serial figure)"
             result["one_step_at_a_time"] = {
-                "value": round(BATCH * args.steps / elapsed_serial, 3),
+                "value": round(scenes / elapsed_serial, 3),
                 "ms_per_step": round(1e3 * elapsed_serial / args.steps, 4),
-                "note": "same K steps replayed back to back on ONE stream (rank 0's own clock): the "
+                "note": "same K steps replayed back to back on ONE stream per rank (max over ranks): the "
                         "latency of a step; `value` overlaps consecutive, independent batches"}
         if timer is not None:
             result["roofline"] = roofline_of(timer, elapsed_events, args.math)
