@@ -1,14 +1,14 @@
 """How far is the fp32 oracle's own backward from exact arithmetic?  Runs the oracle's
 training forward/backward in float32 and in float64 (same parameters, inputs and warp grids)
 and prints the per-tensor gradient deviation -- the noise floor a HIP-vs-oracle gradient
-comparison cannot go below.   python tools/oracle_fp64_check.py [case]"""
+comparison cannot go below.   python tests/oracle_fp64_check.py [case]"""
 import copy
 import sys
 
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+sys.path.insert(0, __file__.rsplit("/tests/", 1)[0])
 from oracle.train_ref import det_loss  # noqa: E402
 from tests import cases  # noqa: E402
 from tests.test_gpu_train_step import STEP_CASES  # noqa: E402

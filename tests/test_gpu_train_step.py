@@ -6,7 +6,7 @@ parameters after Adam, and the loss of the following step.
 Gradients: this backward is ill-conditioned in fp32 -- BatchNorm's backward subtracts the
 per-channel mean of a gradient that is ~1e4 x larger than what is left (the cls head's
 shift-invariant component), so the fp32 oracle itself sits 0.2-2 % (relative to each tensor's
-largest gradient) away from the same oracle run in float64 (tools/oracle_fp64_check.py).
+largest gradient) away from the same oracle run in float64 (tests/oracle_fp64_check.py).
 The test therefore takes the float64 run as the truth and requires, per tensor,
     err(HIP vs fp64) <= max(5 x err(fp32 oracle vs fp64), 2e-3)
 (see _assert_grads for the ReLU-mask-flip allowance) and a cosine similarity > 0.9995 -- the HIP
