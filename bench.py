@@ -32,8 +32,12 @@ sys.path.insert(0, ROOT)
 AGENTS, BATCH, MAP_HW = 5, 4, 256
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks
 MFMA_PEAK_TFLOPS = {"f32": 157.3,      # v_mfma_f32_32x32x2_f32
-                    "f16x3": 2500.0}   # v_mfma_f32_32x32x16_f16 (the split-f16 path runs 3 per product)
-EXECUTED_FLOP_FACTOR = {"f32": 1, "f16x3": 3}
+                    "f16x3": 2500.0,   # v_mfma_f32_32x32x16_f16 (the split-f16 paths run 3 per product)
+                    "sp": 2500.0}
+EXECUTED_FLOP_FACTOR = {"f32": 1, "f16x3": 3, "sp": 3}
+CONV_KERNELS = ("conv_mfma_kernel", "conv_sp_kernel")
+MATH_LABEL = {"f32": "exact-fp32", "f16x3": "split-f16x3 (fp32 NHWC activations)",
+              "sp": "split-f16x3, split-planar activations staged by LDS-DMA"}
 
 
 def parse():
@@ -45,8 +49,9 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-launch HIP events in the timed region")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table (stderr)")
-    ap.add_argument("--math", choices=["f32", "f16x3"], default=os.environ.get("DISCONET_CONV_MATH", "f16x3"),
-                    help="conv arithmetic: split-f16 (3 f16 MFMAs / product, default) or exact-fp32 MFMA")
+    ap.add_argument("--math", choices=["f32", "f16x3", "sp"], default=os.environ.get("DISCONET_CONV_MATH", "sp"),
+                    help="conv engine: sp = split-f16 (3 f16 MFMAs / product) on split-planar activations "
+                         "(default); f16x3 = the same arithmetic on fp32 NHWC activations; f32 = exact-fp32 MFMA")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the other math mode's timed region")
     ap.add_argument("--mode", choices=["scene", "agent"], default="scene",
                     help="multi-GPU partitioning: 'scene' = every rank its own scenes (default, weak "
@@ -311,7 +316,7 @@ def main():
 
     def roofline_of(timer, elapsed_events, math):
         summ = timer.summary()
-        conv = {k: v for k, v in summ.items() if v["kernel"] == "conv_mfma_kernel"}
+        conv = {k: v for k, v in summ.items() if v["kernel"] in CONV_KERNELS}
         flops = sum(v["flops"] for v in conv.values())
         ms = sum(v["ms_total"] for v in conv.values())
         launches = sum(v["calls"] for v in conv.values())
@@ -327,8 +332,9 @@ def main():
             pass
         alg_bytes = sum(v["bytes"] for v in conv.values())
         roof = {
-            "kernel": "conv_mfma_kernel (%s MFMA implicit-GEMM conv, all %d launches/step)"
-                      % ("exact-fp32" if math == "f32" else "split-f16x3", launches // args.steps),
+            "kernel": "%s (%s MFMA implicit-GEMM conv, all %d launches/step)"
+                      % ("conv_sp_kernel" if math == "sp" else "conv_mfma_kernel", MATH_LABEL[math],
+                         launches // args.steps),
             "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "note": "achieved = algorithmic FLOP (true channel counts) / HIP-event kernel time",
@@ -341,7 +347,7 @@ def main():
             "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
             "ms_per_step_with_events": round(1e3 * elapsed_events / args.steps, 4),
             "other_kernels_ms_per_step": {k: round(v["ms_total"] / args.steps, 4)
-                                          for k, v in summ.items() if v["kernel"] != "conv_mfma_kernel"},
+                                          for k, v in summ.items() if v["kernel"] not in CONV_KERNELS},
         }
         if args.layers:
             print("[%s] %-12s %8s %10s %9s %8s" % (math, "layer", "ms/step", "GFLOP/step", "TFLOP/s", "GB/s"),
@@ -377,7 +383,9 @@ def main():
         if outputs_same is not None:
             outputs_same = bool(t[2].item() <= -1.0)
 
-    dtype_name = {"f32": "f32", "f16x3": "f32 storage; conv products as split-f16 x3 MFMA, f32 accumulate"}
+    dtype_name = {"f32": "f32", "f16x3": "f32 storage; conv products as split-f16 x3 MFMA, f32 accumulate",
+                  "sp": "f16 hi+lo pair per value (32 bits, 22-bit significand); conv products as split-f16 x3 "
+                        "MFMA, f32 accumulate"}
     scenes = world * BATCH * args.steps
     result = {
         "metric": "scenes/sec (5-agent 256x256 BEV)",
@@ -420,7 +428,7 @@ def main():
             result["roofline"] = roofline_of(timer, elapsed_events, args.math)
         if world == 1 and not args.no_alt_math:
             # the other conv arithmetic on the same workload, K steps each way
-            alt = "f32" if args.math == "f16x3" else "f16x3"
+            alt = "f32" if args.math != "f32" else "sp"
             model.conv_math = alt
             for i in range(args.warmup):
                 run_step(i)

@@ -56,6 +56,18 @@ SIGNATURES = {
     "dn_post1x1_packed_floats": (c_size_t, []),
     "dn_post1x1_pack_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dn_conv2d_post1x1": (c_int, [POINTER(ConvDesc), POINTER(Post1x1Desc)] + [c_void_p] * 11),
+    "dn_sp_tensor_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dn_sp_from_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dn_sp_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dn_spconv_packed_weight_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "dn_spconv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_float, c_void_p, c_void_p]),
+    "dn_spconv2d": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p]),
+    "dn_sp_post1x1_packed_bytes": (c_size_t, []),
+    "dn_sp_post1x1_pack_weights": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "dn_spconv2d_post1x1": (c_int, [POINTER(ConvDesc), POINTER(Post1x1Desc)] + [c_void_p] * 8 +
+                            [c_int, c_void_p, c_void_p, c_void_p]),
+    "dn_spconv_force_config": (c_int, [c_int]),
     "dn_decode_boxes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p,
                                 c_void_p]),
     "dn_warp_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -1,0 +1,921 @@
+// Split-planar ("SP") implicit-GEMM convolution for gfx950: split-f16 x3 MFMA with
+// activations kept PRE-SPLIT in HBM and staged by LDS-DMA.
+//
+// Why a second conv engine beside conv_mfma.hip: in split-f16 mode that kernel spends more
+// time staging than multiplying (fp32 -> hi/lo conversion on the VALU, ds_write of both
+// operands, two barriers per 16-channel chunk; MFMA pipe 14-55 % busy,
+// profiles/r01_pmc_conv_f16x3.txt).  Here
+//   * activations live in HBM as hi/lo f16 planes (sp_layout.h): the producer's epilogue
+//     splits once, every consumer reads MFMA-ready fragments -- no VALU work in the loop;
+//   * both operands go global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR round
+//     trip, no ds_write); out-of-image halo pieces carry an out-of-range offset and the
+//     DMA writes the zero padding;
+//   * stages are double-buffered with ONE barrier per step (a step = TG taps of one
+//     16-channel chunk, or CA chunks of a 1x1 conv); the activation patch of chunk c+1 is
+//     issued a whole chunk ahead, the weights of step s+1 one step ahead;
+//   * the LDS images are plain planes [quarter][pixel] x 16 B, so every ds_read_b128 group
+//     reads 16 consecutive pieces: conflict-free without padding, for stride 1 and (with
+//     de-interleaved columns) stride 2;
+//   * the SP epilogue needs no LDS: two v_permlane32_swap per register pair give every lane
+//     a complete 16-byte piece, stored as 512-byte runs.
+// Arithmetic is that of conv_mfma.hip math mode 1: x = hi + lo, products hi*hi + hi*lo +
+// lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulate, fused affine (+ReLU).
+//
+// Replaces the conv2d + batch_norm + relu (+ interpolate x2 + cat) chains of
+// upstream:coperception/models/det/backbone/Backbone.py :: encode / decode and the heads of
+// upstream:coperception/models/det/base/* (SURVEY.md §8 a3, a8, a9).
+#include "dn_internal.h"
+#include "sp_layout.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kCUs = 256;
+
+struct SpArgs {
+  const unsigned char* src0;   // SP tensors
+  const unsigned char* src1;
+  const unsigned char* wpk;    // SP packed weights
+  const float* scale;
+  const float* shift;
+  unsigned char* out;          // SP tensor (or fp32 NHWC for the two-output POST form)
+  int n_images, h_in, w_in, h_out, w_out;
+  int c0g, c1g;                // 16-channel chunks taken from src0 / src1
+  int up0, c_out, cog, relu;   // cog = chunks of the output tensor
+  int ngroups;                 // A groups (CA chunks each) of the K loop
+  int tiles_x, tiles_y, total_items, xcd_order;
+  int cout_pad, wpk_bytes;
+  // fused 1x1 stage
+  const unsigned char* w2;     // [2 n-tiles][4 k-steps][2 parts][2 h][32 n] x 16 B
+  const float* scale2;
+  const float* shift2;
+  float* out_b;
+  int c_out2, relu2, split2, ldo_a, ldo_b, post_f32;
+};
+
+struct TileCoord {
+  int img, oy0, ox0, n0;
+};
+
+template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
+          int WTM, int WTN, int POST>
+struct SpTile {
+  using P = sp::Patch<KS, STRIDE, TH, TW>;
+  static constexpr int NW = WAVES_M * WAVES_N;
+  static constexpr int NT = NW * 64;
+  static constexpr int TAPS = KS * KS;
+  static constexpr int NS = TAPS / TG;          // steps per A group
+  static constexpr int SUB = CA * TG;           // (chunk, tap) sub-steps per step
+  static constexpr int NPIX = P::NPIX;
+  static constexpr int A_PIECES = CA * 4 * NPIX;
+  static constexpr int A_IT = (A_PIECES + NT - 1) / NT;
+  static constexpr int A_STAGE = A_IT * NT * 16;            // bytes
+  static constexpr int B_PIECES = SUB * 4 * BN;
+  static constexpr int B_IT = (B_PIECES + NT - 1) / NT;
+  static constexpr int B_STAGE = B_IT * NT * 16;
+  static constexpr int RPG = 32 / TW;                       // tile rows per 32-pixel group
+  static constexpr int W2_BYTES = POST ? 2 * 4 * 2 * 2 * 32 * 16 : 0;   // 16 KiB
+  static constexpr int STG_ROW = 68;                                    // floats, fp32 staging row
+  static constexpr int STG_BYTES = POST ? NW * 32 * STG_ROW * 4 : 0;
+  static constexpr int OFF_B = 2 * A_STAGE;
+  static constexpr int OFF_W2 = OFF_B + 2 * B_STAGE;
+  static constexpr int OFF_STG = OFF_W2 + W2_BYTES;
+  static constexpr int LDS_BYTES = OFF_STG + STG_BYTES;
+  static constexpr int OCC_LDS = 160 * 1024 / LDS_BYTES;
+  static constexpr int OCC_W = OCC_LDS < 1 ? 1 : (OCC_LDS > 3 ? 3 : OCC_LDS);
+  // waves per SIMD the launch bounds promise: NW / 4 per workgroup
+  static constexpr int WPS = (OCC_W * NW + 3) / 4;
+  static_assert(TAPS % TG == 0, "tap groups must divide the taps");
+  static_assert(KS == 3 || (TG == 1 && STRIDE == 1), "1x1: one tap, stride 1");
+  static_assert(KS == 1 || CA == 1, "3x3: one chunk per A stage");
+  static_assert(TW == 32 || TW == 16 || TW == 8, "tile width");
+  static_assert(TW != 8 || (WTM == 1 && TH == 8 && WAVES_M == 2), "8-wide tiles: 2 x 1 pixel groups");
+  static_assert(TW == 8 || TH == WAVES_M * WTM * RPG, "pixel tile must match the wave layout");
+  static_assert(BN == WAVES_N * WTN * 32, "channel tile must match the wave layout");
+  static_assert(!(STRIDE == 2 && TW == 32), "stride 2: 16- or 8-wide tiles");
+  static_assert(POST == 0 || (WAVES_N == 1 && BN == 64 && TW == 32), "fused 1x1: 64 channels in one wave");
+  static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
+};
+
+__device__ inline void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ inline void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes, global (per-lane voff + scalar soff) -> LDS at
+// lds + 16 * lane (wave-uniform base through M0).  An out-of-range voff writes zeros.  A plain
+// __device__ function, not a lambda: the builtin inside a lambda makes hipcc's HOST pass drop the
+// kernel's launch stub without a diagnostic.
+__device__ inline void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff,
+                                           soff, 0, 0);
+}
+
+// x -> (hi, lo) halves, 4 values -> two dword pairs
+__device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+  half4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
+    h[e] = (_Float16)x;
+    l[e] = (_Float16)(x - (float)h[e]);
+  }
+  hi = __builtin_bit_cast(u32x2, h);
+  lo = __builtin_bit_cast(u32x2, l);
+}
+
+// Lanes (j, 0) and (j, 1) hold channels 4h..4h+3 of octet X (x) and of octet Y (y).  After the
+// swaps lane (j, 0) holds octet X complete and lane (j, 1) octet Y complete, as 16 bytes.
+__device__ inline u32x4 gather_octet(u32x2 x, u32x2 y) {
+  // v_permlane32_swap(a, b): lanes 32-63 of a <-> lanes 0-31 of b
+  const auto s0 = __builtin_amdgcn_permlane32_swap(x[0], y[0], false, false);
+  const auto s1 = __builtin_amdgcn_permlane32_swap(x[1], y[1], false, false);
+  return u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
+
+// ABL != 0 builds timing-only ablations for tools/sp_conv_check (never launched by the product):
+// 1 = no weight DMA after the first step, 2 = no patch DMA after the first group, 3 = neither,
+// 4 = no epilogue stores, 5 = 3 + operands from registers (pure MFMA stream).
+template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
+          int WTM, int WTN, int POST, int ABL = 0>
+__global__ void __launch_bounds__(
+    (WAVES_M * WAVES_N * 64),
+    (SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST>::WPS))
+conv_sp_kernel(const SpArgs a) {
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST>;
+  using P = typename T::P;
+  constexpr bool kNoB = ABL == 1 || ABL == 3 || ABL == 5, kNoA = ABL == 2 || ABL == 3 || ABL == 5;
+  constexpr bool kNoStore = ABL == 4, kNoLds = ABL == 5;
+  constexpr int NW = T::NW, NT = T::NT, NPIX = T::NPIX, TAPS = T::TAPS, NS = T::NS, SUB = T::SUB;
+  constexpr int A_IT = T::A_IT, B_IT = T::B_IT;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+
+  // ---- work items (channel block, image, tile_y, tile_x), XCD-aware order as in conv_mfma.hip
+  const int G = gridDim.x;
+  const int spatial_items = a.n_images * a.tiles_y * a.tiles_x;
+  const int n_cb = a.total_items / spatial_items;
+  const int sp_full = spatial_items & ~7;
+  auto decode = [&](int item) {
+    TileCoord tc;
+    int cb, spi;
+    if (!a.xcd_order) {
+      cb = item / spatial_items;
+      spi = item % spatial_items;
+    } else if (item < sp_full * n_cb) {
+      const int j = item >> 3;
+      cb = j % n_cb;
+      spi = (item & 7) * (sp_full >> 3) + j / n_cb;
+    } else {
+      const int r = item - sp_full * n_cb, rem = spatial_items - sp_full;
+      cb = r / rem;
+      spi = sp_full + r % rem;
+    }
+    tc.n0 = cb * BN;
+    tc.ox0 = (spi % a.tiles_x) * TW;
+    spi /= a.tiles_x;
+    tc.oy0 = (spi % a.tiles_y) * TH;
+    tc.img = spi / a.tiles_y;
+    return tc;
+  };
+
+  // ---- LDS read offsets (bytes) of this lane's MFMA fragments
+  int a_off[WTM], b_off[WTN], prow[WTM], pcol;
+  pcol = sp::tile_col<TW>(li);
+#pragma unroll
+  for (int wm = 0; wm < WTM; ++wm) {
+    const int gm = wave_m * WTM + wm;
+    prow[wm] = sp::tile_row<TW>(gm, li);
+    a_off[wm] = (lh * NPIX + sp::out_base_pos<KS, STRIDE, TH, TW>(prow[wm], pcol)) * 16;
+  }
+#pragma unroll
+  for (int wn = 0; wn < WTN; ++wn) b_off[wn] = (lh * BN + (wave_n * WTN + wn) * 32 + li) * 16;
+
+  f32x16 acc[WTM][WTN];
+
+  // ---- DMA state
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  const int hs0 = a.up0 ? (a.h_in >> 1) : a.h_in, ws0 = a.up0 ? (a.w_in >> 1) : a.w_in;
+  const unsigned plane0 = (unsigned)(hs0 * ws0) * 16u, plane1 = (unsigned)(a.h_in * a.w_in) * 16u;
+  const size_t img0_bytes = (size_t)a.c0g * 4 * plane0, img1_bytes = (size_t)a.c1g * 4 * plane1;
+  auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src0), 0, 0, 0x00020000);
+  auto rsrc1 = rsrc0;
+  const auto rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wpk), 0,
+                                                        a.wpk_bytes, 0x00020000);
+  unsigned voff_a[A_IT], voff_b[B_IT];
+
+  auto opaque = [](int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  };
+  // per-lane source offsets of the A pieces this lane moves: piece (it * NW + wave) * 64 + lane
+  auto setup_voff_a = [&](const TileCoord& tc, bool from1) {
+    const int t = opaque(tid);
+    const int iy0 = tc.oy0 * STRIDE - KS / 2, ix0 = tc.ox0 * STRIDE - KS / 2;
+    const unsigned plane = from1 ? plane1 : plane0;
+    const int ws = from1 ? a.w_in : ws0;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int piece = (it * NW + (t >> 6)) * 64 + (t & 63);
+      const int cq = piece / NPIX, pp = piece % NPIX;   // cq = cu * 4 + q
+      const int r = pp / P::PITCH, cc = sp::patch_col_of<KS, STRIDE, TH, TW>(pp % P::PITCH);
+      const int iy = iy0 + r, ix = ix0 + cc;
+      const bool ok = piece < T::A_PIECES && cc >= 0 && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+      const int sy = (!from1 && a.up0) ? (iy >> 1) : iy, sx = (!from1 && a.up0) ? (ix >> 1) : ix;
+      voff_a[it] = ok ? (unsigned)cq * plane + (unsigned)(sy * ws + sx) * 16u : OOB;
+    }
+  };
+  auto setup_voff_b = [&](const TileCoord& tc) {
+    const int t = opaque(tid);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int piece = (it * NW + (t >> 6)) * 64 + (t & 63);
+      const int u = piece / (4 * BN), q = (piece / BN) % 4, nn = piece % BN;
+      const int cu = u / TG, tl = u % TG;
+      voff_b[it] = piece < T::B_PIECES
+                       ? (unsigned)((((cu * TAPS + tl) * 4 + q) * a.cout_pad + tc.n0 + nn) * 16)
+                       : OOB;
+    }
+  };
+  auto setup_rsrc = [&](const TileCoord& tc) {
+    rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src0 + tc.img * img0_bytes),
+                                              0, (int)img0_bytes, 0x00020000);
+    rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(a.c1g ? a.src1 + tc.img * img1_bytes : a.src0), 0,
+        a.c1g ? (int)img1_bytes : 0, 0x00020000);
+  };
+  // A group g of the current source set -> stage sa
+  auto issue_a = [&](int g, int sa, bool steady = true) {
+    if (kNoA && steady) return;
+    const int cg = g * CA;
+    const bool from1 = cg >= a.c0g;
+    const int soff = from1 ? (cg - a.c0g) * 4 * (int)plane1 : cg * 4 * (int)plane0;
+    unsigned char* base = smem + sa * T::A_STAGE + wave * 1024;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      if (from1)
+        dma16(rsrc1, base + it * NW * 1024, voff_a[it], soff);
+      else
+        dma16(rsrc0, base + it * NW * 1024, voff_a[it], soff);
+    }
+  };
+  auto issue_b = [&](int g, int st, int sb, bool steady = true) {
+    if (kNoB && steady) return;
+    const int soff = ((g * CA * TAPS + st * TG) * 4 * a.cout_pad) * 16;
+    unsigned char* base = smem + T::OFF_B + sb * T::B_STAGE + wave * 1024;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      dma16(rsrcw, base + it * NW * 1024, voff_b[it], soff);
+  };
+
+  // ---- one step's MFMAs: stage sa of A, stage sb of B, taps ST * TG .. + TG - 1
+  auto compute = [&](auto st_c, int sa, int sb) {
+    constexpr int ST = decltype(st_c)::value;
+    const unsigned char* As = smem + sa * T::A_STAGE;
+    const unsigned char* Bs = smem + T::OFF_B + sb * T::B_STAGE;
+#pragma unroll
+    for (int u = 0; u < SUB; ++u) {
+      const int cu = u / TG, tap = ST * TG + u % TG;
+      const int toff = (cu * 4 * NPIX + sp::tap_offset<KS, STRIDE, TH, TW>(tap / KS, tap % KS)) * 16;
+      half8 ah[WTM], al[WTM], bh[WTN], bl[WTN];
+      if constexpr (kNoLds) {
+        const half8 k = {(_Float16)(li * 1e-3f), (_Float16)0.5f, (_Float16)-0.25f, (_Float16)lh, 0, 0, 0, 0};
+#pragma unroll
+        for (int wm = 0; wm < WTM; ++wm) ah[wm] = al[wm] = k;
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn) bh[wn] = bl[wn] = k;
+      } else {
+#pragma unroll
+        for (int wm = 0; wm < WTM; ++wm) {
+          ah[wm] = *reinterpret_cast<const half8*>(As + a_off[wm] + toff);
+          al[wm] = *reinterpret_cast<const half8*>(As + a_off[wm] + toff + 2 * NPIX * 16);
+        }
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn) {
+          bh[wn] = *reinterpret_cast<const half8*>(Bs + b_off[wn] + u * 4 * BN * 16);
+          bl[wn] = *reinterpret_cast<const half8*>(Bs + b_off[wn] + (u * 4 + 2) * BN * 16);
+        }
+      }
+      // D[i = channel][j = pixel]; small terms first; independent accumulators interleaved
+#pragma unroll
+      for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn)
+          acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[wn], ah[wm], acc[wm][wn], 0, 0, 0);
+#pragma unroll
+      for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn)
+          acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[wn], al[wm], acc[wm][wn], 0, 0, 0);
+#pragma unroll
+      for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn)
+          acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[wn], ah[wm], acc[wm][wn], 0, 0, 0);
+    }
+  };
+
+  // ---- SP epilogue of a 32-pixel x 32-channel accumulator tile: channel tile index ct32 of the
+  // output tensor (two 16-channel chunks), pixel (oy, ox); sc/sh indexed by the tile's channels
+  auto store_sp_tile = [&](const f32x16& c, const float* scale, const float* shift, int relu,
+                           int ch0, int c_lim, unsigned char* out, int cog, int img, int oy, int ox) {
+    const bool inside = oy < a.h_out && ox < a.w_out;
+    const size_t plane = (size_t)a.h_out * a.w_out * 16;
+    unsigned char* obase = out + (size_t)img * cog * 4 * plane + ((size_t)oy * a.w_out + ox) * 16;
+    u32x2 hi[4], lo[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = ch0 + 8 * g + 4 * lh;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // clamped index + select: no divergent branch per channel
+        const int ci = min(co + e, c_lim - 1);
+        v[e] = c[4 * g + e] * scale[ci] + shift[ci];
+        if (relu) v[e] = fmaxf(v[e], 0.f);
+        v[e] = co + e < c_lim ? v[e] : 0.f;
+      }
+      split4(v, hi[g], lo[g]);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      // chunk ch0 / 16 + m: lane half 0 ends up with octet 0, lane half 1 with octet 1
+      const u32x4 ph = gather_octet(hi[2 * m], hi[2 * m + 1]);
+      const u32x4 pl = gather_octet(lo[2 * m], lo[2 * m + 1]);
+      const int cg = ch0 / 16 + m;
+      if (inside && cg < cog && (!kNoStore || ph[0] == 0x12345678u)) {
+        *reinterpret_cast<u32x4*>(obase + (size_t)(cg * 4 + lh) * plane) = ph;
+        *reinterpret_cast<u32x4*>(obase + (size_t)(cg * 4 + 2 + lh) * plane) = pl;
+      }
+    }
+  };
+
+  auto epilogue = [&](const TileCoord& tc) {
+    if constexpr (POST == 0) {
+#pragma unroll
+      for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn)
+          store_sp_tile(acc[wm][wn], a.scale, a.shift, a.relu, tc.n0 + (wave_n * WTN + wn) * 32, a.c_out,
+                        a.out, a.cog, tc.img, tc.oy0 + prow[wm], tc.ox0 + pcol);
+    } else {
+      // ---- fused 1x1 stage.  This wave owns all 64 stage-1 channels of its pixels: after the
+      // affine + ReLU + split, the permlane gather yields exactly the B-operand fragments
+      // (lane (j, h): k = 16 ks + 8 h .. + 7) of stage 2 -- the tile never leaves the registers.
+      const unsigned char* W2 = smem + T::OFF_W2;
+      f32x16 acc2[WTM][2];
+#pragma unroll
+      for (int wm = 0; wm < WTM; ++wm) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[wm][nt][r] = 0.f;
+#pragma unroll
+        for (int wn = 0; wn < 2; ++wn) {
+          u32x2 hi[4], lo[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int co = wn * 32 + 8 * g + 4 * lh;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = acc[wm][wn][4 * g + e] * a.scale[co + e] + a.shift[co + e];
+              if (a.relu) v[e] = fmaxf(v[e], 0.f);
+            }
+            split4(v, hi[g], lo[g]);
+          }
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int ks = wn * 2 + m;
+            const half8 xh = __builtin_bit_cast(half8, gather_octet(hi[2 * m], hi[2 * m + 1]));
+            const half8 xl = __builtin_bit_cast(half8, gather_octet(lo[2 * m], lo[2 * m + 1]));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              // W2 image: [nt][ks][part][h][32] x 16 B
+              const half8 wh = *reinterpret_cast<const half8*>(W2 + ((((nt * 4 + ks) * 2 + 0) * 2 + lh) * 32 + li) * 16);
+              const half8 wl = *reinterpret_cast<const half8*>(W2 + ((((nt * 4 + ks) * 2 + 1) * 2 + lh) * 32 + li) * 16);
+              acc2[wm][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc2[wm][nt], 0, 0, 0);
+              acc2[wm][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc2[wm][nt], 0, 0, 0);
+              acc2[wm][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc2[wm][nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (!a.post_f32) {
+#pragma unroll
+        for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            store_sp_tile(acc2[wm][nt], a.scale2, a.shift2, a.relu2, nt * 32, a.c_out2, a.out, a.cog,
+                          tc.img, tc.oy0 + prow[wm], tc.ox0 + pcol);
+      } else {
+        // fp32 NHWC, two outputs: columns [0, split2) -> out (ldo_a), the rest -> out_b (ldo_b).
+        // Wave-local staging [32 px][STG_ROW] so that every store instruction is one contiguous run.
+        float* stg = reinterpret_cast<float*>(smem + T::OFF_STG) + wave * 32 * T::STG_ROW;
+        const int nc4 = a.c_out2 >> 2, sp4 = a.split2 >> 2;
+#pragma unroll
+        for (int wm = 0; wm < WTM; ++wm) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int co = nt * 32 + 8 * g + 4 * lh;
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int ci = min(co + e, a.c_out2 - 1);
+                v[e] = acc2[wm][nt][4 * g + e] * a.scale2[ci] + a.shift2[ci];
+                if (a.relu2) v[e] = fmaxf(v[e], 0.f);
+                v[e] = co + e < a.c_out2 ? v[e] : 0.f;
+              }
+              *reinterpret_cast<f32x4*>(&stg[li * T::STG_ROW + co]) = v;
+            }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // TW == 32: the group's 32 pixels are one tile row, consecutive in x
+          const int oy = tc.oy0 + wave_m * WTM + wm;
+          const size_t px0 = ((size_t)tc.img * a.h_out + oy) * a.w_out + tc.ox0;
+          if (oy < a.h_out) {
+            for (int idx = lane; idx < 32 * sp4; idx += 64) {
+              const int m = idx / sp4, c4 = idx % sp4;
+              if (tc.ox0 + m < a.w_out)
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (px0 + m) * a.ldo_a + 4 * c4) =
+                    *reinterpret_cast<const f32x4*>(&stg[m * T::STG_ROW + 4 * c4]);
+            }
+            const int nb4 = nc4 - sp4;
+            for (int idx = lane; idx < 32 * nb4; idx += 64) {
+              const int m = idx / nb4, c4 = idx % nb4;
+              if (tc.ox0 + m < a.w_out)
+                *reinterpret_cast<f32x4*>(a.out_b + (px0 + m) * a.ldo_b + 4 * c4) =
+                    *reinterpret_cast<const f32x4*>(&stg[m * T::STG_ROW + 4 * (sp4 + c4)]);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+      }
+    }
+  };
+
+  // ---- main loop
+  int item = blockIdx.x;
+  if (item >= a.total_items) return;
+  if constexpr (POST != 0) {
+    // stage-2 weights: one linear 16 KiB copy, resident for the whole launch
+    for (int i = tid; i < T::W2_BYTES / 16; i += NT)
+      *reinterpret_cast<u32x4*>(smem + T::OFF_W2 + i * 16) = *reinterpret_cast<const u32x4*>(a.w2 + i * 16);
+    __syncthreads();
+  }
+  TileCoord cur = decode(item);
+  setup_rsrc(cur);
+  setup_voff_b(cur);
+  setup_voff_a(cur, a.c0g == 0);
+  issue_b(0, 0, 0, false);
+  issue_a(0, 0, false);
+  int sa = 0, sb = 0;
+  bool a_pending = true;   // A DMAs issued after the B DMAs the next step waits for
+
+  while (true) {
+#pragma unroll
+    for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+      for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+
+    const bool has_next = item + G < a.total_items;
+    TileCoord nxt = cur;
+    if (has_next) nxt = decode(item + G);
+
+    for (int g = 0; g < a.ngroups; ++g) {
+      const bool last_g = g + 1 == a.ngroups;
+      auto step = [&](auto st_c) {
+        constexpr int ST = decltype(st_c)::value;
+        // this step's operands have landed: B (and, at ST == 0, A) were issued one step (one
+        // group) ago.  At ST == 1 the A patch of the NEXT group may still be in flight behind B.
+        // Raw s_barrier: __syncthreads() would add a fence that drains vmcnt to 0 (the LDS-DMA
+        // counts as a pending LDS write) and with it the patch still in flight at ST == 1.
+        if (ST == 1 && a_pending) wait_vm<A_IT>(); else wait_vm0();
+        __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is done with the previous step
+        asm volatile("" ::: "memory");
+        // issue the next step's weights, then (first step of a group) the next group's patch
+        if (ST + 1 < NS) {
+          issue_b(g, ST + 1, sb ^ 1);
+        } else if (!last_g) {
+          issue_b(g + 1, 0, sb ^ 1);
+        } else if (has_next) {
+          setup_voff_b(nxt);
+          issue_b(0, 0, sb ^ 1);
+        }
+        if (ST == 0) {
+          a_pending = true;
+          if (!last_g) {
+            if ((g + 1) * CA == a.c0g && a.c1g) setup_voff_a(cur, true);   // concat: switch source
+            issue_a(g + 1, sa ^ 1);
+          } else if (has_next) {
+            setup_rsrc(nxt);
+            setup_voff_a(nxt, a.c0g == 0);
+            issue_a(0, sa ^ 1);
+          } else {
+            a_pending = false;
+          }
+        }
+        compute(st_c, sa, sb);
+        sb ^= 1;
+      };
+      step(std::integral_constant<int, 0>{});
+      if constexpr (NS > 1) step(std::integral_constant<int, 1>{});
+      if constexpr (NS > 2) step(std::integral_constant<int, 2>{});
+      if constexpr (NS > 3) {
+        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+      }
+      sa ^= 1;
+    }
+    epilogue(cur);
+    if (!has_next) break;
+    item += G;
+    cur = nxt;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// layout conversions and weight packing
+// ---------------------------------------------------------------------------
+
+// fp32 NHWC [n][h][w][ld] (c channels) -> SP [n][cg][4][h][w] pieces; one thread per piece pair
+__global__ void sp_from_nhwc_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
+                                    int c, int ld, int cg_total, long hw, long total) {
+  // idx over (img, cg, oct, pixel): pixel fastest -> coalesced 16-byte stores per plane
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long px = idx % hw;
+    long r = idx / hw;
+    const int oct = r % 2; r /= 2;
+    const int cg = r % cg_total;
+    const long img = r / cg_total;
+    const float* s = src + (img * hw + px) * ld + cg * 16 + oct * 8;
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = (cg * 16 + oct * 8 + e < c) ? s[e] : 0.f;
+      x = fminf(fmaxf(x, -65504.f), 65504.f);
+      hi[e] = (_Float16)x;
+      lo[e] = (_Float16)(x - (float)hi[e]);
+    }
+    unsigned char* d = dst + (((img * cg_total + cg) * 4 + oct) * hw + px) * 16;
+    *reinterpret_cast<half8*>(d) = hi;
+    *reinterpret_cast<half8*>(d + 2 * hw * 16) = lo;
+  }
+}
+
+__global__ void sp_to_nhwc_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst,
+                                  int c, int ld, int cg_total, long hw, long total) {
+  // idx over (img, pixel, octet): octet fastest -> 32-byte runs per thread, rows contiguous
+  const int noct = (c + 7) / 8;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int o = idx % noct;
+    const long r = idx / noct;
+    const long px = r % hw, img = r / hw;
+    const int cg = o / 2, oct = o % 2;
+    const unsigned char* s = src + (((img * cg_total + cg) * 4 + oct) * hw + px) * 16;
+    const half8 hi = *reinterpret_cast<const half8*>(s);
+    const half8 lo = *reinterpret_cast<const half8*>(s + 2 * hw * 16);
+    float* d = dst + (img * hw + px) * ld + o * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (o * 8 + e < c) d[e] = (float)hi[e] + (float)lo[e];
+  }
+}
+
+// weight_oihw [c_out][c_in][k][k] * wmul -> [chunk][tap][q][cout_pad] pieces
+__global__ void sp_pack_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ wpk,
+                                       int c_out, int c_in, int taps, int cout_pad, int nchunks,
+                                       float wmul, long total) {
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int n = r % cout_pad; r /= cout_pad;
+    const int oct = r % 2; r /= 2;
+    const int tap = r % taps;
+    const int cg = r / taps;
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ci = cg * 16 + oct * 8 + e;
+      float v = (n < c_out && ci < c_in) ? w[((size_t)n * c_in + ci) * taps + tap] * wmul : 0.f;
+      v = fminf(fmaxf(v, -65504.f), 65504.f);
+      hi[e] = (_Float16)v;
+      lo[e] = (_Float16)(v - (float)hi[e]);
+    }
+    unsigned char* d = wpk + ((((size_t)cg * taps + tap) * 4 + oct) * cout_pad + n) * 16;
+    *reinterpret_cast<half8*>(d) = hi;
+    *reinterpret_cast<half8*>(d + (size_t)2 * cout_pad * 16) = lo;
+  }
+}
+
+// w2 [c_out2][c_in2] * wmul -> [nt 2][ks 4][part 2][h 2][n 32] pieces (A-operand fragments)
+__global__ void sp_pack_post_kernel(const float* __restrict__ w2, unsigned char* __restrict__ out,
+                                    int c_out2, int c_in2, float wmul) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (nt, ks, h, n)
+  if (idx >= 2 * 4 * 2 * 32) return;
+  const int n = idx % 32, h = (idx / 32) % 2, ks = (idx / 64) % 4, nt = idx / 256;
+  half8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int row = nt * 32 + n, k = ks * 16 + h * 8 + e;
+    float v = (row < c_out2 && k < c_in2) ? w2[(size_t)row * c_in2 + k] * wmul : 0.f;
+    v = fminf(fmaxf(v, -65504.f), 65504.f);
+    hi[e] = (_Float16)v;
+    lo[e] = (_Float16)(v - (float)hi[e]);
+  }
+  *reinterpret_cast<half8*>(out + ((((nt * 4 + ks) * 2 + 0) * 2 + h) * 32 + n) * 16) = hi;
+  *reinterpret_cast<half8*>(out + ((((nt * 4 + ks) * 2 + 1) * 2 + h) * 32 + n) * 16) = lo;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+inline int out_dim(int in, int ksize, int stride) {
+  const int pad = ksize / 2;
+  return (in + 2 * pad - ksize) / stride + 1;
+}
+inline int cout_pad_of(int c_out) { return (c_out + 63) / 64 * 64; }
+inline int chunks_of(int c) { return (c + 15) / 16; }
+// weights are padded to whole groups of 4 chunks so that a 1x1 A group never runs past them
+inline int packed_chunks(const dn_conv_desc& d) { return (chunks_of(d.c0) + chunks_of(d.c1) + 3) / 4 * 4; }
+
+int validate(const dn_conv_desc* d) {
+  DN_REQUIRE(d != nullptr, "spconv: null descriptor");
+  DN_REQUIRE(d->ksize == 1 || d->ksize == 3, "spconv: ksize %d unsupported (1 or 3)", d->ksize);
+  DN_REQUIRE(d->stride == 1 || (d->stride == 2 && d->ksize == 3),
+             "spconv: stride %d with ksize %d unsupported", d->stride, d->ksize);
+  DN_REQUIRE(d->n_images > 0 && d->h_in > 0 && d->w_in > 0, "spconv: empty input");
+  DN_REQUIRE(d->c0 > 0 && d->c1 >= 0 && d->c_out > 0, "spconv: bad channel counts");
+  DN_REQUIRE(d->up0 == 0 || d->up0 == 1, "spconv: up0 must be 0 or 1");
+  DN_REQUIRE(!d->up0 || (d->h_in % 2 == 0 && d->w_in % 2 == 0), "spconv: x2-upsampled source needs even h_in/w_in");
+  DN_REQUIRE(d->c1 == 0 || (d->c0 % 16 == 0 && d->ksize == 3), "spconv: concat needs 3x3 and c0 %% 16 == 0 (c0 = %d)", d->c0);
+  const size_t hs0 = d->up0 ? d->h_in / 2 : d->h_in, ws0 = d->up0 ? d->w_in / 2 : d->w_in;
+  DN_REQUIRE(hs0 * ws0 * chunks_of(d->c0) * 64 < (1ull << 31) &&
+                 (size_t)d->h_in * d->w_in * chunks_of(d->c1) * 64 < (1ull << 31),
+             "spconv: one image must stay below 2 GiB");
+  return DN_OK;
+}
+
+enum SpCfgId { S3_256x64, S3_256x32, S3_128x64, S3_64x64, S3S2_128x64, S3S2_64x64, S1_256x64, S1_64x64,
+               S3_256x64_T9, S3_512x64, S3_256x128, S1_256x64_C1, SP_CFG_COUNT };
+// chunks per A stage of the 1x1 tiles: the chunk count of the input must be a multiple
+inline int ca_of(SpCfgId id) { return id == S1_256x64 ? 2 : id == S1_64x64 ? 4 : 1; }
+struct SpCfg { SpCfgId id; int th, tw, bn; float bias; };
+// biases: measured time per unit of tile area relative to 256x64 (tools/sp_conv_check.hip sweep)
+float g_sp_bias[SP_CFG_COUNT] = {1.00f, 1.15f, 1.10f, 1.50f, 1.00f, 1.30f, 1.00f, 1.30f, 1.f, 1.f, 1.f, 1.2f};
+const SpCfg kSpCfgs[SP_CFG_COUNT] = {
+    {S3_256x64, 8, 32, 64, 0},   {S3_256x32, 8, 32, 32, 0},   {S3_128x64, 8, 16, 64, 0},
+    {S3_64x64, 8, 8, 64, 0},     {S3S2_128x64, 8, 16, 64, 0}, {S3S2_64x64, 8, 8, 64, 0},
+    {S1_256x64, 8, 32, 64, 0},   {S1_64x64, 8, 8, 64, 0},
+    {S3_256x64_T9, 8, 32, 64, 0}, {S3_512x64, 16, 32, 64, 0}, {S3_256x128, 8, 32, 128, 0},
+    {S1_256x64_C1, 8, 32, 64, 0},
+};
+int g_sp_force = -1;   // tools: force one configuration
+
+SpCfg select_cfg(const dn_conv_desc& d) {
+  const int ho = out_dim(d.h_in, d.ksize, d.stride), wo = out_dim(d.w_in, d.ksize, d.stride);
+  static const SpCfgId c3[] = {S3_256x64, S3_256x32, S3_128x64, S3_64x64};
+  static const SpCfgId c3s2[] = {S3S2_128x64, S3S2_64x64};
+  static const SpCfgId c1[] = {S1_256x64, S1_64x64, S1_256x64_C1};
+  const SpCfgId* cand = d.ksize == 1 ? c1 : (d.stride == 2 ? c3s2 : c3);
+  const int ncand = d.ksize == 1 ? 3 : (d.stride == 2 ? 2 : 4);
+  const int nchunks = chunks_of(d.c0) + chunks_of(d.c1);
+  if (g_sp_force >= 0) {
+    for (int k = 0; k < ncand; ++k)
+      if (cand[k] == g_sp_force && nchunks % ca_of(cand[k]) == 0) return kSpCfgs[cand[k]];
+    if (d.ksize == 3 && d.stride == 1 && g_sp_force >= S3_256x64_T9 && g_sp_force < SP_CFG_COUNT)
+      return kSpCfgs[g_sp_force];
+  }
+  SpCfg best = kSpCfgs[cand[0]];
+  double best_cost = 1e300;
+  for (int k = 0; k < ncand; ++k) {
+    const SpCfg& c = kSpCfgs[cand[k]];
+    if (nchunks % ca_of(c.id) != 0) continue;
+    const long tiles = (long)d.n_images * ((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
+    const long blocks = tiles * ((d.c_out + c.bn - 1) / c.bn);
+    const double rounds = (double)((blocks + kCUs - 1) / kCUs);
+    const double cost = rounds * c.th * c.tw * c.bn * g_sp_bias[c.id];
+    if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
+          int WTM, int WTN, int POST = 0, int ABL = 0>
+int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST>;
+  auto kern = conv_sp_kernel<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, ABL>;
+  // opt in to > 64 KiB of dynamic LDS; the attribute write is idempotent, so two first
+  // callers racing here only repeat it
+  static int occupancy = 0;
+  if (occupancy == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+    if (e != hipSuccess)
+      return dn::fail(DN_ERR_LAUNCH, "spconv: hipFuncSetAttribute(%d B LDS): %s", (int)T::LDS_BYTES,
+                      hipGetErrorString(e));
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, T::NT, T::LDS_BYTES) != hipSuccess || occ < 1)
+      occ = 1;
+    occupancy = occ > T::OCC_W ? T::OCC_W : occ;
+  }
+  const int nchunks = a.c0g + a.c1g;
+  DN_REQUIRE(nchunks % CA == 0, "spconv: chunk count %d not a multiple of %d", nchunks, CA);
+  a.ngroups = nchunks / CA;
+  a.tiles_x = (a.w_out + TW - 1) / TW;
+  a.tiles_y = (a.h_out + TH - 1) / TH;
+  const long total = (long)a.n_images * a.tiles_y * a.tiles_x * ((d.c_out + BN - 1) / BN);
+  DN_REQUIRE(total < (1L << 31), "spconv: too many tiles (%ld)", total);
+  a.total_items = (int)total;
+  a.xcd_order = 1;
+  const long resident = (long)occupancy * kCUs;
+  dim3 grid((unsigned)(total > resident ? resident : total));
+  hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, stream, a);
+  return dn::check_launch("conv_sp_kernel");
+}
+
+int fill_args(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed,
+              const float* scale, const float* shift, void* out, SpArgs& a) {
+  a.src0 = (const unsigned char*)src0; a.src1 = (const unsigned char*)src1;
+  a.wpk = (const unsigned char*)packed; a.scale = scale; a.shift = shift; a.out = (unsigned char*)out;
+  a.n_images = d->n_images; a.h_in = d->h_in; a.w_in = d->w_in;
+  a.h_out = out_dim(d->h_in, d->ksize, d->stride);
+  a.w_out = out_dim(d->w_in, d->ksize, d->stride);
+  a.c0g = chunks_of(d->c0); a.c1g = chunks_of(d->c1);
+  a.up0 = d->up0; a.c_out = d->c_out; a.cog = chunks_of(d->c_out); a.relu = d->relu;
+  a.cout_pad = cout_pad_of(d->c_out);
+  a.wpk_bytes = (int)((size_t)packed_chunks(*d) * d->ksize * d->ksize * 4 * a.cout_pad * 16);
+  a.w2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out_b = nullptr;
+  a.c_out2 = 0; a.relu2 = 0; a.split2 = 0; a.ldo_a = 0; a.ldo_b = 0; a.post_f32 = 0;
+  auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  DN_REQUIRE(aligned16(src0) && aligned16(src1) && aligned16(packed) && aligned16(out),
+             "spconv: tensors must be 16-byte aligned");
+  return DN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dn_sp_tensor_bytes(int n_images, int h, int w, int channels) {
+  return (size_t)n_images * chunks_of(channels) * 4 * h * w * 16;
+}
+
+extern "C" int dn_sp_from_nhwc(const float* src, int n_images, int h, int w, int channels, int ld,
+                               void* dst, void* stream) {
+  DN_REQUIRE(src && dst && n_images > 0 && h > 0 && w > 0 && channels > 0 && ld >= channels,
+             "sp_from_nhwc: bad arguments");
+  const int cg = chunks_of(channels);
+  const long hw = (long)h * w, total = (long)n_images * cg * 2 * hw;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(sp_from_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
+                     (unsigned char*)dst, channels, ld, cg, hw, total);
+  return dn::check_launch("sp_from_nhwc_kernel");
+}
+
+extern "C" int dn_sp_to_nhwc(const void* src, int n_images, int h, int w, int channels, int ld,
+                             float* dst, void* stream) {
+  DN_REQUIRE(src && dst && n_images > 0 && h > 0 && w > 0 && channels > 0 && ld >= channels,
+             "sp_to_nhwc: bad arguments");
+  const int cg = chunks_of(channels);
+  const long hw = (long)h * w, total = (long)n_images * hw * ((channels + 7) / 8);
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(sp_to_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)src, dst, channels, ld, cg, hw, total);
+  return dn::check_launch("sp_to_nhwc_kernel");
+}
+
+extern "C" size_t dn_spconv_packed_weight_bytes(const dn_conv_desc* d) {
+  if (validate(d) != DN_OK) return 0;
+  return (size_t)packed_chunks(*d) * d->ksize * d->ksize * 4 * cout_pad_of(d->c_out) * 16;
+}
+
+extern "C" int dn_spconv_pack_weights(const dn_conv_desc* d, const float* weight_oihw, float wmul,
+                                      void* packed, void* stream) {
+  if (int rc = validate(d)) return rc;
+  DN_REQUIRE(weight_oihw && packed, "spconv pack: null pointer");
+  DN_REQUIRE(d->c1 == 0 || d->c0 % 16 == 0, "spconv pack: concat needs c0 %% 16 == 0");
+  const int taps = d->ksize * d->ksize, cp = cout_pad_of(d->c_out), nch = packed_chunks(*d);
+  const long total = (long)nch * taps * 2 * cp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(sp_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     weight_oihw, (unsigned char*)packed, d->c_out, d->c0 + d->c1, taps, cp, nch, wmul,
+                     total);
+  return dn::check_launch("sp_pack_weights_kernel");
+}
+
+extern "C" size_t dn_sp_post1x1_packed_bytes(void) { return 2 * 4 * 2 * 2 * 32 * 16; }
+
+extern "C" int dn_sp_post1x1_pack_weights(const float* w2, int c_out2, int c_in2, float wmul,
+                                          void* packed, void* stream) {
+  DN_REQUIRE(w2 && packed, "sp post1x1 pack: null pointer");
+  DN_REQUIRE(c_out2 > 0 && c_out2 <= 64 && c_in2 > 0 && c_in2 <= 64,
+             "sp post1x1 pack: c_out2 %d / c_in2 %d must be in 1..64", c_out2, c_in2);
+  hipLaunchKernelGGL(sp_pack_post_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w2,
+                     (unsigned char*)packed, c_out2, c_in2, wmul);
+  return dn::check_launch("sp_pack_post_kernel");
+}
+
+extern "C" int dn_spconv_force_config(int cfg) {
+  g_sp_force = cfg;
+  return DN_OK;
+}
+
+extern "C" int dn_spconv2d(const dn_conv_desc* d, const void* src0, const void* src1,
+                           const void* packed, const float* scale, const float* shift, void* out,
+                           void* stream) {
+  if (int rc = validate(d)) return rc;
+  DN_REQUIRE(src0 && packed && scale && shift && out, "spconv: null pointer");
+  DN_REQUIRE(d->c1 == 0 || src1, "spconv: c1 > 0 but src1 is null");
+  SpArgs a;
+  if (int rc = fill_args(d, src0, src1, packed, scale, shift, out, a)) return rc;
+  const SpCfg c = select_cfg(*d);
+  hipStream_t s = (hipStream_t)stream;
+  if (g_sp_force >= 100 && d->ksize == 3 && d->stride == 1) {   // tools: timing-only ablations
+    switch (g_sp_force) {
+      case 101: return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 0, 1>(a, *d, s);
+      case 102: return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 0, 2>(a, *d, s);
+      case 103: return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 0, 3>(a, *d, s);
+      case 104: return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 0, 4>(a, *d, s);
+      case 105: return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 0, 5>(a, *d, s);
+      case 201: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 1>(a, *d, s);
+      case 202: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 2>(a, *d, s);
+      case 203: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 3>(a, *d, s);
+      case 204: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 4>(a, *d, s);
+      case 205: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 5>(a, *d, s);
+      default: break;
+    }
+  }
+  switch (c.id) {
+    //                               KS S  TH TW  BN TG CA WM WN WTM WTN
+    case S3_256x64:   return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2>(a, *d, s);
+    case S3_256x32:   return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1>(a, *d, s);
+    case S3_128x64:   return launch<3, 1, 8, 16, 64, 3, 1, 2, 2, 2, 1>(a, *d, s);
+    case S3_64x64:    return launch<3, 1, 8, 8, 64, 3, 1, 2, 2, 1, 1>(a, *d, s);
+    case S3S2_128x64: return launch<3, 2, 8, 16, 64, 3, 1, 2, 2, 2, 1>(a, *d, s);
+    case S3S2_64x64:  return launch<3, 2, 8, 8, 64, 3, 1, 2, 2, 1, 1>(a, *d, s);
+    case S1_256x64:   return launch<1, 1, 8, 32, 64, 1, 2, 4, 1, 2, 2>(a, *d, s);
+    case S1_64x64:    return launch<1, 1, 8, 8, 64, 1, 4, 2, 2, 1, 1>(a, *d, s);
+    case S3_256x64_T9: return launch<3, 1, 8, 32, 64, 9, 1, 4, 1, 2, 2>(a, *d, s);
+    case S3_512x64:   return launch<3, 1, 16, 32, 64, 3, 1, 8, 1, 2, 2>(a, *d, s);
+    case S3_256x128:  return launch<3, 1, 8, 32, 128, 3, 1, 4, 2, 2, 2>(a, *d, s);
+    case S1_256x64_C1: return launch<1, 1, 8, 32, 64, 1, 1, 4, 1, 2, 2>(a, *d, s);
+    default: break;
+  }
+  return dn::fail(DN_ERR_UNSUPPORTED, "spconv: no tile configuration");
+}
+
+extern "C" int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p, const void* src0,
+                                   const void* src1, const void* packed, const float* scale,
+                                   const float* shift, const void* packed2, const float* scale2,
+                                   const float* shift2, int out_f32, void* out_a, float* out_b,
+                                   void* stream) {
+  if (int rc = validate(d)) return rc;
+  DN_REQUIRE(p && src0 && packed && scale && shift && packed2 && scale2 && shift2 && out_a,
+             "spconv+1x1: null pointer");
+  DN_REQUIRE(d->ksize == 3 && d->stride == 1 && d->c_out == 64,
+             "spconv+1x1: needs a 3x3 stride-1 conv with 64 output channels");
+  DN_REQUIRE(p->c_out2 > 0 && p->c_out2 <= 64, "spconv+1x1: c_out2 %d must be in 1..64", p->c_out2);
+  if (out_f32) {
+    DN_REQUIRE(p->c_out2 % 4 == 0 && p->split % 4 == 0 && p->split > 0 && p->split <= p->c_out2,
+               "spconv+1x1: c_out2 %d / split %d must be multiples of 4, split in (0, c_out2]",
+               p->c_out2, p->split);
+    DN_REQUIRE(p->ldo_a >= p->split && p->ldo_a % 4 == 0, "spconv+1x1: bad ldo_a");
+    DN_REQUIRE(p->split == p->c_out2 || (out_b && p->ldo_b >= p->c_out2 - p->split && p->ldo_b % 4 == 0),
+               "spconv+1x1: second output missing or too narrow");
+    DN_REQUIRE((reinterpret_cast<uintptr_t>(out_b) & 15) == 0, "spconv+1x1: out_b must be 16-byte aligned");
+  }
+  SpArgs a;
+  if (int rc = fill_args(d, src0, src1, packed, scale, shift, out_a, a)) return rc;
+  DN_REQUIRE((reinterpret_cast<uintptr_t>(packed2) & 15) == 0, "spconv+1x1: packed2 must be 16-byte aligned");
+  a.w2 = (const unsigned char*)packed2; a.scale2 = scale2; a.shift2 = shift2; a.out_b = out_b;
+  a.c_out2 = p->c_out2; a.relu2 = p->relu2; a.split2 = p->split; a.ldo_a = p->ldo_a; a.ldo_b = p->ldo_b;
+  a.post_f32 = out_f32 ? 1 : 0;
+  a.cog = chunks_of(p->c_out2);   // SP output: the second stage's channels
+  return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 1>(a, *d, (hipStream_t)stream);
+}

@@ -117,7 +117,7 @@ class _ConvLayer:
     """One packed conv of the plan: weights in tile-major layout + folded affine."""
 
     __slots__ = ("name", "packed", "scale", "shift", "c_in", "c_out", "ksize", "stride", "relu",
-                 "math")
+                 "math", "affine")
 
     def __init__(self, name, weight, bias, bn, ksize, stride=1, relu=True, scale_shift=None,
                  math=0):
@@ -126,11 +126,16 @@ class _ConvLayer:
         c_out = weight.shape[0]
         c_in = weight.shape[1]
         d = ops.conv_desc(1, 8, 8, c_in, c_out, ksize, stride, relu, math=math)
-        self.packed = ops.pack_conv_weights(d, weight)
         if scale_shift is not None:
             self.scale, self.shift = scale_shift
         else:
             self.scale, self.shift = ops.fold_bn(bias, bn, c_out)
+        self.affine = (self.scale, self.shift)      # the layer's own y = acc * scale + shift
+        if math == 2:     # SP engine: weights lifted by a power of two, undone in the scale
+            self.packed, wmul = ops.sp_pack_conv_weights(d, weight)
+            self.scale = (self.scale / wmul).contiguous()
+        else:
+            self.packed = ops.pack_conv_weights(d, weight)
         self.c_in, self.c_out, self.ksize, self.stride, self.relu = c_in, c_out, ksize, stride, relu
 
     def run(self, src0, src1=None, up0=False):
@@ -145,6 +150,12 @@ class _ConvLayer:
         flops = 2.0 * n * ho * wo * self.c_out * self.c_in * self.ksize * self.ksize
         nbytes = 4.0 * (src0.numel() + (src1.numel() if src1 is not None else 0)
                         + n * ho * wo * self.c_out + self.c_out * self.c_in * self.ksize ** 2)
+        if self.math == 2:
+            # split-planar engine: NHWC inputs (the voxel grid, the fused map) are split once here
+            src0, src1 = ops.as_sp(src0), (ops.as_sp(src1) if src1 is not None else None)
+            with region(self.name, "conv_sp_kernel", flops, nbytes):
+                return ops.sp_conv2d(d, src0, self.packed, self.scale, self.shift, src1=src1)
+        src0, src1 = ops.as_nhwc(src0), (ops.as_nhwc(src1) if src1 is not None else None)
         out = torch.empty((n, ho, wo, self.c_out), dtype=torch.float32, device=src0.device)
         with region(self.name, "conv_mfma_kernel", flops, nbytes):
             return ops.conv2d(d, src0, self.packed, self.scale, self.shift, src1=src1, out=out)
@@ -155,28 +166,50 @@ class _ConvPostLayer:
     (dn_conv2d_post1x1): split-f16 math only.  out_a gets columns [0, split) of the
     1x1 stage, out_b the rest (two-headed use) -- or everything goes to out_a."""
 
-    def __init__(self, name, weight, scale, shift, w2, scale2, shift2, split, relu2):
+    def __init__(self, name, weight, scale, shift, w2, scale2, shift2, split, relu2, math=1):
         self.name = name
+        self.math = math
         self.c_out, self.c_in = weight.shape[0], weight.shape[1]
         assert self.c_out == 64
-        d = ops.conv_desc(1, 8, 8, self.c_in, 64, 3, 1, True, math=1)
-        self.packed = ops.pack_conv_weights(d, weight)
-        self.scale, self.shift = scale.contiguous(), shift.contiguous()
+        d = ops.conv_desc(1, 8, 8, self.c_in, 64, 3, 1, True, math=math)
         self.c_out2, self.split, self.relu2 = w2.shape[0], split, relu2
-        self.packed2 = ops.pack_post1x1_weights(w2)
-        self.scale2, self.shift2 = scale2.contiguous(), shift2.contiguous()
+        if math == 2:
+            self.packed, wmul = ops.sp_pack_conv_weights(d, weight)
+            self.packed2, wmul2 = ops.sp_pack_post1x1_weights(w2)
+            # `scale`/`shift` may belong to another layer of the plan: scale copies, never in place
+            self.scale, self.scale2 = (scale / wmul).contiguous(), (scale2 / wmul2).contiguous()
+        else:
+            self.packed = ops.pack_conv_weights(d, weight)
+            self.packed2 = ops.pack_post1x1_weights(w2)
+            self.scale, self.scale2 = scale.contiguous(), scale2.contiguous()
+        self.shift, self.shift2 = shift.contiguous(), shift2.contiguous()
 
     def run(self, src0):
         n, h, w, c0 = src0.shape
         assert c0 == self.c_in
+        flops = 2.0 * n * h * w * (64 * self.c_in * 9 + self.c_out2 * 64)
+        nbytes = 4.0 * (src0.numel() + n * h * w * self.c_out2)
+        if self.math == 2:
+            d = ops.conv_desc(n, h, w, c0, 64, 3, 1, True, math=2)
+            src0 = ops.as_sp(src0)
+            if self.split < self.c_out2:      # two-headed fp32 NHWC output (the detection heads)
+                out_a = torch.empty((n, h, w, self.split), dtype=torch.float32, device=src0.device)
+                out_b = torch.empty((n, h, w, self.c_out2 - self.split), dtype=torch.float32,
+                                    device=src0.device)
+            else:                             # one SP output (conv*_2 + the 1x1x1 Conv3D)
+                out_a, out_b = ops.SpTensor(n, h, w, self.c_out2, device=src0.device), None
+            with region(self.name, "conv_sp_kernel", flops, nbytes):
+                ops.sp_conv2d_post1x1(d, src0, self.packed, self.scale, self.shift, self.packed2,
+                                      self.scale2, self.shift2, self.c_out2, self.split, self.relu2,
+                                      out_a, out_b)
+            return out_a, out_b
+        src0 = ops.as_nhwc(src0)
         d = ops.conv_desc(n, h, w, c0, 64, 3, 1, True, math=1)
         out_a = torch.empty((n, h, w, self.split), dtype=torch.float32, device=src0.device)
         out_b = None
         if self.split < self.c_out2:
             out_b = torch.empty((n, h, w, self.c_out2 - self.split), dtype=torch.float32,
                                 device=src0.device)
-        flops = 2.0 * n * h * w * (64 * self.c_in * 9 + self.c_out2 * 64)
-        nbytes = 4.0 * (src0.numel() + n * h * w * self.c_out2)
         with region(self.name, "conv_mfma_kernel", flops, nbytes):
             ops.conv2d_post1x1(d, src0, self.packed, self.scale, self.shift, self.packed2,
                                self.scale2, self.shift2, self.c_out2, self.split, self.relu2,
@@ -212,7 +245,9 @@ class DiscoNet(nn.Module):
         # summation-order noise); needs |activations|, |weights| < 65504.  "f32" = exact-fp32
         # MFMA at half the throughput.  Not a constructor argument so the reference's signature
         # is untouched: set model.conv_math or DISCONET_CONV_MATH before the first forward.
-        self.conv_math = os.environ.get("DISCONET_CONV_MATH", "f16x3")
+        # "sp" (the default) = the same split-f16 arithmetic with the activations kept pre-split in HBM
+        # (ops.SpTensor, csrc/conv_sp.hip): no conversion work in the conv loop.
+        self.conv_math = os.environ.get("DISCONET_CONV_MATH", "sp")
         # fold the 1x1 layers that follow a 64-channel 3x3 conv into that conv's launch
         self.fuse_1x1 = os.environ.get("DISCONET_FUSE_1X1", "1") != "0"
         # run the encoder levels above the exchanged one beside the fusion block on a second HIP stream
@@ -293,7 +328,7 @@ class DiscoNet(nn.Module):
         P["reg1"] = _Layer("reg1", reg[0].weight, reg[0].bias, reg[1], 3)
         P["reg2"] = _Layer("reg2", reg[3].weight, reg[3].bias, None, 1, relu=False)
 
-        if math == 1 and self.fuse_1x1:
+        if math in (1, 2) and self.fuse_1x1:
             # split-f16 only: 1x1 layers ride in the epilogue of the 3x3 conv before them
             dev = cls.conv1.weight.device
             n_cls, n_reg = cls.conv2.weight.shape[0], reg[3].weight.shape[0]
@@ -303,15 +338,15 @@ class DiscoNet(nn.Module):
                 w2[:n_cls, :32] = cls.conv2.weight.detach().reshape(n_cls, 32)
                 w2[n_cls:, 32:] = reg[3].weight.detach().reshape(n_reg, 32)
                 P["heads_fused"] = _ConvPostLayer(
-                    "heads", w1, torch.cat([P["cls1"].scale, P["reg1"].scale]),
-                    torch.cat([P["cls1"].shift, P["reg1"].shift]), w2,
+                    "heads", w1, torch.cat([P["cls1"].affine[0], P["reg1"].affine[0]]),
+                    torch.cat([P["cls1"].affine[1], P["reg1"].affine[1]]), w2,
                     torch.ones(n_cls + n_reg, device=dev),
-                    torch.cat([cls.conv2.bias, reg[3].bias]).detach().float(), n_cls, False)
+                    torch.cat([cls.conv2.bias, reg[3].bias]).detach().float(), n_cls, False, math=math)
             c3 = enc.conv3d_1
             s3, t3 = ops.fold_bn(c3.conv3d.bias, c3.bn3d, 64)
             P["conv1_2_3d"] = _ConvPostLayer(
-                "conv1_2+3d", enc.conv1_2.weight.detach(), P["conv1_2"].scale, P["conv1_2"].shift,
-                c3.conv3d.weight.detach().reshape(64, 64), s3, t3, 64, True)
+                "conv1_2+3d", enc.conv1_2.weight.detach(), P["conv1_2"].affine[0], P["conv1_2"].affine[1],
+                c3.conv3d.weight.detach().reshape(64, 64), s3, t3, 64, True, math=math)
 
         # attention MLP: layer 1 split W1 = [W1_ego | W1_nbr] (see fuse_tail.hip)
         f = self.pixel_weighted_fusion
@@ -321,11 +356,13 @@ class DiscoNet(nn.Module):
         w_cat = torch.cat([w1[:, :C], w1[:, C:]], 0).contiguous()          # [256, C]
         ones256 = torch.ones(256, device=dev)
         shift_g = torch.cat([f.conv1_1.bias.detach().float(), torch.zeros(128, device=dev)])
-        P["mlp_g"] = _Layer("mlp_g", w_cat.reshape(256, C, 1, 1), None, None, 1, relu=False,
-                            scale_shift=(ones256, shift_g.contiguous()))
-        P["mlp_f"] = _Layer("mlp_f", w1[:, C:].contiguous().reshape(128, C, 1, 1), None, None, 1,
-                            relu=False, scale_shift=(torch.ones(128, device=dev),
-                                                     torch.zeros(128, device=dev)))
+        # the fusion block's kernels read fp32 NHWC maps: its two 1x1 launches stay on the NHWC engine
+        nmath = ops.nhwc_math(math)
+        P["mlp_g"] = _ConvLayer("mlp_g", w_cat.reshape(256, C, 1, 1), None, None, 1, relu=False,
+                                scale_shift=(ones256, shift_g.contiguous()), math=nmath)
+        P["mlp_f"] = _ConvLayer("mlp_f", w1[:, C:].contiguous().reshape(128, C, 1, 1), None, None, 1,
+                                relu=False, scale_shift=(torch.ones(128, device=dev),
+                                                         torch.zeros(128, device=dev)), math=nmath)
         bn1_scale, bn1_shift = ops.fold_bn(None, f.bn1_1, 128)
         s2, t2 = ops.fold_bn(f.conv1_2.bias, f.bn1_2, 32)
         s3, t3 = ops.fold_bn(f.conv1_3.bias, f.bn1_3, 8)
@@ -382,6 +419,8 @@ class DiscoNet(nn.Module):
             enc.append(x)
         if "compress" in P:
             enc[3] = P["decompress"].run(P["compress"].run(enc[3]))
+        # the exchanged level leaves the conv engine (fusion kernels, the agent all-gather): fp32 NHWC
+        enc[self.layer] = ops.as_nhwc(enc[self.layer])
         return enc
 
     def fuse(self, feat, trans_matrices, num_agent, batch_size, P, want_weights=False,
@@ -392,6 +431,7 @@ class DiscoNet(nn.Module):
         agents when a scene is sharded one agent per GPU (sharded.py)."""
         A = self.agent_num
         E = A if ego_count is None else ego_count
+        feat = ops.as_nhwc(feat)
         n, h, w, c = feat.shape
         B = batch_size
         map_bytes = 4.0 * h * w * c
@@ -422,8 +462,8 @@ class DiscoNet(nn.Module):
         if "heads_fused" in P:                          # conv1 of both heads + both conv2, one launch
             cls, loc = P["heads_fused"].run(x8)
         else:
-            cls = P["cls2"].run(P["cls1"].run(x8))      # [N, H, W, A_loc*cat]  (NHWC: the
-            loc = P["reg2"].run(P["reg1"].run(x8))      #  reference's permute(0,2,3,1) is free)
+            cls = ops.as_nhwc(P["cls2"].run(P["cls1"].run(x8)))   # [N, H, W, A_loc*cat]  (NHWC: the
+            loc = ops.as_nhwc(P["reg2"].run(P["reg1"].run(x8)))   #  reference's permute(0,2,3,1) is free)
         n, h, w = cls.shape[0], cls.shape[1], cls.shape[2]
         cls_preds = cls.view(n, -1, self.category_num)
         loc_preds = loc.view(n, h, w, self.anchor_num_per_loc, self.out_seq_len, self.box_code_size)
@@ -461,7 +501,7 @@ class DiscoNet(nn.Module):
                 for k in range(self.layer + 1, 5):
                     up = self._enc_group(k, up, P)
                     enc.append(up)
-            feat = enc[self.layer]
+            feat = ops.as_nhwc(enc[self.layer])
             if "compress" in P and self.layer != 3:
                 with torch.cuda.stream(side):                       # x3 is on the side branch then
                     enc[3] = P["decompress"].run(P["compress"].run(enc[3]))
@@ -481,6 +521,6 @@ class DiscoNet(nn.Module):
         result = self.heads(x8, P)
         if self.kd_flag == 1:
             # NCHW-shaped, channels-last-strided views of the NHWC buffers
-            nchw = lambda t: t.permute(0, 3, 1, 2)
+            nchw = lambda t: ops.as_nhwc(t).permute(0, 3, 1, 2)
             return (result, nchw(x8), nchw(x7), nchw(x6), nchw(x5), nchw(fused))
         return result

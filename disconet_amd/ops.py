@@ -87,7 +87,16 @@ def scatter_dense(indices, offsets, n_images, dims):
 # ---------------------------------------------------------------------------
 # K2/K3/K7
 # ---------------------------------------------------------------------------
-MATH_MODES = {"f32": 0, "f16x3": 1}
+# "f32": exact-fp32 MFMA; "f16x3": split-f16 x3 MFMA on fp32 NHWC activations (conv_mfma.hip);
+# "sp": the same split-f16 x3 arithmetic on activations kept pre-split in HBM (split-planar,
+# conv_sp.hip) -- the inference default.  Training kernels take NHWC: they read "sp" as "f16x3".
+MATH_MODES = {"f32": 0, "f16x3": 1, "sp": 2}
+
+
+def nhwc_math(mode):
+    """math value for the NHWC engine (dn_conv2d): the SP engine's arithmetic is mode 1"""
+    m = MATH_MODES.get(mode, mode)
+    return 1 if m == 2 else m
 
 
 def conv_desc(n_images, h_in, w_in, c0, c_out, ksize, stride=1, relu=True, c1=0, up0=False,
@@ -151,6 +160,134 @@ def conv2d(d, src0, packed, scale, shift, src1=None, out=None):
     check(_lib.load().dn_conv2d(ctypes.byref(d), _ptr(src0), _ptr(src1), _ptr(packed), _ptr(scale),
                                 _ptr(shift), _ptr(out), _stream()), "dn_conv2d")
     return out
+
+
+# ---------------------------------------------------------------------------
+# split-planar (SP) activations and the SP conv engine
+# ---------------------------------------------------------------------------
+class SpTensor:
+    """An activation map in the SP layout of include/disconet_hip.h:
+    data [n, ceil(c/16), 4, h, w, 8] float16 (quarter = 2*part + oct; part 0 = half(x),
+    part 1 = half(x - half(x))).  `shape` is the logical NHWC shape."""
+
+    __slots__ = ("data", "n", "h", "w", "c")
+
+    def __init__(self, n, h, w, c, device=None, data=None):
+        self.n, self.h, self.w, self.c = int(n), int(h), int(w), int(c)
+        if data is None:
+            data = torch.empty((self.n, (self.c + 15) // 16, 4, self.h, self.w, 8), dtype=torch.float16,
+                               device=device)
+        self.data = data
+
+    shape = property(lambda self: (self.n, self.h, self.w, self.c))
+    device = property(lambda self: self.data.device)
+    is_cuda = property(lambda self: self.data.is_cuda)
+
+    def numel(self):
+        return self.n * self.h * self.w * self.c
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def record_stream(self, stream):
+        self.data.record_stream(stream)
+
+    def nhwc(self, out=None):
+        """-> float32 [n, h, w, c] (x = hi + lo)"""
+        if out is None:
+            out = torch.empty((self.n, self.h, self.w, self.c), dtype=torch.float32, device=self.data.device)
+        check(_lib.load().dn_sp_to_nhwc(_ptr(self.data), self.n, self.h, self.w, self.c, out.stride(2),
+                                        _ptr(out), _stream()), "dn_sp_to_nhwc")
+        return out
+
+    @staticmethod
+    def from_nhwc(x):
+        """float32 [n, h, w, c] (pixel stride x.stride(2)) -> SpTensor"""
+        _need_gpu(x)
+        if x.dtype != torch.float32 or x.stride(3) != 1:
+            raise _lib.DnError("SpTensor.from_nhwc needs float32 channels-last data")
+        n, h, w, c = x.shape
+        if x.stride(1) != w * x.stride(2) or x.stride(0) != h * x.stride(1):
+            x = x.contiguous()
+        t = SpTensor(n, h, w, c, device=x.device)
+        check(_lib.load().dn_sp_from_nhwc(_ptr(x), n, h, w, c, x.stride(2), _ptr(t.data), _stream()),
+              "dn_sp_from_nhwc")
+        return t
+
+
+def as_sp(x):
+    return x if isinstance(x, SpTensor) else SpTensor.from_nhwc(x)
+
+
+def as_nhwc(x):
+    return x.nhwc() if isinstance(x, SpTensor) else x
+
+
+def _pow2_lift(weight):
+    """power of two that lifts max|w| to [2^12, 2^13): the lo halves of the split then sit in
+    the f16 normal range; 1/wmul is folded into the layer's scale (exact in fp32)"""
+    m = float(weight.detach().abs().max())
+    if not (m > 0.0) or m != m or m == float("inf"):
+        return 1.0
+    import math
+    return float(2.0 ** max(-20, min(30, 12 - math.floor(math.log2(m)))))
+
+
+def sp_pack_conv_weights(d, weight):
+    """-> (packed uint8 buffer, wmul)"""
+    _need_gpu(weight)
+    w = weight.detach().reshape(d.c_out, d.c0 + d.c1, d.ksize, d.ksize).contiguous().float()
+    lib = _lib.load()
+    nbytes = lib.dn_spconv_packed_weight_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        check(-1, "dn_spconv_packed_weight_bytes")
+    wmul = _pow2_lift(w)
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    check(lib.dn_spconv_pack_weights(ctypes.byref(d), _ptr(w), wmul, _ptr(packed), _stream()),
+          "dn_spconv_pack_weights")
+    return packed, wmul
+
+
+def sp_conv2d(d, src0, packed, scale, shift, src1=None, out=None):
+    """SP conv: src0 / src1 SpTensors -> SpTensor [n_images, h_out, w_out, c_out]"""
+    _need_gpu(src0, packed, scale, shift, src1)
+    ho, wo = conv_out_hw(d)
+    if out is None:
+        out = SpTensor(d.n_images, ho, wo, d.c_out, device=src0.device)
+    check(_lib.load().dn_spconv2d(ctypes.byref(d), _ptr(src0.data), _ptr(src1.data) if src1 is not None else None,
+                                  _ptr(packed), _ptr(scale), _ptr(shift), _ptr(out.data), _stream()),
+          "dn_spconv2d")
+    return out
+
+
+def sp_pack_post1x1_weights(weight):
+    """weight [c_out2, c_in2(, 1, 1)] -> (packed A-operand fragments, wmul)"""
+    _need_gpu(weight)
+    w = weight.detach().reshape(weight.shape[0], -1).contiguous().float()
+    lib = _lib.load()
+    wmul = _pow2_lift(w)
+    packed = torch.empty(lib.dn_sp_post1x1_packed_bytes(), dtype=torch.uint8, device=weight.device)
+    check(lib.dn_sp_post1x1_pack_weights(_ptr(w), w.shape[0], w.shape[1], wmul, _ptr(packed), _stream()),
+          "dn_sp_post1x1_pack_weights")
+    return packed, wmul
+
+
+def sp_conv2d_post1x1(d, src0, packed, scale, shift, packed2, scale2, shift2, c_out2, split, relu2,
+                      out_a, out_b=None):
+    """SP 3x3 conv (64 ch) + affine + ReLU fused with a 1x1 stage.  out_a an SpTensor (one SP
+    output of c_out2 channels) or a float32 NHWC tensor (+ out_b: two-headed fp32 output)."""
+    _need_gpu(src0, packed, packed2)
+    p = Post1x1Desc()
+    p.c_out2, p.relu2, p.split = c_out2, int(bool(relu2)), split
+    f32 = not isinstance(out_a, SpTensor)
+    p.ldo_a = out_a.shape[-1] if f32 else 0
+    p.ldo_b = out_b.shape[-1] if out_b is not None else 0
+    check(_lib.load().dn_spconv2d_post1x1(ctypes.byref(d), ctypes.byref(p), _ptr(src0.data), None,
+                                          _ptr(packed), _ptr(scale), _ptr(shift), _ptr(packed2),
+                                          _ptr(scale2), _ptr(shift2), int(f32),
+                                          _ptr(out_a if f32 else out_a.data), _ptr(out_b), _stream()),
+          "dn_spconv2d_post1x1")
+    return out_a, out_b
 
 
 def pack_post1x1_weights(weight):

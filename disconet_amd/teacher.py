@@ -40,7 +40,7 @@ class TeacherNet(nn.Module):
         self.stpn = _BackboneParams(in_channels)
         self.classification = _ClsHeadParams(config)
         self.regression = _RegHeadParams(config, 1 if config.only_det else config.pred_len)
-        self.conv_math = os.environ.get("DISCONET_CONV_MATH", "f16x3")
+        self.conv_math = os.environ.get("DISCONET_CONV_MATH", "sp")
         self._plan, self._plan_sig = None, None
 
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -91,7 +91,7 @@ class TeacherNet(nn.Module):
         x6 = P["conv6_2"].run(P["conv6_1"].run(x5, x2, up0=True))
         x7 = P["conv7_2"].run(P["conv7_1"].run(x6, x1, up0=True))
         x8 = P["conv8_2"].run(P["conv8_1"].run(x7, x0, up0=True))
-        return x8, x7, x6, x5, x3, x2
+        return tuple(ops.as_nhwc(t) for t in (x8, x7, x6, x5, x3, x2))
 
     def forward(self, bevs):
         with torch.no_grad():

@@ -180,7 +180,7 @@ class TrainEngine:
     # one conv + BN(train) + ReLU
     # ------------------------------------------------------------------
     def _math(self):
-        return ops.MATH_MODES[self.model.conv_math]
+        return ops.nhwc_math(self.model.conv_math)      # the training kernels take fp32 NHWC
 
     def _conv(self, w, bias, src0, src1=None, up0=0, stride=1, ksize=3, out=None, h_in=None, w_in=None):
         """raw conv + bias through the forward engine (weights packed on the fly)"""

@@ -20,7 +20,9 @@
  *     reference's tools build with torch.cat over agents;
  *   - return 0 on success, negative on error; dn_last_error() returns a
  *     thread-local message for the last failing call on this thread;
- *   - re-entrant; no global mutable state.
+ *   - re-entrant.  Process-wide state is limited to launch-time caches filled on first use
+ *     (kernel attributes / occupancy per instantiation) and the tools-only knobs
+ *     dn_spconv_force_config() and the DN_* environment variables read once.
  */
 #ifndef DISCONET_HIP_H
 #define DISCONET_HIP_H
@@ -132,6 +134,51 @@ int dn_conv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p, const flo
                       const float* src1, const float* packed, const float* scale,
                       const float* shift, const float* packed2, const float* scale2,
                       const float* shift2, float* out_a, float* out_b, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K2/K3/K7, split-planar ("SP") form -- the inference engine's conv path.
+ * Same layers and same arithmetic as dn_conv2d with math = 1 (x = hi + lo f16
+ * halves, hi*hi + hi*lo + lo*hi on the f16 MFMA, fp32 accumulate), but the
+ * activations stay PRE-SPLIT in HBM and are staged by LDS-DMA, so the kernel's
+ * loop is ds_read + MFMA only (disconet_amd/csrc/conv_sp.hip, sp_layout.h).
+ *
+ * SP tensor (opaque bytes, 16-byte aligned, dn_sp_tensor_bytes() long):
+ *   [image][ceil(C/16) chunk][4 quarter][H][W] x 16 bytes; a piece = 8 halves =
+ *   channels 16*chunk + 8*oct + 0..7 of one pixel; quarter = 2*part + oct,
+ *   part 0 = half(x), part 1 = half(x - half(x)).  Channels past C are zero.
+ * dn_conv_desc is reused: ld0/ld1/ldo and math are ignored; up0 is 0 or 1.
+ * Packed weights are specific to this engine (dn_spconv_pack_weights); `wmul`
+ * is multiplied into the weights before the split -- pass a power of two that
+ * lifts the layer's weights out of the f16 subnormal range and fold 1/wmul into
+ * `scale` (exact in fp32).
+ * ------------------------------------------------------------------------ */
+size_t dn_sp_tensor_bytes(int n_images, int h, int w, int channels);
+/* fp32 NHWC [n][h][w][ld] (first `channels` of each pixel) <-> SP */
+int dn_sp_from_nhwc(const float* src, int n_images, int h, int w, int channels, int ld,
+                    void* dst_sp, void* stream);
+int dn_sp_to_nhwc(const void* src_sp, int n_images, int h, int w, int channels, int ld,
+                  float* dst, void* stream);
+size_t dn_spconv_packed_weight_bytes(const dn_conv_desc* d);
+int dn_spconv_pack_weights(const dn_conv_desc* d, const float* weight_oihw, float wmul,
+                           void* packed, void* stream);
+/* out: SP tensor [n_images][ceil(c_out/16)][4][h_out][w_out] */
+int dn_spconv2d(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp,
+                const void* packed, const float* scale, const float* shift, void* out_sp,
+                void* stream);
+/* Fused 3x3 (64 channels) + affine + ReLU, then 1x1 + affine (+ReLU): the 64-channel tile
+ * never leaves the registers between the two layers (cf. dn_conv2d_post1x1).
+ * out_f32 == 0: out_a is an SP tensor of c_out2 channels (p->split, ldo_* ignored);
+ * out_f32 != 0: fp32 NHWC, columns [0, split) -> out_a (ldo_a), the rest -> out_b (ldo_b). */
+size_t dn_sp_post1x1_packed_bytes(void);
+int dn_sp_post1x1_pack_weights(const float* w2, int c_out2, int c_in2, float wmul, void* packed,
+                               void* stream);
+int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p, const void* src0_sp,
+                        const void* src1_sp, const void* packed, const float* scale,
+                        const float* shift, const void* packed2, const float* scale2,
+                        const float* shift2, int out_f32, void* out_a, float* out_b, void* stream);
+/* tools only: force tile configuration `cfg` (an index of conv_sp.hip's menu) where it
+ * applies to the layer, -1 = automatic selection.  Process-wide, not thread-safe. */
+int dn_spconv_force_config(int cfg);
 
 /* ------------------------------------------------------------------------
  * K4 -- pose-based two-pass bilinear warp of neighbour feature maps.

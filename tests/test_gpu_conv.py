@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-MATHS = ["f32", "f16x3"]
+MATHS = ["f32", "f16x3", "sp"]
 
 
 def _run(n, h, w, c0, c_out, k, stride=1, relu=True, c1=0, up0=False, bn=True, seed=0, math="f32"):
@@ -36,10 +36,15 @@ def _run(n, h, w, c0, c_out, k, stride=1, relu=True, c1=0, up0=False, bn=True, s
     if relu:
         y = F.relu(y)
     d = ops.conv_desc(n, h, w, c0, c_out, k, stride, relu, c1=c1, up0=up0, math=math)
-    packed = ops.pack_conv_weights(d, wgt.cuda())
     scale, shift = ops.fold_bn(bias.cuda(), bn_mod.cuda() if bn_mod else None, c_out)
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
-    out = ops.conv2d(d, nhwc(x0), packed, scale, shift, src1=nhwc(x1) if c1 else None)
+    if math == "sp":      # split-planar engine: NHWC -> SP, conv, SP -> NHWC
+        packed, wmul = ops.sp_pack_conv_weights(d, wgt.cuda())
+        out = ops.sp_conv2d(d, ops.SpTensor.from_nhwc(nhwc(x0)), packed, scale / wmul, shift,
+                            src1=ops.SpTensor.from_nhwc(nhwc(x1)) if c1 else None).nhwc()
+    else:
+        packed = ops.pack_conv_weights(d, wgt.cuda())
+        out = ops.conv2d(d, nhwc(x0), packed, scale, shift, src1=nhwc(x1) if c1 else None)
     torch.cuda.synchronize()
     got = out.cpu().permute(0, 3, 1, 2)
     err = (got - y).abs().max().item()
@@ -94,7 +99,8 @@ def test_conv_many_tiles_per_workgroup(math):
     _run(24, 124, 120, 64, 64, 3, math=math)
 
 
-def test_split_f16_extremes():
+@pytest.mark.parametrize("engine", ["f16x3", "sp"])
+def test_split_f16_extremes(engine):
     """split-f16 keeps small magnitudes (fp16-subnormal lo parts) and large ones"""
     from disconet_amd import ops
     g = torch.Generator().manual_seed(3)
@@ -103,10 +109,16 @@ def test_split_f16_extremes():
     x[:, 8:16] *= 300.0
     w = torch.randn(32, 32, 3, 3, generator=g) * 0.05
     y = F.conv2d(x.double(), w.double(), None, padding=1).float()
-    d = ops.conv_desc(1, 16, 16, 32, 32, 3, 1, False, math="f16x3")
-    packed = ops.pack_conv_weights(d, w.cuda())
+    d = ops.conv_desc(1, 16, 16, 32, 32, 3, 1, False, math=engine)
     scale, shift = ops.fold_bn(torch.zeros(32).cuda(), None, 32)
-    out = ops.conv2d(d, x.permute(0, 2, 3, 1).contiguous().cuda(), packed, scale, shift)
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    if engine == "sp":
+        packed, wmul = ops.sp_pack_conv_weights(d, w.cuda())
+        assert wmul >= 1024.0            # |w| ~ 0.05: lifted out of the f16 subnormal range
+        out = ops.sp_conv2d(d, ops.SpTensor.from_nhwc(xin), packed, scale / wmul, shift).nhwc()
+    else:
+        packed = ops.pack_conv_weights(d, w.cuda())
+        out = ops.conv2d(d, xin, packed, scale, shift)
     got = out.cpu().permute(0, 3, 1, 2)
     rel = ((got - y).abs().max() / y.abs().max()).item()
     assert rel <= 2e-6, rel
@@ -121,9 +133,10 @@ def test_conv_rejects_bad_arguments():
         ops.conv2d(ops.conv_desc(1, 8, 8, 32, 32, 3), torch.zeros(1, 8, 8, 32), None, None, None)
 
 
+@pytest.mark.parametrize("engine", ["f16x3", "sp"])
 @pytest.mark.parametrize("c_in,c_out2,split,relu2", [(32, 48, 12, False), (64, 64, 64, True),
                                                      (96, 8, 4, False)])
-def test_conv3x3_fused_1x1_stage(c_in, c_out2, split, relu2):
+def test_conv3x3_fused_1x1_stage(c_in, c_out2, split, relu2, engine):
     """dn_conv2d_post1x1: 3x3 conv (64 ch) + affine + ReLU, then 1x1 + affine (+ReLU),
     one or two outputs, vs the two torch ops"""
     from disconet_amd import ops
@@ -138,13 +151,24 @@ def test_conv3x3_fused_1x1_stage(c_in, c_out2, split, relu2):
     y = F.conv2d(hmid, w2.view(c_out2, 64, 1, 1)) * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1)
     if relu2:
         y = F.relu(y)
-    d = ops.conv_desc(n, h, w, c_in, 64, 3, 1, True, math="f16x3")
-    packed = ops.pack_conv_weights(d, w1.cuda())
-    packed2 = ops.pack_post1x1_weights(w2.cuda())
+    d = ops.conv_desc(n, h, w, c_in, 64, 3, 1, True, math=engine)
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
     out_a = torch.empty(n, h, w, split, device="cuda")
     out_b = torch.empty(n, h, w, c_out2 - split, device="cuda") if split < c_out2 else None
-    ops.conv2d_post1x1(d, x.permute(0, 2, 3, 1).contiguous().cuda(), packed, s1.cuda(), t1.cuda(),
-                       packed2, s2.cuda(), t2.cuda(), c_out2, split, relu2, out_a, out_b)
+    if engine == "sp":
+        packed, m1 = ops.sp_pack_conv_weights(d, w1.cuda())
+        packed2, m2 = ops.sp_pack_post1x1_weights(w2.cuda())
+        if out_b is None:                 # single output: the SP form
+            out_a = ops.SpTensor(n, h, w, c_out2, device="cuda")
+        ops.sp_conv2d_post1x1(d, ops.SpTensor.from_nhwc(xin), packed, s1.cuda() / m1, t1.cuda(), packed2,
+                              s2.cuda() / m2, t2.cuda(), c_out2, split, relu2, out_a, out_b)
+        if out_b is None:
+            out_a = out_a.nhwc()
+    else:
+        packed = ops.pack_conv_weights(d, w1.cuda())
+        packed2 = ops.pack_post1x1_weights(w2.cuda())
+        ops.conv2d_post1x1(d, xin, packed, s1.cuda(), t1.cuda(),
+                           packed2, s2.cuda(), t2.cuda(), c_out2, split, relu2, out_a, out_b)
     torch.cuda.synchronize()
     got = out_a.cpu() if out_b is None else torch.cat([out_a.cpu(), out_b.cpu()], -1)
     err = (got.permute(0, 3, 1, 2) - y).abs().max().item()
@@ -175,6 +199,8 @@ def test_conv_random_shapes_fuzz():
             c0, c1 = rnd.choice([3, 13, 16, 24, 32, 40, 64, 100]), 0
         c_out = rnd.choice([1, 6, 12, 32, 36, 64, 72, 100, 128])
         relu, bn = rnd.random() < 0.7, rnd.random() < 0.7
+        if math == "sp" and c1 and (k == 1 or c0 % 16):
+            c1 = 0                        # the SP engine concatenates only in front of 3x3 convs
         try:
             _run(n, h, w, c0, c_out, k, stride=stride, relu=relu, c1=c1, up0=up0, bn=bn,
                  seed=100 + case, math=math)

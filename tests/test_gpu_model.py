@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-MATHS = ["f32", "f16x3"]
+MATHS = ["f32", "f16x3", "sp"]
 
 
 def _product(ref, map_hw, agents, kd_flag=1, math="f32", **kw):
@@ -150,8 +150,9 @@ def test_fused_1x1_layers_match_unfused():
     ref = cases.ref_model(128, 3)
     bevs, trans, na = make_scene_batch(2, 3, 128, jitter_seed=2)
     outs = []
-    for fuse in (True, False):
+    for fuse in (True, False, True, False):
         m = DiscoNet(Config(map_hw=128), kd_flag=0, num_agent=3).eval()
+        m.conv_math = "sp" if len(outs) < 2 else "f16x3"
         m.load_state_dict(ref.state_dict())
         m.fuse_1x1 = fuse
         m.cuda()
@@ -160,3 +161,5 @@ def test_fused_1x1_layers_match_unfused():
         assert ("heads_fused" in m._plan) == fuse
     for k in ("cls", "loc"):
         assert (outs[0][k] - outs[1][k]).abs().max().item() <= 2e-5
+        assert (outs[2][k] - outs[3][k]).abs().max().item() <= 2e-5
+        assert (outs[0][k] - outs[2][k]).abs().max().item() <= 2e-5    # the two split-f16 engines agree

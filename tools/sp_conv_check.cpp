@@ -1,0 +1,245 @@
+// Correctness + timing of the split-planar conv engine (dn_spconv2d*) against the
+// already parity-tested NHWC engine (dn_conv2d, math = 1: identical arithmetic up to the
+// fp32 summation order) on the layer shapes of the BASELINE workload.  Not part of the
+// product library; links libdisconet_hip.so:
+//   hipcc -O2 -std=c++17 -I include tools/sp_conv_check.cpp -L disconet_amd -ldisconet_hip \
+//         -Wl,-rpath,'$ORIGIN/../disconet_amd' -o tools/sp_conv_check.bin
+//   tools/sp_conv_check.bin [n_images] [quick]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "disconet_hip.h"
+
+#define CK(x) do { int rc_ = (x); if (rc_ != 0) { printf("FAILED %s -> %d: %s\n", #x, rc_, dn_last_error()); exit(2); } } while (0)
+#define HCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP %s: %s\n", #x, hipGetErrorString(e_)); exit(3); } } while (0)
+
+static unsigned g_seed = 12345;
+static float frand() { g_seed = g_seed * 1664525u + 1013904223u; return ((g_seed >> 8) / 8388608.0f) - 1.0f; }
+
+static float* dev_random(size_t n, float amp, bool nonneg = false) {
+  std::vector<float> h(n);
+  for (auto& x : h) { x = frand() * amp; if (nonneg) x = fabsf(x); }
+  float* d; HCK(hipMalloc(&d, n * 4)); HCK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+  return d;
+}
+
+struct Timer {
+  hipEvent_t e0, e1;
+  Timer() { hipEventCreate(&e0); hipEventCreate(&e1); }
+  template <class F> float us(F f, int iters = 10) {
+    for (int i = 0; i < 2; ++i) f();
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) f();
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    return ms / iters * 1e3f;
+  }
+};
+
+static double compare(const float* d_a, const float* d_b, size_t n, const char* what, double* maxref = nullptr) {
+  std::vector<float> a(n), b(n);
+  HCK(hipMemcpy(a.data(), d_a, n * 4, hipMemcpyDeviceToHost));
+  HCK(hipMemcpy(b.data(), d_b, n * 4, hipMemcpyDeviceToHost));
+  double md = 0, mr = 0; size_t bad = 0, first = n;
+  for (size_t i = 0; i < n; ++i) {
+    if (std::isnan(a[i]) || std::isnan(b[i])) { ++bad; if (first == n) first = i; continue; }
+    const double d = fabs((double)a[i] - b[i]);
+    if (d > md) { md = d; if (d > 1e-3) first = first == n ? i : first; }
+    mr = fmax(mr, fabs((double)b[i]));
+  }
+  if (maxref) *maxref = mr;
+  if (bad) printf("   [%s] %zu NaNs (first at %zu)\n", what, bad, first);
+  return bad ? 1e30 : md / (mr > 0 ? mr : 1);
+}
+
+static int g_fail = 0;
+
+// names of conv_sp.hip's tile menu
+static const char* kCfgName[] = {"256x64", "256x32", "128x64", "64x64", "s2_128x64", "s2_64x64", "p256x64", "p64x64",
+                                 "256x64/T9", "512x64", "256x128"};
+static const char* g_filter = nullptr;   // substring of the layer name
+static int g_mode = 0;                   // 0 = every tile, 1 = automatic selection only, 2 = + ablations
+
+static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int up0, int cout, int ks,
+                      int stride, bool quick) {
+  if (g_filter && !strstr(name, g_filter)) return;
+  Timer tm;
+  dn_conv_desc d = {n, h, w, c0, c1, up0, cout, ks, stride, 1, c0, c1, cout, 1};
+  const int ho = (h + 2 * (ks / 2) - ks) / stride + 1, wo = (w + 2 * (ks / 2) - ks) / stride + 1;
+  const int h0 = up0 ? h / 2 : h, w0 = up0 ? w / 2 : w;
+  const size_t n0 = (size_t)n * h0 * w0 * c0, n1 = (size_t)n * h * w * c1, no = (size_t)n * ho * wo * cout;
+  float* s0 = dev_random(n0, 1.5f, true);
+  float* s1 = c1 ? dev_random(n1, 1.5f, true) : nullptr;
+  const int cin = c0 + c1;
+  const float wamp = sqrtf(6.f / (cin * ks * ks));
+  float* wt = dev_random((size_t)cout * cin * ks * ks, wamp);
+  float* sc = dev_random(cout, 0.5f, true); float* sh = dev_random(cout, 0.3f);
+  // scale in [0.75, 1.25]
+  { std::vector<float> hsc(cout); for (auto& x : hsc) x = 1.f + 0.25f * frand(); hipMemcpy(sc, hsc.data(), cout * 4, hipMemcpyHostToDevice); }
+  float *out_ref, *out_new;
+  HCK(hipMalloc(&out_ref, no * 4)); HCK(hipMalloc(&out_new, no * 4));
+  // ---- reference engine
+  float* pk_ref; HCK(hipMalloc(&pk_ref, dn_conv_packed_weight_floats(&d) * 4));
+  CK(dn_conv_pack_weights(&d, wt, pk_ref, 0));
+  CK(dn_conv2d(&d, s0, s1, pk_ref, sc, sh, out_ref, 0));
+  const float t_ref = tm.us([&] { dn_conv2d(&d, s0, s1, pk_ref, sc, sh, out_ref, 0); });
+  // ---- SP engine; weights pre-scaled by 2^8 with 2^-8 folded into the scale
+  void *sp0, *sp1 = nullptr, *spo, *pk;
+  HCK(hipMalloc(&sp0, dn_sp_tensor_bytes(n, h0, w0, c0)));
+  if (c1) HCK(hipMalloc(&sp1, dn_sp_tensor_bytes(n, h, w, c1)));
+  HCK(hipMalloc(&spo, dn_sp_tensor_bytes(n, ho, wo, cout)));
+  HCK(hipMemset(spo, 0xFF, dn_sp_tensor_bytes(n, ho, wo, cout)));   // NaN poison
+  HCK(hipMalloc(&pk, dn_spconv_packed_weight_bytes(&d)));
+  CK(dn_sp_from_nhwc(s0, n, h0, w0, c0, c0, sp0, 0));
+  if (c1) CK(dn_sp_from_nhwc(s1, n, h, w, c1, c1, sp1, 0));
+  const float wmul = 256.f;
+  CK(dn_spconv_pack_weights(&d, wt, wmul, pk, 0));
+  float* sc2; HCK(hipMalloc(&sc2, cout * 4));
+  { std::vector<float> hsc(cout); hipMemcpy(hsc.data(), sc, cout * 4, hipMemcpyDeviceToHost); for (auto& x : hsc) x /= wmul; hipMemcpy(sc2, hsc.data(), cout * 4, hipMemcpyHostToDevice); }
+  const double gf = 2.0 * n * ho * wo * cout * (double)cin * ks * ks / 1e9;
+  printf("%-30s %7.2f GF  ref %7.1f us (%6.1f TF) |", name, gf, t_ref, gf / t_ref * 1e3);
+  std::vector<int> cfgs = {-1};
+  if (!quick) {
+    if (ks == 1) cfgs.insert(cfgs.end(), {6, 7});
+    else if (stride == 2) cfgs.insert(cfgs.end(), {4, 5});
+    else cfgs.insert(cfgs.end(), {0, 1, 2, 3, 8, 9, 10});
+    if (g_mode == 2 && ks == 3 && stride == 1) cfgs.insert(cfgs.end(), {101, 102, 103, 104, 105, 201, 202, 203, 204, 205});
+  }
+  for (int cfg : cfgs) {
+    dn_spconv_force_config(cfg);
+    if (cfg >= 100) {   // ablation: timing only (results are garbage by construction)
+      if (cfg >= 200 && cout > 32 && 0) continue;
+      CK(dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, spo, 0));
+      const float t = tm.us([&] { dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, spo, 0); });
+      printf(" abl%d %6.1f us |", cfg, t);
+      continue;
+    }
+    HCK(hipMemset(spo, 0xFF, dn_sp_tensor_bytes(n, ho, wo, cout)));
+    CK(dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, spo, 0));
+    CK(dn_sp_to_nhwc(spo, n, ho, wo, cout, cout, out_new, 0));
+    HCK(hipDeviceSynchronize());
+    const double err = compare(out_new, out_ref, no, name);
+    const float t = tm.us([&] { dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, spo, 0); });
+    const bool ok = err < 2e-5;
+    if (!ok) ++g_fail;
+    printf(" %s %6.1f us %6.1f TF err %.1e%s |", cfg < 0 ? "auto" : kCfgName[cfg], t, gf / t * 1e3, err,
+           ok ? "" : " FAIL");
+  }
+  dn_spconv_force_config(-1);
+  printf("\n");
+  fflush(stdout);
+  hipFree(s0); hipFree(s1); hipFree(wt); hipFree(sc); hipFree(sh); hipFree(out_ref); hipFree(out_new);
+  hipFree(pk_ref); hipFree(sp0); hipFree(sp1); hipFree(spo); hipFree(pk); hipFree(sc2);
+}
+
+// fused 3x3 (cin -> 64) + 1x1 (64 -> c2): fp32 two-output form (heads) and SP form (conv1_2 + Conv3D)
+static void run_post(const char* name, int n, int h, int w, int cin, int c2, int split, bool f32) {
+  if (g_filter && !strstr(name, g_filter)) return;
+  Timer tm;
+  dn_conv_desc d = {n, h, w, cin, 0, 0, 64, 3, 1, 1, cin, 0, 64, 1};
+  dn_post1x1_desc p = {c2, f32 ? 0 : 1, split, split, c2 - split};
+  const size_t px = (size_t)n * h * w;
+  float* s0 = dev_random(px * cin, 1.5f, true);
+  float* wt = dev_random((size_t)64 * cin * 9, sqrtf(6.f / (cin * 9)));
+  float* w2 = dev_random((size_t)c2 * 64, sqrtf(6.f / 64));
+  float* sc = dev_random(64, 0.5f, true); float* sh = dev_random(64, 0.3f);
+  float* sc2 = dev_random(64, 0.5f, true); float* sh2 = dev_random(64, 0.3f);
+  { std::vector<float> v(64); for (auto& x : v) x = 1.f + 0.25f * frand(); hipMemcpy(sc, v.data(), 256, hipMemcpyHostToDevice);
+    for (auto& x : v) x = 1.f + 0.25f * frand(); hipMemcpy(sc2, v.data(), 256, hipMemcpyHostToDevice); }
+  float *ra, *rb = nullptr, *na, *nb = nullptr;
+  HCK(hipMalloc(&ra, px * split * 4)); HCK(hipMalloc(&na, px * split * 4));
+  if (split < c2) { HCK(hipMalloc(&rb, px * (c2 - split) * 4)); HCK(hipMalloc(&nb, px * (c2 - split) * 4)); }
+  float *pk_ref, *pk2_ref;
+  HCK(hipMalloc(&pk_ref, dn_conv_packed_weight_floats(&d) * 4)); HCK(hipMalloc(&pk2_ref, dn_post1x1_packed_floats() * 4));
+  CK(dn_conv_pack_weights(&d, wt, pk_ref, 0)); CK(dn_post1x1_pack_weights(w2, c2, 64, pk2_ref, 0));
+  CK(dn_conv2d_post1x1(&d, &p, s0, nullptr, pk_ref, sc, sh, pk2_ref, sc2, sh2, ra, rb, 0));
+  const float t_ref = tm.us([&] { dn_conv2d_post1x1(&d, &p, s0, nullptr, pk_ref, sc, sh, pk2_ref, sc2, sh2, ra, rb, 0); });
+  void *sp0, *pk, *pk2, *spo = nullptr;
+  HCK(hipMalloc(&sp0, dn_sp_tensor_bytes(n, h, w, cin))); CK(dn_sp_from_nhwc(s0, n, h, w, cin, cin, sp0, 0));
+  HCK(hipMalloc(&pk, dn_spconv_packed_weight_bytes(&d))); HCK(hipMalloc(&pk2, dn_sp_post1x1_packed_bytes()));
+  const float wmul = 64.f;
+  CK(dn_spconv_pack_weights(&d, wt, wmul, pk, 0)); CK(dn_sp_post1x1_pack_weights(w2, c2, 64, wmul, pk2, 0));
+  float *scs, *sc2s; HCK(hipMalloc(&scs, 256)); HCK(hipMalloc(&sc2s, 256));
+  { std::vector<float> v(64); hipMemcpy(v.data(), sc, 256, hipMemcpyDeviceToHost); for (auto& x : v) x /= wmul; hipMemcpy(scs, v.data(), 256, hipMemcpyHostToDevice);
+    hipMemcpy(v.data(), sc2, 256, hipMemcpyDeviceToHost); for (auto& x : v) x /= wmul; hipMemcpy(sc2s, v.data(), 256, hipMemcpyHostToDevice); }
+  double err;
+  float t;
+  if (f32) {
+    HCK(hipMemset(na, 0xFF, px * split * 4)); if (nb) HCK(hipMemset(nb, 0xFF, px * (c2 - split) * 4));
+    CK(dn_spconv2d_post1x1(&d, &p, sp0, nullptr, pk, scs, sh, pk2, sc2s, sh2, 1, na, nb, 0));
+    HCK(hipDeviceSynchronize());
+    err = compare(na, ra, px * split, name);
+    if (nb) err = fmax(err, compare(nb, rb, px * (c2 - split), name));
+    t = tm.us([&] { dn_spconv2d_post1x1(&d, &p, sp0, nullptr, pk, scs, sh, pk2, sc2s, sh2, 1, na, nb, 0); });
+  } else {
+    HCK(hipMalloc(&spo, dn_sp_tensor_bytes(n, h, w, c2))); HCK(hipMemset(spo, 0xFF, dn_sp_tensor_bytes(n, h, w, c2)));
+    CK(dn_spconv2d_post1x1(&d, &p, sp0, nullptr, pk, scs, sh, pk2, sc2s, sh2, 0, spo, nullptr, 0));
+    CK(dn_sp_to_nhwc(spo, n, h, w, c2, c2, na, 0));
+    HCK(hipDeviceSynchronize());
+    err = compare(na, ra, px * c2, name);
+    t = tm.us([&] { dn_spconv2d_post1x1(&d, &p, sp0, nullptr, pk, scs, sh, pk2, sc2s, sh2, 0, spo, nullptr, 0); });
+  }
+  const double gf = 2.0 * px * (64.0 * cin * 9 + (double)c2 * 64) / 1e9;
+  const bool ok = err < 2e-5;
+  if (!ok) ++g_fail;
+  printf("%-30s %7.2f GF  ref %7.1f us (%6.1f TF) | sp %6.1f us %6.1f TF err %.1e%s\n", name, gf, t_ref,
+         gf / t_ref * 1e3, t, gf / t * 1e3, err, ok ? "" : " FAIL");
+  fflush(stdout);
+  hipFree(s0); hipFree(wt); hipFree(w2); hipFree(sc); hipFree(sh); hipFree(sc2); hipFree(sh2); hipFree(ra); hipFree(rb);
+  hipFree(na); hipFree(nb); hipFree(pk_ref); hipFree(pk2_ref); hipFree(sp0); hipFree(pk); hipFree(pk2); hipFree(spo);
+  hipFree(scs); hipFree(sc2s);
+}
+
+static void roundtrip() {
+  const int n = 2, h = 20, w = 24, c = 45;
+  float* s = dev_random((size_t)n * h * w * c, 3.f);
+  void* sp; HCK(hipMalloc(&sp, dn_sp_tensor_bytes(n, h, w, c)));
+  float* back; HCK(hipMalloc(&back, (size_t)n * h * w * c * 4));
+  CK(dn_sp_from_nhwc(s, n, h, w, c, c, sp, 0)); CK(dn_sp_to_nhwc(sp, n, h, w, c, c, back, 0));
+  HCK(hipDeviceSynchronize());
+  const double err = compare(back, s, (size_t)n * h * w * c, "roundtrip");
+  printf("nhwc -> sp -> nhwc round trip (45 ch): rel err %.2e %s\n", err, err < 1e-6 ? "ok" : "FAIL");
+  if (!(err < 1e-6)) ++g_fail;
+}
+
+int main(int argc, char** argv) {
+  // sp_conv_check.bin [n_images] [layer-name filter | all] [tiles | auto | abl]
+  const int n = argc > 1 ? atoi(argv[1]) : 20;
+  if (argc > 2 && strcmp(argv[2], "all")) g_filter = argv[2];
+  if (argc > 3) g_mode = !strcmp(argv[3], "auto") ? 1 : !strcmp(argv[3], "abl") ? 2 : 0;
+  const bool quick = g_mode == 1;
+  printf("dn_version %d, %d images\n", dn_version(), n);
+  roundtrip();
+  // odd shapes first: ragged maps, channel counts that are not tile multiples
+  run_layer("ragged 3x3 40x72 48->80", 2, 40, 72, 48, 0, 0, 80, 3, 1, quick);
+  run_layer("ragged 3x3 s2 40x72 32->96", 2, 40, 72, 32, 0, 0, 96, 3, 2, quick);
+  run_layer("ragged 3x3 up+cat 24x40", 2, 24, 40, 32, 16, 1, 48, 3, 1, quick);
+  run_layer("ragged 1x1 24x40 64->96", 2, 24, 40, 64, 0, 0, 96, 1, 1, quick);
+  run_post("post f32 2x40x64 32->64->48", 2, 40, 64, 32, 48, 12, true);
+  run_post("post sp  2x40x64 64->64->64", 2, 40, 64, 64, 64, 64, false);
+  // the BASELINE layers
+  run_layer("conv_pre_2 256^2 32->32", n, 256, 256, 32, 0, 0, 32, 3, 1, quick);
+  run_layer("conv1_1 256^2 32->64 s2", n, 256, 256, 32, 0, 0, 64, 3, 2, quick);
+  run_layer("conv1_2 128^2 64->64", n, 128, 128, 64, 0, 0, 64, 3, 1, quick);
+  run_layer("conv2_1 128^2 64->128 s2", n, 128, 128, 64, 0, 0, 128, 3, 2, quick);
+  run_layer("conv2_2 64^2 128->128", n, 64, 64, 128, 0, 0, 128, 3, 1, quick);
+  run_layer("conv3d_2 64^2 128->128 1x1", n, 64, 64, 128, 0, 0, 128, 1, 1, quick);
+  run_layer("conv3_1 64^2 128->256 s2", n, 64, 64, 128, 0, 0, 256, 3, 2, quick);
+  run_layer("conv3_2 32^2 256->256", n, 32, 32, 256, 0, 0, 256, 3, 1, quick);
+  run_layer("conv4_1 32^2 256->512 s2", n, 32, 32, 256, 0, 0, 512, 3, 2, quick);
+  run_layer("conv4_2 16^2 512->512", n, 16, 16, 512, 0, 0, 512, 3, 1, quick);
+  run_layer("conv5_1 32^2 768->256 up+cat", n, 32, 32, 512, 256, 1, 256, 3, 1, quick);
+  run_layer("conv6_1 64^2 384->128 up+cat", n, 64, 64, 256, 128, 1, 128, 3, 1, quick);
+  run_layer("conv7_1 128^2 192->64 up+cat", n, 128, 128, 128, 64, 1, 64, 3, 1, quick);
+  run_layer("conv8_1 256^2 96->32 up+cat", n, 256, 256, 64, 32, 1, 32, 3, 1, quick);
+  run_layer("conv8_2 256^2 32->32", n, 256, 256, 32, 0, 0, 32, 3, 1, quick);
+  run_layer("mlp 1x1 32^2 256->256", n, 32, 32, 256, 0, 0, 256, 1, 1, quick);
+  run_post("heads 256^2 32->64->48 f32", n, 256, 256, 32, 48, 12, true);
+  run_post("conv1_2+3d 128^2 64->64->64", n, 128, 128, 64, 64, 64, false);
+  printf("%s (%d failures)\n", g_fail ? "SP CONV CHECK FAILED" : "SP CONV CHECK PASSED", g_fail);
+  return g_fail ? 1 : 0;
+}
