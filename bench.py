@@ -257,7 +257,11 @@ def main():
     n_img = AGENTS * BATCH
 
     def step():
-        bevs = ops.scatter_dense(indices, offsets, n_img, dims)
+        # dense rebuild of the batch (K1/a2) in the layout the conv engine of the chosen mode reads
+        if model.conv_math == "sp":
+            bevs = ops.scatter_dense_sp(indices, offsets, n_img, dims)
+        else:
+            bevs = ops.scatter_dense(indices, offsets, n_img, dims)
         with torch.no_grad():
             return model(bevs, trans, na, BATCH)
 

@@ -26,6 +26,7 @@
 // upstream:coperception/models/det/base/* (SURVEY.md §8 a3, a8, a9).
 #include "dn_internal.h"
 #include "sp_layout.h"
+#include <cstdlib>
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -58,14 +59,20 @@ struct SpArgs {
   const float* shift2;
   float* out_b;
   int c_out2, relu2, split2, ldo_a, ldo_b, post_f32;
+  int b_total;   // stationary form: bytes of the resident weight block (ngroups * NS * B_STEP)
+  int stg_row;   // floats per staged fp32 output row (POST, fp32 out)
 };
 
 struct TileCoord {
   int img, oy0, ox0, n0;
 };
 
+// BSTAT: weight-stationary form for short-K layers whose whole packed weight block fits the LDS
+// beside two patch stages (the full-resolution 32-/64-channel layers): the weights are loaded once
+// per workgroup, a step never waits for them, and the only barrier left is the one per 16-channel
+// chunk that hands over the patch stage.
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST>
+          int WTM, int WTN, int POST, int BSTAT = 0>
 struct SpTile {
   using P = sp::Patch<KS, STRIDE, TH, TW>;
   static constexpr int NW = WAVES_M * WAVES_N;
@@ -75,21 +82,34 @@ struct SpTile {
   static constexpr int SUB = CA * TG;           // (chunk, tap) sub-steps per step
   static constexpr int NPIX = P::NPIX;
   static constexpr int A_PIECES = CA * 4 * NPIX;
-  static constexpr int A_IT = (A_PIECES + NT - 1) / NT;
-  static constexpr int A_STAGE = A_IT * NT * 16;            // bytes
+  // streaming form: every wave issues the same number of DMA instructions per stage (counted
+  // vmcnt waits), so a stage is padded to whole rounds of NW instructions; stationary form:
+  // only patch DMAs are ever in flight (vmcnt(0) waits), a stage is padded to whole instructions
+  static constexpr int A_INSTR = BSTAT ? (A_PIECES + 63) / 64 : ((A_PIECES + NT - 1) / NT) * NW;
+  static constexpr int A_IT = (A_INSTR + NW - 1) / NW;
+  static constexpr int A_STAGE = A_INSTR * 1024;            // bytes
   static constexpr int B_PIECES = SUB * 4 * BN;
   static constexpr int B_IT = (B_PIECES + NT - 1) / NT;
   static constexpr int B_STAGE = B_IT * NT * 16;
+  static constexpr int B_STEP = B_PIECES * 16;              // stationary form: steps packed tight
+  static_assert(!BSTAT || B_STEP % 1024 == 0, "stationary weights: whole DMA instructions per step");
   static constexpr int RPG = 32 / TW;                       // tile rows per 32-pixel group
   static constexpr int W2_BYTES = POST ? 2 * 4 * 2 * 2 * 32 * 16 : 0;   // 16 KiB
-  static constexpr int STG_ROW = 68;                                    // floats, fp32 staging row
+  static constexpr int STG_ROW = 68;                                    // floats, fp32 staging row (max)
   static constexpr int STG_BYTES = POST ? NW * 32 * STG_ROW * 4 : 0;
   static constexpr int OFF_B = 2 * A_STAGE;
-  static constexpr int OFF_W2 = OFF_B + 2 * B_STAGE;
+  static constexpr int OFF_W2 = OFF_B + 2 * B_STAGE;        // streaming form (stationary: runtime)
   static constexpr int OFF_STG = OFF_W2 + W2_BYTES;
-  static constexpr int LDS_BYTES = OFF_STG + STG_BYTES;
-  static constexpr int OCC_LDS = 160 * 1024 / LDS_BYTES;
-  static constexpr int OCC_W = OCC_LDS < 1 ? 1 : (OCC_LDS > 3 ? 3 : OCC_LDS);
+  static constexpr int LDS_BYTES = BSTAT ? OFF_B + W2_BYTES : OFF_STG + STG_BYTES;   // stationary: + weights
+  // stationary form: LDS bytes for `nsteps` weight steps and (POST, fp32 out) staging rows of
+  // c_out2 + 4 floats
+  static constexpr int lds_stationary(int nsteps, int stg_row) {
+    return OFF_B + nsteps * B_STEP + W2_BYTES + (POST ? NW * 32 * stg_row * 4 : 0);
+  }
+  static constexpr int OCC_LDS = BSTAT ? (POST ? 1 : 2) : 160 * 1024 / LDS_BYTES;
+  // four accumulator tiles per wave + two fragment sets want > 168 VGPRs: at most 2 workgroups
+  static constexpr int OCC_MAX = WTM * WTN >= 4 ? 2 : 3;
+  static constexpr int OCC_W = OCC_LDS < 1 ? 1 : (OCC_LDS > OCC_MAX ? OCC_MAX : OCC_LDS);
   // waves per SIMD the launch bounds promise: NW / 4 per workgroup
   static constexpr int WPS = (OCC_W * NW + 3) / 4;
   static_assert(TAPS % TG == 0, "tap groups must divide the taps");
@@ -146,12 +166,12 @@ __device__ inline u32x4 gather_octet(u32x2 x, u32x2 y) {
 // 1 = no weight DMA after the first step, 2 = no patch DMA after the first group, 3 = neither,
 // 4 = no epilogue stores, 5 = 3 + operands from registers (pure MFMA stream).
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST, int ABL = 0>
+          int WTM, int WTN, int POST, int ABL = 0, int BSTAT = 0>
 __global__ void __launch_bounds__(
     (WAVES_M * WAVES_N * 64),
-    (SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST>::WPS))
+    (SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT>::WPS))
 conv_sp_kernel(const SpArgs a) {
-  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST>;
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT>;
   using P = typename T::P;
   constexpr bool kNoB = ABL == 1 || ABL == 3 || ABL == 5, kNoA = ABL == 2 || ABL == 3 || ABL == 5;
   constexpr bool kNoStore = ABL == 4, kNoLds = ABL == 5;
@@ -237,7 +257,7 @@ conv_sp_kernel(const SpArgs a) {
       const int cq = piece / NPIX, pp = piece % NPIX;   // cq = cu * 4 + q
       const int r = pp / P::PITCH, cc = sp::patch_col_of<KS, STRIDE, TH, TW>(pp % P::PITCH);
       const int iy = iy0 + r, ix = ix0 + cc;
-      const bool ok = piece < T::A_PIECES && cc >= 0 && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+      const bool ok = piece < T::A_PIECES && cc >= 0 && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;   // (piece % NPIX etc. of a pad piece are in range but meaningless: `ok` is false)
       const int sy = (!from1 && a.up0) ? (iy >> 1) : iy, sx = (!from1 && a.up0) ? (ix >> 1) : ix;
       voff_a[it] = ok ? (unsigned)cq * plane + (unsigned)(sy * ws + sx) * 16u : OOB;
     }
@@ -270,6 +290,7 @@ conv_sp_kernel(const SpArgs a) {
     unsigned char* base = smem + sa * T::A_STAGE + wave * 1024;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
+      if ((it + 1) * NW > T::A_INSTR && it * NW + wave >= T::A_INSTR) break;   // ragged last round (stationary)
       if (from1)
         dma16(rsrc1, base + it * NW * 1024, voff_a[it], soff);
       else
@@ -285,51 +306,76 @@ conv_sp_kernel(const SpArgs a) {
       dma16(rsrcw, base + it * NW * 1024, voff_b[it], soff);
   };
 
-  // ---- one step's MFMAs: stage sa of A, stage sb of B, taps ST * TG .. + TG - 1
-  auto compute = [&](auto st_c, int sa, int sb) {
-    constexpr int ST = decltype(st_c)::value;
-    const unsigned char* As = smem + sa * T::A_STAGE;
-    const unsigned char* Bs = smem + T::OFF_B + sb * T::B_STAGE;
-#pragma unroll
-    for (int u = 0; u < SUB; ++u) {
-      const int cu = u / TG, tap = ST * TG + u % TG;
-      const int toff = (cu * 4 * NPIX + sp::tap_offset<KS, STRIDE, TH, TW>(tap / KS, tap % KS)) * 16;
-      half8 ah[WTM], al[WTM], bh[WTN], bl[WTN];
+  // ---- MFMAs of sub-steps [U0, U0 + NU) of the tap sequence starting at tap T0: A fragments from
+  // the patch stage As, weights from Bs (sub-step u at Bs + u * 4 * BN * 16).  The fragments of
+  // sub-step u + 1 are read before the MFMAs of sub-step u are issued (two register sets).
+  auto compute = [&](auto t0_c, auto nu_c, const unsigned char* As, const unsigned char* Bs) {
+    constexpr int T0 = decltype(t0_c)::value, NU = decltype(nu_c)::value;
+    half8 ah[2][WTM], al[2][WTM], bh[2][WTN], bl[2][WTN];
+    auto load = [&](auto u_c) {
+      constexpr int u = decltype(u_c)::value;
+      constexpr int cu = (KS == 1) ? u : 0, tap = (KS == 1) ? 0 : T0 + u;
+      constexpr int toff = (cu * 4 * NPIX + sp::tap_offset<KS, STRIDE, TH, TW>(tap / KS, tap % KS)) * 16;
+      constexpr int s = u & 1;
       if constexpr (kNoLds) {
         const half8 k = {(_Float16)(li * 1e-3f), (_Float16)0.5f, (_Float16)-0.25f, (_Float16)lh, 0, 0, 0, 0};
 #pragma unroll
-        for (int wm = 0; wm < WTM; ++wm) ah[wm] = al[wm] = k;
+        for (int wm = 0; wm < WTM; ++wm) ah[s][wm] = al[s][wm] = k;
 #pragma unroll
-        for (int wn = 0; wn < WTN; ++wn) bh[wn] = bl[wn] = k;
+        for (int wn = 0; wn < WTN; ++wn) bh[s][wn] = bl[s][wn] = k;
       } else {
 #pragma unroll
         for (int wm = 0; wm < WTM; ++wm) {
-          ah[wm] = *reinterpret_cast<const half8*>(As + a_off[wm] + toff);
-          al[wm] = *reinterpret_cast<const half8*>(As + a_off[wm] + toff + 2 * NPIX * 16);
+          ah[s][wm] = *reinterpret_cast<const half8*>(As + a_off[wm] + toff);
+          al[s][wm] = *reinterpret_cast<const half8*>(As + a_off[wm] + toff + 2 * NPIX * 16);
         }
 #pragma unroll
         for (int wn = 0; wn < WTN; ++wn) {
-          bh[wn] = *reinterpret_cast<const half8*>(Bs + b_off[wn] + u * 4 * BN * 16);
-          bl[wn] = *reinterpret_cast<const half8*>(Bs + b_off[wn] + (u * 4 + 2) * BN * 16);
+          bh[s][wn] = *reinterpret_cast<const half8*>(Bs + b_off[wn] + u * 4 * BN * 16);
+          bl[s][wn] = *reinterpret_cast<const half8*>(Bs + b_off[wn] + (u * 4 + 2) * BN * 16);
         }
       }
+    };
+    auto mma = [&](auto u_c) {
+      constexpr int s = decltype(u_c)::value & 1;
       // D[i = channel][j = pixel]; small terms first; independent accumulators interleaved
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
         for (int wn = 0; wn < WTN; ++wn)
-          acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[wn], ah[wm], acc[wm][wn], 0, 0, 0);
+          acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s][wn], ah[s][wm], acc[wm][wn], 0, 0, 0);
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
         for (int wn = 0; wn < WTN; ++wn)
-          acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[wn], al[wm], acc[wm][wn], 0, 0, 0);
+          acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s][wn], al[s][wm], acc[wm][wn], 0, 0, 0);
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
         for (int wn = 0; wn < WTN; ++wn)
-          acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[wn], ah[wm], acc[wm][wn], 0, 0, 0);
-    }
+          acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s][wn], ah[s][wm], acc[wm][wn], 0, 0, 0);
+    };
+    load(std::integral_constant<int, 0>{});
+    auto body = [&](auto u_c) {
+      constexpr int u = decltype(u_c)::value;
+      // Fences pin "reads of sub-step u + 1, then the MFMAs of sub-step u": left alone, the
+      // scheduler sinks every read to just before its first use and the wave stalls on the LDS
+      // latency once per sub-step.
+      if constexpr (u + 1 < NU) load(std::integral_constant<int, u + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(u_c);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    body(std::integral_constant<int, 0>{});
+    if constexpr (NU > 1) body(std::integral_constant<int, 1>{});
+    if constexpr (NU > 2) body(std::integral_constant<int, 2>{});
+    if constexpr (NU > 3) body(std::integral_constant<int, 3>{});
+    if constexpr (NU > 4) body(std::integral_constant<int, 4>{});
+    if constexpr (NU > 5) body(std::integral_constant<int, 5>{});
+    if constexpr (NU > 6) body(std::integral_constant<int, 6>{});
+    if constexpr (NU > 7) body(std::integral_constant<int, 7>{});
+    if constexpr (NU > 8) body(std::integral_constant<int, 8>{});
+    static_assert(NU <= 9, "at most 9 sub-steps per compute call");
   };
 
   // ---- SP epilogue of a 32-pixel x 32-channel accumulator tile: channel tile index ct32 of the
@@ -379,7 +425,7 @@ conv_sp_kernel(const SpArgs a) {
       // ---- fused 1x1 stage.  This wave owns all 64 stage-1 channels of its pixels: after the
       // affine + ReLU + split, the permlane gather yields exactly the B-operand fragments
       // (lane (j, h): k = 16 ks + 8 h .. + 7) of stage 2 -- the tile never leaves the registers.
-      const unsigned char* W2 = smem + T::OFF_W2;
+      const unsigned char* W2 = smem + (BSTAT ? T::OFF_B + a.b_total : T::OFF_W2);
       f32x16 acc2[WTM][2];
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm) {
@@ -428,7 +474,9 @@ conv_sp_kernel(const SpArgs a) {
       } else {
         // fp32 NHWC, two outputs: columns [0, split2) -> out (ldo_a), the rest -> out_b (ldo_b).
         // Wave-local staging [32 px][STG_ROW] so that every store instruction is one contiguous run.
-        float* stg = reinterpret_cast<float*>(smem + T::OFF_STG) + wave * 32 * T::STG_ROW;
+        const int stg_row = BSTAT ? a.stg_row : T::STG_ROW;
+        float* stg = reinterpret_cast<float*>(smem + (BSTAT ? T::OFF_B + a.b_total + T::W2_BYTES : T::OFF_STG)) +
+                     wave * 32 * stg_row;
         const int nc4 = a.c_out2 >> 2, sp4 = a.split2 >> 2;
 #pragma unroll
         for (int wm = 0; wm < WTM; ++wm) {
@@ -445,7 +493,7 @@ conv_sp_kernel(const SpArgs a) {
                 if (a.relu2) v[e] = fmaxf(v[e], 0.f);
                 v[e] = co + e < a.c_out2 ? v[e] : 0.f;
               }
-              *reinterpret_cast<f32x4*>(&stg[li * T::STG_ROW + co]) = v;
+              if (co < stg_row - 4) *reinterpret_cast<f32x4*>(&stg[li * stg_row + co]) = v;
             }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -458,14 +506,14 @@ conv_sp_kernel(const SpArgs a) {
               const int m = idx / sp4, c4 = idx % sp4;
               if (tc.ox0 + m < a.w_out)
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (px0 + m) * a.ldo_a + 4 * c4) =
-                    *reinterpret_cast<const f32x4*>(&stg[m * T::STG_ROW + 4 * c4]);
+                    *reinterpret_cast<const f32x4*>(&stg[m * stg_row + 4 * c4]);
             }
             const int nb4 = nc4 - sp4;
             for (int idx = lane; idx < 32 * nb4; idx += 64) {
               const int m = idx / nb4, c4 = idx % nb4;
               if (tc.ox0 + m < a.w_out)
                 *reinterpret_cast<f32x4*>(a.out_b + (px0 + m) * a.ldo_b + 4 * c4) =
-                    *reinterpret_cast<const f32x4*>(&stg[m * T::STG_ROW + 4 * (sp4 + c4)]);
+                    *reinterpret_cast<const f32x4*>(&stg[m * stg_row + 4 * (sp4 + c4)]);
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -482,26 +530,78 @@ conv_sp_kernel(const SpArgs a) {
   if constexpr (POST != 0) {
     // stage-2 weights: one linear 16 KiB copy, resident for the whole launch
     for (int i = tid; i < T::W2_BYTES / 16; i += NT)
-      *reinterpret_cast<u32x4*>(smem + T::OFF_W2 + i * 16) = *reinterpret_cast<const u32x4*>(a.w2 + i * 16);
+      *reinterpret_cast<u32x4*>(smem + (BSTAT ? T::OFF_B + a.b_total : T::OFF_W2) + i * 16) =
+          *reinterpret_cast<const u32x4*>(a.w2 + i * 16);
     __syncthreads();
   }
   TileCoord cur = decode(item);
   setup_rsrc(cur);
-  setup_voff_b(cur);
-  setup_voff_a(cur, a.c0g == 0);
-  issue_b(0, 0, 0, false);
-  issue_a(0, 0, false);
-  int sa = 0, sb = 0;
-  bool a_pending = true;   // A DMAs issued after the B DMAs the next step waits for
-
-  while (true) {
+  auto zero_acc = [&]() {
 #pragma unroll
     for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
       for (int wn = 0; wn < WTN; ++wn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+  };
+  int sa = 0;
 
+  if constexpr (BSTAT != 0) {
+    // ---- weight-stationary form.  The whole weight block of this layer (one channel block:
+    // the launcher guarantees c_out <= BN) goes to LDS once; afterwards only patches move.
+    {
+      const int n_instr = a.b_total >> 10;
+      for (int i = wave; i < n_instr; i += NW) {
+        const int piece = i * 64 + lane;
+        const int step = piece / T::B_PIECES, rem = piece % T::B_PIECES;
+        const int u = rem / (4 * BN), q = (rem / BN) % 4, nn = rem % BN;
+        const int g = step / NS, st = step % NS, cu = u / TG, tl = u % TG;
+        const unsigned idx = (((g * CA + cu) * TAPS + st * TG + tl) * 4 + q) * a.cout_pad + cur.n0 + nn;
+        dma16(rsrcw, smem + T::OFF_B + i * 1024, idx * 16u, 0);
+      }
+    }
+    setup_voff_a(cur, false);
+    issue_a(0, 0, false);
+    while (true) {
+      zero_acc();
+      const bool has_next = item + G < a.total_items;
+      TileCoord nxt = cur;
+      if (has_next) nxt = decode(item + G);
+      for (int g = 0; g < a.ngroups; ++g) {
+        const bool last_g = g + 1 == a.ngroups;
+        wait_vm0();                      // this group's patch (first time: and the weights) has landed ...
+        __builtin_amdgcn_s_barrier();    // ... for every wave, and every wave is done with the other stage
+        asm volatile("" ::: "memory");
+        if (!last_g) {
+          if ((g + 1) * CA == a.c0g && a.c1g) setup_voff_a(cur, true);
+          issue_a(g + 1, sa ^ 1);
+        } else if (has_next) {
+          setup_rsrc(nxt);
+          setup_voff_a(nxt, false);
+          issue_a(0, sa ^ 1);
+        }
+        // all taps of the chunk back to back: nothing in LDS changes under them
+        compute(std::integral_constant<int, 0>{}, std::integral_constant<int, NS * SUB>{},
+                smem + sa * T::A_STAGE, smem + T::OFF_B + g * (NS * T::B_STEP));
+        sa ^= 1;
+      }
+      epilogue(cur);
+      if (!has_next) break;
+      item += G;
+      cur = nxt;
+    }
+    return;
+  }
+
+  setup_voff_b(cur);
+  setup_voff_a(cur, a.c0g == 0);
+  issue_b(0, 0, 0, false);
+  issue_a(0, 0, false);
+  int sb = 0;
+  bool a_pending = true;   // A DMAs issued after the B DMAs the next step waits for
+
+  while (true) {
+    zero_acc();
     const bool has_next = item + G < a.total_items;
     TileCoord nxt = cur;
     if (has_next) nxt = decode(item + G);
@@ -539,7 +639,8 @@ conv_sp_kernel(const SpArgs a) {
             a_pending = false;
           }
         }
-        compute(st_c, sa, sb);
+        compute(std::integral_constant<int, ST * TG>{}, std::integral_constant<int, SUB>{},
+                smem + sa * T::A_STAGE, smem + T::OFF_B + sb * T::B_STAGE);
         sb ^= 1;
       };
       step(std::integral_constant<int, 0>{});
@@ -689,7 +790,7 @@ enum SpCfgId { S3_256x64, S3_256x32, S3_128x64, S3_64x64, S3S2_128x64, S3S2_64x6
 inline int ca_of(SpCfgId id) { return id == S1_256x64 ? 2 : id == S1_64x64 ? 4 : 1; }
 struct SpCfg { SpCfgId id; int th, tw, bn; float bias; };
 // biases: measured time per unit of tile area relative to 256x64 (tools/sp_conv_check.hip sweep)
-float g_sp_bias[SP_CFG_COUNT] = {1.00f, 1.15f, 1.10f, 1.50f, 1.00f, 1.30f, 1.00f, 1.30f, 1.f, 1.f, 1.f, 1.2f};
+float g_sp_bias[SP_CFG_COUNT] = {1.00f, 1.15f, 1.10f, 1.40f, 1.45f, 1.00f, 1.00f, 1.30f, 1.f, 1.f, 1.f, 1.2f};
 const SpCfg kSpCfgs[SP_CFG_COUNT] = {
     {S3_256x64, 8, 32, 64, 0},   {S3_256x32, 8, 32, 32, 0},   {S3_128x64, 8, 16, 64, 0},
     {S3_64x64, 8, 8, 64, 0},     {S3S2_128x64, 8, 16, 64, 0}, {S3S2_64x64, 8, 8, 64, 0},
@@ -728,27 +829,36 @@ SpCfg select_cfg(const dn_conv_desc& d) {
 }
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST = 0, int ABL = 0>
+          int WTM, int WTN, int POST = 0, int ABL = 0, int BSTAT = 0>
 int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
-  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST>;
-  auto kern = conv_sp_kernel<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, ABL>;
-  // opt in to > 64 KiB of dynamic LDS; the attribute write is idempotent, so two first
-  // callers racing here only repeat it
-  static int occupancy = 0;
-  if (occupancy == 0) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
-    if (e != hipSuccess)
-      return dn::fail(DN_ERR_LAUNCH, "spconv: hipFuncSetAttribute(%d B LDS): %s", (int)T::LDS_BYTES,
-                      hipGetErrorString(e));
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, T::NT, T::LDS_BYTES) != hipSuccess || occ < 1)
-      occ = 1;
-    occupancy = occ > T::OCC_W ? T::OCC_W : occ;
-  }
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT>;
+  auto kern = conv_sp_kernel<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, ABL, BSTAT>;
   const int nchunks = a.c0g + a.c1g;
   DN_REQUIRE(nchunks % CA == 0, "spconv: chunk count %d not a multiple of %d", nchunks, CA);
   a.ngroups = nchunks / CA;
+  int lds_bytes = T::LDS_BYTES;
+  if (BSTAT) {
+    a.b_total = a.ngroups * T::NS * T::B_STEP;
+    a.stg_row = a.c_out2 + 4;
+    lds_bytes = T::lds_stationary(a.ngroups * T::NS, a.post_f32 ? a.stg_row : 0);
+    DN_REQUIRE(lds_bytes <= 160 * 1024 && d.c_out <= BN, "spconv: layer does not fit the weight-stationary form");
+  }
+  // opt in to > 64 KiB of dynamic LDS; the attribute write is idempotent, so two first
+  // callers racing here only repeat it
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       BSTAT ? 160 * 1024 : (int)T::LDS_BYTES);
+    if (e != hipSuccess)
+      return dn::fail(DN_ERR_LAUNCH, "spconv: hipFuncSetAttribute(%d B LDS): %s", (int)T::LDS_BYTES,
+                      hipGetErrorString(e));
+    attr_set = true;
+  }
+  // resident workgroups per CU: what the LDS admits, capped by the register budget the
+  // launch bounds were compiled for
+  int occupancy = 160 * 1024 / lds_bytes;
+  occupancy = occupancy < 1 ? 1 : (occupancy > T::OCC_W ? T::OCC_W : occupancy);
   a.tiles_x = (a.w_out + TW - 1) / TW;
   a.tiles_y = (a.h_out + TH - 1) / TH;
   const long total = (long)a.n_images * a.tiles_y * a.tiles_x * ((d.c_out + BN - 1) / BN);
@@ -757,8 +867,16 @@ int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   a.xcd_order = 1;
   const long resident = (long)occupancy * kCUs;
   dim3 grid((unsigned)(total > resident ? resident : total));
-  hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, grid, dim3(T::NT), lds_bytes, stream, a);
   return dn::check_launch("conv_sp_kernel");
+}
+
+// does the layer fit the weight-stationary form of tile <BN, TG> beside `wgs` workgroups per CU?
+inline bool fits_stationary(const dn_conv_desc& d, int bn, int a_stage, int extra, int wgs) {
+  if (d.ksize != 3 || d.stride != 1 || d.c_out > bn) return false;
+  const int nchunks = chunks_of(d.c0) + chunks_of(d.c1);
+  const int bytes = 2 * a_stage + nchunks * 9 * 4 * bn * 16 + extra;
+  return bytes * wgs <= 160 * 1024;
 }
 
 int fill_args(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed,
@@ -774,6 +892,7 @@ int fill_args(const dn_conv_desc* d, const void* src0, const void* src1, const v
   a.wpk_bytes = (int)((size_t)packed_chunks(*d) * d->ksize * d->ksize * 4 * a.cout_pad * 16);
   a.w2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out_b = nullptr;
   a.c_out2 = 0; a.relu2 = 0; a.split2 = 0; a.ldo_a = 0; a.ldo_b = 0; a.post_f32 = 0;
+  a.b_total = 0; a.stg_row = 0;
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   DN_REQUIRE(aligned16(src0) && aligned16(src1) && aligned16(packed) && aligned16(out),
              "spconv: tensors must be 16-byte aligned");
@@ -871,6 +990,14 @@ extern "C" int dn_spconv2d(const dn_conv_desc* d, const void* src0, const void* 
       default: break;
     }
   }
+  // weight-stationary forms (short-K full-resolution layers): two workgroups per CU
+  static const int stat_env = [] { const char* e = getenv("DN_SP_STATIONARY"); return e ? atoi(e) : 1; }();
+  if (stat_env && g_sp_force < 0) {
+    using T32 = SpTile<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 1>;
+    if (c.id == S3_256x32 && fits_stationary(*d, 32, T32::A_STAGE, 0, 2))
+      return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1>(a, *d, s);
+  }
+  if (g_sp_force == 12) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1>(a, *d, s);
   switch (c.id) {
     //                               KS S  TH TW  BN TG CA WM WN WTM WTN
     case S3_256x64:   return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2>(a, *d, s);
@@ -917,5 +1044,12 @@ extern "C" int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc*
   a.c_out2 = p->c_out2; a.relu2 = p->relu2; a.split2 = p->split; a.ldo_a = p->ldo_a; a.ldo_b = p->ldo_b;
   a.post_f32 = out_f32 ? 1 : 0;
   a.cog = chunks_of(p->c_out2);   // SP output: the second stage's channels
+  {
+    using TP = SpTile<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 1, 1>;
+    static const int stat_env = [] { const char* e = getenv("DN_SP_STATIONARY"); return e ? atoi(e) : 1; }();
+    const int extra = TP::W2_BYTES + (out_f32 ? TP::NW * 32 * (p->c_out2 + 4) * 4 : 0);
+    if (stat_env && g_sp_force != 0 && fits_stationary(*d, 64, TP::A_STAGE, extra, 1))
+      return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 1, 0, 1>(a, *d, (hipStream_t)stream);
+  }
   return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 1>(a, *d, (hipStream_t)stream);
 }

@@ -134,6 +134,28 @@ __global__ void scatter_dense_kernel(const int32_t* __restrict__ indices,
   }
 }
 
+// the same rebuild, straight into the split-planar layout of the conv engine (sp_layout.h):
+// occupancy 1.0 is the f16 0x3C00 in the hi plane of the voxel's z bin, its lo plane stays 0
+__global__ void scatter_dense_sp_kernel(const int32_t* __restrict__ indices,
+                                        const int32_t* __restrict__ offsets, int n_images, int total,
+                                        int dx, int dy, int dz, unsigned short* __restrict__ sp) {
+  const size_t hw = (size_t)dx * dy;
+  const int chunks = (dz + 15) / 16;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_images;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int ix = indices[3 * (size_t)i], iy = indices[3 * (size_t)i + 1],
+              iz = indices[3 * (size_t)i + 2];
+    if ((unsigned)ix < (unsigned)dx && (unsigned)iy < (unsigned)dy && (unsigned)iz < (unsigned)dz) {
+      const int cg = iz >> 4, oct = (iz >> 3) & 1, e = iz & 7;
+      sp[((((size_t)lo * chunks + cg) * 4 + oct) * hw + (size_t)ix * dy + iy) * 8 + e] = 0x3C00;
+    }
+  }
+}
+
 inline int ntiles_of(const int* dims) {
   const long ncell = (long)dims[0] * dims[1] * dims[2];
   return (int)((ncell + COMPACT_TILE - 1) / COMPACT_TILE);
@@ -204,4 +226,19 @@ extern "C" int dn_scatter_dense(const int32_t* indices, const int32_t* offsets, 
   hipLaunchKernelGGL(scatter_dense_kernel, dim3(blocks), dim3(256), 0, s, indices, offsets,
                      n_images, total, dims[0], dims[1], dims[2], dense);
   return dn::check_launch("scatter_dense_kernel");
+}
+
+extern "C" int dn_scatter_dense_sp(const int32_t* indices, const int32_t* offsets, int n_images,
+                                   int total, const int* dims, void* dense_sp, void* stream) {
+  DN_REQUIRE(dims && dense_sp && offsets, "scatter_dense_sp: null pointer");
+  DN_REQUIRE(n_images > 0 && total >= 0 && (total == 0 || indices), "scatter_dense_sp: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t bytes = (size_t)n_images * ((dims[2] + 15) / 16) * 4 * dims[0] * dims[1] * 16;
+  hipError_t e = hipMemsetAsync(dense_sp, 0, bytes, s);
+  if (e != hipSuccess) return dn::fail(DN_ERR_LAUNCH, "scatter_dense_sp: memset: %s", hipGetErrorString(e));
+  if (total == 0) return DN_OK;
+  const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+  hipLaunchKernelGGL(scatter_dense_sp_kernel, dim3(blocks), dim3(256), 0, s, indices, offsets, n_images,
+                     total, dims[0], dims[1], dims[2], (unsigned short*)dense_sp);
+  return dn::check_launch("scatter_dense_sp_kernel");
 }

@@ -390,6 +390,8 @@ class DiscoNet(nn.Module):
     # forward
     # ------------------------------------------------------------------
     def _enc_input(self, bevs):
+        if isinstance(bevs, ops.SpTensor):      # ops.scatter_dense_sp: already in the engine's layout
+            return bevs
         n = bevs.shape[0] * bevs.shape[1]
         h, w, z = bevs.shape[2], bevs.shape[3], bevs.shape[4]
         # [A*B, 1, H, W, Z] is already NHWC with Z as the channel: the reference's
@@ -474,6 +476,9 @@ class DiscoNet(nn.Module):
             raise ops._lib.DnError("DiscoNet.forward needs GPU tensors; there is no CPU path")
         if self.training:
             from .train import train_forward
+            if isinstance(bevs, ops.SpTensor):
+                n, h, w, z = bevs.shape
+                bevs = bevs.nhwc().view(n, 1, h, w, z)
             return train_forward(self, bevs, trans_matrices, num_agent_tensor, batch_size)
         P = self._get_plan()
         A = self.agent_num

@@ -290,6 +290,19 @@ def sp_conv2d_post1x1(d, src0, packed, scale, shift, packed2, scale2, shift2, c_
     return out_a, out_b
 
 
+def scatter_dense_sp(indices, offsets, n_images, dims):
+    """Batched dense rebuild straight into the conv engine's layout: -> SpTensor [n_images, X, Y, Z]
+    (what DiscoNet.forward accepts in place of the float32 bevs tensor)."""
+    _need_gpu(indices, offsets)
+    if indices.dtype != torch.int32 or offsets.dtype != torch.int32:
+        raise _lib.DnError("scatter_dense_sp needs int32 indices/offsets")
+    d = (ctypes.c_int * 3)(*[int(v) for v in dims])
+    out = SpTensor(n_images, int(dims[0]), int(dims[1]), int(dims[2]), device=indices.device)
+    check(_lib.load().dn_scatter_dense_sp(_ptr(indices), _ptr(offsets), n_images, indices.shape[0], d,
+                                          _ptr(out.data), _stream()), "dn_scatter_dense_sp")
+    return out
+
+
 def pack_post1x1_weights(weight):
     """weight [c_out2, c_in2(, 1, 1)] -> packed split-f16 rows for dn_conv2d_post1x1."""
     _need_gpu(weight)

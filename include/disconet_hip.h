@@ -69,6 +69,10 @@ int dn_voxel_compact(const float* dense, const int* dims_host, int32_t* indices,
  * offsets[g]..offsets[g+1] of indices[.][3]; dense[g][X][Y][Z] = 1 there, else 0. */
 int dn_scatter_dense(const int32_t* indices, const int32_t* offsets, int n_images,
                      int n_indices_total, const int* dims_host, float* dense, void* stream);
+/* The same rebuild written in the conv engine's split-planar layout (see "SP tensor" below):
+ * dense_sp is the SP tensor [n_images][ceil(Z/16)][4][X][Y] x 16 bytes of the bevs batch. */
+int dn_scatter_dense_sp(const int32_t* indices, const int32_t* offsets, int n_images,
+                        int n_indices_total, const int* dims_host, void* dense_sp, void* stream);
 
 /* ------------------------------------------------------------------------
  * K2/K3/K7 -- implicit-GEMM convolution on fp32 MFMA with fused

@@ -77,3 +77,21 @@ def test_full_size_properties():
     assert bevs.shape == (5, 1, 256, 256, 13)
     for a in range(5):
         assert torch.equal(bevs[a, 0], denses[a])
+
+
+def test_scatter_dense_sp_matches_dense():
+    """the split-planar rebuild is bit for bit the dense rebuild: 1.0 -> (hi 1.0, lo 0), and the
+    conversion kernel of the dense grid gives the same bytes (padding channels 13..15 zero)"""
+    from disconet_amd.synthetic import make_sparse_scene_batch
+    ops = _ops()
+    indices, offsets, _ = make_sparse_scene_batch(2, 3, 128)
+    indices, offsets = indices.cuda(), offsets.cuda()
+    dims = (128, 128, 13)
+    dense = ops.scatter_dense(indices, offsets, 6, dims)
+    sp = ops.scatter_dense_sp(indices, offsets, 6, dims)
+    assert sp.shape == (6, 128, 128, 13) and sp.data.shape == (6, 1, 4, 128, 128, 8)
+    assert torch.equal(sp.nhwc(), dense.view(6, 128, 128, 13))
+    assert torch.equal(sp.data, ops.SpTensor.from_nhwc(dense.view(6, 128, 128, 13)).data)
+    # empty batch entry / no voxels at all
+    empty = ops.scatter_dense_sp(indices[:0], torch.zeros(3, dtype=torch.int32, device="cuda"), 2, dims)
+    assert float(empty.data.float().abs().sum()) == 0.0

@@ -60,7 +60,7 @@ static int g_fail = 0;
 
 // names of conv_sp.hip's tile menu
 static const char* kCfgName[] = {"256x64", "256x32", "128x64", "64x64", "s2_128x64", "s2_64x64", "p256x64", "p64x64",
-                                 "256x64/T9", "512x64", "256x128"};
+                                 "256x64/T9", "512x64", "256x128", "p256x64/C1", "256x32/stat"};
 static const char* g_filter = nullptr;   // substring of the layer name
 static int g_mode = 0;                   // 0 = every tile, 1 = automatic selection only, 2 = + ablations
 
@@ -106,7 +106,7 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
   if (!quick) {
     if (ks == 1) cfgs.insert(cfgs.end(), {6, 7});
     else if (stride == 2) cfgs.insert(cfgs.end(), {4, 5});
-    else cfgs.insert(cfgs.end(), {0, 1, 2, 3, 8, 9, 10});
+    else cfgs.insert(cfgs.end(), {0, 1, 2, 3, 8, 9, 10, 12});
     if (g_mode == 2 && ks == 3 && stride == 1) cfgs.insert(cfgs.end(), {101, 102, 103, 104, 105, 201, 202, 203, 204, 205});
   }
   for (int cfg : cfgs) {
@@ -119,7 +119,10 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
       continue;
     }
     HCK(hipMemset(spo, 0xFF, dn_sp_tensor_bytes(n, ho, wo, cout)));
-    CK(dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, spo, 0));
+    if (dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, spo, 0) != 0) {   // a forced tile that does not apply
+      printf(" %s n/a |", cfg < 0 ? "auto" : kCfgName[cfg]);
+      continue;
+    }
     CK(dn_sp_to_nhwc(spo, n, ho, wo, cout, cout, out_new, 0));
     HCK(hipDeviceSynchronize());
     const double err = compare(out_new, out_ref, no, name);
