@@ -30,6 +30,11 @@ class Post1x1Desc(Structure):
     _fields_ = [(n, c_int32) for n in ("c_out2", "relu2", "split", "ldo_a", "ldo_b")]
 
 
+class FuseMlpParams(Structure):
+    """struct dn_fuse_mlp_params"""
+    _fields_ = [(n, c_void_p) for n in ("packed", "s1", "t1", "s2", "t2", "s3", "t3", "w4", "b4")]
+
+
 class MlpTailParams(Structure):
     """struct dn_mlp_tail_params"""
     _fields_ = [(n, c_void_p) for n in (
@@ -77,6 +82,13 @@ SIGNATURES = {
     "dn_disco_fuse_tail": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    POINTER(MlpTailParams), c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dn_fuse_mlp_supported": (c_int, [c_int]),
+    "dn_fuse_mlp_packed_bytes": (c_size_t, [c_int]),
+    "dn_fuse_mlp_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p,
+                                 c_void_p]),
+    "dn_disco_fuse_mlp": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(FuseMlpParams), c_int, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
     # ---- include/disconet_train.h ----
     "dn_conv_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "dn_conv_wgrad": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1,0 +1,442 @@
+// K5 + K6 in one launch: the whole per-pixel pairwise attention MLP of the DiscoGraph fusion
+// (2C -> 128 -> 32 -> 8 -> 1), the exp / sum softmax over the agents of a scene and the weighted
+// sum of the (warped) neighbour maps -- lanes over PIXELS, every layer on the f16 MFMA (split-f16
+// x3, fp32 accumulate, the conv engine's arithmetic), the activations of all four layers in
+// registers from the first operand load to the last store.
+//
+// Replaces the chain  dn_conv2d(mlp_g) -> dn_conv2d(mlp_f) -> dn_disco_fuse_tail -> dn_sp_from_nhwc
+// (g and fw, 63 MB per step, are never materialised; the maps are read where they lie).
+//
+// One WAVE owns 32 consecutive pixels of one (sample, ego).  Lane (j, h) holds, of pixel j, the
+// channels {16 ks + 8 h + e}: exactly the B-operand fragment of v_mfma_f32_32x32x16_f16, so an
+// NHWC row piece of 8 floats becomes an MFMA operand with one split and no LDS transpose.  Layer
+// outputs come back as D[i = unit][j = pixel] with lane (j, h) holding units 8g + 4h + e; two
+// v_permlane32_swap per register pair turn them into the next layer's B fragments (the trick of
+// conv_sp.hip's fused 1x1 stage).  Weights are read as A-operand fragments straight from L2.
+//
+//   pass 1, per neighbour k (ego first, then j ascending, as the reference's list):
+//     acc = W1_ego . x_ego (once)  +  W1_nbr . y_k ;  h1 = relu(bn1(acc + b1)) ; h2, h3 likewise;
+//     s_k = relu(w4 . h3 + b4) ;  e_k = exp(s_k)                       (no max-shift, as upstream)
+//   pass 2:  w_k = e_k / sum_k e_k ;  fused = sum_k w_k * y_k   (fp32, list order; y_k re-read: the
+//     rows were read microseconds ago and sit in L2), written as split-planar pieces for the decoder
+//     and/or as fp32 NHWC rows.
+//
+// Replaces PixelWeightedFusionSoftmax.forward and the fusion loop body of
+// upstream:coperception/models/det/DiscoNet.py :: DiscoNet.forward (Appx A.5).
+#include "dn_internal.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int MAX_AGENTS = 8;
+constexpr size_t kW2Bytes = 8 * 2 * 2 * 32 * 16, kW3Bytes = 2 * 2 * 2 * 32 * 16;
+constexpr int FUSE_G = 3;   // list slots per layer-1 pass: 3 accumulator sets (192 AGPRs) is what hipcc allocates without spilling
+
+struct FuseMlpArgs {
+  const float* feat;
+  const float* warped;
+  const int32_t* num_agent;
+  const unsigned char* w1;   // [mat 2 (ego, nbr)][nt 4][ks C/16][part 2][h 2][row 32] x 16 B
+  const unsigned char* w2;   // [ks 8][part 2][h 2][row 32] x 16 B   (32 x 128)
+  const unsigned char* w3;   // [ks 2][part 2][h 2][row 32] x 16 B   (8 x 32, rows 8..31 zero)
+  const float *s1, *t1, *s2, *t2, *s3, *t3, *w4, *b4;
+  unsigned char* fused_sp;
+  float* fused_nhwc;
+  float* weights_out;
+  int batch, agents, hw, only_v2i, ego_first, ego_count, tiles;
+};
+
+__device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+  half4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
+    h[e] = (_Float16)x;
+    l[e] = (_Float16)(x - (float)h[e]);
+  }
+  hi = __builtin_bit_cast(u32x2, h);
+  lo = __builtin_bit_cast(u32x2, l);
+}
+
+// lanes (j, 0) / (j, 1) hold units 4h..4h+3 of octet X (x) and of octet Y (y) -> lane (j, 0) gets
+// octet X complete, lane (j, 1) octet Y complete
+__device__ inline u32x4 gather_octet(u32x2 x, u32x2 y) {
+  const auto s0 = __builtin_amdgcn_permlane32_swap(x[0], y[0], false, false);
+  const auto s1 = __builtin_amdgcn_permlane32_swap(x[1], y[1], false, false);
+  return u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
+
+__device__ inline half8 frag_of(const unsigned char* base, int idx) {
+  return *reinterpret_cast<const half8*>(base + (size_t)idx * 16);
+}
+
+// G = neighbour-list slots processed together: the layer-1 weight fragments of a k-step are read
+// once per group (they are the kernel's L2 traffic: 128 KB per pass at C = 256) and each slot adds
+// 12 MFMAs behind them, which is what hides the fragment loads' latency.  One wave per workgroup:
+// G accumulator sets of 64 registers need the whole 512-entry register file of a SIMD lane.
+template <int C, int G>
+__global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs a) {
+  constexpr int KS = C / 16;
+  __shared__ float ek_s[MAX_AGENTS][64];   // exp(s_k) of this wave's pixels, per list slot
+  __shared__ float e_s[64][64];            // layer-1 ego term of this wave's pixels: [reg][lane]
+  __shared__ int jl_s[MAX_AGENTS];         // agent of each list slot (slot 0 = the ego)
+  // layers 2-4: weight fragments and affines, read by every tail() -- LDS-resident (an L2 round
+  // trip per dependent stage of the tail was ~40 % of the kernel)
+  __shared__ __attribute__((aligned(16))) unsigned char w23_s[kW2Bytes + kW3Bytes];
+  __shared__ __attribute__((aligned(16))) float aff_s[2 * 128 + 2 * 32 + 3 * 8];   // s1 t1 s2 t2 s3 t3 w4
+
+  const int lane = threadIdx.x;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wid = blockIdx.x;
+  const int tile = wid % a.tiles, il = (wid / a.tiles) % a.ego_count, b = wid / (a.tiles * a.ego_count);
+  const int i = a.ego_first + il;
+  const int p = tile * 32 + li;
+  const bool pvalid = p < a.hw;
+  const int pc = pvalid ? p : a.hw - 1;
+  int live = a.num_agent[b];
+  live = live < a.agents ? live : a.agents;            // never index past the agents that exist
+  const size_t oimg = (size_t)il * a.batch + b;
+
+  const float* xrow = a.feat + (((size_t)i * a.batch + b) * a.hw + pc) * C + 8 * lh;
+  auto yrow_of = [&](int j) {
+    const int jj = j - (j > i ? 1 : 0);
+    return a.warped + ((((size_t)b * a.ego_count + il) * (a.agents - 1) + jj) * a.hw + pc) * C + 8 * lh;
+  };
+
+  // ---- store helpers: this lane's 8 channels of k-step ks
+  auto store_piece = [&](int ks, const f32x4 v0, const f32x4 v1) {
+    if (!pvalid) return;
+    if (a.fused_sp) {
+      u32x2 h0, l0, h1, l1;
+      split4(v0, h0, l0);
+      split4(v1, h1, l1);
+      const size_t plane = (size_t)a.hw * 16;
+      unsigned char* o = a.fused_sp + ((oimg * KS + ks) * 4 + lh) * plane + (size_t)p * 16;
+      *reinterpret_cast<u32x4*>(o) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+      *reinterpret_cast<u32x4*>(o + 2 * plane) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    }
+    if (a.fused_nhwc) {
+      float* o = a.fused_nhwc + (oimg * a.hw + p) * C + 16 * ks + 8 * lh;
+      *reinterpret_cast<f32x4*>(o) = v0;
+      *reinterpret_cast<f32x4*>(o + 4) = v1;
+    }
+  };
+
+  if (i < live) {
+    for (int q = lane; q < (int)((kW2Bytes + kW3Bytes) / 16); q += 64)   // w3 follows w2 in the packed block
+      *reinterpret_cast<u32x4*>(w23_s + q * 16) = *reinterpret_cast<const u32x4*>(a.w2 + (size_t)q * 16);
+    for (int q = lane; q < 128; q += 64) { aff_s[q] = a.s1[q]; aff_s[128 + q] = a.t1[q]; }
+    if (lane < 32) { aff_s[256 + lane] = a.s2[lane]; aff_s[288 + lane] = a.t2[lane]; }
+    if (lane < 8) { aff_s[320 + lane] = a.s3[lane]; aff_s[328 + lane] = a.t3[lane]; aff_s[336 + lane] = a.w4[lane]; }
+  }
+  const unsigned char* w2l = w23_s;
+  const unsigned char* w3l = w23_s + kW2Bytes;
+  const float *s1l = aff_s, *t1l = aff_s + 128, *s2l = aff_s + 256, *t2l = aff_s + 288, *s3l = aff_s + 320,
+              *t3l = aff_s + 328, *w4l = aff_s + 336;
+
+  if (i >= live) {   // padded agent: its map passes through un-fused
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      store_piece(ks, *reinterpret_cast<const f32x4*>(xrow + 16 * ks),
+                  *reinterpret_cast<const f32x4*>(xrow + 16 * ks + 4));
+    return;
+  }
+
+  // neighbour list, in the reference's order: the ego, then j ascending
+  int n = 1;
+  jl_s[0] = i;
+  for (int j = 0; j < live; ++j)
+    if (j != i && (!a.only_v2i || i == 0 || j == 0)) jl_s[n++] = j;
+  auto row_of = [&](int k) { return k == 0 ? xrow : yrow_of(jl_s[k]); };
+
+  auto frag_from = [&](const f32x4 v0, const f32x4 v1, half8& fh, half8& fl) {
+    u32x2 h0, l0, h1, l1;
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    fh = __builtin_bit_cast(half8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+    fl = __builtin_bit_cast(half8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+  };
+
+  // ---- layer 1 for NG rows at once: acc[g][nt] += W[mat][nt] . row_g.  The k loop runs two k-steps
+  // per trip (never unrolled as a whole: hipcc would hoist every fragment load and spill) with the
+  // next step's weight fragments and row pieces in flight under the current step's MFMAs.
+  auto layer1 = [&](auto ng_c, const float* const (&rows)[G], int cnt, int mat, f32x16 (&acc)[G][4]) {
+    constexpr int NG = decltype(ng_c)::value;
+    const unsigned char* wbase = a.w1 + (size_t)mat * 4 * KS * 2 * 2 * 32 * 16 + (size_t)(lh * 32 + li) * 16;
+    // fragment (nt, ks, part) at wbase + (((nt * KS + ks) * 2 + part) * 64) * 16
+    half8 wh[2][4], wl[2][4];
+    f32x4 r0[4][NG], r1[4][NG];   // row pieces: ring of 4 k-steps (the maps come from HBM / far L2)
+    auto wload = [&](int ks, int s) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        wh[s][nt] = *reinterpret_cast<const half8*>(wbase + (size_t)(((nt * KS + ks) * 2 + 0) * 64) * 16);
+        wl[s][nt] = *reinterpret_cast<const half8*>(wbase + (size_t)(((nt * KS + ks) * 2 + 1) * 64) * 16);
+      }
+    };
+    auto rload = [&](int ks, int s) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (g < cnt) {
+          r0[s][g] = *reinterpret_cast<const f32x4*>(rows[g] + 16 * ks);
+          r1[s][g] = *reinterpret_cast<const f32x4*>(rows[g] + 16 * ks + 4);
+        }
+    };
+    auto mma = [&](int sw, int sr) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (g < cnt) {
+          half8 fh, fl;
+          frag_from(r0[sr][g], r1[sr][g], fh, fl);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[sw][nt], fh, acc[g][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sw][nt], fl, acc[g][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sw][nt], fh, acc[g][nt], 0, 0, 0);
+        }
+    };
+    static_assert(KS % 4 == 0, "k loop runs four k-steps per trip");
+    rload(0, 0);
+    rload(1, 1);
+    rload(2, 2);
+    wload(0, 0);
+#pragma unroll 1
+    for (int ks0 = 0; ks0 < KS; ks0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ks = ks0 + u;
+        if (ks + 3 < KS) rload(ks + 3, (u + 3) & 3);
+        if (ks + 1 < KS) wload(ks + 1, (u + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(u & 1, u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // ---- layers 2-4 on acc (= E + F_k) -> exp(s)
+  auto tail = [&](f32x16 (&acc)[4]) -> float {
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      u32x2 hi[4], lo[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int u = nt * 32 + 8 * g + 4 * lh;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(s1l + u), sh = *reinterpret_cast<const f32x4*>(t1l + u);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[nt][4 * g + e] * sc[e] + sh[e], 0.f);
+        split4(v, hi[g], lo[g]);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int ks = nt * 2 + m;
+        const half8 xh = __builtin_bit_cast(half8, gather_octet(hi[2 * m], hi[2 * m + 1]));
+        const half8 xl = __builtin_bit_cast(half8, gather_octet(lo[2 * m], lo[2 * m + 1]));
+        const half8 wh = frag_of(w2l, ((ks * 2 + 0) * 2 + lh) * 32 + li), wl = frag_of(w2l, ((ks * 2 + 1) * 2 + lh) * 32 + li);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc2, 0, 0, 0);
+      }
+    }
+    f32x16 acc3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+    {
+      u32x2 hi[4], lo[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int u = 8 * g + 4 * lh;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(s2l + u), sh = *reinterpret_cast<const f32x4*>(t2l + u);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc2[4 * g + e] * sc[e] + sh[e], 0.f);
+        split4(v, hi[g], lo[g]);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const half8 xh = __builtin_bit_cast(half8, gather_octet(hi[2 * m], hi[2 * m + 1]));
+        const half8 xl = __builtin_bit_cast(half8, gather_octet(lo[2 * m], lo[2 * m + 1]));
+        const half8 wh = frag_of(w3l, ((m * 2 + 0) * 2 + lh) * 32 + li), wl = frag_of(w3l, ((m * 2 + 1) * 2 + lh) * 32 + li);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc3, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc3, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc3, 0, 0, 0);
+      }
+    }
+    // units 0..7 of layer 3: register quad 0 of lane (j, h) = units 4h..4h+3
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(s3l + 4 * lh), sh = *reinterpret_cast<const f32x4*>(t3l + 4 * lh);
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(w4l + 4 * lh);
+    float part = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part += fmaxf(acc3[e] * sc[e] + sh[e], 0.f) * w4[e];
+    // the other four units sit in lane (j, 1 - h); the sum is taken in unit order 0..7 on both lanes
+    const float other = __shfl_xor(part, 32, 64);
+    const float s = fmaxf((lh ? other + part : part + other) + a.b4[0], 0.f);
+    return expf(s);
+  };
+
+  // ---- pass 1a: E = W1_ego . x_ego, parked in LDS between the groups ([reg][lane])
+  {
+    f32x16 acc[G][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][nt][r] = 0.f;
+    const float* rows[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) rows[g] = xrow;
+    layer1(std::integral_constant<int, 1>{}, rows, 1, 0, acc);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) e_s[nt * 16 + r][lane] = acc[0][nt][r];
+  }
+  // ---- pass 1b: scores of the list, G slots at a time
+  for (int g0 = 0; g0 < n; g0 += G) {
+    const int cnt = n - g0 < G ? n - g0 : G;
+    f32x16 acc[G][4];
+    const float* rows[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      rows[g] = row_of(g0 + g < n ? g0 + g : 0);
+      if (g < cnt) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[g][nt][r] = e_s[nt * 16 + r][lane];
+      }
+    }
+    layer1(std::integral_constant<int, G>{}, rows, cnt, 1, acc);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      if (g < cnt) ek_s[g0 + g][lane] = tail(acc[g]);
+  }
+  float den = 0.f;
+  for (int k = 0; k < n; ++k) den += ek_s[k][lane];
+
+  // ---- pass 2: weighted sum in list order; the next slot's row is in flight under the FMAs
+  f32x4 f0[KS], f1[KS], y0[2][KS], y1[2][KS];
+  auto yload = [&](int k, int s) {
+    const float* row = row_of(k);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      y0[s][ks] = *reinterpret_cast<const f32x4*>(row + 16 * ks);
+      y1[s][ks] = *reinterpret_cast<const f32x4*>(row + 16 * ks + 4);
+    }
+  };
+  auto yacc = [&](int k, int s) {
+    const float w = ek_s[k][lane] / den;
+    if (a.weights_out && pvalid && lh == 0)
+      a.weights_out[(((size_t)b * a.ego_count + il) * a.agents + k) * a.hw + p] = w;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f0[ks] += y0[s][ks] * w;
+      f1[ks] += y1[s][ks] * w;
+    }
+  };
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) f0[ks] = f1[ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+  yload(0, 0);
+  for (int k = 0; k < n; k += 2) {
+    if (k + 1 < n) yload(k + 1, 1);
+    yacc(k, 0);
+    if (k + 1 < n) {
+      if (k + 2 < n) yload(k + 2, 0);
+      yacc(k + 1, 1);
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) store_piece(ks, f0[ks], f1[ks]);
+}
+
+// weights [rows][cols] * wmul -> A-operand fragments [nt][ks][part][h][32 rows] x 16 B (rows / cols
+// past the matrix are zero); `col0` = first column of the source matrix (row stride ld)
+__global__ void pack_frags_kernel(const float* __restrict__ w, int ld, int col0, int rows, int cols,
+                                  int n_tiles, int ksteps, float wmul, unsigned char* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (nt, ks, h, row)
+  if (idx >= n_tiles * ksteps * 2 * 32) return;
+  const int row = idx % 32, h = (idx / 32) % 2, ks = (idx / 64) % ksteps, nt = idx / (64 * ksteps);
+  half8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int r = nt * 32 + row, c = ks * 16 + h * 8 + e;
+    float v = (r < rows && c < cols) ? w[(size_t)r * ld + col0 + c] * wmul : 0.f;
+    v = fminf(fmaxf(v, -65504.f), 65504.f);
+    hi[e] = (_Float16)v;
+    lo[e] = (_Float16)(v - (float)hi[e]);
+  }
+  *reinterpret_cast<half8*>(out + (size_t)((((nt * ksteps + ks) * 2 + 0) * 2 + h) * 32 + row) * 16) = hi;
+  *reinterpret_cast<half8*>(out + (size_t)((((nt * ksteps + ks) * 2 + 1) * 2 + h) * 32 + row) * 16) = lo;
+}
+
+inline size_t w1_bytes(int c) { return (size_t)2 * 4 * (c / 16) * 2 * 2 * 32 * 16; }
+
+}  // namespace
+
+extern "C" int dn_fuse_mlp_supported(int c) { return c == 64 || c == 128 || c == 256; }
+
+extern "C" size_t dn_fuse_mlp_packed_bytes(int c) { return w1_bytes(c) + kW2Bytes + kW3Bytes; }
+
+extern "C" int dn_fuse_mlp_pack(const float* w1, const float* w2, const float* w3, int c, float wmul1,
+                                float wmul2, float wmul3, void* packed, void* stream) {
+  DN_REQUIRE(w1 && w2 && w3 && packed, "fuse_mlp pack: null pointer");
+  DN_REQUIRE(dn_fuse_mlp_supported(c), "fuse_mlp pack: %d channels unsupported (64, 128 or 256)", c);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* out = (unsigned char*)packed;
+  const int ks = c / 16;
+  // W1 [128][2C] = [W_ego | W_nbr]
+  for (int mat = 0; mat < 2; ++mat)
+    hipLaunchKernelGGL(pack_frags_kernel, dim3((4 * ks * 64 + 255) / 256), dim3(256), 0, s, w1, 2 * c, mat * c,
+                       128, c, 4, ks, wmul1, out + (size_t)mat * (w1_bytes(c) / 2));
+  hipLaunchKernelGGL(pack_frags_kernel, dim3((8 * 64 + 255) / 256), dim3(256), 0, s, w2, 128, 0, 32, 128, 1, 8,
+                     wmul2, out + w1_bytes(c));
+  hipLaunchKernelGGL(pack_frags_kernel, dim3((2 * 64 + 255) / 256), dim3(256), 0, s, w3, 32, 0, 8, 32, 1, 2,
+                     wmul3, out + w1_bytes(c) + kW2Bytes);
+  return dn::check_launch("pack_frags_kernel");
+}
+
+extern "C" int dn_disco_fuse_mlp(const float* feat, const float* warped, const int32_t* num_agent,
+                                 const dn_fuse_mlp_params* p, int batch, int agents, int hw, int c,
+                                 int only_v2i, int ego_first, int ego_count, void* fused_sp,
+                                 float* fused_nhwc, float* weights_out, void* stream) {
+  DN_REQUIRE(feat && num_agent && p && (fused_sp || fused_nhwc), "fuse_mlp: null pointer");
+  DN_REQUIRE(agents < 2 || warped, "fuse_mlp: neighbours present but warped is null");
+  DN_REQUIRE(batch > 0 && agents > 0 && hw > 0, "fuse_mlp: empty problem");
+  DN_REQUIRE(dn_fuse_mlp_supported(c), "fuse_mlp: %d channels unsupported (64, 128 or 256)", c);
+  DN_REQUIRE(ego_first >= 0 && ego_count > 0 && ego_first + ego_count <= agents,
+             "fuse_mlp: ego range [%d, %d) outside 0..%d", ego_first, ego_first + ego_count, agents);
+  DN_REQUIRE(agents <= MAX_AGENTS, "fuse_mlp: at most %d agents supported (got %d)", MAX_AGENTS, agents);
+  DN_REQUIRE(p->packed && p->s1 && p->t1 && p->s2 && p->t2 && p->s3 && p->t3 && p->w4 && p->b4,
+             "fuse_mlp: null MLP parameter");
+  auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  DN_REQUIRE(aligned16(feat) && aligned16(warped) && aligned16(p->packed) && aligned16(fused_sp) &&
+                 aligned16(fused_nhwc) && aligned16(p->s1) && aligned16(p->t1) && aligned16(p->s2) &&
+                 aligned16(p->t2) && aligned16(p->s3) && aligned16(p->t3) && aligned16(p->w4),
+             "fuse_mlp: buffers must be 16-byte aligned");
+  FuseMlpArgs a;
+  a.feat = feat; a.warped = warped; a.num_agent = num_agent;
+  a.w1 = (const unsigned char*)p->packed;
+  a.w2 = a.w1 + w1_bytes(c);
+  a.w3 = a.w2 + kW2Bytes;
+  a.s1 = p->s1; a.t1 = p->t1; a.s2 = p->s2; a.t2 = p->t2; a.s3 = p->s3; a.t3 = p->t3; a.w4 = p->w4; a.b4 = p->b4;
+  a.fused_sp = (unsigned char*)fused_sp; a.fused_nhwc = fused_nhwc; a.weights_out = weights_out;
+  a.batch = batch; a.agents = agents; a.hw = hw; a.only_v2i = only_v2i;
+  a.ego_first = ego_first; a.ego_count = ego_count;
+  a.tiles = (hw + 31) / 32;
+  dim3 grid(batch * ego_count * a.tiles);   // one wave per 32 pixels of one (sample, ego)
+  hipStream_t s = (hipStream_t)stream;
+  if (c == 256) hipLaunchKernelGGL((disco_fuse_mlp_kernel<256, FUSE_G>), grid, dim3(64), 0, s, a);
+  else if (c == 128) hipLaunchKernelGGL((disco_fuse_mlp_kernel<128, FUSE_G>), grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((disco_fuse_mlp_kernel<64, FUSE_G>), grid, dim3(64), 0, s, a);
+  return dn::check_launch("disco_fuse_mlp_kernel");
+}

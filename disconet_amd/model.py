@@ -250,6 +250,9 @@ class DiscoNet(nn.Module):
         self.conv_math = os.environ.get("DISCONET_CONV_MATH", "sp")
         # fold the 1x1 layers that follow a 64-channel 3x3 conv into that conv's launch
         self.fuse_1x1 = os.environ.get("DISCONET_FUSE_1X1", "1") != "0"
+        # one-launch attention MLP + softmax + weighted sum (csrc/fuse_mlp.hip) instead of
+        # two 1x1 conv launches + the tail kernel (split-f16 engines, C in {64, 128, 256})
+        self.fuse_mlp = os.environ.get("DISCONET_FUSE_MLP", "1") != "0"
         # run the encoder levels above the exchanged one beside the fusion block on a second HIP stream
         # (+2.2 % per step, bit-exact against the serial order in tools/det_check.py).  Opt-in
         # (DISCONET_OVERLAP=1 or model.overlap_streams = True; bench.py switches it on and guards its
@@ -297,7 +300,7 @@ class DiscoNet(nn.Module):
     def _signature(self):
         if self.conv_math not in ops.MATH_MODES:
             raise ValueError("conv_math must be one of %s" % sorted(ops.MATH_MODES))
-        return (self.conv_math, self.fuse_1x1) + tuple((t.data_ptr(), t._version) for t in
+        return (self.conv_math, self.fuse_1x1, self.fuse_mlp) + tuple((t.data_ptr(), t._version) for t in
                                          list(self.parameters()) + list(self.buffers()))
 
     def _build_plan(self):
@@ -377,6 +380,13 @@ class DiscoNet(nn.Module):
         }
         P["_tail_tensors"] = tail                 # keep the storage alive
         P["_tail"] = ops.make_tail_params(tail)
+        if math != 0 and self.fuse_mlp and ops.fuse_mlp_supported(C):
+            # split-f16 engines: the whole attention MLP + agent softmax + weighted sum in one launch
+            P["_fuse_mlp"], P["_fuse_mlp_tensors"] = ops.make_fuse_mlp_params(
+                w1, f.conv1_1.bias, (bn1_scale, bn1_shift),
+                f.conv1_2.weight.reshape(32, 128), f.conv1_2.bias, ops.fold_bn(None, f.bn1_2, 32),
+                f.conv1_3.weight.reshape(8, 32), f.conv1_3.bias, ops.fold_bn(None, f.bn1_3, 8),
+                f.conv1_4.weight, f.conv1_4.bias, C)
         return P
 
     def _get_plan(self):
@@ -426,7 +436,7 @@ class DiscoNet(nn.Module):
         return enc
 
     def fuse(self, feat, trans_matrices, num_agent, batch_size, P, want_weights=False,
-             ego_first=0, ego_count=None):
+             ego_first=0, ego_count=None, sp_out=False):
         """DiscoGraph fusion of the layer-`layer` maps.  `feat` holds the maps of
         ALL agents (agent-major NHWC); the result covers the egos
         [ego_first, ego_first + ego_count) -- every agent on one GPU, this rank's
@@ -443,6 +453,11 @@ class DiscoNet(nn.Module):
         with region("warp", "warp_neighbors_kernel", 0.0, map_bytes * (n + pairs)):
             ops.warp_neighbors(feat, trans_matrices, num_agent, B, A, self.only_v2i,
                                ego_first, E, out=warped)
+        if "_fuse_mlp" in P:
+            flops = 2.0 * B * E * h * w * (128.0 * c * (2 + (A - 1)) + A * (128 * 32 + 32 * 8 + 8))
+            with region("fuse_mlp", "disco_fuse_mlp_kernel", flops, map_bytes * (3 * E * B + 2 * pairs)):
+                return ops.disco_fuse_mlp(feat, warped, num_agent, P["_fuse_mlp"], B, A, self.only_v2i,
+                                          want_weights, ego_first, E, sp_out=sp_out)
         g = P["mlp_g"].run(feat[ego_first * B:(ego_first + E) * B])
         fw = None
         if A > 1:
@@ -512,14 +527,14 @@ class DiscoNet(nn.Module):
                     enc[3] = P["decompress"].run(P["compress"].run(enc[3]))
             elif "compress" in P:
                 feat = P["decompress"].run(P["compress"].run(feat))
-            fused = self.fuse(feat, trans, num_agent, batch_size, P)
+            fused = self.fuse(feat, trans, num_agent, batch_size, P, sp_out=self.conv_math == "sp")
             main.wait_stream(side)
             for t in enc[self.layer + 1:]:
                 t.record_stream(main)
             enc[self.layer] = fused
         else:
             enc = self.encode(bevs, P)
-            fused = self.fuse(enc[self.layer], trans, num_agent, batch_size, P)
+            fused = self.fuse(enc[self.layer], trans, num_agent, batch_size, P, sp_out=self.conv_math == "sp")
             enc[self.layer] = fused
         x8, x7, x6, x5 = self.decode(enc, P)
 

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, MlpTailParams, Post1x1Desc, check
+from ._lib import ConvDesc, FuseMlpParams, MlpTailParams, Post1x1Desc, check
 
 
 def _ptr(t):
@@ -364,6 +364,55 @@ def disco_fuse_tail(feat, warped, g, fw, num_agent, tail_params, batch, agents, 
                                          h * w, c, int(only_v2i), ego_first, ego_count, _ptr(fused),
                                          _ptr(weights), _stream()), "dn_disco_fuse_tail")
     return (fused, weights) if want_weights else fused
+
+
+def fuse_mlp_supported(c):
+    return bool(_lib.load().dn_fuse_mlp_supported(int(c)))
+
+
+def make_fuse_mlp_params(w1, b1, bn1, w2, b2, bn2, w3, b3, bn3, w4, b4, c):
+    """Packs the attention MLP for dn_disco_fuse_mlp.  w1 [128, 2c], w2 [32, 128], w3 [8, 32],
+    w4 [8]; bn* = (scale, shift) of the eval BatchNorm after each of the first three layers.
+    Returns (FuseMlpParams, tensors-to-keep-alive)."""
+    lib = _lib.load()
+    dev = w1.device
+    w1, w2, w3 = (t.detach().float().contiguous() for t in (w1, w2, w3))
+    m1, m2, m3 = _pow2_lift(w1), _pow2_lift(w2), _pow2_lift(w3)
+    packed = torch.empty(lib.dn_fuse_mlp_packed_bytes(c), dtype=torch.uint8, device=dev)
+    check(lib.dn_fuse_mlp_pack(_ptr(w1), _ptr(w2), _ptr(w3), c, m1, m2, m3, _ptr(packed), _stream()),
+          "dn_fuse_mlp_pack")
+    keep = {"packed": packed}
+    for name, (scale, shift), bias, m in (("1", bn1, b1, m1), ("2", bn2, b2, m2), ("3", bn3, b3, m3)):
+        # relu(bn(acc / m + bias)) = relu(acc * (scale / m) + (scale * bias + shift))
+        keep["s" + name] = (scale.float() / m).contiguous()
+        keep["t" + name] = (scale.float() * bias.detach().float() + shift.float()).contiguous()
+    keep["w4"] = w4.detach().float().reshape(8).contiguous()
+    keep["b4"] = b4.detach().float().reshape(1).contiguous()
+    p = FuseMlpParams()
+    for name, _ in FuseMlpParams._fields_:
+        setattr(p, name, keep[name].data_ptr())
+    return p, keep
+
+
+def disco_fuse_mlp(feat, warped, num_agent, params, batch, agents, only_v2i=False, want_weights=False,
+                   ego_first=0, ego_count=None, sp_out=False):
+    """Attention MLP + agent softmax + weighted sum in one launch.  feat [A*B, h, w, C] NHWC (all
+    agents), warped [B, E, A-1, h, w, C]; -> SpTensor (sp_out) or float32 NHWC [E*B, h, w, C]
+    (+ weights [B, E, A, h*w] when want_weights)."""
+    _need_gpu(feat, num_agent, warped)
+    _f32c(feat, "feat")
+    ego_count = agents if ego_count is None else ego_count
+    n, h, w, c = feat.shape
+    out_sp = SpTensor(ego_count * batch, h, w, c, device=feat.device) if sp_out else None
+    out = None if sp_out else torch.empty((ego_count * batch, h, w, c), dtype=torch.float32, device=feat.device)
+    weights = (torch.zeros((batch, ego_count, agents, h * w), dtype=torch.float32, device=feat.device)
+               if want_weights else None)
+    check(_lib.load().dn_disco_fuse_mlp(_ptr(feat), _ptr(warped), _ptr(num_agent), ctypes.byref(params),
+                                        batch, agents, h * w, c, int(only_v2i), ego_first, ego_count,
+                                        _ptr(out_sp.data) if sp_out else None, _ptr(out), _ptr(weights),
+                                        _stream()), "dn_disco_fuse_mlp")
+    res = out_sp if sp_out else out
+    return (res, weights) if want_weights else res
 
 
 def make_tail_params(tensors):

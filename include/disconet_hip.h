@@ -239,6 +239,36 @@ int dn_disco_fuse_tail(const float* feat, const float* warped, const float* g,
                        weights in neighbour-list order */ void* stream);
 
 /* ------------------------------------------------------------------------
+ * K5 + K6 in ONE launch (disconet_amd/csrc/fuse_mlp.hip): all four layers of the pairwise
+ * attention MLP on the f16 MFMA (split-f16 x3, fp32 accumulate), exp / sum over the agents
+ * and the weighted sum, lanes over pixels, no intermediate tensors.  Same semantics, inputs
+ * (feat, warped, num_agent, ego range, only_v2i) and neighbour order as dn_disco_fuse_tail;
+ * replaces the dn_conv2d (layer 1) + dn_disco_fuse_tail pair for c in {64, 128, 256}.
+ *   packed: dn_fuse_mlp_pack() of conv1_1.weight [128][2c] (= [W_ego | W_nbr]),
+ *           conv1_2.weight [32][128], conv1_3.weight [8][32]; each matrix is multiplied by
+ *           its wmul (a power of two, see dn_spconv_pack_weights) before the f16 split;
+ *   s1/t1[128]: y = relu(acc * s1 + t1) after layer 1 (bias, BN and 1/wmul1 folded),
+ *   s2/t2[32], s3/t3[8] likewise; w4[8], b4[1] of the last layer (fp32 dot, ReLU).
+ *   fused_sp (SP tensor [ego_count*batch][c/16][4][hw] x 16 B) and/or fused_nhwc
+ *   ([ego_count*batch][hw][c] float32); weights_out as dn_disco_fuse_tail.
+ * ------------------------------------------------------------------------ */
+typedef struct dn_fuse_mlp_params {
+  const void* packed;
+  const float* s1; const float* t1;
+  const float* s2; const float* t2;
+  const float* s3; const float* t3;
+  const float* w4; const float* b4;
+} dn_fuse_mlp_params;
+int dn_fuse_mlp_supported(int c);
+size_t dn_fuse_mlp_packed_bytes(int c);
+int dn_fuse_mlp_pack(const float* w1, const float* w2, const float* w3, int c, float wmul1,
+                     float wmul2, float wmul3, void* packed, void* stream);
+int dn_disco_fuse_mlp(const float* feat, const float* warped, const int32_t* num_agent,
+                      const dn_fuse_mlp_params* p, int batch, int agents, int hw, int c,
+                      int only_v2i, int ego_first, int ego_count, void* fused_sp,
+                      float* fused_nhwc, float* weights_out, void* stream);
+
+/* ------------------------------------------------------------------------
  * Detection decode (first step after the hot path).
  * Replaces the dense part of upstream:coperception/utils/postprocess.py that
  * CoDetModule.predict_all runs on the CPU: foreground probability = softmax of

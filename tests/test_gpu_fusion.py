@@ -92,3 +92,33 @@ def test_fusion_block_at_baseline_map_size_vs_oracle_and_golden(golden_dir):
     got = fused.cpu().permute(0, 3, 1, 2)
     assert (got - want).abs().max().item() <= TOL
     assert np.abs(got.numpy()[:, ::4, ::2, ::2] - g["fused"]).max() <= TOL
+
+
+@pytest.mark.parametrize("case", ["cfg1_f1", "ragged_a4"])
+def test_one_launch_fusion_matches_the_three_launch_form(case):
+    """dn_disco_fuse_mlp (all MLP layers + softmax + sum in one launch) against the
+    dn_conv2d x2 + dn_disco_fuse_tail chain it replaces: same fused maps and weights, and the
+    split-planar output is the split of the fp32 one"""
+    from disconet_amd import Config, DiscoNet, ops
+    c = cases.MODEL_CASES[case]
+    ref = cases.ref_model(c["map_hw"], c["agents"])
+    bevs, trans, na = cases.model_inputs(case)
+    with torch.no_grad():
+        x3 = ref.u_encoder(bevs.permute(0, 1, 4, 2, 3))[3]
+    feat = _nhwc(x3).cuda()
+    num_agent = na[:, 0].to(torch.int32).cuda()
+    outs = {}
+    for one_launch in (True, False):
+        m = DiscoNet(Config(map_hw=c["map_hw"]), kd_flag=1, num_agent=c["agents"]).eval()
+        m.load_state_dict(ref.state_dict())
+        m.fuse_mlp = one_launch
+        m.cuda()
+        P = m._get_plan()
+        assert ("_fuse_mlp" in P) == one_launch
+        outs[one_launch] = m.fuse(feat, trans.cuda().contiguous(), num_agent, c["batch"], P, want_weights=True)
+        if one_launch:
+            sp = m.fuse(feat, trans.cuda().contiguous(), num_agent, c["batch"], P, sp_out=True)
+            assert isinstance(sp, ops.SpTensor)
+            assert torch.equal(sp.data, ops.SpTensor.from_nhwc(outs[True][0]).data)
+    assert (outs[True][0] - outs[False][0]).abs().max().item() <= 2e-5
+    assert (outs[True][1] - outs[False][1]).abs().max().item() <= 2e-5
