@@ -27,7 +27,7 @@ class ConvDesc(Structure):
 
 class Post1x1Desc(Structure):
     """struct dn_post1x1_desc"""
-    _fields_ = [(n, c_int32) for n in ("c_out2", "relu2", "split", "ldo_a", "ldo_b")]
+    _fields_ = [(n, c_int32) for n in ("c_out2", "relu2", "split", "ldo_a", "ldo_b", "block_diag")]
 
 
 class FuseMlpParams(Structure):
@@ -72,6 +72,7 @@ SIGNATURES = {
                             c_void_p, c_void_p]),
     "dn_sp_post1x1_packed_bytes": (c_size_t, []),
     "dn_sp_post1x1_pack_weights": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "dn_sp_post1x1_pack_heads": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "dn_spconv2d_post1x1": (c_int, [POINTER(ConvDesc), POINTER(Post1x1Desc)] + [c_void_p] * 8 +
                             [c_int, c_void_p, c_void_p, c_void_p]),
     "dn_spconv_force_config": (c_int, [c_int]),

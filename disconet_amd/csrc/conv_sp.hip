@@ -94,19 +94,19 @@ struct SpTile {
   static constexpr int B_STEP = B_PIECES * 16;              // stationary form: steps packed tight
   static_assert(!BSTAT || B_STEP % 1024 == 0, "stationary weights: whole DMA instructions per step");
   static constexpr int RPG = 32 / TW;                       // tile rows per 32-pixel group
-  static constexpr int W2_BYTES = POST ? 2 * 4 * 2 * 2 * 32 * 16 : 0;   // 16 KiB
+  static constexpr int W2_BYTES = POST == 1 ? 2 * 4 * 2 * 2 * 32 * 16 : 0;   // 16 KiB
   static constexpr int STG_ROW = 68;                                    // floats, fp32 staging row (max)
-  static constexpr int STG_BYTES = POST ? NW * 32 * STG_ROW * 4 : 0;
+  static constexpr int STG_BYTES = POST == 1 ? NW * 32 * STG_ROW * 4 : 0;
   static constexpr int OFF_B = 2 * A_STAGE;
   static constexpr int OFF_W2 = OFF_B + 2 * B_STAGE;        // streaming form (stationary: runtime)
   static constexpr int OFF_STG = OFF_W2 + W2_BYTES;
-  static constexpr int LDS_BYTES = BSTAT ? OFF_B + W2_BYTES : OFF_STG + STG_BYTES;   // stationary: + weights
+  static constexpr int LDS_BYTES = BSTAT ? OFF_B + W2_BYTES : OFF_STG + STG_BYTES;   // stationary (1): + weights
   // stationary form: LDS bytes for `nsteps` weight steps and (POST, fp32 out) staging rows of
   // c_out2 + 4 floats
   static constexpr int lds_stationary(int nsteps, int stg_row) {
-    return OFF_B + nsteps * B_STEP + W2_BYTES + (POST ? NW * 32 * stg_row * 4 : 0);
+    return OFF_B + nsteps * B_STEP + W2_BYTES + (POST == 1 ? NW * 32 * stg_row * 4 : 0);
   }
-  static constexpr int OCC_LDS = BSTAT ? (POST ? 1 : 2) : 160 * 1024 / LDS_BYTES;
+  static constexpr int OCC_LDS = BSTAT ? (POST == 1 ? 1 : 2) : 160 * 1024 / LDS_BYTES;
   // four accumulator tiles per wave + two fragment sets want > 168 VGPRs: at most 2 workgroups
   static constexpr int OCC_MAX = WTM * WTN >= 4 ? 2 : 3;
   static constexpr int OCC_W = OCC_LDS < 1 ? 1 : (OCC_LDS > OCC_MAX ? OCC_MAX : OCC_LDS);
@@ -120,7 +120,8 @@ struct SpTile {
   static_assert(TW == 8 || TH == WAVES_M * WTM * RPG, "pixel tile must match the wave layout");
   static_assert(BN == WAVES_N * WTN * 32, "channel tile must match the wave layout");
   static_assert(!(STRIDE == 2 && TW == 32), "stride 2: 16- or 8-wide tiles");
-  static_assert(POST == 0 || (WAVES_N == 1 && BN == 64 && TW == 32), "fused 1x1: 64 channels in one wave");
+  static_assert(POST != 1 || (WAVES_N == 1 && BN == 64 && TW == 32), "fused 1x1: 64 channels in one wave");
+  static_assert(POST != 2 || (WAVES_N == 1 && BN == 32), "fused block-diagonal 1x1: one 32-channel head per workgroup");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
 };
 
@@ -414,7 +415,72 @@ conv_sp_kernel(const SpArgs a) {
   };
 
   auto epilogue = [&](const TileCoord& tc) {
-    if constexpr (POST == 0) {
+    if constexpr (POST == 2) {
+      // ---- fused BLOCK-DIAGONAL 1x1 stage (the two detection heads): this workgroup's 32 stage-1
+      // channels are one head's hidden layer, its 1x1 conv reads nothing else.  Channel block 0 writes
+      // columns [0, split2) to `out`, block 1 the rest to `out_b` (fp32 NHWC).  Stage-2 weights come
+      // as A fragments straight from L2 (4 KB per head); every lane stores its own 16-byte pieces.
+      const int cb = tc.n0 >> 5;
+      const int c2 = cb ? a.c_out2 - a.split2 : a.split2, c2_0 = cb ? a.split2 : 0;
+      float* obase = cb ? a.out_b : reinterpret_cast<float*>(a.out);
+      const int ldo = cb ? a.ldo_b : a.ldo_a;
+#pragma unroll
+      for (int wm = 0; wm < WTM; ++wm) {
+        u32x2 hi[4], lo[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = tc.n0 + 8 * g + 4 * lh;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[wm][0][4 * g + e] * a.scale[co + e] + a.shift[co + e];
+            if (a.relu) v[e] = fmaxf(v[e], 0.f);
+          }
+          split4(v, hi[g], lo[g]);
+        }
+        half8 xh[2], xl[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          xh[m] = __builtin_bit_cast(half8, gather_octet(hi[2 * m], hi[2 * m + 1]));
+          xl[m] = __builtin_bit_cast(half8, gather_octet(lo[2 * m], lo[2 * m + 1]));
+        }
+        const int oy = tc.oy0 + prow[wm], ox = tc.ox0 + pcol;
+        const bool inside = oy < a.h_out && ox < a.w_out;
+        float* opx = obase + (((size_t)tc.img * a.h_out + oy) * a.w_out + ox) * ldo;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          if (nt * 32 >= c2) break;
+          f32x16 acc2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            // W2 image: [cb][nt][ks][part][h][32] x 16 B
+            const unsigned char* wp = a.w2 + (size_t)((((((cb * 2 + nt) * 2 + ks) * 2 + 0) * 2 + lh) * 32 + li)) * 16;
+            const half8 wh = *reinterpret_cast<const half8*>(wp);
+            const half8 wl = *reinterpret_cast<const half8*>(wp + 2 * 32 * 16);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[ks], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], acc2, 0, 0, 0);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int ch = nt * 32 + 8 * g + 4 * lh;        // c2 is a multiple of 4: whole pieces
+            if (ch < c2) {
+              const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale2 + c2_0 + ch);
+              const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift2 + c2_0 + ch);
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[e] = acc2[4 * g + e] * sc[e] + sh[e];
+                if (a.relu2) v[e] = fmaxf(v[e], 0.f);
+              }
+              if (inside) *reinterpret_cast<f32x4*>(opx + ch) = v;
+            }
+          }
+        }
+      }
+    } else if constexpr (POST == 0) {
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
@@ -527,7 +593,7 @@ conv_sp_kernel(const SpArgs a) {
   // ---- main loop
   int item = blockIdx.x;
   if (item >= a.total_items) return;
-  if constexpr (POST != 0) {
+  if constexpr (POST == 1) {
     // stage-2 weights: one linear 16 KiB copy, resident for the whole launch
     for (int i = tid; i < T::W2_BYTES / 16; i += NT)
       *reinterpret_cast<u32x4*>(smem + (BSTAT ? T::OFF_B + a.b_total : T::OFF_W2) + i * 16) =
@@ -549,17 +615,19 @@ conv_sp_kernel(const SpArgs a) {
   if constexpr (BSTAT != 0) {
     // ---- weight-stationary form.  The whole weight block of this layer (one channel block:
     // the launcher guarantees c_out <= BN) goes to LDS once; afterwards only patches move.
-    {
+    auto load_weights = [&](int n0) {
       const int n_instr = a.b_total >> 10;
       for (int i = wave; i < n_instr; i += NW) {
         const int piece = i * 64 + lane;
         const int step = piece / T::B_PIECES, rem = piece % T::B_PIECES;
         const int u = rem / (4 * BN), q = (rem / BN) % 4, nn = rem % BN;
         const int g = step / NS, st = step % NS, cu = u / TG, tl = u % TG;
-        const unsigned idx = (((g * CA + cu) * TAPS + st * TG + tl) * 4 + q) * a.cout_pad + cur.n0 + nn;
+        const unsigned idx = (((g * CA + cu) * TAPS + st * TG + tl) * 4 + q) * a.cout_pad + n0 + nn;
         dma16(rsrcw, smem + T::OFF_B + i * 1024, idx * 16u, 0);
       }
-    }
+    };
+    int b_n0 = cur.n0;
+    load_weights(b_n0);
     setup_voff_a(cur, false);
     issue_a(0, 0, false);
     while (true) {
@@ -589,6 +657,12 @@ conv_sp_kernel(const SpArgs a) {
       if (!has_next) break;
       item += G;
       cur = nxt;
+      if (cur.n0 != b_n0) {              // another channel block (rare: the launch picks a grid whose
+        __builtin_amdgcn_s_barrier();    // stride keeps a workgroup on one block): swap the weights once
+        asm volatile("" ::: "memory");   // every wave is done multiplying with the old ones
+        b_n0 = cur.n0;
+        load_weights(b_n0);
+      }
     }
     return;
   }
@@ -841,7 +915,8 @@ int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
     a.b_total = a.ngroups * T::NS * T::B_STEP;
     a.stg_row = a.c_out2 + 4;
     lds_bytes = T::lds_stationary(a.ngroups * T::NS, a.post_f32 ? a.stg_row : 0);
-    DN_REQUIRE(lds_bytes <= 160 * 1024 && d.c_out <= BN, "spconv: layer does not fit the weight-stationary form");
+    DN_REQUIRE(lds_bytes <= 160 * 1024 && (d.c_out <= BN || POST == 2),
+               "spconv: layer does not fit the weight-stationary form");
   }
   // opt in to > 64 KiB of dynamic LDS; the attribute write is idempotent, so two first
   // callers racing here only repeat it
@@ -872,8 +947,9 @@ int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
 }
 
 // does the layer fit the weight-stationary form of tile <BN, TG> beside `wgs` workgroups per CU?
-inline bool fits_stationary(const dn_conv_desc& d, int bn, int a_stage, int extra, int wgs) {
-  if (d.ksize != 3 || d.stride != 1 || d.c_out > bn) return false;
+inline bool fits_stationary(const dn_conv_desc& d, int bn, int a_stage, int extra, int wgs,
+                            bool any_blocks = false) {
+  if (d.ksize != 3 || d.stride != 1 || (d.c_out > bn && !any_blocks)) return false;
   const int nchunks = chunks_of(d.c0) + chunks_of(d.c1);
   const int bytes = 2 * a_stage + nchunks * 9 * 4 * bn * 16 + extra;
   return bytes * wgs <= 160 * 1024;
@@ -960,6 +1036,40 @@ extern "C" int dn_sp_post1x1_pack_weights(const float* w2, int c_out2, int c_in2
   return dn::check_launch("sp_pack_post_kernel");
 }
 
+namespace {
+// w2 [c_out2][64] block-diagonal (rows < split read columns 0..31, the rest columns 32..63)
+// -> [cb 2][nt 2][ks 2][part 2][h 2][n 32] pieces
+__global__ void sp_pack_heads_kernel(const float* __restrict__ w2, unsigned char* __restrict__ out,
+                                     int c_out2, int split, float wmul) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (cb, nt, ks, h, n)
+  if (idx >= 2 * 2 * 2 * 2 * 32) return;
+  const int n = idx % 32, h = (idx / 32) % 2, ks = (idx / 64) % 2, nt = (idx / 128) % 2, cb = idx / 256;
+  const int rows = cb ? c_out2 - split : split, row0 = cb ? split : 0;
+  half8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int r = nt * 32 + n, k = ks * 16 + h * 8 + e;
+    float v = r < rows ? w2[(size_t)(row0 + r) * 64 + cb * 32 + k] * wmul : 0.f;
+    v = fminf(fmaxf(v, -65504.f), 65504.f);
+    hi[e] = (_Float16)v;
+    lo[e] = (_Float16)(v - (float)hi[e]);
+  }
+  unsigned char* o = out + (size_t)((((((cb * 2 + nt) * 2 + ks) * 2 + 0) * 2 + h) * 32 + n)) * 16;
+  *reinterpret_cast<half8*>(o) = hi;
+  *reinterpret_cast<half8*>(o + 2 * 32 * 16) = lo;
+}
+}  // namespace
+
+extern "C" int dn_sp_post1x1_pack_heads(const float* w2, int c_out2, int split, float wmul, void* packed,
+                                        void* stream) {
+  DN_REQUIRE(w2 && packed, "sp heads pack: null pointer");
+  DN_REQUIRE(split > 0 && split < c_out2 && split <= 64 && c_out2 - split <= 64,
+             "sp heads pack: split %d of %d outputs", split, c_out2);
+  hipLaunchKernelGGL(sp_pack_heads_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w2,
+                     (unsigned char*)packed, c_out2, split, wmul);
+  return dn::check_launch("sp_pack_heads_kernel");
+}
+
 extern "C" int dn_spconv_force_config(int cfg) {
   g_sp_force = cfg;
   return DN_OK;
@@ -991,10 +1101,15 @@ extern "C" int dn_spconv2d(const dn_conv_desc* d, const void* src0, const void* 
     }
   }
   // weight-stationary forms (short-K full-resolution layers): two workgroups per CU
+  // DN_SP_STATIONARY=0: weights streamed per step everywhere (A/B runs)
   static const int stat_env = [] { const char* e = getenv("DN_SP_STATIONARY"); return e ? atoi(e) : 1; }();
-  if (stat_env && g_sp_force < 0) {
+  // (a 16x32-pixel stationary tile -- four MFMA tiles per wave, ONE workgroup per CU -- measured
+  // 14 % slower on conv8_2 and 33 % slower on the heads than 8x32 with two workgroups per CU, and
+  // weights held in registers instead of LDS spilled at the 256-VGPR budget of two workgroups: what
+  // these short-K layers need is a second workgroup to run under the first one's waits)
+  if (stat_env && g_sp_force < 0 && c.id == S3_256x32) {
     using T32 = SpTile<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 1>;
-    if (c.id == S3_256x32 && fits_stationary(*d, 32, T32::A_STAGE, 0, 2))
+    if (fits_stationary(*d, 32, T32::A_STAGE, 0, 2))
       return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1>(a, *d, s);
   }
   if (g_sp_force == 12) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1>(a, *d, s);
@@ -1044,6 +1159,16 @@ extern "C" int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc*
   a.c_out2 = p->c_out2; a.relu2 = p->relu2; a.split2 = p->split; a.ldo_a = p->ldo_a; a.ldo_b = p->ldo_b;
   a.post_f32 = out_f32 ? 1 : 0;
   a.cog = chunks_of(p->c_out2);   // SP output: the second stage's channels
+  if (p->block_diag) {
+    DN_REQUIRE(out_f32 && p->split < p->c_out2 && p->split <= 64 &&
+                   p->c_out2 - p->split <= 64,
+               "spconv+1x1: the block-diagonal form needs two fp32 outputs of <= 64 columns each");
+    using TS = SpTile<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 1>;
+    static const int stat_env = [] { const char* e = getenv("DN_SP_STATIONARY"); return e ? atoi(e) : 1; }();
+    if (stat_env && fits_stationary(*d, 32, TS::A_STAGE, 0, 2, true))
+      return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 0, 1>(a, *d, (hipStream_t)stream);
+    return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 0, 0>(a, *d, (hipStream_t)stream);
+  }
   {
     using TP = SpTile<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 1, 1>;
     static const int stat_env = [] { const char* e = getenv("DN_SP_STATIONARY"); return e ? atoi(e) : 1; }();

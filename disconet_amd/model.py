@@ -166,16 +166,21 @@ class _ConvPostLayer:
     (dn_conv2d_post1x1): split-f16 math only.  out_a gets columns [0, split) of the
     1x1 stage, out_b the rest (two-headed use) -- or everything goes to out_a."""
 
-    def __init__(self, name, weight, scale, shift, w2, scale2, shift2, split, relu2, math=1):
+    def __init__(self, name, weight, scale, shift, w2, scale2, shift2, split, relu2, math=1,
+                 block_diag=False):
         self.name = name
         self.math = math
+        # the 1x1 stage is two independent heads: outputs [0, split) read hidden channels 0..31, the
+        # rest channels 32..63 (SP engine: one 32-channel head per workgroup, weights LDS-resident)
+        self.block_diag = block_diag and math == 2 and split < w2.shape[0]
         self.c_out, self.c_in = weight.shape[0], weight.shape[1]
         assert self.c_out == 64
         d = ops.conv_desc(1, 8, 8, self.c_in, 64, 3, 1, True, math=math)
         self.c_out2, self.split, self.relu2 = w2.shape[0], split, relu2
         if math == 2:
             self.packed, wmul = ops.sp_pack_conv_weights(d, weight)
-            self.packed2, wmul2 = ops.sp_pack_post1x1_weights(w2)
+            self.packed2, wmul2 = (ops.sp_pack_heads_weights(w2, split) if self.block_diag
+                                   else ops.sp_pack_post1x1_weights(w2))
             # `scale`/`shift` may belong to another layer of the plan: scale copies, never in place
             self.scale, self.scale2 = (scale / wmul).contiguous(), (scale2 / wmul2).contiguous()
         else:
@@ -201,7 +206,7 @@ class _ConvPostLayer:
             with region(self.name, "conv_sp_kernel", flops, nbytes):
                 ops.sp_conv2d_post1x1(d, src0, self.packed, self.scale, self.shift, self.packed2,
                                       self.scale2, self.shift2, self.c_out2, self.split, self.relu2,
-                                      out_a, out_b)
+                                      out_a, out_b, block_diag=self.block_diag)
             return out_a, out_b
         src0 = ops.as_nhwc(src0)
         d = ops.conv_desc(n, h, w, c0, 64, 3, 1, True, math=1)
@@ -344,7 +349,8 @@ class DiscoNet(nn.Module):
                     "heads", w1, torch.cat([P["cls1"].affine[0], P["reg1"].affine[0]]),
                     torch.cat([P["cls1"].affine[1], P["reg1"].affine[1]]), w2,
                     torch.ones(n_cls + n_reg, device=dev),
-                    torch.cat([cls.conv2.bias, reg[3].bias]).detach().float(), n_cls, False, math=math)
+                    torch.cat([cls.conv2.bias, reg[3].bias]).detach().float(), n_cls, False, math=math,
+                    block_diag=True)
             c3 = enc.conv3d_1
             s3, t3 = ops.fold_bn(c3.conv3d.bias, c3.bn3d, 64)
             P["conv1_2_3d"] = _ConvPostLayer(

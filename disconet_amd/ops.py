@@ -272,14 +272,28 @@ def sp_pack_post1x1_weights(weight):
     return packed, wmul
 
 
+def sp_pack_heads_weights(weight, split):
+    """block-diagonal 1x1 stage [c_out2, 64]: rows < split read stage-1 channels 0..31, the rest
+    channels 32..63 -> (packed fragments for sp_conv2d_post1x1(block_diag=True), wmul)"""
+    _need_gpu(weight)
+    w = weight.detach().reshape(weight.shape[0], 64).contiguous().float()
+    lib = _lib.load()
+    wmul = _pow2_lift(w)
+    packed = torch.empty(lib.dn_sp_post1x1_packed_bytes(), dtype=torch.uint8, device=weight.device)
+    check(lib.dn_sp_post1x1_pack_heads(_ptr(w), w.shape[0], split, wmul, _ptr(packed), _stream()),
+          "dn_sp_post1x1_pack_heads")
+    return packed, wmul
+
+
 def sp_conv2d_post1x1(d, src0, packed, scale, shift, packed2, scale2, shift2, c_out2, split, relu2,
-                      out_a, out_b=None):
+                      out_a, out_b=None, block_diag=False):
     """SP 3x3 conv (64 ch) + affine + ReLU fused with a 1x1 stage.  out_a an SpTensor (one SP
     output of c_out2 channels) or a float32 NHWC tensor (+ out_b: two-headed fp32 output)."""
     _need_gpu(src0, packed, packed2)
     p = Post1x1Desc()
     p.c_out2, p.relu2, p.split = c_out2, int(bool(relu2)), split
     f32 = not isinstance(out_a, SpTensor)
+    p.block_diag = int(bool(block_diag))
     p.ldo_a = out_a.shape[-1] if f32 else 0
     p.ldo_b = out_b.shape[-1] if out_b is not None else 0
     check(_lib.load().dn_spconv2d_post1x1(ctypes.byref(d), ctypes.byref(p), _ptr(src0.data), None,

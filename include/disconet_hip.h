@@ -130,6 +130,10 @@ typedef struct dn_post1x1_desc {
   int32_t relu2;
   int32_t split;         /* multiple of 4; == c_out2 for a single output */
   int32_t ldo_a, ldo_b;
+  int32_t block_diag;    /* dn_spconv2d_post1x1 only (dn_conv2d_post1x1 ignores it): the 1x1 stage is
+                            block-diagonal -- outputs [0, split) read stage-1 channels 0..31, the rest
+                            channels 32..63 (two detection heads side by side).  Needs out_f32, two
+                            outputs, packed2 from dn_sp_post1x1_pack_heads. */
 } dn_post1x1_desc;
 size_t dn_post1x1_packed_floats(void);
 /* w2: [c_out2][c_in2] float32, c_in2 <= 64 = channels of the first stage */
@@ -176,6 +180,9 @@ int dn_spconv2d(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp,
 size_t dn_sp_post1x1_packed_bytes(void);
 int dn_sp_post1x1_pack_weights(const float* w2, int c_out2, int c_in2, float wmul, void* packed,
                                void* stream);
+/* w2 [c_out2][64] of a block-diagonal stage (see dn_post1x1_desc.block_diag); dn_sp_post1x1_packed_bytes() */
+int dn_sp_post1x1_pack_heads(const float* w2, int c_out2, int split, float wmul, void* packed,
+                             void* stream);
 int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p, const void* src0_sp,
                         const void* src1_sp, const void* packed, const float* scale,
                         const float* shift, const void* packed2, const float* scale2,

@@ -140,15 +140,23 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
 }
 
 // fused 3x3 (cin -> 64) + 1x1 (64 -> c2): fp32 two-output form (heads) and SP form (conv1_2 + Conv3D)
-static void run_post(const char* name, int n, int h, int w, int cin, int c2, int split, bool f32) {
+static void run_post(const char* name, int n, int h, int w, int cin, int c2, int split, bool f32, bool block = false) {
   if (g_filter && !strstr(name, g_filter)) return;
   Timer tm;
   dn_conv_desc d = {n, h, w, cin, 0, 0, 64, 3, 1, 1, cin, 0, 64, 1};
-  dn_post1x1_desc p = {c2, f32 ? 0 : 1, split, split, c2 - split};
+  dn_post1x1_desc p = {c2, f32 ? 0 : 1, split, split, c2 - split, block ? 1 : 0};
   const size_t px = (size_t)n * h * w;
   float* s0 = dev_random(px * cin, 1.5f, true);
   float* wt = dev_random((size_t)64 * cin * 9, sqrtf(6.f / (cin * 9)));
   float* w2 = dev_random((size_t)c2 * 64, sqrtf(6.f / 64));
+  if (block) {   // two heads side by side: rows < split read hidden 0..31, the rest 32..63
+    std::vector<float> hw2((size_t)c2 * 64);
+    hipMemcpy(hw2.data(), w2, hw2.size() * 4, hipMemcpyDeviceToHost);
+    for (int r = 0; r < c2; ++r)
+      for (int k = 0; k < 64; ++k)
+        if ((r < split) != (k < 32)) hw2[(size_t)r * 64 + k] = 0.f;
+    hipMemcpy(w2, hw2.data(), hw2.size() * 4, hipMemcpyHostToDevice);
+  }
   float* sc = dev_random(64, 0.5f, true); float* sh = dev_random(64, 0.3f);
   float* sc2 = dev_random(64, 0.5f, true); float* sh2 = dev_random(64, 0.3f);
   { std::vector<float> v(64); for (auto& x : v) x = 1.f + 0.25f * frand(); hipMemcpy(sc, v.data(), 256, hipMemcpyHostToDevice);
@@ -165,7 +173,9 @@ static void run_post(const char* name, int n, int h, int w, int cin, int c2, int
   HCK(hipMalloc(&sp0, dn_sp_tensor_bytes(n, h, w, cin))); CK(dn_sp_from_nhwc(s0, n, h, w, cin, cin, sp0, 0));
   HCK(hipMalloc(&pk, dn_spconv_packed_weight_bytes(&d))); HCK(hipMalloc(&pk2, dn_sp_post1x1_packed_bytes()));
   const float wmul = 64.f;
-  CK(dn_spconv_pack_weights(&d, wt, wmul, pk, 0)); CK(dn_sp_post1x1_pack_weights(w2, c2, 64, wmul, pk2, 0));
+  CK(dn_spconv_pack_weights(&d, wt, wmul, pk, 0));
+  if (block) CK(dn_sp_post1x1_pack_heads(w2, c2, split, wmul, pk2, 0));
+  else CK(dn_sp_post1x1_pack_weights(w2, c2, 64, wmul, pk2, 0));
   float *scs, *sc2s; HCK(hipMalloc(&scs, 256)); HCK(hipMalloc(&sc2s, 256));
   { std::vector<float> v(64); hipMemcpy(v.data(), sc, 256, hipMemcpyDeviceToHost); for (auto& x : v) x /= wmul; hipMemcpy(scs, v.data(), 256, hipMemcpyHostToDevice);
     hipMemcpy(v.data(), sc2, 256, hipMemcpyDeviceToHost); for (auto& x : v) x /= wmul; hipMemcpy(sc2s, v.data(), 256, hipMemcpyHostToDevice); }
@@ -223,6 +233,8 @@ int main(int argc, char** argv) {
   run_layer("ragged 3x3 up+cat 24x40", 2, 24, 40, 32, 16, 1, 48, 3, 1, quick);
   run_layer("ragged 1x1 24x40 64->96", 2, 24, 40, 64, 0, 0, 96, 1, 1, quick);
   run_post("post f32 2x40x64 32->64->48", 2, 40, 64, 32, 48, 12, true);
+  run_post("post f32 blockdiag 3x40x72", 3, 40, 72, 32, 48, 12, true, true);
+  run_post("post f32 blockdiag 96->64->8", 2, 24, 40, 96, 8, 4, true, true);
   run_post("post sp  2x40x64 64->64->64", 2, 40, 64, 64, 64, 64, false);
   // the BASELINE layers
   run_layer("conv_pre_2 256^2 32->32", n, 256, 256, 32, 0, 0, 32, 3, 1, quick);
@@ -242,6 +254,7 @@ int main(int argc, char** argv) {
   run_layer("conv8_2 256^2 32->32", n, 256, 256, 32, 0, 0, 32, 3, 1, quick);
   run_layer("mlp 1x1 32^2 256->256", n, 32, 32, 256, 0, 0, 256, 1, 1, quick);
   run_post("heads 256^2 32->64->48 f32", n, 256, 256, 32, 48, 12, true);
+  run_post("heads 256^2 blockdiag f32", n, 256, 256, 32, 48, 12, true, true);
   run_post("conv1_2+3d 128^2 64->64->64", n, 128, 128, 64, 64, 64, false);
   printf("%s (%d failures)\n", g_fail ? "SP CONV CHECK FAILED" : "SP CONV CHECK PASSED", g_fail);
   return g_fail ? 1 : 0;
