@@ -119,6 +119,7 @@ class TrainEngine:
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
+        self.generation = 0          # bumped by every forward(): the saved activations belong to it
         self.overlap_streams = False
         params = _param_order(model)
         dev = params[0].device
@@ -274,7 +275,21 @@ class TrainEngine:
     # ------------------------------------------------------------------
     # forward (training mode)
     # ------------------------------------------------------------------
+    def check_aliasing(self):
+        """The module's Parameters are views into flat_p (what Adam updates).  model.to() / .float() /
+        load_state_dict(assign=True) re-point p.data and silently break that: fail loudly instead."""
+        base, end = self.flat_p.data_ptr(), self.flat_p.data_ptr() + 4 * self.flat_p.numel()
+        for p in self.params:
+            off = self.grad_of[id(p)][0]
+            if p.data_ptr() != base + 4 * off or not (base <= p.data_ptr() < end):
+                raise RuntimeError(
+                    "a Parameter of the model no longer aliases the training engine's flat buffer "
+                    "(model.to()/.float()/load_state_dict(assign=True) after CoDetModule/TrainEngine was "
+                    "built?); rebuild the CoDetModule / TrainEngine after moving or re-assigning parameters")
+
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size):
+        self.check_aliasing()
+        self.generation += 1
         m, L = self.model, self.L
         A, B = m.agent_num, batch_size
         if m.layer != 3 and m.u_encoder.compress_level > 0:
@@ -555,6 +570,7 @@ class _TrainFn(torch.autograd.Function):
     def forward(ctx, engine, bevs, trans, num_agent, batch_size, *params):
         res = engine.forward(bevs, trans, num_agent, batch_size)
         ctx.engine = engine
+        ctx.generation = engine.generation
         ctx.set_materialize_grads(False)      # outputs the loss does not touch come back as None
         o = engine.outs
         nchw = lambda t: t.permute(0, 3, 1, 2)
@@ -564,6 +580,14 @@ class _TrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dcls, dloc, dx8, dx7, dx6, dx5, dfused):
         eng = ctx.engine
+        if ctx.generation != eng.generation:
+            # the reverse pass reads the activations the engine saved in ITS last forward: a second
+            # forward (another micro-batch, a no_grad monitoring pass in train() mode) overwrote them
+            raise RuntimeError(
+                "DiscoNet (train mode): backward() of forward #%d called after forward #%d ran on the same "
+                "model -- the HIP training engine keeps ONE set of saved activations; call backward() "
+                "before the next forward (accumulate gradients across steps with "
+                "CoDetModule / TrainEngine.flat_g instead)" % (ctx.generation, eng.generation))
         if dx8 is not None:
             raise NotImplementedError("a loss on x8 itself is not part of the reference's KD term")
         nhwc = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous()
@@ -607,10 +631,13 @@ class CoDetModule:
         self.model, self.teacher, self.kd_flag = model, teacher, int(bool(kd_flag))
         if self.kd_flag:
             teacher.eval()
+        kw = {}
         if optimizer is not None:      # take the hyper-parameters of the torch optimizer handed in
             grp = optimizer.param_groups[0]
             lr = grp["lr"]
-        self.engine = TrainEngine(model, lr=lr)
+            kw = {"betas": tuple(grp.get("betas", (0.9, 0.999))), "eps": grp.get("eps", 1e-8),
+                  "weight_decay": grp.get("weight_decay", 0.0)}
+        self.engine = TrainEngine(model, lr=lr, **kw)
         model.__dict__["_train_engine"] = self.engine
         self.alpha, self.gamma, self.sigma = alpha, gamma, sigma
 

@@ -163,3 +163,38 @@ def test_fused_1x1_layers_match_unfused():
         assert (outs[0][k] - outs[1][k]).abs().max().item() <= 2e-5
         assert (outs[2][k] - outs[3][k]).abs().max().item() <= 2e-5
         assert (outs[0][k] - outs[2][k]).abs().max().item() <= 2e-5    # the two split-f16 engines agree
+
+
+@pytest.mark.parametrize("live", [[8], [5]])
+def test_eight_agent_scenes(live):
+    """BASELINE configs[4]: 8-agent scenes (the agent-sharded workload), all live and 8 slots with 5
+    live -- the fusion kernels' agent limit (MAX_AGENTS = 8) is reached, whole model vs the oracle"""
+    from disconet_amd.synthetic import make_scene_batch
+    ref = cases.ref_model(128, 8)
+    bevs, trans, na = make_scene_batch(1, 8, 128, live=live, jitter_seed=5)
+    with torch.no_grad():
+        res, _, _, _, x5, fused = ref(bevs, trans, na, 1)
+    m = _product(ref, 128, 8)
+    got = _gpu_outputs(m, bevs, trans, na, 1)
+    for name, w in (("cls", res["cls"]), ("loc", res["loc"]), ("fused", fused), ("x5", x5)):
+        err = (got[name] - w).abs().max().item()
+        assert err <= TOL, "8 agents live=%s %s max abs err %.3e" % (live, name, err)
+
+
+def test_split_planar_bevs_input_equals_dense_input():
+    """forward() takes the voxel batch either as the reference's dense float32 tensor or already
+    scattered into the conv engine's layout (ops.scatter_dense_sp): bit-identical results"""
+    from disconet_amd import Config, DiscoNet, ops
+    from disconet_amd.synthetic import make_sparse_scene_batch, make_trans_matrices
+    A, B, hw = 3, 2, 128
+    torch.manual_seed(1)
+    m = DiscoNet(Config(map_hw=hw), kd_flag=0, num_agent=A).eval().cuda()
+    indices, offsets, _ = make_sparse_scene_batch(B, A, hw)
+    indices, offsets = indices.cuda(), offsets.cuda()
+    trans = make_trans_matrices(B, A, jitter_seed=2).cuda()
+    na = torch.full((B, A), A, dtype=torch.int64).cuda()
+    dims = (hw, hw, 13)
+    with torch.no_grad():
+        dense = m(ops.scatter_dense(indices, offsets, A * B, dims), trans, na, B)
+        sp = m(ops.scatter_dense_sp(indices, offsets, A * B, dims), trans, na, B)
+    assert torch.equal(dense["cls"], sp["cls"]) and torch.equal(dense["loc"], sp["loc"])

@@ -29,6 +29,30 @@ def test_ego_subranges_match_full_fusion():
         assert torch.equal(part, full[first * B:(first + count) * B]), (first, count)
 
 
+def test_eight_agents_one_ego_per_rank_slices():
+    """BASELINE configs[4]: 8-agent scenes sharded one agent per GPU -- every rank fuses ONE ego
+    (ego_count = 1) against the gathered maps of all 8; each slice must be the matching rows of the
+    full fusion, bit for bit (8 slots all live, and 8 slots with 5 live)"""
+    from disconet_amd import Config, DiscoNet
+    from disconet_amd.synthetic import make_scene_batch
+    A, B, hw = 8, 2, 128
+    torch.manual_seed(3)
+    m = DiscoNet(Config(map_hw=hw), kd_flag=0, num_agent=A).eval().cuda()
+    P = m._get_plan()
+    for live in ([8, 8], [5, 8]):
+        bevs, trans, na = make_scene_batch(B, A, hw, live=live, jitter_seed=7)
+        x3 = m.encode(bevs.cuda(), P)[3]
+        num_agent = na[:, 0].to(torch.int32).cuda()
+        tr = trans.cuda().contiguous()
+        full = m.fuse(x3, tr, num_agent, B, P)
+        assert torch.isfinite(full).all()
+        for ego in range(A):
+            part = m.fuse(x3, tr, num_agent, B, P, ego_first=ego, ego_count=1)
+            assert torch.equal(part, full[ego * B:(ego + 1) * B]), (live, ego)
+        # dead slots keep their own (un-fused) map
+        assert torch.equal(full[7 * B + 0], x3[7 * B + 0]) == (live[0] < 8)
+
+
 def test_hip_engine_single_rank_world():
     """world_size 1 (gloo on CPU for the group, tensors on the GPU): the sharded
     forward through HipEngine equals the plain forward."""

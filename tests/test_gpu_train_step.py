@@ -424,3 +424,86 @@ def test_train_step_scene_with_a_single_live_agent(monkeypatch):
     for name, b in model.named_buffers():          # MLP BNs saw 5 calls, in the reference's order
         if "pixel_weighted_fusion" in name and name.endswith("num_batches_tracked"):
             assert int(b) == int(ref_buf[name]) == 5, name
+
+
+def test_backward_after_a_second_forward_fails_loudly():
+    """the HIP engine keeps ONE set of saved activations: a backward whose forward has been
+    overwritten by a later forward (gradient accumulation over micro-batches, a no_grad monitoring
+    pass in train() mode) must raise instead of returning gradients of the wrong batch"""
+    from oracle.train_ref import det_loss
+    c, ref, model, (bevs, trans, na), (labels, targets, mask) = _setup("cfg1", "f16x3")
+    model.train()
+    out1 = model(bevs.cuda(), trans.cuda(), na.cuda(), c["batch"])
+    with torch.no_grad():
+        model(bevs.cuda(), trans.cuda(), na.cuda(), c["batch"])          # overwrites the saved state
+    l_cls, l_loc = det_loss(out1, labels.cuda(), targets.cuda(), mask.cuda(), norm=bevs.shape[0])
+    with pytest.raises(RuntimeError, match="saved activations"):
+        (l_cls + l_loc).backward()
+    # the straight sequence still works afterwards
+    out2 = model(bevs.cuda(), trans.cuda(), na.cuda(), c["batch"])
+    l_cls, l_loc = det_loss(out2, labels.cuda(), targets.cuda(), mask.cuda(), norm=bevs.shape[0])
+    (l_cls + l_loc).backward()
+    assert all(p.grad is not None for p in model.parameters())
+
+
+def test_moved_parameters_fail_loudly():
+    """Parameters are views into the engine's flat buffer; re-pointing them (model.float(),
+    load_state_dict(assign=True), ...) must be reported, not silently train a stale copy"""
+    from disconet_amd import CoDetModule
+    c, ref, model, (bevs, trans, na), _ = _setup("cfg1", "f16x3")
+    mod = CoDetModule(model, optimizer=torch.optim.Adam(model.parameters(), lr=2e-3, betas=(0.8, 0.95), eps=1e-6))
+    assert mod.engine.lr == 2e-3 and mod.engine.betas == (0.8, 0.95) and mod.engine.eps == 1e-6
+    p = next(model.parameters())
+    p.data = p.data.clone()                                   # what model.to()/.float() does
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        mod.engine.forward(bevs.cuda(), trans.cuda(), na.cuda(), c["batch"])
+
+
+def test_kd_train_step_at_baseline_size_properties():
+    """BASELINE configs[2] size (5 agents, batch 4, 256x256x13, kd_flag = 1), through properties that
+    do not need the CPU oracle at this size: finite losses; the train()-mode forward of a scene
+    does not depend on its batch slot's NEIGHBOURS' voxels beyond BatchNorm's batch statistics --
+    checked in eval(); a zero kd_weight leaves exactly the gradients of the plain step; the KD term
+    moves the gradient when switched on; a second step lowers the loss"""
+    from disconet_amd import CoDetModule, Config, DiscoNet, TeacherNet
+    from disconet_amd.synthetic import make_bevs, make_scene_batch, make_train_targets
+    A, B, hw = 5, 4, 256
+    torch.manual_seed(0)
+    model = DiscoNet(Config(map_hw=hw), kd_flag=1, num_agent=A).cuda()
+    teacher = TeacherNet(Config(map_hw=hw)).cuda().eval()
+    bevs, trans, na = make_scene_batch(B, A, hw, jitter_seed=4)
+    labels, targets, mask = make_train_targets(A * B, hw, p_fg=0.02)
+    data = {"bev_seq": bevs.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(),
+            "labels": labels.cuda(), "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda(),
+            "bev_seq_teacher": make_bevs(B, A, hw, p=0.05).cuda(), "kd_weight": 0.0}
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def grads_of(kd_flag, kd_weight):
+        model.load_state_dict(state)
+        mod = CoDetModule(model, teacher if kd_flag else None, kd_flag=kd_flag, lr=0.0)   # lr 0: Adam moves nothing
+        out = mod.step(dict(data, kd_weight=kd_weight), B)
+        return out, mod.engine.flat_g.clone()
+
+    plain, g_plain = grads_of(0, 0.0)
+    zero_kd, g_zero = grads_of(1, 0.0)
+    with_kd, g_kd = grads_of(1, 1e5)
+    for out in (plain, zero_kd, with_kd):
+        assert all(v == v and abs(v) != float("inf") for v in out.values()), out
+    assert zero_kd["kd_loss"] == 0.0 and with_kd["kd_loss"] > 0.0
+    assert torch.equal(g_plain, g_zero)                        # a zeroed teacher term vanishes exactly
+    assert float((g_kd - g_plain).abs().max()) > 0.0
+    # training moves the loss down
+    model.load_state_dict(state)
+    mod = CoDetModule(model, teacher, kd_flag=1, lr=1e-3)
+    first = mod.step(dict(data, kd_weight=1e5), B)
+    second = mod.step(dict(data, kd_weight=1e5), B)
+    assert second["loss"] < first["loss"]
+    # eval(): batch-slot independence of the forward at this size, kd outputs included
+    model.eval()
+    with torch.no_grad():
+        full = model(bevs.cuda(), trans.cuda(), na.cuda(), B)
+        sel = torch.tensor([a * B + 1 for a in range(A)])
+        one = model(bevs[sel].cuda(), trans[1:2].cuda(), na[1:2].cuda(), 1)
+    assert torch.equal(full[0]["cls"][sel.cuda()], one[0]["cls"])
+    for i in range(1, 6):
+        assert torch.equal(full[i][sel.cuda()], one[i]), i

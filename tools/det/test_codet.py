@@ -22,7 +22,7 @@ from disconet_amd import Config, DiscoNet  # noqa: E402
 from disconet_amd.synthetic import make_scene_batch, randomize_bn_stats  # noqa: E402
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("-d", "--data", default=None, help="(unused here: synthetic scenes)")
     ap.add_argument("--com", default="disco")
@@ -38,7 +38,18 @@ def main():
     ap.add_argument("--compress_level", type=int, default=0)
     ap.add_argument("--only_v2i", type=int, default=0)
     ap.add_argument("--frames", type=int, default=4)
-    args = ap.parse_args()
+    # accepted for command-line compatibility (/root/reference/README.md:72,74): the tracking dump and
+    # the PNG visualisation are downstream CPU consumers of the detections, out of scope here
+    ap.add_argument("--tracking", action="store_true", help="accepted; the tracking dump is out of scope")
+    ap.add_argument("--visualization", type=int, default=0, help="accepted; visualisation is out of scope")
+    return ap
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.tracking or args.visualization:
+        print("note: --tracking / --visualization are accepted for compatibility; this shim only runs "
+              "the detector")
     if args.com != "disco":
         raise SystemExit("only --com disco is built on the MI355X path (SURVEY.md §2.1 #8)")
     num_agent = args.num_agent + (1 if args.rsu else 0)

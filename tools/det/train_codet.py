@@ -27,7 +27,36 @@ from disconet_amd import CoDetModule, Config, DiscoNet, TeacherNet  # noqa: E402
 from disconet_amd.synthetic import make_bevs, make_scene_batch, make_train_targets  # noqa: E402
 
 
-def main():
+def _rsu_from_leftovers(args, rest):
+    """The README writes the last flag as `-- rsu [0/1]` (a space after the dashes,
+    /root/reference/README.md:63): argparse then sees "--" and the words `rsu` and `<value>`.
+    Accept that spelling; anything else left over is an error, as argparse would report."""
+    rest = [r for r in rest if r != "--"]
+    if len(rest) == 2 and rest[0] == "rsu":
+        digits = "".join(ch for ch in rest[1] if ch.isdigit())
+        args.rsu = int(digits[-1]) if digits else 0     # "[0/1]" -> the placeholder's second choice
+        rest = []
+    if rest:
+        raise SystemExit("unrecognized arguments: " + " ".join(rest))
+    return args
+
+
+def newest_checkpoint(path):
+    """--auto_resume_path: the epoch_N.pth with the largest N under `path` (None if there is none)"""
+    best, best_n = None, -1
+    if path and os.path.isdir(path):
+        for name in os.listdir(path):
+            if name.startswith("epoch_") and name.endswith(".pth"):
+                try:
+                    n = int(name[len("epoch_"):-len(".pth")])
+                except ValueError:
+                    continue
+                if n > best_n:
+                    best, best_n = os.path.join(path, name), n
+    return best
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("-d", "--data", default=None, help="(unused here: synthetic scenes)")
     ap.add_argument("--com", default="disco")
@@ -47,7 +76,22 @@ def main():
     ap.add_argument("--rsu", type=int, default=0)
     ap.add_argument("--compress_level", type=int, default=0)
     ap.add_argument("--only_v2i", type=int, default=0)
-    args = ap.parse_args()
+    ap.add_argument("--auto_resume_path", default="",
+                    help="resume from the newest epoch_N.pth under this directory, if any")
+    return ap
+
+
+def parse_args(argv=None):
+    args, rest = build_parser().parse_known_args(argv)
+    return _rsu_from_leftovers(args, rest)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.auto_resume_path and not args.resume:
+        found = newest_checkpoint(args.auto_resume_path)
+        if found:
+            args.resume = found
     if args.com != "disco":
         raise SystemExit("only --com disco is built on the MI355X path (SURVEY.md §2.1 #8)")
     num_agent = args.num_agent + (1 if args.rsu else 0)
