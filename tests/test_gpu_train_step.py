@@ -490,8 +490,11 @@ def test_kd_train_step_at_baseline_size_properties():
     for out in (plain, zero_kd, with_kd):
         assert all(v == v and abs(v) != float("inf") for v in out.values()), out
     assert zero_kd["kd_loss"] == 0.0 and with_kd["kd_loss"] > 0.0
-    assert torch.equal(g_plain, g_zero)                        # a zeroed teacher term vanishes exactly
-    assert float((g_kd - g_plain).abs().max()) > 0.0
+    # a zeroed teacher term vanishes: what is left between the two runs is the run-to-run noise of the
+    # backward's atomics (BatchNorm / bias sums); the live KD term moves the gradient far beyond it
+    gmax = float(g_plain.abs().max())
+    assert float((g_plain - g_zero).abs().max()) <= 1e-5 * gmax
+    assert float((g_kd - g_plain).abs().max()) > 1e-3 * gmax
     # training moves the loss down
     model.load_state_dict(state)
     mod = CoDetModule(model, teacher, kd_flag=1, lr=1e-3)
