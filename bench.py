@@ -58,6 +58,9 @@ def parse():
                          "scaling, no data-path collective); 'agent' = BASELINE configs[4]: 8-agent "
                          "scenes, agents sharded across ranks, one RCCL all-gather of the layer-3 maps "
                          "per step (strong scaling of a fixed batch of scenes)")
+    ap.add_argument("--task", choices=["det", "seg"], default="det",
+                    help="det = BASELINE configs[1] (the headline metric); seg = configs[3]: the segmentation "
+                         "variant (UNet + DiscoGraph fusion at the bottleneck), eval forward + cross entropy")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--in-flight", type=int, default=2,
@@ -214,6 +217,126 @@ def agent_sharded_bench(args, world, rank, dist):
     dist.destroy_process_group()
 
 
+def seg_bench(args, world, rank, dist, use_pg):
+    """BASELINE configs[3]: DiscoNet seg, 5-agent, 256x256 BEV; scene-parallel like the det bench.
+    One step = dense rebuild of the voxel lists (into the conv engine's layout) + the UNet forward with
+    the DiscoGraph fusion at the 512-channel bottleneck + the per-pixel 8-class cross entropy."""
+    from disconet_amd import SegDiscoNet, SegModule, ops
+    from disconet_amd.graph import GraphedStep
+    from disconet_amd.profiling import KernelTimer, timing
+    from disconet_amd.synthetic import make_sparse_scene_batch, make_trans_matrices, randomize_bn_stats
+    torch.manual_seed(0)
+    model = SegDiscoNet(num_agent=AGENTS)
+    randomize_bn_stats(model)
+    model.eval().cuda()
+    mod = SegModule(model)
+    indices, offsets, _ = make_sparse_scene_batch(BATCH, AGENTS, MAP_HW)
+    indices, offsets = indices.cuda(), offsets.cuda()
+    trans = make_trans_matrices(BATCH, AGENTS, jitter_seed=rank).cuda()
+    na = torch.full((BATCH, AGENTS), AGENTS, dtype=torch.int64).cuda()
+    labels = torch.randint(0, 8, (AGENTS * BATCH, MAP_HW, MAP_HW), device="cuda", dtype=torch.int32)
+    dims, n_img = (MAP_HW, MAP_HW, 13), AGENTS * BATCH
+
+    def step():
+        bevs = ops.scatter_dense_sp(indices, offsets, n_img, dims)
+        with torch.no_grad():
+            logits = model(bevs, trans, na, BATCH)
+            z = logits.permute(0, 2, 3, 1)
+            return ops.seg_ce_loss(z, labels, want_grad=False)[0], logits
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_pg:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    graphed = None
+    if not args.no_graph:
+        try:
+            graphed = GraphedStep(step)
+        except Exception as e:      # noqa: BLE001
+            print("bench: hipGraph capture failed (%r); launching eagerly" % (e,), file=sys.stderr)
+            torch.cuda.synchronize()
+    run = graphed if graphed is not None else step
+    for _ in range(args.warmup):
+        run()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, logits = run()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_pg:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    result = {
+        "metric": "scenes/sec (5-agent 256x256 BEV, seg)", "value": round(world * BATCH * args.steps / elapsed, 3),
+        "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16 hi+lo pair per value (32 bits, 22-bit significand); conv products as split-f16 x3 MFMA, "
+                 "f32 accumulate",
+        "data": "synthetic",
+        "config": {"workload": "DiscoNet seg eval forward (UNet 13->64..512, DiscoGraph fusion at the 512-channel "
+                               "bottleneck, 8 classes) + per-pixel cross entropy, 5-agent, batch 4 per GPU, "
+                               "256x256x13 BEV (BASELINE configs[3])",
+                   "agents": AGENTS, "batch_per_gpu": BATCH, "bev": [MAP_HW, MAP_HW, 13], "conv_math": "sp",
+                   "launch": "hipGraph replay" if graphed is not None else "eager",
+                   "parallelism": "scene-parallel x%d (no data-path collective)" % world},
+        "loss": round(float(loss), 6)}
+    if not args.no_kernel_events:
+        timer = KernelTimer()
+        torch.cuda.synchronize()
+        with timing(timer):
+            for _ in range(args.steps):
+                step()
+        summ = timer.summary()
+        conv = {k: v for k, v in summ.items() if v["kernel"] in CONV_KERNELS}
+        flops = sum(v["flops"] for v in conv.values())
+        ms = sum(v["ms_total"] for v in conv.values())
+        ach = flops / (ms * 1e-3) / 1e12 if ms else 0.0
+        result["roofline"] = {
+            "kernel": "conv_sp_kernel (%s, all %d launches/step)" % (MATH_LABEL["sp"], sum(
+                v["calls"] for v in conv.values()) // args.steps),
+            "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_PEAK_TFLOPS["sp"], "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_PEAK_TFLOPS["sp"], 4), "executed_flop_factor": 3,
+            "frac_executed": round(3 * ach / MFMA_PEAK_TFLOPS["sp"], 4), "traffic": None,
+            "flop_per_step": flops / args.steps, "kernel_ms_per_step": round(ms / args.steps, 4),
+            "note": "achieved = algorithmic FLOP (true channel counts) / HIP-event kernel time"}
+        if args.layers:
+            for k, v in summ.items():
+                print("[seg] %-12s %8.4f ms/step %9.2f TFLOP/s" % (
+                    k, v["ms_total"] / args.steps, v["flops"] / (v["ms_total"] * 1e-3) / 1e12 if v["ms_total"] else 0),
+                    file=sys.stderr)
+    if world == 1 and not args.no_cpu_baseline:
+        # the CPU oracle of the same model on ONE scene (bounded sample), all usable cores
+        from oracle.seg_ref import SegDiscoNetRef, seg_loss
+        from disconet_amd.synthetic import make_scene_batch
+        threads = usable_cores()
+        torch.set_num_threads(threads)
+        ref = SegDiscoNetRef(num_agent=AGENTS).eval()
+        ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+        bevs1, trans1, na1 = make_scene_batch(1, AGENTS, MAP_HW)
+        x1 = bevs1[:, 0].permute(0, 3, 1, 2).contiguous()
+        best = float("inf")
+        with torch.no_grad():
+            want = ref(x1, trans1, na1, 1)
+            for _ in range(2):
+                t0 = time.perf_counter()
+                ref(x1, trans1, na1, 1)
+                best = min(best, time.perf_counter() - t0)
+            got = model(x1.cuda(), trans1.cuda(), na1.cuda(), 1)
+        result["cpu_baseline"] = {
+            "value": round(1.0 / best, 4), "unit": "scenes/s", "cores": threads, "kind": "port",
+            "sample": "1 scene (5 agents, 256x256x13), eval fwd, fp32, best of 2 after 1 warm-up; torch-CPU "
+                      "oracle (reference source not in the mount)",
+            "parity_max_abs_err": float((got.cpu() - want).abs().max())}
+    print(json.dumps(result), flush=True)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_child:
@@ -235,6 +358,8 @@ def main():
 
     if args.mode == "agent":
         return agent_sharded_bench(args, world, rank, dist)
+    if args.task == "seg":
+        return seg_bench(args, world, rank, dist, use_pg)
 
     from disconet_amd import Config, DiscoNet, ops
     from disconet_amd.profiling import KernelTimer, timing

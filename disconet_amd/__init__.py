@@ -6,7 +6,8 @@ include/disconet_hip.h).  See DESIGN.md.
 """
 from .config import Config
 from .model import DiscoNet
+from .seg import SegDiscoNet, SegModule
 from .teacher import TeacherNet
 from .train import CoDetModule, TrainEngine
 
-__all__ = ["Config", "DiscoNet", "TeacherNet", "CoDetModule", "TrainEngine"]
+__all__ = ["Config", "DiscoNet", "TeacherNet", "CoDetModule", "TrainEngine", "SegDiscoNet", "SegModule"]

@@ -1,4 +1,4 @@
-"""ctypes binding of libdisconet_hip.so (include/disconet_hip.h, include/disconet_train.h).
+"""ctypes binding of libdisconet_hip.so (include/disconet_hip.h, disconet_train.h, disconet_seg.h).
 
 There is no fallback: if the shared object is missing or a call fails, this
 module raises.  The library is built in-tree by disconet_amd/csrc/build.py
@@ -90,6 +90,11 @@ SIGNATURES = {
     "dn_disco_fuse_mlp": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(FuseMlpParams), c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    # ---- include/disconet_seg.h ----
+    "dn_sp_maxpool2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dn_sp_upsample2_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dn_seg_ce_loss": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p,
+                               c_void_p]),
     # ---- include/disconet_train.h ----
     "dn_conv_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "dn_conv_wgrad": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

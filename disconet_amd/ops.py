@@ -317,6 +317,37 @@ def scatter_dense_sp(indices, offsets, n_images, dims):
     return out
 
 
+def sp_maxpool2(x):
+    """nn.MaxPool2d(2) on an SpTensor"""
+    out = SpTensor(x.n, x.h // 2, x.w // 2, x.c, device=x.device)
+    check(_lib.load().dn_sp_maxpool2(_ptr(x.data), x.n, x.h, x.w, x.c, _ptr(out.data), _stream()),
+          "dn_sp_maxpool2")
+    return out
+
+
+def sp_upsample2_bilinear(x):
+    """nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) on an SpTensor"""
+    out = SpTensor(x.n, 2 * x.h, 2 * x.w, x.c, device=x.device)
+    check(_lib.load().dn_sp_upsample2_bilinear(_ptr(x.data), x.n, x.h, x.w, x.c, _ptr(out.data),
+                                               _stream()), "dn_sp_upsample2_bilinear")
+    return out
+
+
+def seg_ce_loss(logits_nhwc, labels, want_grad=True):
+    """mean per-pixel cross entropy of float32 NHWC logits [n, h, w, 8] vs int labels [n, h, w]
+    -> (loss double scalar tensor, dlogits [n, h, w, 8] or None)"""
+    _need_gpu(logits_nhwc, labels)
+    _f32c(logits_nhwc, "logits")
+    pixels = logits_nhwc.numel() // logits_nhwc.shape[-1]
+    lab = labels.to(device=logits_nhwc.device, dtype=torch.int32).contiguous()
+    loss = torch.empty(1, dtype=torch.float64, device=logits_nhwc.device)
+    grad = torch.empty_like(logits_nhwc) if want_grad else None
+    check(_lib.load().dn_seg_ce_loss(_ptr(logits_nhwc), _ptr(lab), pixels, logits_nhwc.shape[-1],
+                                     logits_nhwc.shape[-1], 1.0 / pixels, _ptr(loss), _ptr(grad), _stream()),
+          "dn_seg_ce_loss")
+    return loss / pixels, grad
+
+
 def pack_post1x1_weights(weight):
     """weight [c_out2, c_in2(, 1, 1)] -> packed split-f16 rows for dn_conv2d_post1x1."""
     _need_gpu(weight)

@@ -1,0 +1,48 @@
+/*
+ * disconet_seg.h -- C ABI of the segmentation variant of `--com disco`
+ * (BASELINE.json configs[3]: "DiscoNet seg head, 5-agent, 256x256 BEV").
+ *
+ * The reference's seg path is upstream:coperception/models/seg/{SegModelBase,DiscoNet}.py +
+ * upstream:coperception/utils/SegModule.py, reached by upstream:tools/seg/{train,test}_seg.py;
+ * none of it is in the mount (/root/reference/coperception is an empty submodule directory,
+ * /root/reference/.gitmodules:1-3) -- the only mounted mention of the task is
+ * /root/reference/README.md:15 -- so every entry point cites the upstream call it replaces by path.
+ *
+ * The UNet's convolutions run on the SP conv engine of disconet_hip.h (dn_spconv2d), the
+ * DiscoGraph fusion at the 512-channel bottleneck on dn_warp_neighbors + dn_conv2d (layer 1 of the
+ * attention MLP) + dn_disco_fuse_tail.  This header adds the three ops that are new:
+ * conventions (device pointers, caller-owned buffers, stream, int status) as disconet_hip.h.
+ */
+#ifndef DISCONET_SEG_H
+#define DISCONET_SEG_H
+
+#include "disconet_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* nn.MaxPool2d(2) of the Down blocks (upstream SegModelBase.py :: Down.maxpool_conv[0]) on a
+ * split-planar tensor [n][ceil(c/16)][4][h][w] x 16 B -> [n][..][4][h/2][w/2]; h, w even.  The
+ * (hi, lo) pair of the largest of the four values is copied: exact. */
+int dn_sp_maxpool2(const void* src_sp, int n_images, int h, int w, int channels, void* dst_sp,
+                   void* stream);
+
+/* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) of the Up blocks
+ * (upstream SegModelBase.py :: Up.up), SP in -> SP out [n][..][4][2h][2w]; ATen's arithmetic:
+ * src = dst * (in - 1) / (out - 1), fp32 lerp weights. */
+int dn_sp_upsample2_bilinear(const void* src_sp, int n_images, int h, int w, int channels,
+                             void* dst_sp, void* stream);
+
+/* Per-pixel cross entropy over `classes` (= 8) logits (upstream SegModule.py :: step,
+ * nn.CrossEntropyLoss): logits [pixels][ld] float32, labels [pixels] int32 (out-of-range = ignored).
+ *   loss_sum (device double, zeroed by the call) += sum_p (logsumexp(z_p) - z_p[y_p])
+ *   dlogits [pixels][ld] (may be NULL) = (softmax(z_p) - onehot(y_p)) * grad_scale
+ * -- pass grad_scale = 1 / pixels for the reference's mean reduction. */
+int dn_seg_ce_loss(const float* logits, const int32_t* labels, long pixels, int classes, int ld,
+                   float grad_scale, double* loss_sum, float* dlogits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISCONET_SEG_H */

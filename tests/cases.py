@@ -180,3 +180,41 @@ def oracle_train_fp64(case, ref, kd_teacher=None):
         F.grid_sample = orig
     losses = [float(l_cls.detach()), float(l_loc.detach())] + ([float(l_kd.detach())] if l_kd is not None else [])
     return losses, {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
+
+
+# --- segmentation variant (BASELINE.json configs[3]) ------------------------
+SEG_CASES = {
+    "seg_a2": dict(map_hw=128, agents=2, batch=1, live=None, jitter=101),
+    "seg_ragged_a4": dict(map_hw=128, agents=4, batch=2, live=[3, 2], jitter=7),
+}
+
+
+def seg_ref_model(agents, **kw):
+    from oracle.seg_ref import build_seg_ref
+    return build_seg_ref(seed=0, init="kaiming", num_agent=agents, **kw)
+
+
+def seg_inputs(case):
+    """(bevs NCHW [A*B, 13, H, W], trans, num_agent, labels [A*B, H, W] int64 in 0..7)"""
+    c = SEG_CASES[case]
+    bevs, trans, na = make_scene_batch(c["batch"], c["agents"], c["map_hw"], live=c["live"], jitter_seed=c["jitter"])
+    x = bevs[:, 0].permute(0, 3, 1, 2).contiguous()
+    g = torch.Generator().manual_seed(31)
+    labels = torch.randint(0, 8, (x.shape[0], c["map_hw"], c["map_hw"]), generator=g)
+    return x, trans, na, labels
+
+
+def run_seg_ref(case, model=None):
+    c = SEG_CASES[case]
+    model = model or seg_ref_model(c["agents"], kd_flag=True)
+    x, trans, na, labels = seg_inputs(case)
+    from oracle.seg_ref import seg_loss
+    with torch.no_grad():
+        logits, x9, x8, x7, x6, x5, fused = model(x, trans, na, c["batch"])
+        loss = seg_loss(logits, labels)
+    return {"logits": logits, "x9": x9, "x6": x6, "fused": fused}, float(loss)
+
+
+def seg_subsample(name, t):
+    t = t.detach().cpu().numpy()
+    return t[:, :, ::7, ::5] if name == "logits" else t[:, ::5, ::3, ::3]

@@ -85,6 +85,16 @@ def main():
             print("train", case, tag, losses)
     np.savez_compressed(os.path.join(HERE, "train_step.npz"), **store)
 
+    # 6. segmentation variant: logits / intermediate maps (strided) and the cross-entropy value
+    store = {}
+    for case in cases.SEG_CASES:
+        outs, loss = cases.run_seg_ref(case)
+        for name, t in outs.items():
+            store["%s/%s" % (case, name)] = cases.seg_subsample(name, t)
+        store["%s/loss" % case] = np.float64(loss)
+        print("seg", case, {k: tuple(v.shape) for k, v in outs.items()}, "loss", loss)
+    np.savez_compressed(os.path.join(HERE, "seg_cases.npz"), **store)
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -493,8 +493,9 @@ def test_kd_train_step_at_baseline_size_properties():
     # a zeroed teacher term vanishes: what is left between the two runs is the run-to-run noise of the
     # backward's atomics (BatchNorm / bias sums); the live KD term moves the gradient far beyond it
     gmax = float(g_plain.abs().max())
-    assert float((g_plain - g_zero).abs().max()) <= 1e-5 * gmax
-    assert float((g_kd - g_plain).abs().max()) > 1e-3 * gmax
+    noise = float((g_plain - g_zero).abs().max())
+    assert noise <= 1e-5 * gmax
+    assert float((g_kd - g_plain).abs().max()) > max(20 * noise, 1e-4 * gmax)
     # training moves the loss down
     model.load_state_dict(state)
     mod = CoDetModule(model, teacher, kd_flag=1, lr=1e-3)
