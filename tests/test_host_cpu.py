@@ -14,7 +14,7 @@ from tests.conftest import ROOT
 
 def _header_functions():
     text = "".join(open(os.path.join(ROOT, "include", f)).read()
-                   for f in ("disconet_hip.h", "disconet_train.h"))
+                   for f in ("disconet_hip.h", "disconet_train.h", "disconet_seg.h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(dn_[a-z0-9_]+)\s*\(", text)))
 
@@ -35,6 +35,8 @@ def test_struct_layouts_match_header():
     from disconet_amd import _lib
     assert ctypes.sizeof(_lib.ConvDesc) == 14 * 4
     assert ctypes.sizeof(_lib.MlpTailParams) == 10 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_lib.Post1x1Desc) == 6 * 4
+    assert ctypes.sizeof(_lib.FuseMlpParams) == 9 * ctypes.sizeof(ctypes.c_void_p)
 
 
 def test_argument_errors_are_reported_not_thrown():
