@@ -63,12 +63,14 @@ def parse():
                          "variant (UNet + DiscoGraph fusion at the bottleneck), eval forward + cross entropy")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from Python instead of replaying a captured hipGraph")
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="steps in flight: consecutive steps (independent batches) are replayed on this many "
-                         "alternating HIP streams, each from its own captured graph with its own buffers, so one "
-                         "batch's small-grid / tail phases overlap the next batch's (+9 %% scenes/s).  The run "
-                         "checks that every graph produced bit-identical outputs and falls back to the serial "
-                         "figure if not; 1 = strictly one step at a time")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="steps in flight.  1 (default) = strictly one step at a time on one stream.  N > 1: "
+                         "consecutive steps (independent batches) are replayed on N alternating HIP streams, each "
+                         "from its own captured graph with its own buffers (+4 %% scenes/s) -- NOT the default "
+                         "because a kernel that shares a SIMD with another stream's f16-MFMA waves has been "
+                         "observed to compute with corrupted VGPR lanes (DESIGN.md 3.6, profiles/r02_hazard_repro.txt). "
+                         "With N > 1 EVERY replay of the timed region is checksummed on its stream and compared "
+                         "with the serial replay's checksum; one mismatch and the serial figure is reported")
     ap.add_argument("--no-voxelize", action="store_true", help="skip the K1 (raw points) timing extra")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
     ap.add_argument("--train-steps", type=int, default=4,
@@ -423,14 +425,26 @@ def main():
             return slots[0][0]()
         g, st = slots[i % depth]
         with torch.cuda.stream(st):
-            return g()
+            out = g()
+            if checks is not None:      # every replay in flight leaves a checksum of everything it returned
+                checks[i].copy_(checksum(out))
+            return out
+
+    def checksum(out):
+        """order-independent 64-bit checksum of the step's outputs (wrapping integer sum of the raw words)"""
+        return out["cls"].view(torch.int64).sum() + 3 * out["loc"].view(torch.int64).sum()
+
+    checks = None
 
     def timed(events, depth=None):
+        nonlocal checks
         """K steps of the hot path.  events=False: nothing but the steps (-> value).
         events=True: a HIP-event pair around every launch, on the launch stream (->
         per-kernel durations); kept apart because each event record drains the queue
         (~30 us per launch), which would understate `value` by ~15 %."""
         timer = KernelTimer() if events else None
+        d = max(1, args.in_flight) if depth is None else depth
+        checks = torch.zeros(args.steps, dtype=torch.int64, device="cuda") if (d > 1 and not events and not args.no_graph) else None
         fence() if not events else torch.cuda.synchronize()
         t0 = time.perf_counter()
         if events:
@@ -467,6 +481,7 @@ def main():
             "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "note": "achieved = algorithmic FLOP (true channel counts) / HIP-event kernel time",
+            "roofline_serial_basis": True,   # every launch timed alone on its stream (eager, event pair around it)
             "executed_flop_factor": factor, "frac_executed": round(achieved * factor / peak, 4),
             "hbm_algorithmic_TBps": round(alg_bytes / (ms * 1e-3) / 1e12, 3) if ms > 0 else None,
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
@@ -492,16 +507,29 @@ def main():
     for i in range(args.warmup):
         run_step(i)
     elapsed, _ = timed(False)                      # timed region #1 -> value
+    replay_checks = checks
     elapsed_serial = timed(False, depth=1)[0] if (args.in_flight > 1 and not args.no_graph) else None
     timer, elapsed_events = None, 0.0
     if rank == 0 and not args.no_kernel_events:
         elapsed_events, timer = timed(True)        # timed region #2 -> roofline
-    # every rank checks that its graphs in flight wrote the same bits as the serial replay
-    outputs_same = None
-    if elapsed_serial is not None and graphed.get(model.conv_math):
-        outs = [g.outputs for g, _ in graphed[model.conv_math]]
-        outputs_same = all(torch.equal(o["cls"], outs[0]["cls"]) and torch.equal(o["loc"], outs[0]["loc"])
-                           for o in outs[1:])
+    # every rank checks that EVERY replay it had in flight wrote the same bits as the serial replay
+    outputs_same, replays_differing = None, None
+    if elapsed_serial is not None and graphed.get(model.conv_math) and replay_checks is not None:
+        serial_out = graphed[model.conv_math][0][0]()        # one more replay, alone on the device
+        torch.cuda.synchronize()
+        want = checksum(serial_out)
+        replays_differing = int((replay_checks != want).sum().item())
+        outputs_same = replays_differing == 0
+    # the captured graph must reproduce the eager step bit for bit (profiles/r02_hazard_repro.txt part A)
+    graph_ok = None
+    if graphed.get(model.conv_math):
+        eager = step()
+        eager = {k: eager[k].clone() for k in ("cls", "loc")}
+        replay = graphed[model.conv_math][0][0]()
+        torch.cuda.synchronize()
+        graph_ok = bool(torch.equal(replay["cls"], eager["cls"]) and torch.equal(replay["loc"], eager["loc"]))
+        if not graph_ok:
+            print("bench: the hipGraph replay differs from the eager step -- the figure is INVALID", file=sys.stderr)
     if use_pg:
         t = torch.tensor([elapsed, elapsed_serial or 0.0, -float(outputs_same is not False)], device="cuda",
                          dtype=torch.float64)
@@ -541,9 +569,16 @@ def main():
     }
 
     if rank == 0:
+        if graph_ok is not None:
+            result["graph_equals_eager"] = graph_ok
+            if not graph_ok:
+                result["invalid"] = "hipGraph replay of the step differs from the eager step"
         if elapsed_serial is not None:
             if outputs_same is not None:
                 result["in_flight_outputs_identical"] = outputs_same
+                result["in_flight_replays_checked"] = {"replays": args.steps, "differing": replays_differing,
+                                                       "how": "64-bit checksum of cls+loc after every replay, on its stream, "
+                                                              "inside the timed region, vs the checksum of a replay run alone"}
                 if not outputs_same:  # never report a throughput whose results are not the serial ones
                     result["value"] = round(scenes / elapsed_serial, 3)
                     result["ms_per_step"] = round(1e3 * elapsed_serial / args.steps, 4)
@@ -553,6 +588,10 @@ def main():
                 "ms_per_step": round(1e3 * elapsed_serial / args.steps, 4),
                 "note": "same K steps replayed back to back on ONE stream per rank (max over ranks): the "
                         "latency of a step; `value` overlaps consecutive, independent batches"}
+        else:
+            result["one_step_at_a_time"] = {"value": result["value"], "ms_per_step": result["ms_per_step"],
+                                            "note": "the headline itself: one captured step replayed back to back "
+                                                    "on one stream per rank (--in-flight 1, the default)"}
         if timer is not None:
             result["roofline"] = roofline_of(timer, elapsed_events, args.math)
         if world == 1 and not args.no_alt_math:

@@ -5,6 +5,29 @@ char* err_buf() {
   static thread_local char buf[512] = {0};
   return buf;
 }
+namespace {
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// head/tail bytes one at a time, the 16-byte aligned middle as 128-bit stores (grid-stride)
+__global__ void __launch_bounds__(256) zero_fill_kernel(unsigned char* p, size_t head, size_t vecs, size_t tail) {
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (tid < head) p[tid] = 0;
+  u32x4* v = reinterpret_cast<u32x4*>(p + head);
+  for (size_t i = tid; i < vecs; i += stride) v[i] = u32x4{0u, 0u, 0u, 0u};
+  if (tid < tail) p[head + 16 * vecs + tid] = 0;
+}
+}  // namespace
+
+hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return hipSuccess;
+  unsigned char* p = static_cast<unsigned char*>(ptr);
+  size_t head = (16 - (reinterpret_cast<size_t>(p) & 15)) & 15;
+  if (head > bytes) head = bytes;
+  const size_t vecs = (bytes - head) / 16, tail = bytes - head - 16 * vecs;
+  const size_t want = (vecs + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, stream, p, head, vecs, tail);
+  return hipGetLastError();
+}
 }  // namespace dn
 
 extern "C" int dn_version(void) { return 100; }  // 0.1.0

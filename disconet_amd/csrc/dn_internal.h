@@ -18,6 +18,11 @@ inline int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// Zero `bytes` bytes at `ptr` on `stream` with a kernel launch.  NOT hipMemsetAsync: a memset captured into a
+// hipGraph was measured to write a garbage 16-byte pattern from the second replay on (tools/hazard/ptr_audit.py,
+// DESIGN.md 3.6) -- a kernel node carries its arguments by value and replays exactly.
+hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t stream);
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(DN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));

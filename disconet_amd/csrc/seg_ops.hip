@@ -161,7 +161,7 @@ extern "C" int dn_seg_ce_loss(const float* logits, const int32_t* labels, long p
   DN_REQUIRE(logits && labels && loss_sum && pixels > 0, "seg_ce_loss: bad arguments");
   DN_REQUIRE(classes == 8 && ld >= classes, "seg_ce_loss: %d classes unsupported (8)", classes);
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(loss_sum, 0, sizeof(double), s) != hipSuccess)
+  if (dn::zero_fill(loss_sum, sizeof(double), s) != hipSuccess)
     return dn::fail(DN_ERR_LAUNCH, "seg_ce_loss: memset failed");
   const int blocks = (int)((pixels + 255) / 256 < 2048 ? (pixels + 255) / 256 : 2048);
   hipLaunchKernelGGL(seg_ce_kernel<8>, dim3(blocks), dim3(256), 0, s, logits, labels, pixels, ld, grad_scale,

@@ -593,7 +593,7 @@ extern "C" int dn_bn_train_stats(const float* z, int n_groups, long rows_per_gro
   DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0 && c <= kMaxC && ldz >= c,
              "bn stats: bad shape (groups %d rows %ld c %d ld %d)", n_groups, rows_per_group, c, ldz);
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * c * n_groups, s) != hipSuccess)
+  if (dn::zero_fill(sums, sizeof(double) * 2 * c * n_groups, s) != hipSuccess)
     return dn::fail(DN_ERR_LAUNCH, "bn stats: memset failed");
   if (vec4_ok(c, {ldz}, {z}))
     hipLaunchKernelGGL(bn_stats_v4_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
@@ -648,7 +648,7 @@ extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const
              "bn backward: bad shape");
   hipStream_t s = (hipStream_t)stream;
   const long rows_per_group = (long)images_per_group * h * w;
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * c * n_groups, s) != hipSuccess)
+  if (dn::zero_fill(sums, sizeof(double) * 2 * c * n_groups, s) != hipSuccess)
     return dn::fail(DN_ERR_LAUNCH, "bn backward: memset failed");
   GradSrc src{dy_a, dy_b, y, ld_a, up_a, ld_b, relu, h, w, c};
   const long total = (long)n_groups * rows_per_group * c;
@@ -673,7 +673,7 @@ extern "C" int dn_channel_sum(const float* x, long rows, int c, int ld, double* 
   DN_REQUIRE(x && sums && out, "channel sum: null pointer");
   DN_REQUIRE(rows > 0 && c > 0 && c <= kMaxC && ld >= c, "channel sum: bad shape");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(double) * c, s) != hipSuccess)
+  if (dn::zero_fill(sums, sizeof(double) * c, s) != hipSuccess)
     return dn::fail(DN_ERR_LAUNCH, "channel sum: memset failed");
   if (vec4_ok(c, {ld}, {x}))
     hipLaunchKernelGGL(channel_sum_v4_kernel, dim3(blocks_per_group(rows, 1)), dim3(256), 0, s, x, rows,
@@ -761,7 +761,7 @@ extern "C" int dn_det_loss(const float* cls, const float* labels, const float* l
   DN_REQUIRE(cls && labels && loc && targets && mask && losses && dcls && dloc, "det loss: null pointer");
   DN_REQUIRE(n > 0 && code > 0 && norm > 0.f && sigma > 0.f, "det loss: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(losses, 0, 2 * sizeof(double), s) != hipSuccess)
+  if (dn::zero_fill(losses, 2 * sizeof(double), s) != hipSuccess)
     return dn::fail(DN_ERR_LAUNCH, "det loss: memset failed");
   hipLaunchKernelGGL(det_loss_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, cls, labels, loc, targets,
                      mask, n, code, alpha, gamma, sigma, 1.f / norm, losses, dcls, dloc);
@@ -835,7 +835,7 @@ extern "C" int dn_kd_kl_loss(const float* student, const float* teacher, long ro
   DN_REQUIRE(student && teacher && loss && dstudent, "kd loss: null pointer");
   DN_REQUIRE(rows > 0 && c > 0, "kd loss: bad shape");
   hipStream_t s = (hipStream_t)stream;
-  if (zero_loss && hipMemsetAsync(loss, 0, sizeof(double), s) != hipSuccess)
+  if (zero_loss && dn::zero_fill(loss, sizeof(double), s) != hipSuccess)
     return dn::fail(DN_ERR_LAUNCH, "kd loss: memset failed");
   const long blocks = (rows + 3) / 4;
   hipLaunchKernelGGL(kd_kl_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s,

@@ -184,7 +184,7 @@ extern "C" int dn_voxelize_occupy(const float* pts, int n_pts, int pt_stride,
   g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
   hipStream_t s = (hipStream_t)stream;
   const size_t bytes = (size_t)g.dx * g.dy * g.dz * sizeof(float);
-  hipError_t e = hipMemsetAsync(dense, 0, bytes, s);
+  hipError_t e = dn::zero_fill(dense, bytes, s);
   if (e != hipSuccess) return dn::fail(DN_ERR_LAUNCH, "voxelize: memset: %s", hipGetErrorString(e));
   if (n_pts == 0) return DN_OK;
   const int blocks = (n_pts + 255) / 256 < 2048 ? (n_pts + 255) / 256 : 2048;
@@ -219,7 +219,7 @@ extern "C" int dn_scatter_dense(const int32_t* indices, const int32_t* offsets, 
   DN_REQUIRE(n_images > 0 && total >= 0 && (total == 0 || indices), "scatter_dense: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   const size_t bytes = (size_t)n_images * dims[0] * dims[1] * dims[2] * sizeof(float);
-  hipError_t e = hipMemsetAsync(dense, 0, bytes, s);
+  hipError_t e = dn::zero_fill(dense, bytes, s);
   if (e != hipSuccess) return dn::fail(DN_ERR_LAUNCH, "scatter_dense: memset: %s", hipGetErrorString(e));
   if (total == 0) return DN_OK;
   const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
@@ -234,7 +234,7 @@ extern "C" int dn_scatter_dense_sp(const int32_t* indices, const int32_t* offset
   DN_REQUIRE(n_images > 0 && total >= 0 && (total == 0 || indices), "scatter_dense_sp: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   const size_t bytes = (size_t)n_images * ((dims[2] + 15) / 16) * 4 * dims[0] * dims[1] * 16;
-  hipError_t e = hipMemsetAsync(dense_sp, 0, bytes, s);
+  hipError_t e = dn::zero_fill(dense_sp, bytes, s);
   if (e != hipSuccess) return dn::fail(DN_ERR_LAUNCH, "scatter_dense_sp: memset: %s", hipGetErrorString(e));
   if (total == 0) return DN_OK;
   const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;

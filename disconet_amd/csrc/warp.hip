@@ -109,11 +109,10 @@ warp_neighbors_kernel(const float* __restrict__ feat, const float* __restrict__ 
   const float x_trans = (4.f * m[3]) / 128.f;
   const float y_trans = -(4.f * m[7]) / 128.f;
 
-  // Channel loop with a wave-uniform trip count and, for whole rows of 64 lanes (c % 256 == 0),
-  // no per-lane condition at all: the loop must not depend on an EXEC mask derived from a VALU
-  // compare (tools/det_check.py, DESIGN.md 3.6: with a lane-dependent exit `c4 < c4n`, lanes 48..63
-  // of a wave occasionally ran one extra iteration -- channels 192..255 of the NEXT pixel, from the
-  // next pixel's taps -- when MFMA-dense waves of another kernel shared the SIMD).
+  // Channel loop with a wave-uniform trip count; whole rows of 64 lanes (c % 256 == 0) carry no per-lane
+  // condition.  (Round 1 believed a lane-dependent exit here was behind the corruption seen beside the conv
+  // engine on a second stream; profiles/r02_hazard_repro.txt shows this form fails the same way -- the loop
+  // form is a convenience, not a fix.)
   const int n_it = (c4n + 63) >> 6;
   const bool full = (c4n & 63) == 0;
   for (int pp = wave; pp < PIX_PER_BLOCK; pp += 4) {
@@ -364,7 +363,7 @@ extern "C" int dn_warp_backward(const float* d_warped, const float* poses, const
                        src_image, n_warps, h, w, c, d_src);
     return dn::check_launch("warp_gather kernels");
   }
-  if (hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)n_warps * h * w * c, s) != hipSuccess)
+  if (dn::zero_fill(scratch, sizeof(float) * (size_t)n_warps * h * w * c, s) != hipSuccess)
     return dn::fail(DN_ERR_LAUNCH, "warp backward: memset failed");
   hipLaunchKernelGGL(warp_scatter_kernel<2>, grid, dim3(256), 0, s, d_warped, poses, src_image, h, w, c,
                      scratch);
