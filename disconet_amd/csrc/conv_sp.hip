@@ -121,7 +121,7 @@ struct SpTile {
   static_assert(BN == WAVES_N * WTN * 32, "channel tile must match the wave layout");
   static_assert(!(STRIDE == 2 && TW == 32), "stride 2: 16- or 8-wide tiles");
   static_assert(POST != 1 || (WAVES_N == 1 && BN == 64 && TW == 32), "fused 1x1: 64 channels in one wave");
-  static_assert(POST != 2 || (WAVES_N == 1 && BN == 32), "fused block-diagonal 1x1: one 32-channel head per workgroup");
+  static_assert(POST != 2 || (WAVES_N == 1 && (BN == 32 || BN == 64)), "fused block-diagonal 1x1: whole 32-channel heads per wave");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
 };
 
@@ -420,7 +420,9 @@ conv_sp_kernel(const SpArgs a) {
       // channels are one head's hidden layer, its 1x1 conv reads nothing else.  Channel block 0 writes
       // columns [0, split2) to `out`, block 1 the rest to `out_b` (fp32 NHWC).  Stage-2 weights come
       // as A fragments straight from L2 (4 KB per head); every lane stores its own 16-byte pieces.
-      const int cb = tc.n0 >> 5;
+#pragma unroll
+      for (int wn = 0; wn < WTN; ++wn) {      // BN == 64: this wave holds both heads' hidden layers
+      const int cb = (tc.n0 >> 5) + wn;
       const int c2 = cb ? a.c_out2 - a.split2 : a.split2, c2_0 = cb ? a.split2 : 0;
       float* obase = cb ? a.out_b : reinterpret_cast<float*>(a.out);
       const int ldo = cb ? a.ldo_b : a.ldo_a;
@@ -429,11 +431,11 @@ conv_sp_kernel(const SpArgs a) {
         u32x2 hi[4], lo[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int co = tc.n0 + 8 * g + 4 * lh;
+          const int co = tc.n0 + 32 * wn + 8 * g + 4 * lh;
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[e] = acc[wm][0][4 * g + e] * a.scale[co + e] + a.shift[co + e];
+            v[e] = acc[wm][wn][4 * g + e] * a.scale[co + e] + a.shift[co + e];
             if (a.relu) v[e] = fmaxf(v[e], 0.f);
           }
           split4(v, hi[g], lo[g]);
@@ -475,10 +477,11 @@ conv_sp_kernel(const SpArgs a) {
                 v[e] = acc2[4 * g + e] * sc[e] + sh[e];
                 if (a.relu2) v[e] = fmaxf(v[e], 0.f);
               }
-              if (inside) *reinterpret_cast<f32x4*>(opx + ch) = v;
+              if (inside && (!kNoStore || v[0] == 12345.678f)) *reinterpret_cast<f32x4*>(opx + ch) = v;
             }
           }
         }
+      }
       }
     } else if constexpr (POST == 0) {
 #pragma unroll
@@ -1165,6 +1168,18 @@ extern "C" int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc*
                "spconv+1x1: the block-diagonal form needs two fp32 outputs of <= 64 columns each");
     using TS = SpTile<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 1>;
     static const int stat_env = [] { const char* e = getenv("DN_SP_STATIONARY"); return e ? atoi(e) : 1; }();
+    // both heads in one workgroup (the input patch is staged once): 1 = streaming weights, 2 = LDS-resident
+    static const int heads64 = [] { const char* e = getenv("DN_SP_HEADS64"); return e ? atoi(e) : 0; }();
+    using TS64 = SpTile<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 2, 1>;
+    if (heads64 == 2 && fits_stationary(*d, 64, TS64::A_STAGE, 0, 1, true))
+      return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 2, 0, 1>(a, *d, (hipStream_t)stream);
+    if (heads64 >= 1) return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 2, 0, 0>(a, *d, (hipStream_t)stream);
+    // ablations of the heads launch (measurement only): 3 = no operand DMA, 4 = no stores, 5 = no LDS reads
+    static const int heads_abl = [] { const char* e = getenv("DN_SP_HEADS_ABL"); return e ? atoi(e) : 0; }();
+    if (heads_abl == 3) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 3, 0>(a, *d, (hipStream_t)stream);
+    if (heads_abl == 4) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 4, 0>(a, *d, (hipStream_t)stream);
+    if (heads_abl == 5) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 5, 0>(a, *d, (hipStream_t)stream);
+    if (heads_abl == 9) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 0, 0>(a, *d, (hipStream_t)stream);
     if (stat_env && fits_stationary(*d, 32, TS::A_STAGE, 0, 2, true))
       return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 0, 1>(a, *d, (hipStream_t)stream);
     return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 0, 0>(a, *d, (hipStream_t)stream);

@@ -17,6 +17,7 @@
 // Replaces upstream:coperception/models/det/base/* :: feature_transformation
 // (SURVEY.md §8 a5).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "disconet_train.h"
 #include "dn_internal.h"
@@ -337,7 +338,88 @@ warp_gather1_kernel(const float* __restrict__ d_out1, const float* __restrict__ 
   }
 }
 
+// ---- tile-shared form of the same two passes.  Every output pixel p of an 8x8 tile reads the four
+// rotated-map pixels q = (x0(p) + {0,1}, y0(p) + {0,1}); the translation is one offset per (ego, neighbour)
+// pair, so the tile's q pixels form a (T+1)^2 block (T+2 allowed for a rounding split of floor()).  The
+// rotated map R(q) of that block is computed ONCE per workgroup into LDS (4 taps of the source map each,
+// with sample_src's arithmetic) and the tile's 64 outputs are blended from LDS with the per-pixel weights
+// of the one-pixel-per-wave kernel -- the same values in the same order, with ~3x fewer L2 tap reads
+// (the one-pixel kernel re-derives every R(q) four times and is bound by L2 -> L1 bandwidth, ~1.3 GB per
+// step).  A workgroup covers one 64-channel slice of the tile: 100 x 256 B = 25.6 KB of LDS.
+constexpr int WT = 8, WQ = WT + 2, WCS = 64;
+
+__global__ void __launch_bounds__(256)
+warp_neighbors_tiled_kernel(const float* __restrict__ feat, const float* __restrict__ trans,
+                            const int32_t* __restrict__ num_agent, int batch, int agents, int h, int w,
+                            int c, int only_v2i, int ego_first, int ego_count, int tiles_x,
+                            float* __restrict__ warped) {
+  __shared__ f32x4 rot[WQ * WQ][WCS / 4];
+  const int n_slices = c / WCS;
+  const int slice = blockIdx.x % n_slices, tile = blockIdx.x / n_slices;
+  const int tile_x0 = (tile % tiles_x) * WT, tile_y0 = (tile / tiles_x) * WT;
+  const int jj = blockIdx.y, bi = blockIdx.z;
+  const int b = bi / ego_count, i = ego_first + bi % ego_count;
+  const int j = jj + (jj >= i ? 1 : 0);
+  int n_live = num_agent[b];
+  n_live = n_live < 0 ? 0 : (n_live > agents ? agents : n_live);
+  const int tid = threadIdx.x, l = tid & 15;
+  const int hw = h * w;
+  float* dst = warped + ((size_t)bi * (agents - 1) + jj) * hw * c + slice * WCS + 4 * l;
+  const bool live = i < n_live && j < n_live && !(only_v2i && i != 0 && j != 0);
+  if (!live) {
+    for (int pl = tid >> 4; pl < WT * WT; pl += 16) {
+      const int px = tile_x0 + pl % WT, py = tile_y0 + pl / WT;
+      if (px < w && py < h) *reinterpret_cast<f32x4*>(dst + (size_t)(py * w + px) * c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
+  const SrcImage src = make_src_image(feat + ((size_t)j * batch + b) * hw * c, (size_t)hw * c * 4);
+  const float* m = trans + (((size_t)b * agents + i) * agents + j) * 16;
+  const float r00 = m[0], r01 = m[1], r10 = m[4], r11 = m[5];
+  const float x_trans = (4.f * m[3]) / 128.f;
+  const float y_trans = -(4.f * m[7]) / 128.f;
+  // north-west q of the tile: the smallest x0(p) - (p - tile origin) over the tile's columns / rows
+  int qx_base = 1 << 30, qy_base = 1 << 30;
+#pragma unroll
+  for (int k = 0; k < WT; ++k) {
+    const Bilinear t = bilinear_taps((2.f * (tile_x0 + k) + 1.f) / w - 1.f + x_trans,
+                                     (2.f * (tile_y0 + k) + 1.f) / h - 1.f + y_trans, w, h);
+    qx_base = min(qx_base, t.x0 - k);
+    qy_base = min(qy_base, t.y0 - k);
+  }
+  // pass 1 (rotation) of the tile's q block
+  for (int idx = tid; idx < WQ * WQ * 16; idx += 256) {
+    const int q = idx >> 4;
+    const int qx = qx_base + q % WQ, qy = qy_base + q / WQ;
+    const float qbx = (2.f * qx + 1.f) / w - 1.f;
+    const float qby = (2.f * qy + 1.f) / h - 1.f;
+    const Bilinear t1 = bilinear_taps(r00 * qbx + r01 * qby, r10 * qbx + r11 * qby, w, h);
+    rot[q][l] = sample_src(src, t1, w, h, c, slice * (WCS / 4) + l);
+  }
+  __syncthreads();
+  // pass 2 (translation): blend the four q of every output pixel
+  for (int pl = tid >> 4; pl < WT * WT; pl += 16) {
+    const int px = tile_x0 + pl % WT, py = tile_y0 + pl / WT;
+    if (px >= w || py >= h) continue;
+    const float bx = (2.f * px + 1.f) / w - 1.f;
+    const float by = (2.f * py + 1.f) / h - 1.f;
+    const Bilinear t2 = bilinear_taps(bx + x_trans, by + y_trans, w, h);
+    const float qw[4] = {t2.w_nw, t2.w_ne, t2.w_sw, t2.w_se};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int qx = t2.x0 + (k & 1), qy = t2.y0 + (k >> 1);
+      const bool qok = qx >= 0 && qx < w && qy >= 0 && qy < h;
+      const int lx = min(max(qx - qx_base, 0), WQ - 1), ly = min(max(qy - qy_base, 0), WQ - 1);
+      acc += rot[ly * WQ + lx][l] * (qok ? qw[k] : 0.f);
+    }
+    *reinterpret_cast<f32x4*>(dst + (size_t)(py * w + px) * c) = acc;
+  }
+}
+
 }  // namespace
+
+
 
 extern "C" int dn_warp_list(const float* src, const float* poses, const int32_t* src_image,
                             int n_warps, int h, int w, int c, float* warped, void* stream) {
@@ -382,6 +464,14 @@ extern "C" int dn_warp_neighbors(const float* feat, const float* trans, const in
              "warp: ego range [%d, %d) outside 0..%d", ego_first, ego_first + ego_count, agents);
   if (agents < 2) return DN_OK;   // no neighbours to warp
   const int hw = h * w;
+  static const int tiled_env = [] { const char* e = getenv("DN_WARP_TILED"); return e ? atoi(e) : 1; }();
+  if (tiled_env && c % WCS == 0) {
+    const int tiles_x = (w + WT - 1) / WT, tiles_y = (h + WT - 1) / WT;
+    dim3 tgrid(tiles_x * tiles_y * (c / WCS), agents - 1, batch * ego_count);
+    hipLaunchKernelGGL(warp_neighbors_tiled_kernel, tgrid, dim3(256), 0, (hipStream_t)stream, feat, trans,
+                       num_agent, batch, agents, h, w, c, only_v2i, ego_first, ego_count, tiles_x, warped);
+    return dn::check_launch("warp_neighbors_tiled_kernel");
+  }
   dim3 grid((hw + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, agents - 1, batch * ego_count);
   hipLaunchKernelGGL(warp_neighbors_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, trans,
                      num_agent, batch, agents, h, w, c, only_v2i, ego_first, ego_count, warped);

@@ -19,9 +19,9 @@ def load(f):
 
 
 def short(n):
-    m = re.search(r'conv_mfma_kernel<([^>]*)>', n)
+    m = re.search(r'conv_(mfma|sp)_kernel<([^>]*)>', n)
     if m:
-        return 'conv<' + m.group(1).replace(' ', '') + '>'
+        return ('sp<' if m.group(1) == 'sp' else 'conv<') + m.group(2).replace(' ', '').replace('(anonymousnamespace)::', '')[:28] + '>'
     return n.split('(')[0][-34:]
 
 

@@ -1,0 +1,29 @@
+"""Conv time per step from a rocprofv3 kernel trace of the DEFAULT bench command (graph replay): the sum of
+the conv kernel's durations over the last `steps` steps / steps.  bench.py reports it beside its own HIP-event
+figure (roofline.rocprof).     python tools/rocprof_conv.py kernel_trace.csv conv_sp_kernel 20
+"""
+import csv
+import json
+import sys
+
+
+def main(path, kernel, steps):
+    rows = [r for r in csv.DictReader(open(path))]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # a step starts at the voxel grid's zero fill
+    starts = [i for i, r in enumerate(rows) if "zero_fill_kernel" in r["Kernel_Name"]]
+    assert len(starts) >= steps, (len(starts), steps)
+    sel = rows[starts[-steps]:]
+    conv = [r for r in sel if kernel in r["Kernel_Name"]]
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in conv]
+    span = (int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])) / 1e3
+    print(json.dumps({"round": 2, "kernel": kernel, "steps": steps, "launches_per_step": len(conv) / steps,
+                      "conv_ms_per_step": sum(dur) / steps / 1e3, "avg_launch_us": sum(dur) / len(dur),
+                      "all_kernels_ms_per_step": sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in sel) / steps / 1e6,
+                      "span_ms_per_step": span / steps / 1e3,
+                      "note": "rocprofv3 --kernel-trace over `python bench.py` (hipGraph replay, one stream): kernel "
+                              "durations of the last %d steps" % steps}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]))

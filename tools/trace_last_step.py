@@ -7,9 +7,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 # a step starts at its scatter_dense memset
-starts = [i for i, r in enumerate(rows) if "fillBufferAligned" in r["Kernel_Name"]]
-first = starts[-1] if starts else max(0, len(rows) - n)
-sel = rows[first:]
+starts = [i for i, r in enumerate(rows) if "zero_fill_kernel" in r["Kernel_Name"]]
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 3      # the bench ends with an eager check step + extras: go back a few
+first = starts[-skip] if len(starts) >= skip else max(0, len(rows) - n)
+sel = rows[first:starts[-skip + 1]] if len(starts) >= skip and skip > 1 else rows[first:]
 t0 = int(sel[0]["Start_Timestamp"])
 prev_end = t0
 for r in sel:
