@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
   const bool pvalid = p < a.hw;
   const int pc = pvalid ? p : a.hw - 1;
   int live = a.num_agent[b];
-  live = live < a.agents ? live : a.agents;            // never index past the agents that exist
+  live = live < 0 ? 0 : (live < a.agents ? live : a.agents);   // never index past the agents that exist
   const size_t oimg = (size_t)il * a.batch + b;
 
   const float* xrow = a.feat + (((size_t)i * a.batch + b) * a.hw + pc) * C + 8 * lh;

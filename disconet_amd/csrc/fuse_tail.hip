@@ -48,7 +48,8 @@ disco_fuse_tail_kernel(const TailArgs a) {
   const int bi = blockIdx.y;                             // b * ego_count + (i - ego_first)
   const int b = bi / a.ego_count, il = bi % a.ego_count, i = a.ego_first + il;
   const int p0 = blockIdx.x * PIX;
-  const int n_live = a.num_agent[b];
+  int n_live = a.num_agent[b];
+  n_live = n_live < 0 ? 0 : (n_live > a.agents ? a.agents : n_live);   // a bad count never indexes past the agents
   const int img = il * a.batch + b;                      // agent-major index among LOCAL egos
   const float* ego = a.feat + ((size_t)i * a.batch + b) * a.hw * a.c;   // feat holds all agents
   float* out = a.fused + (size_t)img * a.hw * a.c;

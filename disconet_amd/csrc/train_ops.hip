@@ -414,7 +414,9 @@ fuse_combine_kernel(const float* __restrict__ z4, const float* __restrict__ maps
   const long item = blockIdx.x * 4L + (threadIdx.x >> 6);
   if (item >= (long)n_egos * hw) return;
   const int e = (int)(item / hw), px = (int)(item % hw);
-  const int k0 = first[e], kn = first[e + 1] - k0;
+  const int k0 = first[e];
+  int kn = first[e + 1] - k0;
+  kn = kn < 0 ? 0 : (kn > kMaxNbr ? kMaxNbr : kn);   // the per-lane arrays hold kMaxNbr entries (host side: train.py refuses more agents)
   float wk[kMaxNbr];
   float sum = 0.f;
   for (int k = 0; k < kn; ++k) {
@@ -447,7 +449,9 @@ fuse_combine_bwd_kernel(const float* __restrict__ dfused, int ld_df, const float
   const long item = blockIdx.x * 4L + (threadIdx.x >> 6);
   if (item >= (long)n_egos * hw) return;
   const int e = (int)(item / hw), px = (int)(item % hw);
-  const int k0 = first[e], kn = first[e + 1] - k0;
+  const int k0 = first[e];
+  int kn = first[e + 1] - k0;
+  kn = kn < 0 ? 0 : (kn > kMaxNbr ? kMaxNbr : kn);   // the per-lane arrays hold kMaxNbr entries (host side: train.py refuses more agents)
   const float* df = dfused + ((size_t)ego_out[e] * hw + px) * ld_df;
   float wk[kMaxNbr], dot[kMaxNbr];
   for (int k = 0; k < kn; ++k) {

@@ -96,7 +96,8 @@ warp_neighbors_kernel(const float* __restrict__ feat, const float* __restrict__ 
   const int bi = blockIdx.z;              // b * ego_count + (i - ego_first)
   const int b = bi / ego_count, i = ego_first + bi % ego_count;
   const int j = jj + (jj >= i ? 1 : 0);
-  const int n_live = num_agent[b];
+  int n_live = num_agent[b];
+  n_live = n_live < 0 ? 0 : (n_live > agents ? agents : n_live);     // a bad count never indexes past the agents
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c4n = c >> 2;
   const int hw = h * w;

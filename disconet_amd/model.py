@@ -21,6 +21,7 @@ NHWC (channels-last) end to end.  There is no torch/CPU fallback: tensors must
 be on the GPU and the shared object must be built.
 """
 import os
+import re
 
 import torch
 import torch.nn as nn
@@ -111,6 +112,16 @@ class _RegHeadParams(nn.Module):
         self.box_prediction = nn.Sequential(
             nn.Conv2d(32, 32, 3, 1, 1), nn.BatchNorm2d(32), nn.ReLU(),
             nn.Conv2d(32, len(config.anchor_size) * config.box_code_size * out_seq_len, 1))
+
+
+# The reference's encoder and decoder both instantiate the WHOLE Backbone, so its checkpoints carry the decoder's
+# layers under u_encoder.* and the encoder's under decoder.* -- parameters that never run.  Only these names
+# are dropped on load; any other unknown key reaches torch's strict check.
+_TENSORS = r"(weight|bias|running_mean|running_var|num_batches_tracked)"
+_DUPLICATE_BACKBONE_KEY = re.compile(
+    r"^(u_encoder\.(conv|bn)[5-8]_[12]\." + _TENSORS +
+    r"|decoder\.((conv|bn)_pre_[12]|(conv|bn)[1-4]_[12]|conv3d_[12]\.(conv3d|bn3d)"
+    r"|com_compresser|bn_compress|com_decompresser|bn_decompress)\." + _TENSORS + r")$")
 
 
 class _ConvLayer:
@@ -278,12 +289,10 @@ class DiscoNet(nn.Module):
         cleaned, dropped = {}, []
         for k, v in state_dict.items():
             k = k[len("module."):] if k.startswith("module.") else k
-            if k in own:
-                cleaned[k] = v
-            elif k.startswith(("u_encoder.", "decoder.")):
-                dropped.append(k)      # unused duplicate of the shared Backbone definition
+            if k not in own and _DUPLICATE_BACKBONE_KEY.match(k):
+                dropped.append(k)      # the half of the shared Backbone definition this side never runs
             else:
-                cleaned[k] = v         # let torch report genuinely unexpected keys
+                cleaned[k] = v         # anything else: torch reports it when it is unexpected (strict)
         self._plan = None
         return super().load_state_dict(cleaned, strict=strict, **kw)
 

@@ -87,6 +87,9 @@ def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev):
                 order.append(NI + wi)
             first.append(len(pair_index))
     nw = len(src_image)
+    longest = max([first[k + 1] - first[k] for k in range(len(first) - 1)] or [0])
+    if longest > 16:      # kMaxNbr of csrc/train_ops.hip :: fuse_combine kernels (per-lane weight arrays)
+        raise ops._lib.DnError("training fusion: %d maps in one ego's list; the combine kernels hold at most 16" % longest)
     ego_image = list(range(NI)) + warp_ego
     # pairs per ego image, for dE = sum over the ego's pairs
     per = [[] for _ in range(NI)]

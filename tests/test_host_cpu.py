@@ -75,6 +75,11 @@ def test_reference_state_dict_names_load():
         assert torch.equal(v, ref.state_dict()[k]), k
     with pytest.raises(RuntimeError):
         m.load_state_dict({"classification.conv9.weight": torch.zeros(1)}, strict=True)
+    # only the known duplicate halves of the shared Backbone are dropped: a typo inside the encoder /
+    # decoder namespaces is still an unexpected key
+    for bad in ("decoder.conv_pre_3.weight", "u_encoder.conv9_1.weight", "decoder.typo.bias"):
+        with pytest.raises(RuntimeError):
+            m.load_state_dict(dict(sd, **{bad: torch.zeros(1)}), strict=True)
     for key in ("u_encoder.conv3d_1.conv3d.weight", "u_encoder.conv3d_2.bn3d.running_var",
                 "decoder.bn8_2.weight", "pixel_weighted_fusion.conv1_4.bias",
                 "classification.conv2.weight", "regression.box_prediction.3.bias"):
