@@ -1168,8 +1168,9 @@ extern "C" int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc*
                "spconv+1x1: the block-diagonal form needs two fp32 outputs of <= 64 columns each");
     using TS = SpTile<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 1>;
     static const int stat_env = [] { const char* e = getenv("DN_SP_STATIONARY"); return e ? atoi(e) : 1; }();
-    // both heads in one workgroup (the input patch is staged once): 1 = streaming weights, 2 = LDS-resident
-    static const int heads64 = [] { const char* e = getenv("DN_SP_HEADS64"); return e ? atoi(e) : 0; }();
+    // both heads in one workgroup (the input patch is staged once; -4 % on the heads launch): 1 = streaming
+    // weights (default), 2 = LDS-resident weights, 0 = one head per workgroup
+    static const int heads64 = [] { const char* e = getenv("DN_SP_HEADS64"); return e ? atoi(e) : 1; }();
     using TS64 = SpTile<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 2, 1>;
     if (heads64 == 2 && fits_stationary(*d, 64, TS64::A_STAGE, 0, 1, true))
       return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 2, 0, 1>(a, *d, (hipStream_t)stream);

@@ -16,11 +16,9 @@ def main(path, kernel, steps):
     sel = rows[starts[-steps]:]
     conv = [r for r in sel if kernel in r["Kernel_Name"]]
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in conv]
-    span = (int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])) / 1e3
     print(json.dumps({"round": 2, "kernel": kernel, "steps": steps, "launches_per_step": len(conv) / steps,
                       "conv_ms_per_step": sum(dur) / steps / 1e3, "avg_launch_us": sum(dur) / len(dur),
                       "all_kernels_ms_per_step": sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in sel) / steps / 1e6,
-                      "span_ms_per_step": span / steps / 1e3,
                       "note": "rocprofv3 --kernel-trace over `python bench.py` (hipGraph replay, one stream): kernel "
                               "durations of the last %d steps" % steps}, indent=1))
 
