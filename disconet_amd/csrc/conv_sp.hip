@@ -174,12 +174,15 @@ __global__ void __launch_bounds__(
 conv_sp_kernel(const SpArgs a) {
   using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT>;
   using P = typename T::P;
-  constexpr bool kNoB = ABL == 1 || ABL == 3 || ABL == 5, kNoA = ABL == 2 || ABL == 3 || ABL == 5;
-  constexpr bool kNoStore = ABL == 4, kNoLds = ABL == 5;
+  constexpr bool kNoB = ABL == 1 || ABL == 3 || ABL >= 5, kNoA = ABL == 2 || ABL == 3 || ABL >= 5;
+  constexpr bool kNoStore = ABL == 4 || ABL == 6 || ABL == 7, kNoLds = ABL >= 5;
+  constexpr bool kNoBarrier = ABL == 7;   // 6: + no stores; 7: + no barriers (pure MFMA + epilogue arithmetic)
   constexpr int NW = T::NW, NT = T::NT, NPIX = T::NPIX, TAPS = T::TAPS, NS = T::NS, SUB = T::SUB;
   constexpr int A_IT = T::A_IT, B_IT = T::B_IT;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // POST 1: both stages' affines (<= 64 channels each), staged once: scale, shift, scale2, shift2
+  __shared__ __attribute__((aligned(16))) float aff1_s[POST == 1 ? 4 : 1][POST == 1 ? 64 : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -381,8 +384,30 @@ conv_sp_kernel(const SpArgs a) {
 
   // ---- SP epilogue of a 32-pixel x 32-channel accumulator tile: channel tile index ct32 of the
   // output tensor (two 16-channel chunks), pixel (oy, ox); sc/sh indexed by the tile's channels
+  // POST 0: the affine of this lane's channels (8 g + 4 lh + e of every 32-channel tile of the block) lives in
+  // registers for as long as the workgroup stays on one channel block: 64 dependent global loads per tile and
+  // their address arithmetic in front of every epilogue were a third of the short-K layers' time
+  constexpr bool kRegAffine = POST == 0 || POST == 2;
+  f32x4 sc_r[kRegAffine ? WTN : 1][4], sh_r[kRegAffine ? WTN : 1][4];
+  int aff_n0 = -1;
+  auto load_affine = [&](int n0) {
+    if (!kRegAffine || n0 == aff_n0) return;
+    aff_n0 = n0;
+#pragma unroll
+    for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = n0 + (wave_n * WTN + wn) * 32 + 8 * g + 4 * lh + e;
+          const int ci = min(co, a.c_out - 1);            // clamped index + select: no divergent branch
+          sc_r[wn][g][e] = co < a.c_out ? a.scale[ci] : 0.f;
+          sh_r[wn][g][e] = co < a.c_out ? a.shift[ci] : 0.f;
+        }
+  };
   auto store_sp_tile = [&](const f32x16& c, const float* scale, const float* shift, int relu,
-                           int ch0, int c_lim, unsigned char* out, int cog, int img, int oy, int ox) {
+                           int ch0, int c_lim, unsigned char* out, int cog, int img, int oy, int ox,
+                           int wn_r = -1) {
     const bool inside = oy < a.h_out && ox < a.w_out;
     const size_t plane = (size_t)a.h_out * a.w_out * 16;
     unsigned char* obase = out + (size_t)img * cog * 4 * plane + ((size_t)oy * a.w_out + ox) * 16;
@@ -391,13 +416,30 @@ conv_sp_kernel(const SpArgs a) {
     for (int g = 0; g < 4; ++g) {
       const int co = ch0 + 8 * g + 4 * lh;
       f32x4 v;
+      if (wn_r >= 0) {            // register-resident affine (channels past c_out: scale = shift = 0 -> 0)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // clamped index + select: no divergent branch per channel
-        const int ci = min(co + e, c_lim - 1);
-        v[e] = c[4 * g + e] * scale[ci] + shift[ci];
-        if (relu) v[e] = fmaxf(v[e], 0.f);
-        v[e] = co + e < c_lim ? v[e] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          v[e] = c[4 * g + e] * sc_r[kRegAffine ? wn_r : 0][g][e] + sh_r[kRegAffine ? wn_r : 0][g][e];
+          if (relu) v[e] = fmaxf(v[e], 0.f);
+        }
+      } else if (POST == 1 && wn_r == -2) {   // stage-2 affine of the fused 1x1 from LDS (zero past c_out2)
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 2 : 0][co & 63]);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 3 : 0][co & 63]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = c[4 * g + e] * sc[e] + sh[e];
+          if (relu) v[e] = fmaxf(v[e], 0.f);
+          v[e] = co + e < c_lim ? v[e] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // clamped index + select: no divergent branch per channel
+          const int ci = min(co + e, c_lim - 1);
+          v[e] = c[4 * g + e] * scale[ci] + shift[ci];
+          if (relu) v[e] = fmaxf(v[e], 0.f);
+          v[e] = co + e < c_lim ? v[e] : 0.f;
+        }
       }
       split4(v, hi[g], lo[g]);
     }
@@ -435,7 +477,7 @@ conv_sp_kernel(const SpArgs a) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[e] = acc[wm][wn][4 * g + e] * a.scale[co + e] + a.shift[co + e];
+            v[e] = acc[wm][wn][4 * g + e] * sc_r[kRegAffine ? wn : 0][g][e] + sh_r[kRegAffine ? wn : 0][g][e];
             if (a.relu) v[e] = fmaxf(v[e], 0.f);
           }
           split4(v, hi[g], lo[g]);
@@ -489,7 +531,7 @@ conv_sp_kernel(const SpArgs a) {
 #pragma unroll
         for (int wn = 0; wn < WTN; ++wn)
           store_sp_tile(acc[wm][wn], a.scale, a.shift, a.relu, tc.n0 + (wave_n * WTN + wn) * 32, a.c_out,
-                        a.out, a.cog, tc.img, tc.oy0 + prow[wm], tc.ox0 + pcol);
+                        a.out, a.cog, tc.img, tc.oy0 + prow[wm], tc.ox0 + pcol, wn);
     } else {
       // ---- fused 1x1 stage.  This wave owns all 64 stage-1 channels of its pixels: after the
       // affine + ReLU + split, the permlane gather yields exactly the B-operand fragments
@@ -509,9 +551,11 @@ conv_sp_kernel(const SpArgs a) {
           for (int g = 0; g < 4; ++g) {
             const int co = wn * 32 + 8 * g + 4 * lh;
             f32x4 v;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(&aff1_s[0][POST == 1 ? co : 0]);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 1 : 0][POST == 1 ? co : 0]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              v[e] = acc[wm][wn][4 * g + e] * a.scale[co + e] + a.shift[co + e];
+              v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
               if (a.relu) v[e] = fmaxf(v[e], 0.f);
             }
             split4(v, hi[g], lo[g]);
@@ -539,7 +583,7 @@ conv_sp_kernel(const SpArgs a) {
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
             store_sp_tile(acc2[wm][nt], a.scale2, a.shift2, a.relu2, nt * 32, a.c_out2, a.out, a.cog,
-                          tc.img, tc.oy0 + prow[wm], tc.ox0 + pcol);
+                          tc.img, tc.oy0 + prow[wm], tc.ox0 + pcol, -2);
       } else {
         // fp32 NHWC, two outputs: columns [0, split2) -> out (ldo_a), the rest -> out_b (ldo_b).
         // Wave-local staging [32 px][STG_ROW] so that every store instruction is one contiguous run.
@@ -601,6 +645,12 @@ conv_sp_kernel(const SpArgs a) {
     for (int i = tid; i < T::W2_BYTES / 16; i += NT)
       *reinterpret_cast<u32x4*>(smem + (BSTAT ? T::OFF_B + a.b_total : T::OFF_W2) + i * 16) =
           *reinterpret_cast<const u32x4*>(a.w2 + i * 16);
+    if (tid < 64) {
+      aff1_s[0][tid] = a.scale[tid];
+      aff1_s[POST == 1 ? 1 : 0][tid] = a.shift[tid];
+      aff1_s[POST == 1 ? 2 : 0][tid] = tid < a.c_out2 ? a.scale2[tid] : 0.f;
+      aff1_s[POST == 1 ? 3 : 0][tid] = tid < a.c_out2 ? a.shift2[tid] : 0.f;
+    }
     __syncthreads();
   }
   TileCoord cur = decode(item);
@@ -635,6 +685,7 @@ conv_sp_kernel(const SpArgs a) {
     issue_a(0, 0, false);
     while (true) {
       zero_acc();
+      load_affine(cur.n0);
       const bool has_next = item + G < a.total_items;
       TileCoord nxt = cur;
       if (has_next) nxt = decode(item + G);
@@ -679,6 +730,7 @@ conv_sp_kernel(const SpArgs a) {
 
   while (true) {
     zero_acc();
+    load_affine(cur.n0);
     const bool has_next = item + G < a.total_items;
     TileCoord nxt = cur;
     if (has_next) nxt = decode(item + G);
@@ -692,7 +744,7 @@ conv_sp_kernel(const SpArgs a) {
         // Raw s_barrier: __syncthreads() would add a fence that drains vmcnt to 0 (the LDS-DMA
         // counts as a pending LDS write) and with it the patch still in flight at ST == 1.
         if (ST == 1 && a_pending) wait_vm<A_IT>(); else wait_vm0();
-        __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is done with the previous step
+        if (!kNoBarrier) __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is done with the previous step
         asm volatile("" ::: "memory");
         // issue the next step's weights, then (first step of a group) the next group's patch
         if (ST + 1 < NS) {
@@ -914,11 +966,12 @@ int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   DN_REQUIRE(nchunks % CA == 0, "spconv: chunk count %d not a multiple of %d", nchunks, CA);
   a.ngroups = nchunks / CA;
   int lds_bytes = T::LDS_BYTES;
+  constexpr int kStaticLds = POST == 1 ? 1024 : 0;   // aff1_s of the fused-1x1 kernel (static, on top of the dynamic block)
   if (BSTAT) {
     a.b_total = a.ngroups * T::NS * T::B_STEP;
     a.stg_row = a.c_out2 + 4;
     lds_bytes = T::lds_stationary(a.ngroups * T::NS, a.post_f32 ? a.stg_row : 0);
-    DN_REQUIRE(lds_bytes <= 160 * 1024 && (d.c_out <= BN || POST == 2),
+    DN_REQUIRE(lds_bytes <= 160 * 1024 - kStaticLds && (d.c_out <= BN || POST == 2),
                "spconv: layer does not fit the weight-stationary form");
   }
   // opt in to > 64 KiB of dynamic LDS; the attribute write is idempotent, so two first
@@ -927,7 +980,7 @@ int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       BSTAT ? 160 * 1024 : (int)T::LDS_BYTES);
+                                       BSTAT ? 160 * 1024 - kStaticLds : (int)T::LDS_BYTES);
     if (e != hipSuccess)
       return dn::fail(DN_ERR_LAUNCH, "spconv: hipFuncSetAttribute(%d B LDS): %s", (int)T::LDS_BYTES,
                       hipGetErrorString(e));
@@ -1100,6 +1153,8 @@ extern "C" int dn_spconv2d(const dn_conv_desc* d, const void* src0, const void* 
       case 203: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 3>(a, *d, s);
       case 204: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 4>(a, *d, s);
       case 205: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 5>(a, *d, s);
+      case 206: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 6>(a, *d, s);
+      case 207: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 7>(a, *d, s);
       default: break;
     }
   }
@@ -1188,7 +1243,7 @@ extern "C" int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc*
   {
     using TP = SpTile<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 1, 1>;
     static const int stat_env = [] { const char* e = getenv("DN_SP_STATIONARY"); return e ? atoi(e) : 1; }();
-    const int extra = TP::W2_BYTES + (out_f32 ? TP::NW * 32 * (p->c_out2 + 4) * 4 : 0);
+    const int extra = TP::W2_BYTES + (out_f32 ? TP::NW * 32 * (p->c_out2 + 4) * 4 : 0) + 1024;   // + the static affine block
     if (stat_env && g_sp_force != 0 && fits_stationary(*d, 64, TP::A_STAGE, extra, 1))
       return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 1, 0, 1>(a, *d, (hipStream_t)stream);
   }
