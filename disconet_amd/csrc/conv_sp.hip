@@ -182,7 +182,7 @@ conv_sp_kernel(const SpArgs a) {
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // POST 1: both stages' affines (<= 64 channels each), staged once: scale, shift, scale2, shift2
-  __shared__ __attribute__((aligned(16))) float aff1_s[POST == 1 ? 4 : 1][POST == 1 ? 64 : 4];
+  __shared__ __attribute__((aligned(16))) float aff1_s[POST != 0 ? 4 : 1][POST != 0 ? 64 : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -387,9 +387,13 @@ conv_sp_kernel(const SpArgs a) {
   // POST 0: the affine of this lane's channels (8 g + 4 lh + e of every 32-channel tile of the block) lives in
   // registers for as long as the workgroup stays on one channel block: 64 dependent global loads per tile and
   // their address arithmetic in front of every epilogue were a third of the short-K layers' time
-  constexpr bool kRegAffine = POST == 0 || POST == 2;
+  constexpr bool kRegAffine = POST == 0;
   f32x4 sc_r[kRegAffine ? WTN : 1][4], sh_r[kRegAffine ? WTN : 1][4];
   int aff_n0 = -1;
+  half8 w2h[POST == 2 ? WTN : 1][2][2], w2l[POST == 2 ? WTN : 1][2][2];   // POST 2: the heads' 1x1 weights
+  int w2_cb[POST == 2 ? WTN : 1];
+#pragma unroll
+  for (int wn = 0; wn < (POST == 2 ? WTN : 1); ++wn) w2_cb[wn] = -1;
   auto load_affine = [&](int n0) {
     if (!kRegAffine || n0 == aff_n0) return;
     aff_n0 = n0;
@@ -468,16 +472,30 @@ conv_sp_kernel(const SpArgs a) {
       const int c2 = cb ? a.c_out2 - a.split2 : a.split2, c2_0 = cb ? a.split2 : 0;
       float* obase = cb ? a.out_b : reinterpret_cast<float*>(a.out);
       const int ldo = cb ? a.ldo_b : a.ldo_a;
+      if (cb != w2_cb[wn]) {                  // stage-2 weight fragments of this head: registers, once per head
+        w2_cb[wn] = cb;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            // W2 image: [cb][nt][ks][part][h][32] x 16 B
+            const unsigned char* wp = a.w2 + (size_t)((((((cb * 2 + nt) * 2 + ks) * 2 + 0) * 2 + lh) * 32 + li)) * 16;
+            w2h[wn][nt][ks] = *reinterpret_cast<const half8*>(wp);
+            w2l[wn][nt][ks] = *reinterpret_cast<const half8*>(wp + 2 * 32 * 16);
+          }
+      }
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm) {
         u32x2 hi[4], lo[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int co = tc.n0 + 32 * wn + 8 * g + 4 * lh;
+          const f32x4 sc1 = *reinterpret_cast<const f32x4*>(&aff1_s[0][POST == 2 ? co & 63 : 0]);
+          const f32x4 sh1 = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 1 : 0][POST == 2 ? co & 63 : 0]);
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[e] = acc[wm][wn][4 * g + e] * sc_r[kRegAffine ? wn : 0][g][e] + sh_r[kRegAffine ? wn : 0][g][e];
+            v[e] = acc[wm][wn][4 * g + e] * sc1[e] + sh1[e];
             if (a.relu) v[e] = fmaxf(v[e], 0.f);
           }
           split4(v, hi[g], lo[g]);
@@ -499,10 +517,7 @@ conv_sp_kernel(const SpArgs a) {
           for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            // W2 image: [cb][nt][ks][part][h][32] x 16 B
-            const unsigned char* wp = a.w2 + (size_t)((((((cb * 2 + nt) * 2 + ks) * 2 + 0) * 2 + lh) * 32 + li)) * 16;
-            const half8 wh = *reinterpret_cast<const half8*>(wp);
-            const half8 wl = *reinterpret_cast<const half8*>(wp + 2 * 32 * 16);
+            const half8 wh = w2h[wn][nt][ks], wl = w2l[wn][nt][ks];
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], acc2, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[ks], acc2, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], acc2, 0, 0, 0);
@@ -511,8 +526,8 @@ conv_sp_kernel(const SpArgs a) {
           for (int g = 0; g < 4; ++g) {
             const int ch = nt * 32 + 8 * g + 4 * lh;        // c2 is a multiple of 4: whole pieces
             if (ch < c2) {
-              const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale2 + c2_0 + ch);
-              const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift2 + c2_0 + ch);
+              const f32x4 sc = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 2 : 0][POST == 2 ? (c2_0 + ch) & 63 : 0]);
+              const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 3 : 0][POST == 2 ? (c2_0 + ch) & 63 : 0]);
               f32x4 v;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -640,6 +655,15 @@ conv_sp_kernel(const SpArgs a) {
   // ---- main loop
   int item = blockIdx.x;
   if (item >= a.total_items) return;
+  if constexpr (POST == 2) {   // both stages' affines (64 hidden channels; <= 64 outputs over the two heads)
+    if (tid < 64) {
+      aff1_s[0][tid] = a.scale[tid];
+      aff1_s[POST == 2 ? 1 : 0][tid] = a.shift[tid];
+      aff1_s[POST == 2 ? 2 : 0][tid] = tid < a.c_out2 ? a.scale2[tid] : 0.f;
+      aff1_s[POST == 2 ? 3 : 0][tid] = tid < a.c_out2 ? a.shift2[tid] : 0.f;
+    }
+    __syncthreads();
+  }
   if constexpr (POST == 1) {
     // stage-2 weights: one linear 16 KiB copy, resident for the whole launch
     for (int i = tid; i < T::W2_BYTES / 16; i += NT)
@@ -966,7 +990,7 @@ int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   DN_REQUIRE(nchunks % CA == 0, "spconv: chunk count %d not a multiple of %d", nchunks, CA);
   a.ngroups = nchunks / CA;
   int lds_bytes = T::LDS_BYTES;
-  constexpr int kStaticLds = POST == 1 ? 1024 : 0;   // aff1_s of the fused-1x1 kernel (static, on top of the dynamic block)
+  constexpr int kStaticLds = POST != 0 ? 1024 : 0;   // aff1_s of the fused-1x1 kernel (static, on top of the dynamic block)
   if (BSTAT) {
     a.b_total = a.ngroups * T::NS * T::B_STEP;
     a.stg_row = a.c_out2 + 4;
@@ -1227,7 +1251,7 @@ extern "C" int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc*
     // weights (default), 2 = LDS-resident weights, 0 = one head per workgroup
     static const int heads64 = [] { const char* e = getenv("DN_SP_HEADS64"); return e ? atoi(e) : 1; }();
     using TS64 = SpTile<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 2, 1>;
-    if (heads64 == 2 && fits_stationary(*d, 64, TS64::A_STAGE, 0, 1, true))
+    if (heads64 == 2 && fits_stationary(*d, 64, TS64::A_STAGE, 1024, 1, true))
       return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 2, 0, 1>(a, *d, (hipStream_t)stream);
     if (heads64 >= 1) return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 2, 0, 0>(a, *d, (hipStream_t)stream);
     // ablations of the heads launch (measurement only): 3 = no operand DMA, 4 = no stores, 5 = no LDS reads
@@ -1236,7 +1260,7 @@ extern "C" int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc*
     if (heads_abl == 4) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 4, 0>(a, *d, (hipStream_t)stream);
     if (heads_abl == 5) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 5, 0>(a, *d, (hipStream_t)stream);
     if (heads_abl == 9) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 0, 0>(a, *d, (hipStream_t)stream);
-    if (stat_env && fits_stationary(*d, 32, TS::A_STAGE, 0, 2, true))
+    if (stat_env && fits_stationary(*d, 32, TS::A_STAGE, 1024, 2, true))
       return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 0, 1>(a, *d, (hipStream_t)stream);
     return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 2, 0, 0>(a, *d, (hipStream_t)stream);
   }

@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
     if (lane < 32) { aff_s[256 + lane] = a.s2[lane]; aff_s[288 + lane] = a.t2[lane]; }
     if (lane < 8) { aff_s[320 + lane] = a.s3[lane]; aff_s[328 + lane] = a.t3[lane]; aff_s[336 + lane] = a.w4[lane]; }
   }
+  const float b4v = a.b4[0];   // read once: a global load inside every tail() sat on its critical path
   const unsigned char* w2l = w23_s;
   const unsigned char* w3l = w23_s + kW2Bytes;
   const float *s1l = aff_s, *t1l = aff_s + 128, *s2l = aff_s + 256, *t2l = aff_s + 288, *s3l = aff_s + 320,
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
     for (int e = 0; e < 4; ++e) part += fmaxf(acc3[e] * sc[e] + sh[e], 0.f) * w4[e];
     // the other four units sit in lane (j, 1 - h); the sum is taken in unit order 0..7 on both lanes
     const float other = __shfl_xor(part, 32, 64);
-    const float s = fmaxf((lh ? other + part : part + other) + a.b4[0], 0.f);
+    const float s = fmaxf((lh ? other + part : part + other) + b4v, 0.f);
     return expf(s);
   };
 
