@@ -71,8 +71,14 @@ struct TileCoord {
 // beside two patch stages (the full-resolution 32-/64-channel layers): the weights are loaded once
 // per workgroup, a step never waits for them, and the only barrier left is the one per 16-channel
 // chunk that hands over the patch stage.
+// UPM: row-merged form of the 3x3 conv over a nearest-upsampled source (the decoder's *_1 layers).  Patch
+// rows 2k+1 and 2k+2 of an upsampled source hold the same low-resolution row, so for an output row of
+// parity pi the taps ty = 0, +1 (pi = 0) or ty = -1, 0 (pi = 1) read identical data: their weights are summed
+// at pack time and the source's chunks run 2 row-taps x 3 instead of 3 x 3 (-33 % MACs on 2/3 of K).  The
+// pixel tile is mapped so that all MFMA tiles of a wave are rows of one parity (parity = wave_m & 1); a step's
+// weight stage carries both parities' blocks.
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST, int BSTAT = 0>
+          int WTM, int WTN, int POST, int BSTAT = 0, int UPM = 0>
 struct SpTile {
   using P = sp::Patch<KS, STRIDE, TH, TW>;
   static constexpr int NW = WAVES_M * WAVES_N;
@@ -89,7 +95,9 @@ struct SpTile {
   static constexpr int A_IT = (A_INSTR + NW - 1) / NW;
   static constexpr int A_STAGE = A_INSTR * 1024;            // bytes
   static constexpr int B_PIECES = SUB * 4 * BN;
-  static constexpr int B_IT = (B_PIECES + NT - 1) / NT;
+  static constexpr int B_PIECES_MAX = (UPM ? 2 : 1) * B_PIECES;          // merged step: both parities
+  static constexpr int B_IT_1 = (B_PIECES + NT - 1) / NT;                // plain step
+  static constexpr int B_IT = (B_PIECES_MAX + NT - 1) / NT;
   static constexpr int B_STAGE = B_IT * NT * 16;
   static constexpr int B_STEP = B_PIECES * 16;              // stationary form: steps packed tight
   static_assert(!BSTAT || B_STEP % 1024 == 0, "stationary weights: whole DMA instructions per step");
@@ -123,6 +131,9 @@ struct SpTile {
   static_assert(POST != 1 || (WAVES_N == 1 && BN == 64 && TW == 32), "fused 1x1: 64 channels in one wave");
   static_assert(POST != 2 || (WAVES_N == 1 && (BN == 32 || BN == 64)), "fused block-diagonal 1x1: whole 32-channel heads per wave");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
+  static_assert(!UPM || (KS == 3 && STRIDE == 1 && TG == 3 && CA == 1 && POST == 0 && BSTAT == 0 && TH == 8 && WTM == 2 &&
+                         ((TW == 32 && WAVES_M == 4) || (TW == 16 && WAVES_M == 2))),
+                "row-merged up-conv: 8 x 32 or 8 x 16 streaming tiles");
 };
 
 __device__ inline void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -167,12 +178,12 @@ __device__ inline u32x4 gather_octet(u32x2 x, u32x2 y) {
 // 1 = no weight DMA after the first step, 2 = no patch DMA after the first group, 3 = neither,
 // 4 = no epilogue stores, 5 = 3 + operands from registers (pure MFMA stream).
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST, int ABL = 0, int BSTAT = 0>
+          int WTM, int WTN, int POST, int ABL = 0, int BSTAT = 0, int UPM = 0>
 __global__ void __launch_bounds__(
     (WAVES_M * WAVES_N * 64),
-    (SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT>::WPS))
+    (SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM>::WPS))
 conv_sp_kernel(const SpArgs a) {
-  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT>;
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM>;
   using P = typename T::P;
   constexpr bool kNoB = ABL == 1 || ABL == 3 || ABL >= 5, kNoA = ABL == 2 || ABL == 3 || ABL >= 5;
   constexpr bool kNoStore = ABL == 4 || ABL == 6 || ABL == 7, kNoLds = ABL >= 5;
@@ -227,6 +238,8 @@ conv_sp_kernel(const SpArgs a) {
   for (int wm = 0; wm < WTM; ++wm) {
     const int gm = wave_m * WTM + wm;
     prow[wm] = sp::tile_row<TW>(gm, li);
+    if constexpr (UPM != 0)   // rows of one parity per wave: TW 32: {w, w + 4}; TW 16: {w + 4 wm, w + 4 wm + 2}
+      prow[wm] = wave_m + 4 * wm + (TW == 16 && sp::in_g2(li) ? 2 : 0);
     a_off[wm] = (lh * NPIX + sp::out_base_pos<KS, STRIDE, TH, TW>(prow[wm], pcol)) * 16;
   }
 #pragma unroll
@@ -273,6 +286,9 @@ conv_sp_kernel(const SpArgs a) {
       const int piece = (it * NW + (t >> 6)) * 64 + (t & 63);
       const int u = piece / (4 * BN), q = (piece / BN) % 4, nn = piece % BN;
       const int cu = u / TG, tl = u % TG;
+      if constexpr (UPM != 0)   // blocks of a step are consecutive in the packed image (CA = 1)
+        voff_b[it] = piece < T::B_PIECES_MAX ? (unsigned)(((u * 4 + q) * a.cout_pad + tc.n0 + nn) * 16) : OOB;
+      else
       voff_b[it] = piece < T::B_PIECES
                        ? (unsigned)((((cu * TAPS + tl) * 4 + q) * a.cout_pad + tc.n0 + nn) * 16)
                        : OOB;
@@ -303,6 +319,17 @@ conv_sp_kernel(const SpArgs a) {
   };
   auto issue_b = [&](int g, int st, int sb, bool steady = true) {
     if (kNoB && steady) return;
+    if constexpr (UPM != 0) {
+      // packed image: the upsampled source's chunks carry 12 blocks [row-tap 2][parity 2][tx 3], the others 9
+      const bool merged = g < a.c0g;
+      const int blk = merged ? g * 12 + st * 6 : a.c0g * 12 + (g - a.c0g) * 9 + st * 3;
+      const int soff = blk * 4 * a.cout_pad * 16;
+      unsigned char* base = smem + T::OFF_B + sb * T::B_STAGE + wave * 1024;
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it)
+        if (merged || it < T::B_IT_1) dma16(rsrcw, base + it * NW * 1024, voff_b[it], soff);
+      return;
+    }
     const int soff = ((g * CA * TAPS + st * TG) * 4 * a.cout_pad) * 16;
     unsigned char* base = smem + T::OFF_B + sb * T::B_STAGE + wave * 1024;
 #pragma unroll
@@ -761,8 +788,10 @@ conv_sp_kernel(const SpArgs a) {
 
     for (int g = 0; g < a.ngroups; ++g) {
       const bool last_g = g + 1 == a.ngroups;
-      auto step = [&](auto st_c) {
+      auto step = [&](auto st_c, auto merged_c) {
         constexpr int ST = decltype(st_c)::value;
+        constexpr bool MERGED = decltype(merged_c)::value;      // UPM: a row-merged step of the upsampled source
+        constexpr int NSG = MERGED ? 2 : NS;                    // steps of this group
         // this step's operands have landed: B (and, at ST == 0, A) were issued one step (one
         // group) ago.  At ST == 1 the A patch of the NEXT group may still be in flight behind B.
         // Raw s_barrier: __syncthreads() would add a fence that drains vmcnt to 0 (the LDS-DMA
@@ -771,7 +800,7 @@ conv_sp_kernel(const SpArgs a) {
         if (!kNoBarrier) __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is done with the previous step
         asm volatile("" ::: "memory");
         // issue the next step's weights, then (first step of a group) the next group's patch
-        if (ST + 1 < NS) {
+        if (ST + 1 < NSG) {
           issue_b(g, ST + 1, sb ^ 1);
         } else if (!last_g) {
           issue_b(g + 1, 0, sb ^ 1);
@@ -792,17 +821,34 @@ conv_sp_kernel(const SpArgs a) {
             a_pending = false;
           }
         }
-        compute(std::integral_constant<int, ST * TG>{}, std::integral_constant<int, SUB>{},
-                smem + sa * T::A_STAGE, smem + T::OFF_B + sb * T::B_STAGE);
+        if constexpr (MERGED) {
+          // row-tap ST of an output row of parity pi reads patch row r + ST + (pi & ST); this wave's
+          // parity block of the stage's six weight blocks
+          const int pi = wave_m & 1;
+          compute(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{},
+                  smem + sa * T::A_STAGE + (ST + (pi & ST)) * (P::PITCH * 16),
+                  smem + T::OFF_B + sb * T::B_STAGE + pi * (3 * 4 * BN * 16));
+        } else {
+          compute(std::integral_constant<int, ST * TG>{}, std::integral_constant<int, SUB>{},
+                  smem + sa * T::A_STAGE, smem + T::OFF_B + sb * T::B_STAGE);
+        }
         sb ^= 1;
       };
-      step(std::integral_constant<int, 0>{});
-      if constexpr (NS > 1) step(std::integral_constant<int, 1>{});
-      if constexpr (NS > 2) step(std::integral_constant<int, 2>{});
-      if constexpr (NS > 3) {
-        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{});
-        step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{});
-        step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+      using Plain = std::false_type;
+      if (UPM != 0 && g < a.c0g) {
+        if constexpr (UPM != 0) {
+          step(std::integral_constant<int, 0>{}, std::true_type{});
+          step(std::integral_constant<int, 1>{}, std::true_type{});
+        }
+      } else {
+        step(std::integral_constant<int, 0>{}, Plain{});
+        if constexpr (NS > 1) step(std::integral_constant<int, 1>{}, Plain{});
+        if constexpr (NS > 2) step(std::integral_constant<int, 2>{}, Plain{});
+        if constexpr (NS > 3) {
+          step(std::integral_constant<int, 3>{}, Plain{}); step(std::integral_constant<int, 4>{}, Plain{});
+          step(std::integral_constant<int, 5>{}, Plain{}); step(std::integral_constant<int, 6>{}, Plain{});
+          step(std::integral_constant<int, 7>{}, Plain{}); step(std::integral_constant<int, 8>{}, Plain{});
+        }
       }
       sa ^= 1;
     }
@@ -864,6 +910,49 @@ __global__ void sp_to_nhwc_kernel(const unsigned char* __restrict__ src, float* 
 }
 
 // weight_oihw [c_out][c_in][k][k] * wmul -> [chunk][tap][q][cout_pad] pieces
+// Row-merged image (SpTile UPM) of a 3x3 weight: chunks of the upsampled source (cg < c0g) carry 12 blocks
+// [row-tap s][parity pi][tx]: pi = 0: {W[-1], W[0] + W[+1]}, pi = 1: {W[-1] + W[0], W[+1]}; the others 9.
+__global__ void sp_pack_weights_up_kernel(const float* __restrict__ w, unsigned char* __restrict__ wpk,
+                                          int c_out, int c_in, int c0g, int cout_pad, int nchunks, float wmul) {
+  const long total = ((long)c0g * 12 + (long)(nchunks - c0g) * 9) * 2 * cout_pad;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int n = r % cout_pad; r /= cout_pad;
+    const int oct = r % 2; r /= 2;             // r = block index
+    int cg, ty0, ty1, tx;                      // source rows summed: ty0 (and ty1 when >= 0)
+    if (r < (long)c0g * 12) {
+      cg = (int)(r / 12);
+      const int k = (int)(r % 12), s_ = k / 6, pi = (k / 3) % 2;
+      tx = k % 3;
+      if (pi == 0) { ty0 = s_ == 0 ? 0 : 1; ty1 = s_ == 0 ? -1 : 2; }
+      else         { ty0 = s_ == 0 ? 0 : 2; ty1 = s_ == 0 ? 1 : -1; }
+    } else {
+      const long q = r - (long)c0g * 12;
+      cg = c0g + (int)(q / 9);
+      ty0 = (int)(q % 9) / 3; ty1 = -1; tx = (int)(q % 3);
+    }
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ci = cg * 16 + oct * 8 + e;
+      float v = 0.f;
+      if (n < c_out && ci < c_in) {
+        const float* wp = w + ((size_t)n * c_in + ci) * 9;
+        v = wp[ty0 * 3 + tx];
+        if (ty1 >= 0) v += wp[ty1 * 3 + tx];
+        v *= wmul;
+      }
+      v = fminf(fmaxf(v, -65504.f), 65504.f);
+      hi[e] = (_Float16)v;
+      lo[e] = (_Float16)(v - (float)hi[e]);
+    }
+    unsigned char* d = wpk + (((size_t)r * 4 + oct) * cout_pad + n) * 16;
+    *reinterpret_cast<half8*>(d) = hi;
+    *reinterpret_cast<half8*>(d + (size_t)2 * cout_pad * 16) = lo;
+  }
+}
+
 __global__ void sp_pack_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ wpk,
                                        int c_out, int c_in, int taps, int cout_pad, int nchunks,
                                        float wmul, long total) {
@@ -918,6 +1007,14 @@ inline int out_dim(int in, int ksize, int stride) {
 inline int cout_pad_of(int c_out) { return (c_out + 63) / 64 * 64; }
 inline int chunks_of(int c) { return (c + 15) / 16; }
 // weights are padded to whole groups of 4 chunks so that a 1x1 A group never runs past them
+// Row-merged form of a 3x3 conv whose first source is nearest-upsampled (SpTile UPM): decided by the layer
+// alone, so that pack time and run time agree (DN_SP_UPMERGE=0 switches it off for the process).
+inline bool up_merged(const dn_conv_desc& d) {
+  static const int env = [] { const char* e = getenv("DN_SP_UPMERGE"); return e ? atoi(e) : 1; }();
+  return env && d.up0 == 1 && d.ksize == 3 && d.stride == 1 && d.c0 > 0 && d.c0 % 16 == 0 && d.h_in % 2 == 0 &&
+         d.w_in % 2 == 0;
+}
+inline size_t packed_blocks(const dn_conv_desc& d);
 inline int packed_chunks(const dn_conv_desc& d) { return (chunks_of(d.c0) + chunks_of(d.c1) + 3) / 4 * 4; }
 
 int validate(const dn_conv_desc* d) {
@@ -935,6 +1032,12 @@ int validate(const dn_conv_desc* d) {
                  (size_t)d->h_in * d->w_in * chunks_of(d->c1) * 64 < (1ull << 31),
              "spconv: one image must stay below 2 GiB");
   return DN_OK;
+}
+
+inline size_t packed_blocks(const dn_conv_desc& d) {   // 16-byte-piece blocks of [4 quarters][cout_pad] in the packed image
+  const int nch = packed_chunks(d);
+  if (up_merged(d)) return (size_t)chunks_of(d.c0) * 12 + (size_t)(nch - chunks_of(d.c0)) * 9;
+  return (size_t)nch * d.ksize * d.ksize;
 }
 
 enum SpCfgId { S3_256x64, S3_256x32, S3_128x64, S3_64x64, S3S2_128x64, S3S2_64x64, S1_256x64, S1_64x64,
@@ -955,11 +1058,14 @@ int g_sp_force = -1;   // tools: force one configuration
 
 SpCfg select_cfg(const dn_conv_desc& d) {
   const int ho = out_dim(d.h_in, d.ksize, d.stride), wo = out_dim(d.w_in, d.ksize, d.stride);
-  static const SpCfgId c3[] = {S3_256x64, S3_256x32, S3_128x64, S3_64x64};
+  static const SpCfgId c3[] = {S3_256x64, S3_256x32, S3_128x64, S3_64x64};   // merged layers: the first three
   static const SpCfgId c3s2[] = {S3S2_128x64, S3S2_64x64};
   static const SpCfgId c1[] = {S1_256x64, S1_64x64, S1_256x64_C1};
-  const SpCfgId* cand = d.ksize == 1 ? c1 : (d.stride == 2 ? c3s2 : c3);
-  const int ncand = d.ksize == 1 ? 3 : (d.stride == 2 ? 2 : 4);
+  // row-merged layers: the 256x64 tile's doubled weight stage leaves one workgroup per CU (201 vs 180 us on conv7_1)
+  static const SpCfgId c3up[] = {S3_256x32, S3_128x64};
+  const bool upm = up_merged(d);
+  const SpCfgId* cand = d.ksize == 1 ? c1 : (d.stride == 2 ? c3s2 : (upm ? c3up : c3));
+  const int ncand = d.ksize == 1 ? 3 : (d.stride == 2 ? 2 : (upm ? 2 : 4));
   const int nchunks = chunks_of(d.c0) + chunks_of(d.c1);
   if (g_sp_force >= 0) {
     for (int k = 0; k < ncand; ++k)
@@ -982,10 +1088,10 @@ SpCfg select_cfg(const dn_conv_desc& d) {
 }
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST = 0, int ABL = 0, int BSTAT = 0>
+          int WTM, int WTN, int POST = 0, int ABL = 0, int BSTAT = 0, int UPM = 0>
 int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
-  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT>;
-  auto kern = conv_sp_kernel<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, ABL, BSTAT>;
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM>;
+  auto kern = conv_sp_kernel<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, ABL, BSTAT, UPM>;
   const int nchunks = a.c0g + a.c1g;
   DN_REQUIRE(nchunks % CA == 0, "spconv: chunk count %d not a multiple of %d", nchunks, CA);
   a.ngroups = nchunks / CA;
@@ -1045,7 +1151,7 @@ int fill_args(const dn_conv_desc* d, const void* src0, const void* src1, const v
   a.c0g = chunks_of(d->c0); a.c1g = chunks_of(d->c1);
   a.up0 = d->up0; a.c_out = d->c_out; a.cog = chunks_of(d->c_out); a.relu = d->relu;
   a.cout_pad = cout_pad_of(d->c_out);
-  a.wpk_bytes = (int)((size_t)packed_chunks(*d) * d->ksize * d->ksize * 4 * a.cout_pad * 16);
+  a.wpk_bytes = (int)(packed_blocks(*d) * 4 * a.cout_pad * 16);
   a.w2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out_b = nullptr;
   a.c_out2 = 0; a.relu2 = 0; a.split2 = 0; a.ldo_a = 0; a.ldo_b = 0; a.post_f32 = 0;
   a.b_total = 0; a.stg_row = 0;
@@ -1087,7 +1193,7 @@ extern "C" int dn_sp_to_nhwc(const void* src, int n_images, int h, int w, int ch
 
 extern "C" size_t dn_spconv_packed_weight_bytes(const dn_conv_desc* d) {
   if (validate(d) != DN_OK) return 0;
-  return (size_t)packed_chunks(*d) * d->ksize * d->ksize * 4 * cout_pad_of(d->c_out) * 16;
+  return packed_blocks(*d) * 4 * cout_pad_of(d->c_out) * 16;
 }
 
 extern "C" int dn_spconv_pack_weights(const dn_conv_desc* d, const float* weight_oihw, float wmul,
@@ -1096,6 +1202,11 @@ extern "C" int dn_spconv_pack_weights(const dn_conv_desc* d, const float* weight
   DN_REQUIRE(weight_oihw && packed, "spconv pack: null pointer");
   DN_REQUIRE(d->c1 == 0 || d->c0 % 16 == 0, "spconv pack: concat needs c0 %% 16 == 0");
   const int taps = d->ksize * d->ksize, cp = cout_pad_of(d->c_out), nch = packed_chunks(*d);
+  if (up_merged(*d)) {
+    hipLaunchKernelGGL(sp_pack_weights_up_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, weight_oihw,
+                       (unsigned char*)packed, d->c_out, d->c0 + d->c1, chunks_of(d->c0), cp, nch, wmul);
+    return dn::check_launch("sp_pack_weights_up_kernel");
+  }
   const long total = (long)nch * taps * 2 * cp;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(sp_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
@@ -1165,6 +1276,14 @@ extern "C" int dn_spconv2d(const dn_conv_desc* d, const void* src0, const void* 
   if (int rc = fill_args(d, src0, src1, packed, scale, shift, out, a)) return rc;
   const SpCfg c = select_cfg(*d);
   hipStream_t s = (hipStream_t)stream;
+  if (up_merged(*d)) {   // the packed image is the row-merged one: only the tiles that implement it
+    switch (c.id) {
+      case S3_256x64: return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 0, 0, 0, 1>(a, *d, s);
+      case S3_256x32: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 0, 1>(a, *d, s);
+      case S3_128x64: return launch<3, 1, 8, 16, 64, 3, 1, 2, 2, 2, 1, 0, 0, 0, 1>(a, *d, s);
+      default: return dn::fail(DN_ERR_UNSUPPORTED, "spconv: tile configuration %d has no row-merged form", (int)c.id);
+    }
+  }
   if (g_sp_force >= 100 && d->ksize == 3 && d->stride == 1) {   // tools: timing-only ablations
     switch (g_sp_force) {
       case 101: return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 0, 1>(a, *d, s);

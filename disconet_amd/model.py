@@ -128,7 +128,7 @@ class _ConvLayer:
     """One packed conv of the plan: weights in tile-major layout + folded affine."""
 
     __slots__ = ("name", "packed", "scale", "shift", "c_in", "c_out", "ksize", "stride", "relu",
-                 "math", "affine")
+                 "math", "affine", "weight", "packed_sig")
 
     def __init__(self, name, weight, bias, bn, ksize, stride=1, relu=True, scale_shift=None,
                  math=0):
@@ -142,9 +142,13 @@ class _ConvLayer:
         else:
             self.scale, self.shift = ops.fold_bn(bias, bn, c_out)
         self.affine = (self.scale, self.shift)      # the layer's own y = acc * scale + shift
+        self.weight, self.packed_sig = None, None
         if math == 2:     # SP engine: weights lifted by a power of two, undone in the scale
             self.packed, wmul = ops.sp_pack_conv_weights(d, weight)
             self.scale = (self.scale / wmul).contiguous()
+            # the packed image of a layer whose first source is upsampled depends on the source split
+            # (row-merged taps, csrc/conv_sp.hip UPM): repacked on the first run that shows it
+            self.weight, self.packed_sig = weight.detach(), (c_in, 0, 0)
         else:
             self.packed = ops.pack_conv_weights(d, weight)
         self.c_in, self.c_out, self.ksize, self.stride, self.relu = c_in, c_out, ksize, stride, relu
@@ -162,6 +166,10 @@ class _ConvLayer:
         nbytes = 4.0 * (src0.numel() + (src1.numel() if src1 is not None else 0)
                         + n * ho * wo * self.c_out + self.c_out * self.c_in * self.ksize ** 2)
         if self.math == 2:
+            sig = (c0, c1, 1 + (h_in % 2) + 2 * (w_in % 2)) if up0 else self.packed_sig
+            if sig != self.packed_sig:
+                self.packed, _ = ops.sp_pack_conv_weights(d, self.weight)      # same wmul: same weights
+                self.packed_sig = sig
             # split-planar engine: NHWC inputs (the voxel grid, the fused map) are split once here
             src0, src1 = ops.as_sp(src0), (ops.as_sp(src1) if src1 is not None else None)
             with region(self.name, "conv_sp_kernel", flops, nbytes):

@@ -1,0 +1,42 @@
+"""Repeats the first training step of the cfg1 case with fresh modules and counts losses that differ from the
+committed float64 golden by more than 2e-5 relative (one such event was seen once in a long pytest process)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests import cases  # noqa: E402
+from disconet_amd import CoDetModule, Config, DiscoNet  # noqa: E402
+from disconet_amd.synthetic import make_scene_batch, make_train_targets  # noqa: E402
+
+gold = np.load(os.path.join(ROOT, "tests", "golden", "train_step.npz"))
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+case = "cfg1"
+c = cases.TRAIN_CASES[case]
+ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=0)
+bevs, trans, na = make_scene_batch(c["batch"], c["agents"], c["map_hw"], live=c["live"], jitter_seed=c["jitter"])
+labels, targets, mask = make_train_targets(bevs.shape[0], c["map_hw"], p_fg=0.02)
+data = {"bev_seq": bevs.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(),
+        "labels": labels.cuda(), "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda()}
+want = gold["%s/det/losses" % case]
+bad = {}
+seen = {}
+for math in ("f32", "f16x3"):
+    for i in range(N):
+        model = DiscoNet(Config(map_hw=c["map_hw"]), kd_flag=0, num_agent=c["agents"])
+        model.load_state_dict(ref.state_dict())
+        model = model.cuda()
+        model.conv_math = math
+        out = CoDetModule(model, lr=1e-3).step(data, c["batch"])
+        rel = max(abs(out["cls_loss"] - want[0]) / want[0], abs(out["loc_loss"] - want[1]) / want[1])
+        seen.setdefault((math, round(out["cls_loss"], 3), round(out["loc_loss"], 3)), 0)
+        seen[(math, round(out["cls_loss"], 3), round(out["loc_loss"], 3))] += 1
+        if rel > 2e-5:
+            bad[math] = bad.get(math, 0) + 1
+print("distinct (math, cls, loc) results and their counts:")
+for k, v in sorted(seen.items()):
+    print("   ", k, v)
+print("mismatching steps:", bad or 0, "of", N, "per math")
