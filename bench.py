@@ -364,8 +364,16 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     elif args.force_process_group and args.mode != "agent":
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29518", rank=0, world_size=1,
-                                device_id=torch.device("cuda", local_rank))
+        import datetime
+        if "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ:
+            # launched by torch.distributed.run with one rank: its agent hosts the store (an explicit tcp://
+            # address would wait 10 minutes for a server nobody started)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=120))
+        else:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29518", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=120))
 
     if args.mode == "agent":
         return agent_sharded_bench(args, world, rank, dist)
