@@ -1,0 +1,41 @@
+"""Per-layer table of one bench step from a rocprofv3 kernel trace of the default command (graph replay):
+launch order -> layer name, duration, algorithmic GFLOP (true channel counts), TFLOP/s.
+    python tools/layers_from_trace.py gpurun_out/r02prof/kernel_trace.csv > profiles/r02_bench_layers.txt"""
+import csv
+import sys
+
+N = 20                                        # 4 scenes x 5 agents
+LAYERS = [  # name, out pixels per image, cin, cout, k   (launch order of DiscoNet.forward, conv_math sp)
+    ("conv_pre_1", 256 * 256, 13, 32, 3), ("conv_pre_2", 256 * 256, 32, 32, 3), ("conv1_1 (s2)", 128 * 128, 32, 64, 3),
+    ("conv1_2 + Conv3D 1x1", 128 * 128, 64, 64, 3), ("conv2_1 (s2)", 64 * 64, 64, 128, 3), ("conv2_2", 64 * 64, 128, 128, 3),
+    ("conv3d_2 (1x1)", 64 * 64, 128, 128, 1), ("conv3_1 (s2)", 32 * 32, 128, 256, 3), ("conv3_2", 32 * 32, 256, 256, 3),
+    ("conv4_1 (s2)", 16 * 16, 256, 512, 3), ("conv4_2", 16 * 16, 512, 512, 3),
+    ("conv5_1 (up+cat)", 32 * 32, 768, 256, 3), ("conv5_2", 32 * 32, 256, 256, 3), ("conv6_1 (up+cat)", 64 * 64, 384, 128, 3),
+    ("conv6_2", 64 * 64, 128, 128, 3), ("conv7_1 (up+cat)", 128 * 128, 192, 64, 3), ("conv7_2", 128 * 128, 64, 64, 3),
+    ("conv8_1 (up+cat)", 256 * 256, 96, 32, 3), ("conv8_2", 256 * 256, 32, 32, 3), ("heads (3x3 + block-diag 1x1)", 256 * 256, 32, 64, 3),
+]
+EXTRA = {3: 2.0 * N * 128 * 128 * 64 * 64, 19: 2.0 * N * 256 * 256 * (32 * 12 + 32 * 36)}   # the fused 1x1 stages
+
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+starts = [i for i, r in enumerate(rows) if "zero_fill_kernel" in r["Kernel_Name"]]
+skip = 4                                       # the bench ends with an eager check step and extras: go back a few
+sel = rows[starts[-skip]:starts[-skip + 1]]
+conv = [r for r in sel if "conv_sp_kernel" in r["Kernel_Name"]]
+assert len(conv) == len(LAYERS), (len(conv), len(LAYERS))
+print("%-30s %9s %10s %9s   %s" % ("layer", "us", "GFLOP", "TFLOP/s", "kernel configuration <KS,S,TH,TW,BN,TG,CA,WM,WN,WTM,WTN,POST,ABL,BSTAT,UPM>"))
+tot_us = tot_gf = 0.0
+for i, (r, (name, px, cin, cout, k)) in enumerate(zip(conv, LAYERS)):
+    us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    gf = (2.0 * N * px * cout * cin * k * k + EXTRA.get(i, 0.0)) / 1e9
+    cfg = r["Kernel_Name"].split("conv_sp_kernel<")[1].split(">")[0].replace(" ", "")
+    print("%-30s %9.1f %10.2f %9.1f   <%s>" % (name, us, gf, gf / (us * 1e-6) / 1e3, cfg))
+    tot_us += us
+    tot_gf += gf
+print("%-30s %9.1f %10.2f %9.1f" % ("all conv launches", tot_us, tot_gf, tot_gf / (tot_us * 1e-6) / 1e3))
+for r in sel:
+    if "conv_sp_kernel" not in r["Kernel_Name"]:
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        nm = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+        nm = nm.split("<")[0].split("(")[0] if not nm.startswith("at::") else "torch elementwise (num_agent cast)"
+        print("%-30s %9.1f" % (nm[-30:], us))
+print("step span %.1f us" % ((int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])) / 1e3))
