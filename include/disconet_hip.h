@@ -159,6 +159,13 @@ int dn_conv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p, const flo
  * is multiplied into the weights before the split -- pass a power of two that
  * lifts the layer's weights out of the f16 subnormal range and fold 1/wmul into
  * `scale` (exact in fp32).
+ * The packed image depends on the layer's SOURCES as well as on its weights: pack
+ * with the descriptor the layer will run with.  A 3x3 stride-1 layer whose first
+ * source is nearest-upsampled (up0 = 1, c0 a multiple of 16, even h_in / w_in) is
+ * packed ROW-MERGED: kernel rows that read the same low-resolution row of that
+ * source are summed (12 blocks per 16-channel chunk of source 0 instead of 9), and
+ * dn_spconv2d runs 2 x 3 taps over those chunks.  dn_spconv_packed_weight_bytes()
+ * accounts for it.
  * ------------------------------------------------------------------------ */
 size_t dn_sp_tensor_bytes(int n_images, int h, int w, int channels);
 /* fp32 NHWC [n][h][w][ld] (first `channels` of each pixel) <-> SP */
