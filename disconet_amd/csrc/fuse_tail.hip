@@ -56,7 +56,8 @@ disco_fuse_tail_kernel(const TailArgs a) {
 
   if (i >= n_live) {
     // padded agent: its map passes through un-fused
-    // wave-uniform trip counts, per-lane `if` inside: no lane-dependent loop exits
+    // wave-uniform trip counts with a per-lane `if` inside (a round-1 convention; DESIGN.md 3.6 (B) shows the
+    // loop form was not what mattered)
     const int n_it = (PIX * a.c + 255) / 256;
     for (int it = 0; it < n_it; ++it) {
       const int idx = tid + 256 * it;

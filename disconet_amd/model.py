@@ -277,11 +277,11 @@ class DiscoNet(nn.Module):
         # one-launch attention MLP + softmax + weighted sum (csrc/fuse_mlp.hip) instead of
         # two 1x1 conv launches + the tail kernel (split-f16 engines, C in {64, 128, 256})
         self.fuse_mlp = os.environ.get("DISCONET_FUSE_MLP", "1") != "0"
-        # run the encoder levels above the exchanged one beside the fusion block on a second HIP stream
-        # (+2.2 % per step, bit-exact against the serial order in tools/det_check.py).  Opt-in
-        # (DISCONET_OVERLAP=1 or model.overlap_streams = True; bench.py switches it on and guards its
-        # figure with an output-identity check): kernels running side by side exposed a mask hazard
-        # once, so the library default stays strictly in stream order.
+        # run the encoder levels above the exchanged one beside the fusion block on a second HIP stream.
+        # Opt-in only (DISCONET_OVERLAP=1 or model.overlap_streams = True; bench.py --in-flight N > 1
+        # switches it on and checksums every replay): a kernel that shares a SIMD with the split-f16 conv
+        # kernels has been observed to compute with corrupted VGPR lanes (DESIGN.md 3.6 (B),
+        # profiles/r02_hazard_repro.txt), so the library runs strictly in stream order.
         self.overlap_streams = os.environ.get("DISCONET_OVERLAP", "0") == "1"
         self._side = {}
 

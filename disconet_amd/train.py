@@ -326,8 +326,8 @@ class TrainEngine:
             a = group(k, a)
             e.append(a)
         # the encoder levels above the exchanged one could run beside the fusion block on a second
-        # stream (self.overlap_streams, default off: the training kernels' grid-stride loops have not
-        # been checked for the co-residency hazard of DESIGN.md 3.6 yet), else in stream order
+        # stream (self.overlap_streams, default off and meant to stay off: no kernel-source rule rules out
+        # the co-residency defect of DESIGN.md 3.6 (B)), else in stream order
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev) if self.overlap_streams else main
         side.wait_stream(main)
