@@ -13,10 +13,17 @@ configs[1]: 5 agents, batch 4, 256x256x13 BEV, no KD, eval forward.
 Multi-GPU: scene-parallel -- every rank runs its own batch of scenes, no
 collective on the data path -> "scaling": "weak".
 
+Steps are replayed from one captured hipGraph on ONE stream, strictly one at a
+time (--in-flight 1, the default; DESIGN.md 3.6 explains why nothing runs side
+by side).  The run checks that a graph replay equals the eager step bit for bit
+(`graph_equals_eager`).  --task seg measures BASELINE configs[3], --mode agent
+configs[4].
+
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-`roofline` (dominant kernel = the fp32-MFMA implicit-GEMM conv, HIP-event timed
-inside the timed region on the launch stream) and `cpu_baseline` (the CPU
-oracle, i.e. a port: the reference itself is not in the mount).
+`roofline` (dominant kernel = the split-f16 MFMA implicit-GEMM conv on
+split-planar activations, HIP-event timed per launch on the launch stream, and
+the committed rocprofv3 figure beside it) and `cpu_baseline` (the CPU oracle,
+i.e. a port: the reference itself is not in the mount; batch 1 and batch 4).
 """
 import argparse
 import json
