@@ -395,6 +395,8 @@ def main():
     model = DiscoNet(Config(map_hw=MAP_HW), kd_flag=0, num_agent=AGENTS)
     randomize_bn_stats(model)
     model.conv_math = args.math
+    if args.in_flight > 1:      # measurement option: every replay is checksummed below
+        os.environ["DISCONET_UNSAFE_OVERLAP"] = "1"
     model.overlap_streams = args.in_flight > 1        # concurrency features together, guarded below
     model.eval().cuda()
     state_dict_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}

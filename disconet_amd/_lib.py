@@ -93,7 +93,8 @@ SIGNATURES = {
     # ---- include/disconet_seg.h ----
     "dn_sp_maxpool2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dn_sp_upsample2_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "dn_seg_ce_loss": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p,
+    "dn_seg_label_count": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p]),
+    "dn_seg_ce_loss": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                c_void_p]),
     # ---- include/disconet_train.h ----
     "dn_conv_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),

@@ -821,7 +821,8 @@ int launch(ConvArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   static_assert(T::LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   // opt in to > 64 KiB of dynamic LDS once per instantiation (idempotent; a race
   // between two first callers only repeats the same attribute write)
-  static bool lds_ready = false;
+  static dn::PerDeviceFlag lds_flag;
+  bool& lds_ready = lds_flag.here();
   static int occupancy = 1;
   if (!lds_ready) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

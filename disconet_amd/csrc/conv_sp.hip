@@ -1106,7 +1106,8 @@ int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   }
   // opt in to > 64 KiB of dynamic LDS; the attribute write is idempotent, so two first
   // callers racing here only repeat it
-  static bool attr_set = false;
+  static dn::PerDeviceFlag attr_flag;
+  bool& attr_set = attr_flag.here();
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -407,7 +407,8 @@ template <int KS, int STRIDE>
 int launch(const WgradArgs& a, const Plan& p, hipStream_t stream) {
   using T = WgradTile<KS, STRIDE>;
   auto kern = conv_wgrad_kernel<KS, STRIDE>;
-  static bool ready = false;
+  static dn::PerDeviceFlag ready_flag;
+  bool& ready = ready_flag.here();
   if (!ready) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_FLOATS * 4);
@@ -456,7 +457,8 @@ extern "C" int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const flo
     // the vector path also needs 16-byte aligned bases
     DN_REQUIRE(a.vec0 && a.vec1 && a.vecz, "wgrad: 64-channel blocks need 16-byte aligned sources");
     constexpr int lds = (6 * 18 * 64 + 64 * 64) * 4;
-    static bool ready = false;
+    static dn::PerDeviceFlag ready_flag;
+    bool& ready = ready_flag.here();
     if (!ready) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad64_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);

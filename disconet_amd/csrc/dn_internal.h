@@ -23,6 +23,17 @@ inline int fail(int code, const char* fmt, ...) {
 // DESIGN.md 3.6) -- a kernel node carries its arguments by value and replays exactly.
 hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t stream);
 
+// Launch-time caches (kernel attributes) are per DEVICE: a process that drives several GPUs must set the
+// dynamic-LDS attribute on each.  `flags` is a function-local static of the caller.
+struct PerDeviceFlag {
+  bool done[64] = {};
+  bool& here() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return done[dev & 63];
+  }
+};
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(DN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));

@@ -97,28 +97,67 @@ __global__ void sp_upsample2_kernel(const unsigned char* __restrict__ src, unsig
   }
 }
 
-// logits [pixels][ld] float32 (first `classes` columns), labels [pixels] int32 (negative = ignored).
-// loss += sum over pixels of (logsumexp - z[label]) in double; dlogits = (softmax - onehot) * gscale.
+// labels [pixels] int32: IGNORE (-100, nn.CrossEntropyLoss's ignore_index) = not counted; any other value
+// outside [0, classes) is counted in counts[1] (torch raises there) and otherwise treated as ignored.
+__global__ void seg_label_count_kernel(const int32_t* __restrict__ labels, long pixels, int classes,
+                                       int32_t* __restrict__ counts) {
+  __shared__ int live_s[256], bad_s[256];
+  int live = 0, bad = 0;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < pixels; p += (long)gridDim.x * blockDim.x) {
+    const int y = labels[p];
+    if (y >= 0 && y < classes) ++live;
+    else if (y != -100) ++bad;
+  }
+  live_s[threadIdx.x] = live;
+  bad_s[threadIdx.x] = bad;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { live_s[threadIdx.x] += live_s[threadIdx.x + st]; bad_s[threadIdx.x] += bad_s[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { atomicAdd(&counts[0], live_s[0]); atomicAdd(&counts[1], bad_s[0]); }   // integer: order-free
+}
+
+// logits [pixels][ld] float32 (first `classes` columns), labels [pixels] int32 (outside [0, classes) = ignored).
+// loss += sum over live pixels of (logsumexp - z[label]) in double; dlogits = (softmax - onehot) * g with
+// g = gscale, or gscale / counts[0] when `counts` is given (mean over the live pixels, as torch).
+// CLS > 0: class count known at compile time (logits in registers); CLS == 0: any count, three passes over
+// the row (the re-reads hit L1).
 template <int CLS>
 __global__ void seg_ce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels, long pixels,
-                              int ld, float gscale, double* __restrict__ loss, float* __restrict__ dlogits) {
+                              int classes, int ld, float gscale, const int32_t* __restrict__ counts,
+                              double* __restrict__ loss, float* __restrict__ dlogits) {
   __shared__ double part[256];
   double acc = 0.0;
+  if (counts) gscale = counts[0] > 0 ? gscale / (float)counts[0] : 0.f;
   for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < pixels; p += (long)gridDim.x * blockDim.x) {
     const float* z = logits + p * ld;
-    float v[CLS], m = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < CLS; ++c) { v[c] = z[c]; m = fmaxf(m, v[c]); }
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < CLS; ++c) { v[c] = expf(v[c] - m); s += v[c]; }
     const int y = labels[p];
-    const bool live = y >= 0 && y < CLS;
-    if (live) acc += (double)(logf(s) + m) - (double)z[y];
-    if (dlogits) {
-      const float inv = live ? gscale / s : 0.f;
+    if constexpr (CLS > 0) {
+      float v[CLS], m = -INFINITY;
 #pragma unroll
-      for (int c = 0; c < CLS; ++c) dlogits[p * ld + c] = v[c] * inv - (live && c == y ? gscale : 0.f);
+      for (int c = 0; c < CLS; ++c) { v[c] = z[c]; m = fmaxf(m, v[c]); }
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < CLS; ++c) { v[c] = expf(v[c] - m); s += v[c]; }
+      const bool live = y >= 0 && y < CLS;
+      if (live) acc += (double)(logf(s) + m) - (double)z[y];
+      if (dlogits) {
+        const float inv = live ? gscale / s : 0.f;
+#pragma unroll
+        for (int c = 0; c < CLS; ++c) dlogits[p * ld + c] = v[c] * inv - (live && c == y ? gscale : 0.f);
+      }
+    } else {
+      float m = -INFINITY, s = 0.f;
+      for (int c = 0; c < classes; ++c) m = fmaxf(m, z[c]);
+      for (int c = 0; c < classes; ++c) s += expf(z[c] - m);
+      const bool live = y >= 0 && y < classes;
+      if (live) acc += (double)(logf(s) + m) - (double)z[y];
+      if (dlogits) {
+        const float inv = live ? gscale / s : 0.f;
+        for (int c = 0; c < classes; ++c)
+          dlogits[p * ld + c] = expf(z[c] - m) * inv - (live && c == y ? gscale : 0.f);
+      }
     }
   }
   part[threadIdx.x] = acc;
@@ -156,15 +195,31 @@ extern "C" int dn_sp_upsample2_bilinear(const void* src_sp, int n_images, int h,
   return dn::check_launch("sp_upsample2_kernel");
 }
 
+extern "C" int dn_seg_label_count(const int32_t* labels, long pixels, int classes, int32_t* counts,
+                                  void* stream) {
+  DN_REQUIRE(labels && counts && pixels > 0 && classes > 0, "seg_label_count: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dn::zero_fill(counts, 2 * sizeof(int32_t), s) != hipSuccess)
+    return dn::fail(DN_ERR_LAUNCH, "seg_label_count: zero fill failed");
+  const int blocks = (int)((pixels + 255) / 256 < 1024 ? (pixels + 255) / 256 : 1024);
+  hipLaunchKernelGGL(seg_label_count_kernel, dim3(blocks), dim3(256), 0, s, labels, pixels, classes, counts);
+  return dn::check_launch("seg_label_count_kernel");
+}
+
 extern "C" int dn_seg_ce_loss(const float* logits, const int32_t* labels, long pixels, int classes, int ld,
-                              float grad_scale, double* loss_sum, float* dlogits, void* stream) {
+                              float grad_scale, const int32_t* counts, double* loss_sum, float* dlogits,
+                              void* stream) {
   DN_REQUIRE(logits && labels && loss_sum && pixels > 0, "seg_ce_loss: bad arguments");
-  DN_REQUIRE(classes == 8 && ld >= classes, "seg_ce_loss: %d classes unsupported (8)", classes);
+  DN_REQUIRE(classes >= 1 && classes <= 1024 && ld >= classes, "seg_ce_loss: %d classes (ld %d) unsupported", classes, ld);
   hipStream_t s = (hipStream_t)stream;
   if (dn::zero_fill(loss_sum, sizeof(double), s) != hipSuccess)
-    return dn::fail(DN_ERR_LAUNCH, "seg_ce_loss: memset failed");
+    return dn::fail(DN_ERR_LAUNCH, "seg_ce_loss: zero fill failed");
   const int blocks = (int)((pixels + 255) / 256 < 2048 ? (pixels + 255) / 256 : 2048);
-  hipLaunchKernelGGL(seg_ce_kernel<8>, dim3(blocks), dim3(256), 0, s, logits, labels, pixels, ld, grad_scale,
-                     loss_sum, dlogits);
+  if (classes == 8)
+    hipLaunchKernelGGL(seg_ce_kernel<8>, dim3(blocks), dim3(256), 0, s, logits, labels, pixels, classes, ld, grad_scale,
+                       counts, loss_sum, dlogits);
+  else
+    hipLaunchKernelGGL(seg_ce_kernel<0>, dim3(blocks), dim3(256), 0, s, logits, labels, pixels, classes, ld, grad_scale,
+                       counts, loss_sum, dlogits);
   return dn::check_launch("seg_ce_kernel");
 }

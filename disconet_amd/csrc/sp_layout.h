@@ -15,7 +15,7 @@
 //   piece = 8 halves = input channels 16*chunk + 8*oct + 0..7 of output channel n.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SP_HD __host__ __device__ inline
 #else
 #define SP_HD inline

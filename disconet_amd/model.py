@@ -131,12 +131,19 @@ class _ConvLayer:
                  "math", "affine", "weight", "packed_sig")
 
     def __init__(self, name, weight, bias, bn, ksize, stride=1, relu=True, scale_shift=None,
-                 math=0):
+                 math=0, up_split=None):
+        """up_split = (c0, c1): the layer always runs as cat([up2(src0), src1]) with these channel counts
+        (the decoder's *_1 convs) -- its SP weight image is the tap-merged one and is packed here, once."""
         self.name = name
         self.math = math
         c_out = weight.shape[0]
         c_in = weight.shape[1]
-        d = ops.conv_desc(1, 8, 8, c_in, c_out, ksize, stride, relu, math=math)
+        if up_split is not None and math == 2:
+            assert sum(up_split) == c_in
+            d = ops.conv_desc(1, 8, 8, up_split[0], c_out, ksize, stride, relu, c1=up_split[1], up0=True, math=math)
+        else:
+            up_split = None
+            d = ops.conv_desc(1, 8, 8, c_in, c_out, ksize, stride, relu, math=math)
         if scale_shift is not None:
             self.scale, self.shift = scale_shift
         else:
@@ -147,8 +154,11 @@ class _ConvLayer:
             self.packed, wmul = ops.sp_pack_conv_weights(d, weight)
             self.scale = (self.scale / wmul).contiguous()
             # the packed image of a layer whose first source is upsampled depends on the source split
-            # (row-merged taps, csrc/conv_sp.hip UPM): repacked on the first run that shows it
-            self.weight, self.packed_sig = weight.detach(), (c_in, 0, 0)
+            # (merged taps, csrc/conv_sp.hip UPM / conv_spq.hip): packed above when the plan knows the
+            # split (even map sizes assumed), else repacked on the first run that shows it (a host
+            # sync + allocation: not inside a hipGraph capture)
+            self.weight = weight.detach()
+            self.packed_sig = (up_split[0], up_split[1], 1) if up_split is not None else (c_in, 0, 0)
         else:
             self.packed = ops.pack_conv_weights(d, weight)
         self.c_in, self.c_out, self.ksize, self.stride, self.relu = c_in, c_out, ksize, stride, relu
@@ -277,13 +287,22 @@ class DiscoNet(nn.Module):
         # one-launch attention MLP + softmax + weighted sum (csrc/fuse_mlp.hip) instead of
         # two 1x1 conv launches + the tail kernel (split-f16 engines, C in {64, 128, 256})
         self.fuse_mlp = os.environ.get("DISCONET_FUSE_MLP", "1") != "0"
-        # run the encoder levels above the exchanged one beside the fusion block on a second HIP stream.
-        # Opt-in only (DISCONET_OVERLAP=1 or model.overlap_streams = True; bench.py --in-flight N > 1
-        # switches it on and checksums every replay): a kernel that shares a SIMD with the split-f16 conv
-        # kernels has been observed to compute with corrupted VGPR lanes (DESIGN.md 3.6 (B),
-        # profiles/r02_hazard_repro.txt), so the library runs strictly in stream order.
+        # run the encoder levels above the exchanged one beside the fusion block on a second HIP stream:
+        # REFUSED unless DISCONET_UNSAFE_OVERLAP=1 (the property below).  A kernel that shares a SIMD with
+        # the split-f16 conv kernels has been observed to compute with corrupted VGPR lanes (DESIGN.md
+        # 3.6 (B), profiles/r02_hazard_repro.txt), so the library runs strictly in stream order;
+        # bench.py --in-flight N > 1 sets the override and checksums every replay.
+        self._overlap_streams = False
         self.overlap_streams = os.environ.get("DISCONET_OVERLAP", "0") == "1"
         self._side = {}
+
+    @property
+    def overlap_streams(self):
+        return self._overlap_streams
+
+    @overlap_streams.setter
+    def overlap_streams(self, value):
+        self._overlap_streams = ops.check_overlap_request(value, "DiscoNet.overlap_streams")
 
     # ------------------------------------------------------------------
     # checkpoint compatibility
@@ -294,13 +313,23 @@ class DiscoNet(nn.Module):
         reference keeps because its encoder and decoder both instantiate the
         whole Backbone (SURVEY.md Appx A.3)."""
         own = set(super().state_dict().keys())
-        cleaned, dropped = {}, []
+        cleaned, dropped, unknown = {}, [], []
         for k, v in state_dict.items():
             k = k[len("module."):] if k.startswith("module.") else k
             if k not in own and _DUPLICATE_BACKBONE_KEY.match(k):
                 dropped.append(k)      # the half of the shared Backbone definition this side never runs
+            elif k not in own and (k.startswith("u_encoder.") or k.startswith("decoder.")):
+                # The duplicate-key list above is written from recollection (the reference source is not in
+                # the mount).  A Backbone key it does not know is dropped WITH a warning rather than failing
+                # the load of a real checkpoint: every parameter this model runs is in `own`, and a missing
+                # one still fails torch's strict check below.
+                unknown.append(k)
             else:
                 cleaned[k] = v         # anything else: torch reports it when it is unexpected (strict)
+        if unknown:
+            import warnings
+            warnings.warn("DiscoNet.load_state_dict: dropped %d Backbone keys this model does not run and the "
+                          "duplicate-Backbone list does not name: %s" % (len(unknown), ", ".join(sorted(unknown)[:8])))
         self._plan = None
         return super().load_state_dict(cleaned, strict=strict, **kw)
 
@@ -344,9 +373,11 @@ class DiscoNet(nn.Module):
                                    enc.bn_compress, 1)
             P["decompress"] = _Layer("decompress", enc.com_decompresser.weight, enc.com_decompresser.bias,
                                      enc.bn_decompress, 1)
-        for name, _, _ in _DEC_CONVS:
+        for name, cin, cout in _DEC_CONVS:
             conv = getattr(dec, name)
-            P[name] = _Layer(name, conv.weight, conv.bias, getattr(dec, _bn_name(name)), 3)
+            # conv5_1..conv8_1 read cat([up2(deeper level), skip]): the deeper level has 2 * cout channels
+            split = (2 * cout, cin - 2 * cout) if name.endswith("_1") else None
+            P[name] = _Layer(name, conv.weight, conv.bias, getattr(dec, _bn_name(name)), 3, up_split=split)
         cls, reg = self.classification, self.regression.box_prediction
         P["cls1"] = _Layer("cls1", cls.conv1.weight, cls.conv1.bias, cls.bn1, 3)
         P["cls2"] = _Layer("cls2", cls.conv2.weight, cls.conv2.bias, None, 1, relu=False)

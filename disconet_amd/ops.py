@@ -27,6 +27,26 @@ def _need_gpu(*tensors):
                                "there is no CPU path" % t.device)
 
 
+def unsafe_overlap_allowed():
+    """Running two of this library's kernels CONCURRENTLY (a second HIP stream, two graphs in flight)
+    has produced silently wrong values on MI355X / ROCm 7.2: lanes 48..63 of a VGPR of one kernel are
+    replaced while a split-f16 conv kernel shares its SIMD (DESIGN.md 3.6 (B),
+    profiles/r02_hazard_repro.txt; not root-caused).  The library's contract is ONE stream per GPU;
+    the overlap toggles exist for the hazard study only and need DISCONET_UNSAFE_OVERLAP=1."""
+    import os
+    return os.environ.get("DISCONET_UNSAFE_OVERLAP", "0") == "1"
+
+
+def check_overlap_request(value, what):
+    if value and not unsafe_overlap_allowed():
+        raise _lib.DnError(
+            "%s = True would co-schedule kernels on two HIP streams; that has produced silently wrong "
+            "results beside the split-f16 conv kernels (DESIGN.md 3.6 (B)).  The library runs in stream "
+            "order; set DISCONET_UNSAFE_OVERLAP=1 to override for measurements that checksum every "
+            "result (bench.py --in-flight, tools/hazard/)." % what)
+    return bool(value)
+
+
 def _f32c(t, name):
     if t.dtype != torch.float32 or not t.is_contiguous():
         raise _lib.DnError("%s must be contiguous float32 (got %s, contiguous=%s)"
@@ -333,19 +353,31 @@ def sp_upsample2_bilinear(x):
     return out
 
 
-def seg_ce_loss(logits_nhwc, labels, want_grad=True):
-    """mean per-pixel cross entropy of float32 NHWC logits [n, h, w, 8] vs int labels [n, h, w]
-    -> (loss double scalar tensor, dlogits [n, h, w, 8] or None)"""
+def seg_ce_loss(logits_nhwc, labels, want_grad=True, check_labels=True):
+    """nn.CrossEntropyLoss (mean over the non-ignored pixels, ignore_index = -100) of float32 NHWC
+    logits [n, h, w, classes] vs int labels [n, h, w] -> (loss double scalar tensor, dlogits or None).
+    check_labels: refuse labels that are neither in [0, classes) nor -100, as torch does (one host
+    sync); the training step passes False and stays asynchronous."""
     _need_gpu(logits_nhwc, labels)
     _f32c(logits_nhwc, "logits")
-    pixels = logits_nhwc.numel() // logits_nhwc.shape[-1]
+    classes = logits_nhwc.shape[-1]
+    pixels = logits_nhwc.numel() // classes
     lab = labels.to(device=logits_nhwc.device, dtype=torch.int32).contiguous()
+    if lab.numel() != pixels:
+        raise _lib.DnError("seg_ce_loss: %d labels for %d pixels" % (lab.numel(), pixels))
+    lib = _lib.load()
+    counts = torch.empty(2, dtype=torch.int32, device=logits_nhwc.device)
+    check(lib.dn_seg_label_count(_ptr(lab), pixels, classes, _ptr(counts), _stream()), "dn_seg_label_count")
     loss = torch.empty(1, dtype=torch.float64, device=logits_nhwc.device)
     grad = torch.empty_like(logits_nhwc) if want_grad else None
-    check(_lib.load().dn_seg_ce_loss(_ptr(logits_nhwc), _ptr(lab), pixels, logits_nhwc.shape[-1],
-                                     logits_nhwc.shape[-1], 1.0 / pixels, _ptr(loss), _ptr(grad), _stream()),
-          "dn_seg_ce_loss")
-    return loss / pixels, grad
+    check(lib.dn_seg_ce_loss(_ptr(logits_nhwc), _ptr(lab), pixels, classes, classes, 1.0, _ptr(counts),
+                             _ptr(loss), _ptr(grad), _stream()), "dn_seg_ce_loss")
+    if check_labels:
+        live, bad = counts.tolist()
+        if bad:
+            raise _lib.DnError("seg_ce_loss: %d labels outside [0, %d) (and not the ignore index -100)"
+                               % (bad, classes))
+    return loss / counts[0].clamp(min=1).to(torch.float64), grad
 
 
 def pack_post1x1_weights(weight):

@@ -118,12 +118,17 @@ def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev):
 
 
 class TrainEngine:
+    # a second stream beside the conv kernels is refused unless DISCONET_UNSAFE_OVERLAP=1 (ops.check_overlap_request)
+    overlap_streams = property(lambda self: self._overlap_streams,
+                               lambda self, v: setattr(self, "_overlap_streams",
+                                                       ops.check_overlap_request(v, "TrainEngine.overlap_streams")))
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.generation = 0          # bumped by every forward(): the saved activations belong to it
-        self.overlap_streams = False
+        self._overlap_streams = False
         params = _param_order(model)
         dev = params[0].device
         if dev.type != "cuda":

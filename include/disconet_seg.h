@@ -34,13 +34,21 @@ int dn_sp_maxpool2(const void* src_sp, int n_images, int h, int w, int channels,
 int dn_sp_upsample2_bilinear(const void* src_sp, int n_images, int h, int w, int channels,
                              void* dst_sp, void* stream);
 
-/* Per-pixel cross entropy over `classes` (= 8) logits (upstream SegModule.py :: step,
- * nn.CrossEntropyLoss): logits [pixels][ld] float32, labels [pixels] int32 (out-of-range = ignored).
- *   loss_sum (device double, zeroed by the call) += sum_p (logsumexp(z_p) - z_p[y_p])
- *   dlogits [pixels][ld] (may be NULL) = (softmax(z_p) - onehot(y_p)) * grad_scale
- * -- pass grad_scale = 1 / pixels for the reference's mean reduction. */
+/* Label census for the mean reduction of nn.CrossEntropyLoss (ignore_index = -100):
+ *   counts[0] = labels in [0, classes)  (the divisor of the mean),
+ *   counts[1] = labels that are neither valid nor -100 (torch raises on these; they are treated as
+ *               ignored here and reported so that the host can refuse them).
+ * counts: 2 device int32, zeroed by the call. */
+int dn_seg_label_count(const int32_t* labels, long pixels, int classes, int32_t* counts, void* stream);
+
+/* Per-pixel cross entropy over `classes` logits (upstream SegModule.py :: step,
+ * nn.CrossEntropyLoss): logits [pixels][ld] float32, labels [pixels] int32 (outside [0, classes) = ignored).
+ *   loss_sum (device double, zeroed by the call) += sum over the live pixels of (logsumexp(z_p) - z_p[y_p])
+ *   dlogits [pixels][ld] (may be NULL) = (softmax(z_p) - onehot(y_p)) * g, zero rows for ignored pixels;
+ *   g = grad_scale, or grad_scale / counts[0] when `counts` (from dn_seg_label_count, may be NULL) is given:
+ *   the reference's mean is over the NON-IGNORED pixels, loss = loss_sum / counts[0]. */
 int dn_seg_ce_loss(const float* logits, const int32_t* labels, long pixels, int classes, int ld,
-                   float grad_scale, double* loss_sum, float* dlogits, void* stream);
+                   float grad_scale, const int32_t* counts, double* loss_sum, float* dlogits, void* stream);
 
 #ifdef __cplusplus
 }

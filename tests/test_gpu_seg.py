@@ -42,6 +42,28 @@ def test_cross_entropy_kernel_vs_torch():
     assert (grad.cpu() - z.grad).abs().max().item() <= 1e-9 + 1e-6 * z.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("classes", [8, 5])
+def test_cross_entropy_ignore_index_and_class_counts(classes):
+    """nn.CrossEntropyLoss semantics: the mean is over the NON-ignored pixels (ignore_index = -100), ignored
+    pixels get zero gradient rows, labels outside [0, classes) that are not -100 are refused (torch raises)."""
+    from disconet_amd import ops
+    from disconet_amd._lib import DnError
+    g = torch.Generator().manual_seed(11)
+    z = (torch.randn(2, 30, 20, classes, generator=g) * 2).requires_grad_(True)
+    y = torch.randint(0, classes, (2, 30, 20), generator=g)
+    y[torch.rand(2, 30, 20, generator=g) < 0.3] = -100
+    want = F.cross_entropy(z.permute(0, 3, 1, 2), y)
+    want.backward()
+    loss, grad = ops.seg_ce_loss(z.detach().cuda().contiguous(), y.cuda())
+    assert abs(float(loss) - float(want)) <= 1e-6 * abs(float(want))
+    assert (grad.cpu() - z.grad).abs().max().item() <= 1e-9 + 1e-6 * z.grad.abs().max().item()
+    assert torch.equal(grad.cpu()[y == -100], torch.zeros_like(grad.cpu()[y == -100]))
+    y_bad = y.clone()
+    y_bad[0, 0, 0] = classes
+    with pytest.raises(DnError):
+        ops.seg_ce_loss(z.detach().cuda().contiguous(), y_bad.cuda())
+
+
 @pytest.mark.parametrize("case", list(cases.SEG_CASES))
 def test_seg_model_vs_oracle_and_golden(case, golden_dir):
     from disconet_amd import SegDiscoNet, SegModule

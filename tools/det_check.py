@@ -1,5 +1,7 @@
 """Bit-exactness of the forward when two steps run concurrently (two streams, eager and as
 captured graphs) against a serial run.   python tools/det_check.py"""
+import os
+os.environ.setdefault("DISCONET_UNSAFE_OVERLAP", "1")   # hazard study: co-scheduling on purpose
 import sys
 
 import torch

@@ -3,6 +3,8 @@ replayed from two captured graphs on two alternating streams; every replay is ch
 and compared with the checksum of a replay run alone.    python tools/hazard/product_check.py [replays]
 """
 import os
+os.environ.setdefault("DISCONET_UNSAFE_OVERLAP", "1")   # hazard study: co-scheduling on purpose
+import os
 import sys
 
 import torch
