@@ -411,8 +411,8 @@ def main():
 
     def step():
         # dense rebuild of the batch (K1/a2) in the layout the conv engine of the chosen mode reads
-        if model.conv_math == "sp":
-            bevs = ops.scatter_dense_sp(indices, offsets, n_img, dims)
+        if model.conv_math == "sp":      # hi-only planes: a 0/1 grid is exact in binary16 (half the bytes)
+            bevs = ops.scatter_dense_sp(indices, offsets, n_img, dims, hi_only=True)
         else:
             bevs = ops.scatter_dense(indices, offsets, n_img, dims)
         with torch.no_grad():

@@ -45,6 +45,7 @@ class MlpTailParams(Structure):
 SIGNATURES = {
     "dn_version": (c_int, []),
     "dn_last_error": (c_char_p, []),
+    "dn_sp_range_flags": (ctypes.c_uint, [c_int]),
     "dn_voxelize_occupy": (c_int, [c_void_p, c_int, c_int, POINTER(c_double), POINTER(c_double),
                                    POINTER(c_int), c_void_p, c_void_p]),
     "dn_voxel_compact_workspace": (c_size_t, [POINTER(c_int)]),
@@ -54,6 +55,8 @@ SIGNATURES = {
                                  c_void_p]),
     "dn_scatter_dense_sp": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_int), c_void_p,
                                     c_void_p]),
+    "dn_scatter_dense_sp_hi": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_int), c_void_p,
+                                       c_void_p]),
     "dn_conv_packed_weight_floats": (c_size_t, [POINTER(ConvDesc)]),
     "dn_conv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
     "dn_fold_bn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
@@ -76,6 +79,7 @@ SIGNATURES = {
     "dn_spconv2d_post1x1": (c_int, [POINTER(ConvDesc), POINTER(Post1x1Desc)] + [c_void_p] * 8 +
                             [c_int, c_void_p, c_void_p, c_void_p]),
     "dn_spconv_force_config": (c_int, [c_int]),
+    "dn_spconv_set_upmode": (c_int, [c_int]),
     "dn_decode_boxes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p,
                                 c_void_p]),
     "dn_warp_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

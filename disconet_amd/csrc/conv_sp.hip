@@ -26,15 +26,9 @@
 // upstream:coperception/models/det/base/* (SURVEY.md §8 a3, a8, a9).
 #include "dn_internal.h"
 #include "sp_layout.h"
+#include "sp_device.h"
 #include <cstdlib>
 #include <type_traits>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -77,8 +71,10 @@ struct TileCoord {
 // at pack time and the source's chunks run 2 row-taps x 3 instead of 3 x 3 (-33 % MACs on 2/3 of K).  The
 // pixel tile is mapped so that all MFMA tiles of a wave are rows of one parity (parity = wave_m & 1); a step's
 // weight stage carries both parities' blocks.
+// AHI: source 0 is a HI-ONLY SP tensor ([image][chunk][2 octets][H][W] x 16 B: values that are exact in binary16,
+// e.g. the 0/1 occupancy grid): half the patch bytes, no lo fragments, two MFMAs per product instead of three.
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST, int BSTAT = 0, int UPM = 0>
+          int WTM, int WTN, int POST, int BSTAT = 0, int UPM = 0, int AHI = 0>
 struct SpTile {
   using P = sp::Patch<KS, STRIDE, TH, TW>;
   static constexpr int NW = WAVES_M * WAVES_N;
@@ -87,7 +83,9 @@ struct SpTile {
   static constexpr int NS = TAPS / TG;          // steps per A group
   static constexpr int SUB = CA * TG;           // (chunk, tap) sub-steps per step
   static constexpr int NPIX = P::NPIX;
-  static constexpr int A_PIECES = CA * 4 * NPIX;
+  static constexpr int AQ = AHI ? 2 : 4;                    // quarter planes of a source-0 chunk
+  static constexpr int A_PIECES = CA * AQ * NPIX;
+  static_assert(!AHI || (KS == 3 && CA == 1 && UPM == 0), "hi-only source: 3x3 layers");
   // streaming form: every wave issues the same number of DMA instructions per stage (counted
   // vmcnt waits), so a stage is padded to whole rounds of NW instructions; stationary form:
   // only patch DMAs are ever in flight (vmcnt(0) waits), a stage is padded to whole instructions
@@ -136,54 +134,16 @@ struct SpTile {
                 "row-merged up-conv: 8 x 32 or 8 x 16 streaming tiles");
 };
 
-__device__ inline void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-template <int N>
-__device__ inline void wait_vm() {
-  static_assert(N >= 0 && N < 64, "vmcnt immediate");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// One LDS-DMA instruction: 64 lanes x 16 bytes, global (per-lane voff + scalar soff) -> LDS at
-// lds + 16 * lane (wave-uniform base through M0).  An out-of-range voff writes zeros.  A plain
-// __device__ function, not a lambda: the builtin inside a lambda makes hipcc's HOST pass drop the
-// kernel's launch stub without a diagnostic.
-__device__ inline void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, int soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff,
-                                           soff, 0, 0);
-}
-
-// x -> (hi, lo) halves, 4 values -> two dword pairs
-__device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
-  half4 h, l;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
-    h[e] = (_Float16)x;
-    l[e] = (_Float16)(x - (float)h[e]);
-  }
-  hi = __builtin_bit_cast(u32x2, h);
-  lo = __builtin_bit_cast(u32x2, l);
-}
-
-// Lanes (j, 0) and (j, 1) hold channels 4h..4h+3 of octet X (x) and of octet Y (y).  After the
-// swaps lane (j, 0) holds octet X complete and lane (j, 1) octet Y complete, as 16 bytes.
-__device__ inline u32x4 gather_octet(u32x2 x, u32x2 y) {
-  // v_permlane32_swap(a, b): lanes 32-63 of a <-> lanes 0-31 of b
-  const auto s0 = __builtin_amdgcn_permlane32_swap(x[0], y[0], false, false);
-  const auto s1 = __builtin_amdgcn_permlane32_swap(x[1], y[1], false, false);
-  return u32x4{s0[0], s1[0], s0[1], s1[1]};
-}
-
 // ABL != 0 builds timing-only ablations for tools/sp_conv_check (never launched by the product):
 // 1 = no weight DMA after the first step, 2 = no patch DMA after the first group, 3 = neither,
 // 4 = no epilogue stores, 5 = 3 + operands from registers (pure MFMA stream).
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST, int ABL = 0, int BSTAT = 0, int UPM = 0>
+          int WTM, int WTN, int POST, int ABL = 0, int BSTAT = 0, int UPM = 0, int AHI = 0>
 __global__ void __launch_bounds__(
     (WAVES_M * WAVES_N * 64),
-    (SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM>::WPS))
+    (SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI>::WPS))
 conv_sp_kernel(const SpArgs a) {
-  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM>;
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI>;
   using P = typename T::P;
   constexpr bool kNoB = ABL == 1 || ABL == 3 || ABL >= 5, kNoA = ABL == 2 || ABL == 3 || ABL >= 5;
   constexpr bool kNoStore = ABL == 4 || ABL == 6 || ABL == 7, kNoLds = ABL >= 5;
@@ -246,12 +206,13 @@ conv_sp_kernel(const SpArgs a) {
   for (int wn = 0; wn < WTN; ++wn) b_off[wn] = (lh * BN + (wave_n * WTN + wn) * 32 + li) * 16;
 
   f32x16 acc[WTM][WTN];
+  float amax = 0.f;   // max |value| this lane has split (range flags, sp_device.h)
 
   // ---- DMA state
   constexpr unsigned OOB = 0xFFFFFFFFu;
   const int hs0 = a.up0 ? (a.h_in >> 1) : a.h_in, ws0 = a.up0 ? (a.w_in >> 1) : a.w_in;
   const unsigned plane0 = (unsigned)(hs0 * ws0) * 16u, plane1 = (unsigned)(a.h_in * a.w_in) * 16u;
-  const size_t img0_bytes = (size_t)a.c0g * 4 * plane0, img1_bytes = (size_t)a.c1g * 4 * plane1;
+  const size_t img0_bytes = (size_t)a.c0g * T::AQ * plane0, img1_bytes = (size_t)a.c1g * 4 * plane1;
   auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src0), 0, 0, 0x00020000);
   auto rsrc1 = rsrc0;
   const auto rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wpk), 0,
@@ -306,7 +267,7 @@ conv_sp_kernel(const SpArgs a) {
     if (kNoA && steady) return;
     const int cg = g * CA;
     const bool from1 = cg >= a.c0g;
-    const int soff = from1 ? (cg - a.c0g) * 4 * (int)plane1 : cg * 4 * (int)plane0;
+    const int soff = from1 ? (cg - a.c0g) * 4 * (int)plane1 : cg * T::AQ * (int)plane0;
     unsigned char* base = smem + sa * T::A_STAGE + wave * 1024;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -358,7 +319,7 @@ conv_sp_kernel(const SpArgs a) {
 #pragma unroll
         for (int wm = 0; wm < WTM; ++wm) {
           ah[s][wm] = *reinterpret_cast<const half8*>(As + a_off[wm] + toff);
-          al[s][wm] = *reinterpret_cast<const half8*>(As + a_off[wm] + toff + 2 * NPIX * 16);
+          if constexpr (AHI == 0) al[s][wm] = *reinterpret_cast<const half8*>(As + a_off[wm] + toff + 2 * NPIX * 16);
         }
 #pragma unroll
         for (int wn = 0; wn < WTN; ++wn) {
@@ -375,11 +336,13 @@ conv_sp_kernel(const SpArgs a) {
 #pragma unroll
         for (int wn = 0; wn < WTN; ++wn)
           acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s][wn], ah[s][wm], acc[wm][wn], 0, 0, 0);
+      if constexpr (AHI == 0) {
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
         for (int wn = 0; wn < WTN; ++wn)
           acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s][wn], al[s][wm], acc[wm][wn], 0, 0, 0);
+      }
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
@@ -472,7 +435,7 @@ conv_sp_kernel(const SpArgs a) {
           v[e] = co + e < c_lim ? v[e] : 0.f;
         }
       }
-      split4(v, hi[g], lo[g]);
+      split4(v, hi[g], lo[g], amax);
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -525,7 +488,7 @@ conv_sp_kernel(const SpArgs a) {
             v[e] = acc[wm][wn][4 * g + e] * sc1[e] + sh1[e];
             if (a.relu) v[e] = fmaxf(v[e], 0.f);
           }
-          split4(v, hi[g], lo[g]);
+          split4(v, hi[g], lo[g], amax);
         }
         half8 xh[2], xl[2];
 #pragma unroll
@@ -600,7 +563,7 @@ conv_sp_kernel(const SpArgs a) {
               v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
               if (a.relu) v[e] = fmaxf(v[e], 0.f);
             }
-            split4(v, hi[g], lo[g]);
+            split4(v, hi[g], lo[g], amax);
           }
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
@@ -759,6 +722,7 @@ conv_sp_kernel(const SpArgs a) {
         sa ^= 1;
       }
       epilogue(cur);
+      note_range(amax);
       if (!has_next) break;
       item += G;
       cur = nxt;
@@ -853,6 +817,7 @@ conv_sp_kernel(const SpArgs a) {
       sa ^= 1;
     }
     epilogue(cur);
+      note_range(amax);
     if (!has_next) break;
     item += G;
     cur = nxt;
@@ -867,6 +832,7 @@ conv_sp_kernel(const SpArgs a) {
 __global__ void sp_from_nhwc_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
                                     int c, int ld, int cg_total, long hw, long total) {
   // idx over (img, cg, oct, pixel): pixel fastest -> coalesced 16-byte stores per plane
+  float amax = 0.f;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
     const long px = idx % hw;
@@ -879,6 +845,7 @@ __global__ void sp_from_nhwc_kernel(const float* __restrict__ src, unsigned char
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float x = (cg * 16 + oct * 8 + e < c) ? s[e] : 0.f;
+      amax = fmaxf(amax, fabsf(x));
       x = fminf(fmaxf(x, -65504.f), 65504.f);
       hi[e] = (_Float16)x;
       lo[e] = (_Float16)(x - (float)hi[e]);
@@ -887,6 +854,7 @@ __global__ void sp_from_nhwc_kernel(const float* __restrict__ src, unsigned char
     *reinterpret_cast<half8*>(d) = hi;
     *reinterpret_cast<half8*>(d + 2 * hw * 16) = lo;
   }
+  note_range(amax);
 }
 
 __global__ void sp_to_nhwc_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst,
@@ -1009,11 +977,17 @@ inline int chunks_of(int c) { return (c + 15) / 16; }
 // weights are padded to whole groups of 4 chunks so that a 1x1 A group never runs past them
 // Row-merged form of a 3x3 conv whose first source is nearest-upsampled (SpTile UPM): decided by the layer
 // alone, so that pack time and run time agree (DN_SP_UPMERGE=0 switches it off for the process).
-inline bool up_merged(const dn_conv_desc& d) {
-  static const int env = [] { const char* e = getenv("DN_SP_UPMERGE"); return e ? atoi(e) : 1; }();
-  return env && d.up0 == 1 && d.ksize == 3 && d.stride == 1 && d.c0 > 0 && d.c0 % 16 == 0 && d.h_in % 2 == 0 &&
-         d.w_in % 2 == 0;
+// -> 0: plain taps; 1: row-merged (UPM, this file); 2: row- and column-merged per parity class (conv_spq.hip, the
+// default).  DN_SP_UPMERGE=0|1|2 / dn_spconv_set_upmode() choose for the process: set before the first pack.
+int g_sp_upmode = -1;
+inline int up_mode(const dn_conv_desc& d) {
+  static const int env = [] { const char* e = getenv("DN_SP_UPMERGE"); return e ? atoi(e) : 2; }();
+  const int mode = g_sp_upmode >= 0 ? g_sp_upmode : env;
+  const bool ok = d.up0 == 1 && d.ksize == 3 && d.stride == 1 && d.c0 > 0 && d.c0 % 16 == 0 && d.h_in % 2 == 0 &&
+                  d.w_in % 2 == 0;
+  return ok ? (mode < 0 ? 0 : mode > 2 ? 2 : mode) : 0;
 }
+inline bool up_merged(const dn_conv_desc& d) { return up_mode(d) == 1; }
 inline size_t packed_blocks(const dn_conv_desc& d);
 inline int packed_chunks(const dn_conv_desc& d) { return (chunks_of(d.c0) + chunks_of(d.c1) + 3) / 4 * 4; }
 
@@ -1025,6 +999,8 @@ int validate(const dn_conv_desc* d) {
   DN_REQUIRE(d->n_images > 0 && d->h_in > 0 && d->w_in > 0, "spconv: empty input");
   DN_REQUIRE(d->c0 > 0 && d->c1 >= 0 && d->c_out > 0, "spconv: bad channel counts");
   DN_REQUIRE(d->up0 == 0 || d->up0 == 1, "spconv: up0 must be 0 or 1");
+  DN_REQUIRE(d->math != 3 || (d->ksize == 3 && d->stride == 1 && d->c1 == 0 && d->up0 == 0),
+             "spconv: a hi-only source 0 (math = 3) needs a 3x3 stride-1 single-source layer");
   DN_REQUIRE(!d->up0 || (d->h_in % 2 == 0 && d->w_in % 2 == 0), "spconv: x2-upsampled source needs even h_in/w_in");
   DN_REQUIRE(d->c1 == 0 || (d->c0 % 16 == 0 && d->ksize == 3), "spconv: concat needs 3x3 and c0 %% 16 == 0 (c0 = %d)", d->c0);
   const size_t hs0 = d->up0 ? d->h_in / 2 : d->h_in, ws0 = d->up0 ? d->w_in / 2 : d->w_in;
@@ -1036,6 +1012,7 @@ int validate(const dn_conv_desc* d) {
 
 inline size_t packed_blocks(const dn_conv_desc& d) {   // 16-byte-piece blocks of [4 quarters][cout_pad] in the packed image
   const int nch = packed_chunks(d);
+  if (up_mode(d) == 2) return dn::spq_packed_blocks(chunks_of(d.c0), nch);
   if (up_merged(d)) return (size_t)chunks_of(d.c0) * 12 + (size_t)(nch - chunks_of(d.c0)) * 9;
   return (size_t)nch * d.ksize * d.ksize;
 }
@@ -1088,10 +1065,10 @@ SpCfg select_cfg(const dn_conv_desc& d) {
 }
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST = 0, int ABL = 0, int BSTAT = 0, int UPM = 0>
+          int WTM, int WTN, int POST = 0, int ABL = 0, int BSTAT = 0, int UPM = 0, int AHI = 0>
 int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
-  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM>;
-  auto kern = conv_sp_kernel<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, ABL, BSTAT, UPM>;
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI>;
+  auto kern = conv_sp_kernel<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, ABL, BSTAT, UPM, AHI>;
   const int nchunks = a.c0g + a.c1g;
   DN_REQUIRE(nchunks % CA == 0, "spconv: chunk count %d not a multiple of %d", nchunks, CA);
   a.ngroups = nchunks / CA;
@@ -1164,6 +1141,8 @@ int fill_args(const dn_conv_desc* d, const void* src0, const void* src1, const v
 
 }  // namespace
 
+namespace dn { unsigned range_flags_conv_sp(bool reset) { return sp_range_flags_here(reset); } }
+
 extern "C" size_t dn_sp_tensor_bytes(int n_images, int h, int w, int channels) {
   return (size_t)n_images * chunks_of(channels) * 4 * h * w * 16;
 }
@@ -1203,6 +1182,9 @@ extern "C" int dn_spconv_pack_weights(const dn_conv_desc* d, const float* weight
   DN_REQUIRE(weight_oihw && packed, "spconv pack: null pointer");
   DN_REQUIRE(d->c1 == 0 || d->c0 % 16 == 0, "spconv pack: concat needs c0 %% 16 == 0");
   const int taps = d->ksize * d->ksize, cp = cout_pad_of(d->c_out), nch = packed_chunks(*d);
+  if (up_mode(*d) == 2)
+    return dn::spq_pack_weights(weight_oihw, packed, d->c_out, d->c0 + d->c1, chunks_of(d->c0), cp, nch, wmul,
+                                (hipStream_t)stream);
   if (up_merged(*d)) {
     hipLaunchKernelGGL(sp_pack_weights_up_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, weight_oihw,
                        (unsigned char*)packed, d->c_out, d->c0 + d->c1, chunks_of(d->c0), cp, nch, wmul);
@@ -1267,6 +1249,11 @@ extern "C" int dn_spconv_force_config(int cfg) {
   return DN_OK;
 }
 
+extern "C" int dn_spconv_set_upmode(int mode) {
+  g_sp_upmode = mode;
+  return DN_OK;
+}
+
 extern "C" int dn_spconv2d(const dn_conv_desc* d, const void* src0, const void* src1,
                            const void* packed, const float* scale, const float* shift, void* out,
                            void* stream) {
@@ -1275,8 +1262,18 @@ extern "C" int dn_spconv2d(const dn_conv_desc* d, const void* src0, const void* 
   DN_REQUIRE(d->c1 == 0 || src1, "spconv: c1 > 0 but src1 is null");
   SpArgs a;
   if (int rc = fill_args(d, src0, src1, packed, scale, shift, out, a)) return rc;
-  const SpCfg c = select_cfg(*d);
   hipStream_t s = (hipStream_t)stream;
+  if (up_mode(*d) == 2) {   // the packed image is the quad-merged one: conv_spq.hip (tools: 20 / 21 force BN = 32 / 64)
+    DN_REQUIRE(a.c1g == 0 || d->c0 % 16 == 0, "spconv: concat needs c0 %% 16 == 0");
+    return dn::spq_conv(d, src0, src1, packed, (size_t)a.wpk_bytes, scale, shift, out, a.cout_pad,
+                        g_sp_force == 20 ? 32 : g_sp_force == 21 ? 64 : 0, s);
+  }
+  if (d->math == 3) {   // hi-only source 0: the 8 x 32 x 32 tile, weight-stationary when the layer fits
+    using T32 = SpTile<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 1, 0, 1>;
+    if (fits_stationary(*d, 32, T32::A_STAGE, 0, 2)) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1, 0, 1>(a, *d, s);
+    return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 0, 0, 1>(a, *d, s);
+  }
+  const SpCfg c = select_cfg(*d);
   if (up_merged(*d)) {   // the packed image is the row-merged one: only the tiles that implement it
     switch (c.id) {
       case S3_256x64: return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 0, 0, 0, 1>(a, *d, s);

@@ -1,0 +1,551 @@
+// Quad-merged 3x3 convolution over cat([nearest-upsample x2 (src0), src1]) -- the decoder's *_1 layers
+// (upstream:coperception/models/det/backbone/Backbone.py :: decode: cat(interpolate(x_prev, x2), skip) ->
+// conv -> BN -> ReLU) -- on the split-planar engine of conv_sp.hip (same SP tensors, same
+// split-f16 x3 arithmetic, same LDS-DMA staging).
+//
+// Why a kernel of its own.  Over a nearest-upsampled source the 3x3 taps of an output pixel read only 2 x 2
+// distinct low-resolution pixels; WHICH taps coincide depends on the pixel's parity class (py, px) =
+// (oy & 1, ox & 1):
+//     rows:  py = 0: {dy 0} {dy 1, dy 2}      py = 1: {dy 0, dy 1} {dy 2}        (columns alike with px)
+// Summing the coinciding weights at pack time turns the 9 taps of the upsampled source's chunks into 4 merged
+// taps per class: 4/9 of the MACs on c0 / (c0 + c1) of K (conv5_1..conv7_1: 2/3 of K -> 0.63 of the plain MAC
+// count; the row-only merge of conv_sp.hip's UPM form reaches 0.78).  The price is that an MFMA pixel tile
+// must be class-pure, so
+//   * a workgroup owns an 8 x 32 output tile, its four waves ARE the four classes: wave w = py + 2 px computes
+//     the 4 x 16 pixels {(py + 2 i, px + 2 k)} as two 32-pixel MFMA tiles, for BN = 32 or 64 channels;
+//   * both sources are staged as the same (8 + 2) x (32 + 2) patch with DE-INTERLEAVED columns (even columns,
+//     then odd ones: conv_sp.hip's stride-2 layout), so that the 16 lanes of a ds_read_b128 group -- one row,
+//     16 columns of one parity -- read 16 consecutive pieces: conflict-free for every tap of every class.  The
+//     upsample is an addressing mode of the patch DMA (sy = iy >> 1, sx = ix >> 1), as in conv_sp.hip;
+//   * a step of the K loop stages, for a chunk of source 0, ONE merged tap x 4 classes of weights (BN = 64;
+//     two taps at BN = 32) and every wave reads its own class block; for a chunk of source 1 three plain taps
+//     shared by all waves.  The per-lane LDS bases absorb the class (registers, not immediates), the tap
+//     offsets stay compile-time.
+// Pipeline (double-buffered patch per chunk, double-buffered weights per step, raw s_barrier + counted
+// vmcnt waits, next tile's first operands under the current tile's last step), persistent workgroups, XCD-aware
+// item order and the register epilogue are those of conv_sp_kernel.
+#include "dn_internal.h"
+#include "sp_layout.h"
+#include "sp_device.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+constexpr int kCUs = 256;
+
+// patch geometry: PH x PW pixels, columns de-interleaved (QHALF even columns, then QHALF odd ones)
+constexpr int QTH = 8, QTW = 32, QPH = QTH + 2, QPW = QTW + 2, QHALF = QPW / 2, QPITCH = QPW, QNPIX = QPH * QPITCH;
+constexpr int QNW = 4, QNT = QNW * 64;
+constexpr int QA_PIECES = 4 * QNPIX;                       // 4 quarters
+constexpr int QA_INSTR = (QA_PIECES + 63) / 64;            // 22 DMA instructions per patch stage
+constexpr int QA_IT = (QA_INSTR + QNW - 1) / QNW;          // rounds; the last one is ragged (waves 0, 1 only)
+constexpr int QA_STAGE = QA_INSTR * 1024;
+constexpr int QB_STAGE = 16 * 1024;                        // one weight stage: 16 blocks of BN = 32 or 4 of BN = 64
+static_assert(QA_INSTR == 22 && QA_IT == 6, "patch stage: 22 instructions, waves 0 / 1 issue 6, waves 2 / 3 issue 5");
+
+struct SpqArgs {
+  const unsigned char* src0;
+  const unsigned char* src1;
+  const unsigned char* wpk;
+  const float* scale;
+  const float* shift;
+  unsigned char* out;
+  int n_images, h, w;          // conv input = output size (src0 is stored at h / 2 x w / 2)
+  int c0g, c1g;                // 16-channel chunks from src0 / src1
+  int c_out, cog, relu;
+  int tiles_x, tiles_y, total_items;
+  int cout_pad, wpk_bytes;
+};
+
+struct QTile {
+  int img, oy0, ox0, n0;
+};
+
+template <int BN>
+struct SpqTile {
+  static constexpr int WTN = BN / 32;
+  static constexpr int TGQ = BN == 64 ? 1 : 2;         // merged taps of source 0 per step
+  static constexpr int NS0 = 4 / TGQ;                  // steps per chunk of source 0
+  static constexpr int BLK = 4 * BN * 16;              // bytes of one weight block [4 quarters][BN] in LDS
+  static constexpr int B_PIECES0 = TGQ * 4 * 4 * BN;   // step of source 0: TGQ taps x 4 classes
+  static constexpr int B_PIECES1 = 3 * 4 * BN;         // step of source 1: 3 taps
+  static constexpr int B_IT0 = (B_PIECES0 + QNT - 1) / QNT;
+  static constexpr int B_IT1 = (B_PIECES1 + QNT - 1) / QNT;
+  static_assert(B_IT0 * QNT * 16 <= QB_STAGE && B_IT1 * QNT * 16 <= QB_STAGE, "weight stage");
+  static constexpr int AFF_BYTES = QNW * 2 * 64 * 4;   // per-wave copy of the epilogue affine (scale, shift) of a channel block
+  static constexpr int LDS_BYTES = 2 * QA_STAGE + 2 * QB_STAGE + AFF_BYTES;
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+template <int BN>
+__global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
+  using T = SpqTile<BN>;
+  constexpr int WTN = T::WTN, TGQ = T::TGQ, NS0 = T::NS0, BLK = T::BLK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int OFF_B = 2 * QA_STAGE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int py = wave & 1, px = wave >> 1;                 // this wave's parity class
+
+  // ---- work items (channel block, image, tile_y, tile_x), XCD-aware order as in conv_sp_kernel
+  const int G = gridDim.x;
+  const int spatial_items = a.n_images * a.tiles_y * a.tiles_x;
+  const int n_cb = a.total_items / spatial_items;
+  const int sp_full = spatial_items & ~7;
+  auto decode = [&](int item) {
+    QTile tc;
+    int cb, spi;
+    if (item < sp_full * n_cb) {
+      const int j = item >> 3;
+      cb = j % n_cb;
+      spi = (item & 7) * (sp_full >> 3) + j / n_cb;
+    } else {
+      const int r = item - sp_full * n_cb, rem = spatial_items - sp_full;
+      cb = r / rem;
+      spi = sp_full + r % rem;
+    }
+    tc.n0 = cb * BN;
+    tc.ox0 = (spi % a.tiles_x) * QTW;
+    spi /= a.tiles_x;
+    tc.oy0 = (spi % a.tiles_y) * QTH;
+    tc.img = spi / a.tiles_y;
+    return tc;
+  };
+
+  // ---- this lane's pixels and LDS read bases (bytes).  MFMA tile wm of the class: tile rows
+  // r = py + 4 wm + 2 rsel, columns c = px + 2 k; one 16-lane ds_read_b128 group = one row, k = 0..15.
+  const int rsel = sp::in_g2(li) ? 1 : 0, kcol = sp::rank16(li);
+  int prow[2], pcol;
+  pcol = px + 2 * kcol;
+  auto colpos = [](int e) { return (e & 1) * QHALF + (e >> 1); };   // row position of patch column 2 k + e, minus k
+  int a_b1[2][3];        // source 1, tap (dy, dx): + dy * QPITCH * 16
+  int a_b0[2][2][2];     // source 0, merged tap (a, b): [wm][b][a]
+#pragma unroll
+  for (int wm = 0; wm < 2; ++wm) {
+    prow[wm] = py + 4 * wm + 2 * rsel;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) a_b1[wm][dx] = (lh * QNPIX + prow[wm] * QPITCH + colpos(px + dx) + kcol) * 16;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int am = 0; am < 2; ++am)   // merged tap (am, b) reads patch row r + am + (py & am), column c + b + (px & b)
+        a_b0[wm][b][am] = (lh * QNPIX + (prow[wm] + am + (py & am)) * QPITCH + colpos(px + b + (px & b)) + kcol) * 16;
+  }
+  int b_off[WTN], b_offq[WTN];   // weight fragment of channel tile wn: block-relative, and + this wave's class block
+#pragma unroll
+  for (int wn = 0; wn < WTN; ++wn) {
+    b_off[wn] = (lh * BN + wn * 32 + li) * 16;
+    b_offq[wn] = b_off[wn] + wave * BLK;
+  }
+
+  f32x16 acc[2][WTN];
+  float amax = 0.f;
+
+  // ---- DMA state
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  const int hs0 = a.h >> 1, ws0 = a.w >> 1;
+  const unsigned plane0 = (unsigned)(hs0 * ws0) * 16u, plane1 = (unsigned)(a.h * a.w) * 16u;
+  const size_t img0_bytes = (size_t)a.c0g * 4 * plane0, img1_bytes = (size_t)a.c1g * 4 * plane1;
+  auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src0), 0, 0, 0x00020000);
+  auto rsrc1 = rsrc0;
+  const auto rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wpk), 0, a.wpk_bytes, 0x00020000);
+  unsigned voff_a[QA_IT], voff_b[T::B_IT0];
+
+  auto opaque = [](int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  };
+  // per-lane source offsets of the patch pieces this lane moves: LDS piece (it * NW + wave) * 64 + lane
+  auto setup_voff_a = [&](const QTile& tc, bool from1) {
+    const int t = opaque(tid);
+    const int iy0 = tc.oy0 - 1, ix0 = tc.ox0 - 1;
+    const unsigned plane = from1 ? plane1 : plane0;
+    const int ws = from1 ? a.w : ws0;
+#pragma unroll
+    for (int it = 0; it < QA_IT; ++it) {
+      const int piece = (it * QNW + (t >> 6)) * 64 + (t & 63);
+      const int cq = piece / QNPIX, pp = piece % QNPIX;
+      const int r = pp / QPITCH, pos = pp % QPITCH;
+      const int cc = pos < QHALF ? 2 * pos : 2 * (pos - QHALF) + 1;
+      const int iy = iy0 + r, ix = ix0 + cc;
+      const bool ok = piece < QA_PIECES && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
+      const int sy = from1 ? iy : (iy >> 1), sx = from1 ? ix : (ix >> 1);
+      voff_a[it] = ok ? (unsigned)cq * plane + (unsigned)(sy * ws + sx) * 16u : OOB;
+    }
+  };
+  // weight pieces: LDS piece -> (block of the step, quarter, channel); the same map serves both step kinds
+  auto setup_voff_b = [&](const QTile& tc) {
+    const int t = opaque(tid);
+#pragma unroll
+    for (int it = 0; it < T::B_IT0; ++it) {
+      const int piece = (it * QNW + (t >> 6)) * 64 + (t & 63);
+      const int blk = piece / (4 * BN), q = (piece / BN) % 4, nn = piece % BN;
+      voff_b[it] = (unsigned)(((blk * 4 + q) * a.cout_pad + tc.n0 + nn) * 16);
+    }
+  };
+  auto setup_rsrc = [&](const QTile& tc) {
+    rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src0 + tc.img * img0_bytes), 0,
+                                              (int)img0_bytes, 0x00020000);
+    rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.c1g ? a.src1 + tc.img * img1_bytes : a.src0),
+                                              0, a.c1g ? (int)img1_bytes : 0, 0x00020000);
+  };
+  // patch of chunk g -> stage sa
+  auto issue_a = [&](int g, int sa) {
+    const bool from1 = g >= a.c0g;
+    const int soff = from1 ? (g - a.c0g) * 4 * (int)plane1 : g * 4 * (int)plane0;
+    unsigned char* base = smem + sa * QA_STAGE + wave * 1024;
+#pragma unroll
+    for (int it = 0; it < QA_IT; ++it) {
+      if (it == QA_IT - 1 && wave >= QA_INSTR - (QA_IT - 1) * QNW) break;   // ragged last round
+      if (from1)
+        dma16(rsrc1, base + it * QNW * 1024, voff_a[it], soff);
+      else
+        dma16(rsrc0, base + it * QNW * 1024, voff_a[it], soff);
+    }
+  };
+  // weights of step st of chunk g -> stage sb.  Packed image: chunks of source 0 carry 16 blocks
+  // [merged tap t = 2 a + b][class], the others 9 blocks [dy][dx]; a block = [4 quarters][cout_pad] pieces.
+  auto issue_b = [&](int g, int st, int sb) {
+    const bool from1 = g >= a.c0g;
+    const int blk = from1 ? a.c0g * 16 + (g - a.c0g) * 9 + st * 3 : g * 16 + st * (TGQ * 4);
+    const int soff = blk * 4 * a.cout_pad * 16;
+    unsigned char* base = smem + OFF_B + sb * QB_STAGE + wave * 1024;
+#pragma unroll
+    for (int it = 0; it < T::B_IT0; ++it)
+      if (!from1 || it < T::B_IT1) dma16(rsrcw, base + it * QNW * 1024, voff_b[it], soff);
+  };
+
+  // ---- one sub-step = one tap: 2 x WTN accumulator tiles x 3 MFMAs
+  struct Frags {
+    half8 ah[2], al[2], bh[WTN], bl[WTN];
+  };
+  auto mma = [&](const Frags& f) {
+#pragma unroll
+    for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+      for (int wn = 0; wn < WTN; ++wn)
+        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[wn], f.ah[wm], acc[wm][wn], 0, 0, 0);
+#pragma unroll
+    for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+      for (int wn = 0; wn < WTN; ++wn)
+        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[wn], f.al[wm], acc[wm][wn], 0, 0, 0);
+#pragma unroll
+    for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+      for (int wn = 0; wn < WTN; ++wn)
+        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[wn], f.ah[wm], acc[wm][wn], 0, 0, 0);
+  };
+  // step ST of a source-1 chunk: taps (dy = ST, dx = 0..2), weights shared by the four waves
+  auto compute1 = [&](auto st_c, const unsigned char* As, const unsigned char* Bs) {
+    constexpr int DY = decltype(st_c)::value;
+    Frags f[2];
+    auto load = [&](auto u_c) {
+      constexpr int u = decltype(u_c)::value;
+      Frags& d = f[u & 1];
+#pragma unroll
+      for (int wm = 0; wm < 2; ++wm) {
+        d.ah[wm] = *reinterpret_cast<const half8*>(As + a_b1[wm][u] + DY * QPITCH * 16);
+        d.al[wm] = *reinterpret_cast<const half8*>(As + a_b1[wm][u] + DY * QPITCH * 16 + 2 * QNPIX * 16);
+      }
+#pragma unroll
+      for (int wn = 0; wn < WTN; ++wn) {
+        d.bh[wn] = *reinterpret_cast<const half8*>(Bs + b_off[wn] + u * BLK);
+        d.bl[wn] = *reinterpret_cast<const half8*>(Bs + b_off[wn] + u * BLK + 2 * BN * 16);
+      }
+    };
+    load(std::integral_constant<int, 0>{});
+    load(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    load(std::integral_constant<int, 2>{});
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f[0]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // step ST of a source-0 chunk: merged taps t = ST * TGQ + u (a = t >> 1, b = t & 1), this wave's class block
+  auto compute0 = [&](auto st_c, const unsigned char* As, const unsigned char* Bs) {
+    constexpr int ST = decltype(st_c)::value;
+    Frags f[2];
+    auto load = [&](auto u_c) {
+      constexpr int u = decltype(u_c)::value;
+      constexpr int t = ST * TGQ + u, am = t >> 1, b = t & 1;
+      Frags& d = f[u & 1];
+#pragma unroll
+      for (int wm = 0; wm < 2; ++wm) {
+        d.ah[wm] = *reinterpret_cast<const half8*>(As + a_b0[wm][b][am]);
+        d.al[wm] = *reinterpret_cast<const half8*>(As + a_b0[wm][b][am] + 2 * QNPIX * 16);
+      }
+#pragma unroll
+      for (int wn = 0; wn < WTN; ++wn) {
+        d.bh[wn] = *reinterpret_cast<const half8*>(Bs + b_offq[wn] + u * 4 * BLK);
+        d.bl[wn] = *reinterpret_cast<const half8*>(Bs + b_offq[wn] + u * 4 * BLK + 2 * BN * 16);
+      }
+    };
+    load(std::integral_constant<int, 0>{});
+    if constexpr (TGQ == 2) {
+      load(std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f[1]);
+    } else {
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f[0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- epilogue: affine (+ ReLU) -> split -> permlane gather -> 16-byte SP pieces, as conv_sp_kernel's POST 0.
+  // The affine of the current channel block lives in a WAVE-PRIVATE 512-byte LDS block (64 registers at BN = 64
+  // would spill): written when the workgroup moves to another block, read by the same wave's epilogue -- in-order
+  // LDS operations of one wave, no barrier.  Channels past c_out get scale = shift = 0.
+  float* aff_s = reinterpret_cast<float*>(smem + 2 * QA_STAGE + 2 * QB_STAGE) + wave * 128;
+  int aff_n0 = -1;
+  auto load_affine = [&](int n0) {
+    if (n0 == aff_n0) return;
+    aff_n0 = n0;
+    if (lane < BN) {
+      const int co = n0 + lane, ci = min(co, a.c_out - 1);
+      aff_s[lane] = co < a.c_out ? a.scale[ci] : 0.f;
+      aff_s[64 + lane] = co < a.c_out ? a.shift[ci] : 0.f;
+    }
+  };
+  auto epilogue = [&](const QTile& tc) {
+    const size_t plane = (size_t)a.h * a.w * 16;
+#pragma unroll
+    for (int wm = 0; wm < 2; ++wm) {
+      const int oy = tc.oy0 + prow[wm], ox = tc.ox0 + pcol;
+      const bool inside = oy < a.h && ox < a.w;
+      unsigned char* obase = a.out + (size_t)tc.img * a.cog * 4 * plane + ((size_t)oy * a.w + ox) * 16;
+#pragma unroll
+      for (int wn = 0; wn < WTN; ++wn) {
+        u32x2 hi[4], lo[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(aff_s + wn * 32 + 8 * g + 4 * lh);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(aff_s + 64 + wn * 32 + 8 * g + 4 * lh);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
+            if (a.relu) v[e] = fmaxf(v[e], 0.f);
+          }
+          split4(v, hi[g], lo[g], amax);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          // chunk (n0 + 32 wn) / 16 + m: lane half 0 ends up with octet 0, lane half 1 with octet 1
+          const u32x4 ph = gather_octet(hi[2 * m], hi[2 * m + 1]);
+          const u32x4 pl = gather_octet(lo[2 * m], lo[2 * m + 1]);
+          const int cg = (tc.n0 + 32 * wn) / 16 + m;
+          if (inside && cg < a.cog) {
+            *reinterpret_cast<u32x4*>(obase + (size_t)(cg * 4 + lh) * plane) = ph;
+            *reinterpret_cast<u32x4*>(obase + (size_t)(cg * 4 + 2 + lh) * plane) = pl;
+          }
+        }
+      }
+    }
+  };
+
+  // ---- main loop
+  int item = blockIdx.x;
+  if (item >= a.total_items) return;
+  QTile cur = decode(item);
+  setup_rsrc(cur);
+  setup_voff_b(cur);
+  setup_voff_a(cur, false);
+  issue_b(0, 0, 0);
+  issue_a(0, 0);
+  int sa = 0, sb = 0;
+  bool a_pending = true;   // patch DMAs issued AFTER the weight DMAs the next step waits for
+  const int nchunks = a.c0g + a.c1g;
+
+  while (true) {
+#pragma unroll
+    for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+      for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+    load_affine(cur.n0);
+    const bool has_next = item + G < a.total_items;
+    QTile nxt = cur;
+    if (has_next) nxt = decode(item + G);
+
+    for (int g = 0; g < nchunks; ++g) {
+      const bool last_g = g + 1 == nchunks;
+      auto step = [&](auto st_c, auto kind_c) {
+        constexpr int ST = decltype(st_c)::value;
+        constexpr bool SRC1 = decltype(kind_c)::value;
+        constexpr int NSG = SRC1 ? 3 : NS0;
+        // This step's weights (and, at ST == 0, this chunk's patch) have landed.  At ST == 1 the NEXT chunk's
+        // patch may still be in flight behind them: it was issued after them, so waiting until only this
+        // wave's patch instructions remain outstanding is enough.  Raw s_barrier: __syncthreads() would drain vmcnt.
+        if (ST == 1 && a_pending) {
+          if (wave < QA_INSTR - (QA_IT - 1) * QNW) wait_vm<QA_IT>(); else wait_vm<QA_IT - 1>();
+        } else {
+          wait_vm0();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ST + 1 < NSG) {
+          issue_b(g, ST + 1, sb ^ 1);
+        } else if (!last_g) {
+          issue_b(g + 1, 0, sb ^ 1);
+        } else if (has_next) {
+          setup_voff_b(nxt);
+          issue_b(0, 0, sb ^ 1);
+        }
+        if (ST == 0) {
+          a_pending = true;
+          if (!last_g) {
+            if (g + 1 == a.c0g) setup_voff_a(cur, true);   // concat: switch to source 1
+            issue_a(g + 1, sa ^ 1);
+          } else if (has_next) {
+            setup_rsrc(nxt);
+            setup_voff_a(nxt, false);
+            issue_a(0, sa ^ 1);
+          } else {
+            a_pending = false;
+          }
+        }
+        if constexpr (SRC1)
+          compute1(st_c, smem + sa * QA_STAGE, smem + OFF_B + sb * QB_STAGE);
+        else
+          compute0(st_c, smem + sa * QA_STAGE, smem + OFF_B + sb * QB_STAGE);
+        sb ^= 1;
+      };
+      if (g < a.c0g) {
+        step(std::integral_constant<int, 0>{}, std::false_type{});
+        step(std::integral_constant<int, 1>{}, std::false_type{});
+        if constexpr (NS0 == 4) {
+          step(std::integral_constant<int, 2>{}, std::false_type{});
+          step(std::integral_constant<int, 3>{}, std::false_type{});
+        }
+      } else {
+        step(std::integral_constant<int, 0>{}, std::true_type{});
+        step(std::integral_constant<int, 1>{}, std::true_type{});
+        step(std::integral_constant<int, 2>{}, std::true_type{});
+      }
+      sa ^= 1;
+    }
+    epilogue(cur);
+    note_range(amax);
+    if (!has_next) break;
+    item += G;
+    cur = nxt;
+  }
+}
+
+// weight_oihw [c_out][c0 + c1][3][3] * wmul -> packed image: chunks of source 0 carry 16 blocks [t = 2 a + b][class
+// = py + 2 px], block (t, class) = sum of W[dy][dx] over dy in R(py, a), dx in R(px, b) with R(0, 0) = {0},
+// R(0, 1) = {1, 2}, R(1, 0) = {0, 1}, R(1, 1) = {2}; chunks of source 1 the 9 plain taps [dy][dx].
+__global__ void spq_pack_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ wpk, int c_out, int c_in,
+                                        int c0g, int cout_pad, int nchunks, float wmul) {
+  const long total = ((long)c0g * 16 + (long)(nchunks - c0g) * 9) * 2 * cout_pad;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int n = r % cout_pad; r /= cout_pad;
+    const int oct = r % 2; r /= 2;             // r = block index
+    int cg, dy0, dy1, dx0, dx1;                // inclusive tap ranges summed
+    if (r < (long)c0g * 16) {
+      cg = (int)(r / 16);
+      const int k = (int)(r % 16), t = k / 4, cls = k % 4;
+      const int am = t >> 1, b = t & 1, py = cls & 1, px = cls >> 1;
+      dy0 = am == 0 ? 0 : (py == 0 ? 1 : 2); dy1 = am == 0 ? (py == 0 ? 0 : 1) : 2;
+      dx0 = b == 0 ? 0 : (px == 0 ? 1 : 2);  dx1 = b == 0 ? (px == 0 ? 0 : 1) : 2;
+    } else {
+      const long q = r - (long)c0g * 16;
+      cg = c0g + (int)(q / 9);
+      dy0 = dy1 = (int)(q % 9) / 3;
+      dx0 = dx1 = (int)(q % 3);
+    }
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ci = cg * 16 + oct * 8 + e;
+      float v = 0.f;
+      if (n < c_out && ci < c_in) {
+        const float* wp = w + ((size_t)n * c_in + ci) * 9;
+        for (int dy = dy0; dy <= dy1; ++dy)
+          for (int dx = dx0; dx <= dx1; ++dx) v += wp[dy * 3 + dx];
+        v *= wmul;
+      }
+      v = fminf(fmaxf(v, -65504.f), 65504.f);
+      hi[e] = (_Float16)v;
+      lo[e] = (_Float16)(v - (float)hi[e]);
+    }
+    unsigned char* d = wpk + (((size_t)r * 4 + oct) * cout_pad + n) * 16;
+    *reinterpret_cast<half8*>(d) = hi;
+    *reinterpret_cast<half8*>(d + (size_t)2 * cout_pad * 16) = lo;
+  }
+}
+
+template <int BN>
+int launch_spq(SpqArgs& a, hipStream_t stream) {
+  using T = SpqTile<BN>;
+  auto kern = conv_spq_kernel<BN>;
+  static dn::PerDeviceFlag attr_flag;
+  bool& attr_set = attr_flag.here();
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)T::LDS_BYTES);
+    if (e != hipSuccess)
+      return dn::fail(DN_ERR_LAUNCH, "spconv (quad-merged): hipFuncSetAttribute(%d B LDS): %s", (int)T::LDS_BYTES,
+                      hipGetErrorString(e));
+    attr_set = true;
+  }
+  a.tiles_x = (a.w + QTW - 1) / QTW;
+  a.tiles_y = (a.h + QTH - 1) / QTH;
+  const long total = (long)a.n_images * a.tiles_y * a.tiles_x * ((a.c_out + BN - 1) / BN);
+  DN_REQUIRE(total < (1L << 31), "spconv (quad-merged): too many tiles (%ld)", total);
+  a.total_items = (int)total;
+  const long resident = 2L * kCUs;
+  dim3 grid((unsigned)(total > resident ? resident : total));
+  hipLaunchKernelGGL(kern, grid, dim3(QNT), T::LDS_BYTES, stream, a);
+  return dn::check_launch("conv_spq_kernel");
+}
+
+}  // namespace
+
+namespace dn {
+
+unsigned range_flags_conv_spq(bool reset) { return sp_range_flags_here(reset); }
+
+size_t spq_packed_blocks(int c0g, int nchunks) { return (size_t)c0g * 16 + (size_t)(nchunks - c0g) * 9; }
+
+int spq_pack_weights(const float* weight_oihw, void* packed, int c_out, int c_in, int c0g, int cout_pad, int nchunks,
+                     float wmul, hipStream_t stream) {
+  hipLaunchKernelGGL(spq_pack_weights_kernel, dim3(2048), dim3(256), 0, stream, weight_oihw, (unsigned char*)packed, c_out,
+                     c_in, c0g, cout_pad, nchunks, wmul);
+  return check_launch("spq_pack_weights_kernel");
+}
+
+// bn: 32 or 64 output channels per workgroup; 0 = choose (enough work items for two workgroups on every CU)
+int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed, size_t packed_bytes,
+             const float* scale, const float* shift, void* out, int cout_pad, int bn, hipStream_t stream) {
+  SpqArgs a;
+  a.src0 = (const unsigned char*)src0; a.src1 = (const unsigned char*)src1; a.wpk = (const unsigned char*)packed;
+  a.scale = scale; a.shift = shift; a.out = (unsigned char*)out;
+  a.n_images = d->n_images; a.h = d->h_in; a.w = d->w_in;
+  a.c0g = (d->c0 + 15) / 16; a.c1g = (d->c1 + 15) / 16;
+  a.c_out = d->c_out; a.cog = (d->c_out + 15) / 16; a.relu = d->relu;
+  a.cout_pad = cout_pad; a.wpk_bytes = (int)packed_bytes;
+  a.tiles_x = a.tiles_y = a.total_items = 0;
+  if (bn == 0) {
+    const long tiles = (long)d->n_images * ((d->h_in + QTH - 1) / QTH) * ((d->w_in + QTW - 1) / QTW);
+    bn = (d->c_out > 32 && tiles * ((d->c_out + 63) / 64) >= 2L * kCUs) ? 64 : 32;
+  }
+  if (bn == 64) return launch_spq<64>(a, stream);
+  return launch_spq<32>(a, stream);
+}
+
+}  // namespace dn

@@ -40,6 +40,18 @@ inline int check_launch(const char* what) {
   return DN_OK;
 }
 
+// quad-merged up-conv (conv_spq.hip), reached through dn_spconv2d / dn_spconv_pack_weights (conv_sp.hip)
+size_t spq_packed_blocks(int c0g, int nchunks);
+int spq_pack_weights(const float* weight_oihw, void* packed, int c_out, int c_in, int c0g, int cout_pad, int nchunks,
+                     float wmul, hipStream_t stream);
+int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed, size_t packed_bytes,
+             const float* scale, const float* shift, void* out, int cout_pad, int bn, hipStream_t stream);
+
+// per-translation-unit words of the split-f16 range flags (sp_device.h); dn_sp_range_flags() ORs them
+unsigned range_flags_conv_sp(bool reset);
+unsigned range_flags_conv_spq(bool reset);
+unsigned range_flags_fuse_mlp(bool reset);
+
 }  // namespace dn
 
 #define DN_REQUIRE(cond, ...) \

@@ -24,14 +24,8 @@
 // Replaces PixelWeightedFusionSoftmax.forward and the fusion loop body of
 // upstream:coperception/models/det/DiscoNet.py :: DiscoNet.forward (Appx A.5).
 #include "dn_internal.h"
+#include "sp_device.h"
 #include <type_traits>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -52,26 +46,6 @@ struct FuseMlpArgs {
   float* weights_out;
   int batch, agents, hw, only_v2i, ego_first, ego_count, tiles;
 };
-
-__device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
-  half4 h, l;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
-    h[e] = (_Float16)x;
-    l[e] = (_Float16)(x - (float)h[e]);
-  }
-  hi = __builtin_bit_cast(u32x2, h);
-  lo = __builtin_bit_cast(u32x2, l);
-}
-
-// lanes (j, 0) / (j, 1) hold units 4h..4h+3 of octet X (x) and of octet Y (y) -> lane (j, 0) gets
-// octet X complete, lane (j, 1) octet Y complete
-__device__ inline u32x4 gather_octet(u32x2 x, u32x2 y) {
-  const auto s0 = __builtin_amdgcn_permlane32_swap(x[0], y[0], false, false);
-  const auto s1 = __builtin_amdgcn_permlane32_swap(x[1], y[1], false, false);
-  return u32x4{s0[0], s1[0], s0[1], s1[1]};
-}
 
 __device__ inline half8 frag_of(const unsigned char* base, int idx) {
   return *reinterpret_cast<const half8*>(base + (size_t)idx * 16);
@@ -110,13 +84,14 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
     return a.warped + ((((size_t)b * a.ego_count + il) * (a.agents - 1) + jj) * a.hw + pc) * C + 8 * lh;
   };
 
+  float amax = 0.f;   // max |value| split into the SP output (range flags, sp_device.h)
   // ---- store helpers: this lane's 8 channels of k-step ks
   auto store_piece = [&](int ks, const f32x4 v0, const f32x4 v1) {
     if (!pvalid) return;
     if (a.fused_sp) {
       u32x2 h0, l0, h1, l1;
-      split4(v0, h0, l0);
-      split4(v1, h1, l1);
+      split4(v0, h0, l0, amax);
+      split4(v1, h1, l1, amax);
       const size_t plane = (size_t)a.hw * 16;
       unsigned char* o = a.fused_sp + ((oimg * KS + ks) * 4 + lh) * plane + (size_t)p * 16;
       *reinterpret_cast<u32x4*>(o) = u32x4{h0[0], h0[1], h1[0], h1[1]};
@@ -147,6 +122,7 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
     for (int ks = 0; ks < KS; ++ks)
       store_piece(ks, *reinterpret_cast<const f32x4*>(xrow + 16 * ks),
                   *reinterpret_cast<const f32x4*>(xrow + 16 * ks + 4));
+    note_range(amax);
     return;
   }
 
@@ -358,6 +334,7 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
   }
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) store_piece(ks, f0[ks], f1[ks]);
+  note_range(amax);
 }
 
 // weights [rows][cols] * wmul -> A-operand fragments [nt][ks][part][h][32 rows] x 16 B (rows / cols
@@ -383,6 +360,8 @@ __global__ void pack_frags_kernel(const float* __restrict__ w, int ld, int col0,
 inline size_t w1_bytes(int c) { return (size_t)2 * 4 * (c / 16) * 2 * 2 * 32 * 16; }
 
 }  // namespace
+
+namespace dn { unsigned range_flags_fuse_mlp(bool reset) { return sp_range_flags_here(reset); } }
 
 extern "C" int dn_fuse_mlp_supported(int c) { return c == 64 || c == 128 || c == 256; }
 

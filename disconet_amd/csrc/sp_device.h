@@ -1,0 +1,80 @@
+// Device helpers shared by the split-planar conv kernels (conv_sp.hip, conv_spq.hip): vector types, counted
+// vmcnt waits, the LDS-DMA instruction, the f16 hi/lo split and the permlane gather that turns MFMA
+// accumulator quads into 16-byte SP pieces.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ inline void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ inline void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes, global (per-lane voff + scalar soff) -> LDS at
+// lds + 16 * lane (wave-uniform base through M0).  An out-of-range voff writes zeros.  A plain
+// __device__ function, not a lambda: the builtin inside a lambda makes hipcc's HOST pass drop the
+// kernel's launch stub without a diagnostic.
+__device__ inline void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff,
+                                           soff, 0, 0);
+}
+
+// Sticky range flags of the split-f16 engines (include/disconet_hip.h :: dn_sp_range_flags): bit 1 = a value
+// with |x| > 2^14 was split (within two binades of the f16 limit), bit 0 = a value was clamped to +-65504 (the
+// result no longer follows the fp32 reference).  One word per translation unit (no relocatable device code in this
+// build); dn_sp_range_flags() ORs them.  Written only by lanes that saw such a value: free in the normal case.
+__device__ unsigned g_sp_range_flags = 0;
+
+__device__ inline void note_range(float amax) {
+  if (amax > 16384.f) atomicOr(&g_sp_range_flags, amax >= 65504.f ? 3u : 2u);
+}
+
+inline unsigned sp_range_flags_here(bool reset) {   // host: this translation unit's word, on the current device
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sp_range_flags), sizeof v) != hipSuccess) return 0x80000000u;
+  if (reset && v) {
+    const unsigned z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sp_range_flags), &z, sizeof z);
+  }
+  return v;
+}
+
+// x -> (hi, lo) halves, 4 values -> two dword pairs.  amax: running max |x| of what this lane has split
+// (note_range() reports it once per epilogue).
+__device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo, float& amax) {
+  half4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    amax = fmaxf(amax, fabsf(v[e]));
+    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
+    h[e] = (_Float16)x;
+    l[e] = (_Float16)(x - (float)h[e]);
+  }
+  hi = __builtin_bit_cast(u32x2, h);
+  lo = __builtin_bit_cast(u32x2, l);
+}
+__device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+  float unused = 0.f;
+  split4(v, hi, lo, unused);
+}
+
+// Lanes (j, 0) and (j, 1) hold channels 4h..4h+3 of octet X (x) and of octet Y (y).  After the
+// swaps lane (j, 0) holds octet X complete and lane (j, 1) octet Y complete, as 16 bytes.
+__device__ inline u32x4 gather_octet(u32x2 x, u32x2 y) {
+  // v_permlane32_swap(a, b): lanes 32-63 of a <-> lanes 0-31 of b
+  const auto s0 = __builtin_amdgcn_permlane32_swap(x[0], y[0], false, false);
+  const auto s1 = __builtin_amdgcn_permlane32_swap(x[1], y[1], false, false);
+  return u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
+
+}  // namespace

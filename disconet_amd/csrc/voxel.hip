@@ -138,7 +138,7 @@ __global__ void scatter_dense_kernel(const int32_t* __restrict__ indices,
 // occupancy 1.0 is the f16 0x3C00 in the hi plane of the voxel's z bin, its lo plane stays 0
 __global__ void scatter_dense_sp_kernel(const int32_t* __restrict__ indices,
                                         const int32_t* __restrict__ offsets, int n_images, int total,
-                                        int dx, int dy, int dz, unsigned short* __restrict__ sp) {
+                                        int dx, int dy, int dz, int quarters, unsigned short* __restrict__ sp) {
   const size_t hw = (size_t)dx * dy;
   const int chunks = (dz + 15) / 16;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -151,7 +151,7 @@ __global__ void scatter_dense_sp_kernel(const int32_t* __restrict__ indices,
               iz = indices[3 * (size_t)i + 2];
     if ((unsigned)ix < (unsigned)dx && (unsigned)iy < (unsigned)dy && (unsigned)iz < (unsigned)dz) {
       const int cg = iz >> 4, oct = (iz >> 3) & 1, e = iz & 7;
-      sp[((((size_t)lo * chunks + cg) * 4 + oct) * hw + (size_t)ix * dy + iy) * 8 + e] = 0x3C00;
+      sp[((((size_t)lo * chunks + cg) * quarters + oct) * hw + (size_t)ix * dy + iy) * 8 + e] = 0x3C00;
     }
   }
 }
@@ -228,17 +228,28 @@ extern "C" int dn_scatter_dense(const int32_t* indices, const int32_t* offsets, 
   return dn::check_launch("scatter_dense_kernel");
 }
 
-extern "C" int dn_scatter_dense_sp(const int32_t* indices, const int32_t* offsets, int n_images,
-                                   int total, const int* dims, void* dense_sp, void* stream) {
+namespace {
+int scatter_dense_sp_impl(const int32_t* indices, const int32_t* offsets, int n_images, int total, const int* dims,
+                          void* dense_sp, int quarters, hipStream_t s) {
   DN_REQUIRE(dims && dense_sp && offsets, "scatter_dense_sp: null pointer");
   DN_REQUIRE(n_images > 0 && total >= 0 && (total == 0 || indices), "scatter_dense_sp: bad sizes");
-  hipStream_t s = (hipStream_t)stream;
-  const size_t bytes = (size_t)n_images * ((dims[2] + 15) / 16) * 4 * dims[0] * dims[1] * 16;
+  const size_t bytes = (size_t)n_images * ((dims[2] + 15) / 16) * quarters * dims[0] * dims[1] * 16;
   hipError_t e = dn::zero_fill(dense_sp, bytes, s);
   if (e != hipSuccess) return dn::fail(DN_ERR_LAUNCH, "scatter_dense_sp: memset: %s", hipGetErrorString(e));
   if (total == 0) return DN_OK;
   const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
   hipLaunchKernelGGL(scatter_dense_sp_kernel, dim3(blocks), dim3(256), 0, s, indices, offsets, n_images,
-                     total, dims[0], dims[1], dims[2], (unsigned short*)dense_sp);
+                     total, dims[0], dims[1], dims[2], quarters, (unsigned short*)dense_sp);
   return dn::check_launch("scatter_dense_sp_kernel");
+}
+}  // namespace
+
+extern "C" int dn_scatter_dense_sp(const int32_t* indices, const int32_t* offsets, int n_images,
+                                   int total, const int* dims, void* dense_sp, void* stream) {
+  return scatter_dense_sp_impl(indices, offsets, n_images, total, dims, dense_sp, 4, (hipStream_t)stream);
+}
+
+extern "C" int dn_scatter_dense_sp_hi(const int32_t* indices, const int32_t* offsets, int n_images,
+                                      int total, const int* dims, void* dense_sp_hi, void* stream) {
+  return scatter_dense_sp_impl(indices, offsets, n_images, total, dims, dense_sp_hi, 2, (hipStream_t)stream);
 }

@@ -190,13 +190,16 @@ class SpTensor:
     data [n, ceil(c/16), 4, h, w, 8] float16 (quarter = 2*part + oct; part 0 = half(x),
     part 1 = half(x - half(x))).  `shape` is the logical NHWC shape."""
 
-    __slots__ = ("data", "n", "h", "w", "c")
+    __slots__ = ("data", "n", "h", "w", "c", "hi_only")
 
-    def __init__(self, n, h, w, c, device=None, data=None):
+    def __init__(self, n, h, w, c, device=None, data=None, hi_only=False):
+        """hi_only: the HI-ONLY form [n, ceil(c/16), 2, h, w, 8] of values that are exact in binary16 (the 0/1
+        occupancy grid of scatter_dense_sp): accepted as source 0 of a 3x3 stride-1 SP conv."""
         self.n, self.h, self.w, self.c = int(n), int(h), int(w), int(c)
+        self.hi_only = bool(hi_only)
         if data is None:
-            data = torch.empty((self.n, (self.c + 15) // 16, 4, self.h, self.w, 8), dtype=torch.float16,
-                               device=device)
+            data = torch.empty((self.n, (self.c + 15) // 16, 2 if hi_only else 4, self.h, self.w, 8),
+                               dtype=torch.float16, device=device)
         self.data = data
 
     shape = property(lambda self: (self.n, self.h, self.w, self.c))
@@ -214,6 +217,12 @@ class SpTensor:
 
     def nhwc(self, out=None):
         """-> float32 [n, h, w, c] (x = hi + lo)"""
+        if self.hi_only:      # not a hot path (training entry, tests): torch reshapes the two octet planes
+            x = self.data.permute(0, 3, 4, 1, 2, 5).reshape(self.n, self.h, self.w, -1)[..., :self.c].float()
+            if out is None:
+                return x.contiguous()
+            out.copy_(x)
+            return out
         if out is None:
             out = torch.empty((self.n, self.h, self.w, self.c), dtype=torch.float32, device=self.data.device)
         check(_lib.load().dn_sp_to_nhwc(_ptr(self.data), self.n, self.h, self.w, self.c, out.stride(2),
@@ -274,6 +283,10 @@ def sp_conv2d(d, src0, packed, scale, shift, src1=None, out=None):
     ho, wo = conv_out_hw(d)
     if out is None:
         out = SpTensor(d.n_images, ho, wo, d.c_out, device=src0.device)
+    if src1 is not None and src1.hi_only:
+        raise _lib.DnError("sp_conv2d: only source 0 may be a hi-only SP tensor")
+    if src0.hi_only:
+        d.math = 3            # include/disconet_hip.h: source 0 is a hi-only SP tensor
     check(_lib.load().dn_spconv2d(ctypes.byref(d), _ptr(src0.data), _ptr(src1.data) if src1 is not None else None,
                                   _ptr(packed), _ptr(scale), _ptr(shift), _ptr(out.data), _stream()),
           "dn_spconv2d")
@@ -324,16 +337,18 @@ def sp_conv2d_post1x1(d, src0, packed, scale, shift, packed2, scale2, shift2, c_
     return out_a, out_b
 
 
-def scatter_dense_sp(indices, offsets, n_images, dims):
+def scatter_dense_sp(indices, offsets, n_images, dims, hi_only=False):
     """Batched dense rebuild straight into the conv engine's layout: -> SpTensor [n_images, X, Y, Z]
-    (what DiscoNet.forward accepts in place of the float32 bevs tensor)."""
+    (what DiscoNet.forward accepts in place of the float32 bevs tensor).  hi_only: the half-size hi-only
+    form (0/1 is exact in binary16; conv_pre_1 then reads half the bytes and runs 2 MFMAs per product)."""
     _need_gpu(indices, offsets)
     if indices.dtype != torch.int32 or offsets.dtype != torch.int32:
         raise _lib.DnError("scatter_dense_sp needs int32 indices/offsets")
     d = (ctypes.c_int * 3)(*[int(v) for v in dims])
-    out = SpTensor(n_images, int(dims[0]), int(dims[1]), int(dims[2]), device=indices.device)
-    check(_lib.load().dn_scatter_dense_sp(_ptr(indices), _ptr(offsets), n_images, indices.shape[0], d,
-                                          _ptr(out.data), _stream()), "dn_scatter_dense_sp")
+    out = SpTensor(n_images, int(dims[0]), int(dims[1]), int(dims[2]), device=indices.device, hi_only=hi_only)
+    fn = _lib.load().dn_scatter_dense_sp_hi if hi_only else _lib.load().dn_scatter_dense_sp
+    check(fn(_ptr(indices), _ptr(offsets), n_images, indices.shape[0], d, _ptr(out.data), _stream()),
+          "dn_scatter_dense_sp")
     return out
 
 

@@ -15,9 +15,16 @@
  *   - the caller owns every buffer (incl. workspaces); nothing is allocated,
  *     nothing synchronises; all work is enqueued on `stream` (a hipStream_t
  *     passed as void*, NULL = the default stream);
- *   - activations are NHWC float32 (channels-last): [image][y][x][channel];
- *     images of a batch are agent-major (image = agent * B + b), the order the
- *     reference's tools build with torch.cat over agents;
+ *   - activations are channels-last.  Two storage forms: float32 NHWC [image][y][x][channel]
+ *     (dn_conv2d*, the warp / fusion kernels' maps, the heads' outputs, everything in
+ *     disconet_train.h) and the split-planar "SP" form of the inference conv engine
+ *     (dn_spconv2d*, see "SP tensor" below: f16 hi/lo planes, opaque bytes);
+ *     dn_sp_from_nhwc / dn_sp_to_nhwc convert.  Images of a batch are agent-major
+ *     (image = agent * B + b), the order the reference's tools build with torch.cat over agents;
+ *   - ONE stream per device: kernels of this library must not run CONCURRENTLY with each other
+ *     (two streams, two graphs in flight).  Beside the split-f16 conv kernels another kernel has
+ *     been observed to compute with corrupted VGPR lanes; calls enqueued on
+ *     one stream, or ordered by events, are safe;
  *   - return 0 on success, negative on error; dn_last_error() returns a
  *     thread-local message for the last failing call on this thread;
  *   - re-entrant.  Process-wide state is limited to launch-time caches filled on first use
@@ -41,6 +48,19 @@ extern "C" {
 
 int dn_version(void);
 const char* dn_last_error(void);
+
+/* Range guard of the split-f16 engines (dn_spconv2d*, dn_sp_from_nhwc, dn_disco_fuse_mlp*).  A value is
+ * stored as hi + lo f16 halves, so the format has the f16 EXPONENT range: a split clamps at +-65504
+ * (the result then no longer follows the fp32 reference) and `lo` is a subnormal below |x| ~ 0.125 (an
+ * absolute error floor of 2^-25 per operand instead of 2^-22 relative).  Every kernel that splits
+ * values keeps a sticky word in device memory:
+ *   bit 1 (2): a value with |x| > 2^14 was split -- within two binades of the limit, rescale;
+ *   bit 0 (1): a value was clamped to +-65504 -- results of this device since the last reset are wrong.
+ * Returns the OR over the library's kernels on the current device and, with reset != 0, clears it.
+ * Blocking (a device -> host copy behind everything enqueued): poll it at plan / validation time, not per
+ * step.  The Python host raises on it when DN_SP_CHECK=1.  NaN inputs are not flagged (a split turns a
+ * NaN into -65504). */
+unsigned dn_sp_range_flags(int reset);
 
 /* ------------------------------------------------------------------------
  * K1 -- point cloud -> BEV occupancy.
@@ -73,6 +93,12 @@ int dn_scatter_dense(const int32_t* indices, const int32_t* offsets, int n_image
  * dense_sp is the SP tensor [n_images][ceil(Z/16)][4][X][Y] x 16 bytes of the bevs batch. */
 int dn_scatter_dense_sp(const int32_t* indices, const int32_t* offsets, int n_images,
                         int n_indices_total, const int* dims_host, void* dense_sp, void* stream);
+/* ... and as a HI-ONLY SP tensor [n_images][ceil(Z/16)][2 octets][X][Y] x 16 bytes (half the bytes): an
+ * occupancy grid is exact in binary16, its lo planes would be all zero.  dn_spconv2d reads it as
+ * source 0 of a 3x3 stride-1 layer when dn_conv_desc.math == 3 (half the operand traffic, two MFMAs per
+ * product instead of three; the results are bit-identical to the full form). */
+int dn_scatter_dense_sp_hi(const int32_t* indices, const int32_t* offsets, int n_images,
+                           int n_indices_total, const int* dims_host, void* dense_sp_hi, void* stream);
 
 /* ------------------------------------------------------------------------
  * K2/K3/K7 -- implicit-GEMM convolution on fp32 MFMA with fused
@@ -154,7 +180,8 @@ int dn_conv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p, const flo
  *   [image][ceil(C/16) chunk][4 quarter][H][W] x 16 bytes; a piece = 8 halves =
  *   channels 16*chunk + 8*oct + 0..7 of one pixel; quarter = 2*part + oct,
  *   part 0 = half(x), part 1 = half(x - half(x)).  Channels past C are zero.
- * dn_conv_desc is reused: ld0/ld1/ldo and math are ignored; up0 is 0 or 1.
+ * dn_conv_desc is reused: ld0/ld1/ldo are ignored; up0 is 0 or 1; math is ignored except
+ * math == 3: source 0 is a HI-ONLY SP tensor (dn_scatter_dense_sp_hi; 3x3, stride 1, c1 == 0).
  * Packed weights are specific to this engine (dn_spconv_pack_weights); `wmul`
  * is multiplied into the weights before the split -- pass a power of two that
  * lifts the layer's weights out of the f16 subnormal range and fold 1/wmul into
@@ -162,10 +189,11 @@ int dn_conv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p, const flo
  * The packed image depends on the layer's SOURCES as well as on its weights: pack
  * with the descriptor the layer will run with.  A 3x3 stride-1 layer whose first
  * source is nearest-upsampled (up0 = 1, c0 a multiple of 16, even h_in / w_in) is
- * packed ROW-MERGED: kernel rows that read the same low-resolution row of that
- * source are summed (12 blocks per 16-channel chunk of source 0 instead of 9), and
- * dn_spconv2d runs 2 x 3 taps over those chunks.  dn_spconv_packed_weight_bytes()
- * accounts for it.
+ * packed TAP-MERGED: the kernel taps that read the same low-resolution pixel of
+ * that source are summed per output-pixel parity class (16 blocks per 16-channel
+ * chunk of source 0 -- 4 merged taps x 4 classes -- instead of 9) and dn_spconv2d
+ * runs 2 x 2 taps over those chunks (disconet_amd/csrc/conv_spq.hip).
+ * dn_spconv_packed_weight_bytes() accounts for it.
  * ------------------------------------------------------------------------ */
 size_t dn_sp_tensor_bytes(int n_images, int h, int w, int channels);
 /* fp32 NHWC [n][h][w][ld] (first `channels` of each pixel) <-> SP */
@@ -197,6 +225,10 @@ int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p, const v
 /* tools only: force tile configuration `cfg` (an index of conv_sp.hip's menu) where it
  * applies to the layer, -1 = automatic selection.  Process-wide, not thread-safe. */
 int dn_spconv_force_config(int cfg);
+/* tools only: form of the packed image / kernel of layers whose first source is upsampled: 0 = plain taps,
+ * 1 = row-merged, 2 = row- and column-merged per parity class (default), -1 = the DN_SP_UPMERGE
+ * environment value.  Process-wide; weights packed under one mode must run under the same mode. */
+int dn_spconv_set_upmode(int mode);
 
 /* ------------------------------------------------------------------------
  * K4 -- pose-based two-pass bilinear warp of neighbour feature maps.

@@ -197,4 +197,7 @@ def test_split_planar_bevs_input_equals_dense_input():
     with torch.no_grad():
         dense = m(ops.scatter_dense(indices, offsets, A * B, dims), trans, na, B)
         sp = m(ops.scatter_dense_sp(indices, offsets, A * B, dims), trans, na, B)
+        hi = m(ops.scatter_dense_sp(indices, offsets, A * B, dims, hi_only=True), trans, na, B)
     assert torch.equal(dense["cls"], sp["cls"]) and torch.equal(dense["loc"], sp["loc"])
+    # hi-only occupancy planes (half the bytes, 2 MFMAs per product in conv_pre_1): the dropped terms are exact zeros
+    assert torch.equal(hi["cls"], sp["cls"]) and torch.equal(hi["loc"], sp["loc"])

@@ -92,6 +92,10 @@ def test_scatter_dense_sp_matches_dense():
     assert sp.shape == (6, 128, 128, 13) and sp.data.shape == (6, 1, 4, 128, 128, 8)
     assert torch.equal(sp.nhwc(), dense.view(6, 128, 128, 13))
     assert torch.equal(sp.data, ops.SpTensor.from_nhwc(dense.view(6, 128, 128, 13)).data)
+    hi = ops.scatter_dense_sp(indices, offsets, 6, dims, hi_only=True)
+    assert hi.data.shape == (6, 1, 2, 128, 128, 8) and torch.equal(hi.data, sp.data[:, :, :2])
+    assert float(sp.data[:, :, 2:].float().abs().sum()) == 0.0          # what the hi-only form leaves out
+    assert torch.equal(hi.nhwc(), dense.view(6, 128, 128, 13))
     # empty batch entry / no voxels at all
     empty = ops.scatter_dense_sp(indices[:0], torch.zeros(3, dtype=torch.int32, device="cuda"), 2, dims)
     assert float(empty.data.float().abs().sum()) == 0.0

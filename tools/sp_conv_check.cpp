@@ -58,6 +58,35 @@ static double compare(const float* d_a, const float* d_b, size_t n, const char* 
 
 static int g_fail = 0;
 
+// where a failing result differs: error counts by (y & 7, x & 1) class and by channel octet, first few positions
+static void dump_mismatch(const float* d_a, const float* d_b, int n, int h, int w, int c) {
+  const size_t tot = (size_t)n * h * w * c;
+  std::vector<float> a(tot), b(tot);
+  hipMemcpy(a.data(), d_a, tot * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(b.data(), d_b, tot * 4, hipMemcpyDeviceToHost);
+  double mr = 0;
+  for (size_t i = 0; i < tot; ++i) mr = fmax(mr, fabs((double)b[i]));
+  long by_row[8] = {0}, by_colpar[2] = {0}, by_x32[32] = {0}, by_oct[64] = {0}, bad = 0;
+  int shown = 0;
+  printf("\n   mismatch map (tolerance 2e-5 of max |ref| = %.3g):", mr);
+  for (size_t i = 0; i < tot; ++i) {
+    const bool nan = std::isnan(a[i]);
+    if (!nan && fabs((double)a[i] - b[i]) <= 2e-5 * mr) continue;
+    const int ch = i % c; size_t r = i / c;
+    const int x = r % w; r /= w;
+    const int y = r % h; const int im = (int)(r / h);
+    ++bad; ++by_row[y & 7]; ++by_colpar[x & 1]; ++by_x32[x & 31]; ++by_oct[(ch / 8) & 63];
+    if (shown < 6) { printf("\n     img %d y %d x %d ch %d: got %g want %g", im, y, x, ch, a[i], b[i]); ++shown; }
+  }
+  printf("\n     %ld of %zu bad; by y&7:", bad, tot);
+  for (int k = 0; k < 8; ++k) printf(" %ld", by_row[k]);
+  printf("; by x&1: %ld %ld; by x&31:", by_colpar[0], by_colpar[1]);
+  for (int k = 0; k < 32; ++k) printf(" %ld", by_x32[k]);
+  printf("; by channel octet:");
+  for (int k = 0; k < (c + 7) / 8 && k < 64; ++k) printf(" %ld", by_oct[k]);
+  printf("\n");
+}
+
 // names of conv_sp.hip's tile menu
 static const char* kCfgName[] = {"256x64", "256x32", "128x64", "64x64", "s2_128x64", "s2_64x64", "p256x64", "p64x64",
                                  "256x64/T9", "512x64", "256x128", "p256x64/C1", "256x32/stat"};
@@ -88,22 +117,30 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
   CK(dn_conv2d(&d, s0, s1, pk_ref, sc, sh, out_ref, 0));
   const float t_ref = tm.us([&] { dn_conv2d(&d, s0, s1, pk_ref, sc, sh, out_ref, 0); });
   // ---- SP engine; weights pre-scaled by 2^8 with 2^-8 folded into the scale
-  void *sp0, *sp1 = nullptr, *spo, *pk;
+  void *sp0, *sp1 = nullptr, *spo, *pk = nullptr;
   HCK(hipMalloc(&sp0, dn_sp_tensor_bytes(n, h0, w0, c0)));
   if (c1) HCK(hipMalloc(&sp1, dn_sp_tensor_bytes(n, h, w, c1)));
   HCK(hipMalloc(&spo, dn_sp_tensor_bytes(n, ho, wo, cout)));
   HCK(hipMemset(spo, 0xFF, dn_sp_tensor_bytes(n, ho, wo, cout)));   // NaN poison
-  HCK(hipMalloc(&pk, dn_spconv_packed_weight_bytes(&d)));
   CK(dn_sp_from_nhwc(s0, n, h0, w0, c0, c0, sp0, 0));
   if (c1) CK(dn_sp_from_nhwc(s1, n, h, w, c1, c1, sp1, 0));
   const float wmul = 256.f;
-  CK(dn_spconv_pack_weights(&d, wt, wmul, pk, 0));
   float* sc2; HCK(hipMalloc(&sc2, cout * 4));
   { std::vector<float> hsc(cout); hipMemcpy(hsc.data(), sc, cout * 4, hipMemcpyDeviceToHost); for (auto& x : hsc) x /= wmul; hipMemcpy(sc2, hsc.data(), cout * 4, hipMemcpyHostToDevice); }
   const double gf = 2.0 * n * ho * wo * cout * (double)cin * ks * ks / 1e9;
   printf("%-30s %7.2f GF  ref %7.1f us (%6.1f TF) |", name, gf, t_ref, gf / t_ref * 1e3);
+  // layers over an upsampled source: the row-merged image / tiles (mode 1), then the quad-merged kernel (mode 2:
+  // automatic BN, then BN = 32 and BN = 64 forced); everything else: one pass
+  for (int upmode = up0 ? 1 : 2; upmode <= 2; ++upmode) {
+  dn_spconv_set_upmode(upmode);
+  if (pk) hipFree(pk);
+  HCK(hipMalloc(&pk, dn_spconv_packed_weight_bytes(&d)));
+  CK(dn_spconv_pack_weights(&d, wt, wmul, pk, 0));
   std::vector<int> cfgs = {-1};
-  if (!quick) {
+  if (up0 && upmode == 2) {
+    printf(" [quad]");
+    cfgs.insert(cfgs.end(), {20, 21});
+  } else if (!quick) {
     if (ks == 1) cfgs.insert(cfgs.end(), {6, 7});
     else if (stride == 2) cfgs.insert(cfgs.end(), {4, 5});
     else cfgs.insert(cfgs.end(), {0, 1, 2, 3, 8, 9, 10, 12});
@@ -120,7 +157,7 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
     }
     HCK(hipMemset(spo, 0xFF, dn_sp_tensor_bytes(n, ho, wo, cout)));
     if (dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, spo, 0) != 0) {   // a forced tile that does not apply
-      printf(" %s n/a |", cfg < 0 ? "auto" : kCfgName[cfg]);
+      printf(" %s n/a |", cfg < 0 ? "auto" : cfg >= 20 ? "q" : kCfgName[cfg]);
       continue;
     }
     CK(dn_sp_to_nhwc(spo, n, ho, wo, cout, cout, out_new, 0));
@@ -129,9 +166,12 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
     const float t = tm.us([&] { dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, spo, 0); });
     const bool ok = err < 2e-5;
     if (!ok) ++g_fail;
-    printf(" %s %6.1f us %6.1f TF err %.1e%s |", cfg < 0 ? "auto" : kCfgName[cfg], t, gf / t * 1e3, err,
-           ok ? "" : " FAIL");
+    printf(" %s %6.1f us %6.1f TF err %.1e%s |", cfg < 0 ? "auto" : cfg == 20 ? "q32" : cfg == 21 ? "q64" : kCfgName[cfg], t,
+           gf / t * 1e3, err, ok ? "" : " FAIL");
+    if (!ok) dump_mismatch(out_new, out_ref, n, ho, wo, cout);
   }
+  }
+  dn_spconv_set_upmode(-1);
   dn_spconv_force_config(-1);
   printf("\n");
   fflush(stdout);
@@ -207,6 +247,44 @@ static void run_post(const char* name, int n, int h, int w, int cin, int c2, int
   hipFree(scs); hipFree(sc2s);
 }
 
+// conv_pre_1: 13 -> 32 over a 0/1 occupancy grid, full SP source vs the hi-only form (math = 3): bit-equal, timed
+static void run_hi_only(const char* name, int n, int h, int w, int cin, int cout) {
+  if (g_filter && !strstr(name, g_filter)) return;
+  Timer tm;
+  dn_conv_desc d = {n, h, w, cin, 0, 0, cout, 3, 1, 1, cin, 0, cout, 2};
+  const size_t nx = (size_t)n * h * w * cin, no = (size_t)n * h * w * cout;
+  std::vector<float> hx(nx);
+  for (auto& x : hx) x = frand() > 0.9f ? 1.f : 0.f;
+  float* x; HCK(hipMalloc(&x, nx * 4)); HCK(hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice));
+  float* wt = dev_random((size_t)cout * cin * 9, sqrtf(6.f / (cin * 9)));
+  float* sc = dev_random(cout, 0.01f, true); float* sh = dev_random(cout, 0.3f);
+  const size_t full_b = dn_sp_tensor_bytes(n, h, w, cin), plane = (size_t)h * w * 16;
+  const int cg = (cin + 15) / 16;
+  void *spf, *sph, *pk, *o1, *o2;
+  HCK(hipMalloc(&spf, full_b)); HCK(hipMalloc(&sph, full_b / 2));
+  CK(dn_sp_from_nhwc(x, n, h, w, cin, cin, spf, 0));
+  for (int i = 0; i < n * cg; ++i)   // quarters 0, 1 (the hi octets) of every chunk
+    HCK(hipMemcpy((char*)sph + (size_t)i * 2 * plane, (char*)spf + (size_t)i * 4 * plane, 2 * plane, hipMemcpyDeviceToDevice));
+  HCK(hipMalloc(&pk, dn_spconv_packed_weight_bytes(&d)));
+  CK(dn_spconv_pack_weights(&d, wt, 256.f, pk, 0));
+  const size_t ob = dn_sp_tensor_bytes(n, h, w, cout);
+  HCK(hipMalloc(&o1, ob)); HCK(hipMalloc(&o2, ob)); HCK(hipMemset(o1, 0xFF, ob)); HCK(hipMemset(o2, 0xFF, ob));
+  CK(dn_spconv2d(&d, spf, nullptr, pk, sc, sh, o1, 0));
+  const float t_full = tm.us([&] { dn_spconv2d(&d, spf, nullptr, pk, sc, sh, o1, 0); });
+  dn_conv_desc dh = d; dh.math = 3;
+  CK(dn_spconv2d(&dh, sph, nullptr, pk, sc, sh, o2, 0));
+  const float t_hi = tm.us([&] { dn_spconv2d(&dh, sph, nullptr, pk, sc, sh, o2, 0); });
+  float *f1, *f2; HCK(hipMalloc(&f1, no * 4)); HCK(hipMalloc(&f2, no * 4));
+  CK(dn_sp_to_nhwc(o1, n, h, w, cout, cout, f1, 0)); CK(dn_sp_to_nhwc(o2, n, h, w, cout, cout, f2, 0));
+  HCK(hipDeviceSynchronize());
+  const double err = compare(f2, f1, no, name);
+  const bool ok = err == 0.0;
+  if (!ok) { ++g_fail; dump_mismatch(f2, f1, n, h, w, cout); }
+  printf("%-30s full %6.1f us | hi-only %6.1f us | max rel diff %.1e%s\n", name, t_full, t_hi, err, ok ? "" : " FAIL");
+  hipFree(x); hipFree(wt); hipFree(sc); hipFree(sh); hipFree(spf); hipFree(sph); hipFree(pk); hipFree(o1); hipFree(o2);
+  hipFree(f1); hipFree(f2);
+}
+
 static void roundtrip() {
   const int n = 2, h = 20, w = 24, c = 45;
   float* s = dev_random((size_t)n * h * w * c, 3.f);
@@ -231,12 +309,17 @@ int main(int argc, char** argv) {
   run_layer("ragged 3x3 40x72 48->80", 2, 40, 72, 48, 0, 0, 80, 3, 1, quick);
   run_layer("ragged 3x3 s2 40x72 32->96", 2, 40, 72, 32, 0, 0, 96, 3, 2, quick);
   run_layer("ragged 3x3 up+cat 24x40", 2, 24, 40, 32, 16, 1, 48, 3, 1, quick);
+  run_layer("ragged 3x3 up+cat 10x70 c1=24", 3, 10, 70, 16, 24, 1, 40, 3, 1, quick);
+  run_layer("ragged 3x3 up only 16x32", 2, 16, 32, 32, 0, 1, 96, 3, 1, quick);
   run_layer("ragged 1x1 24x40 64->96", 2, 24, 40, 64, 0, 0, 96, 1, 1, quick);
   run_post("post f32 2x40x64 32->64->48", 2, 40, 64, 32, 48, 12, true);
   run_post("post f32 blockdiag 3x40x72", 3, 40, 72, 32, 48, 12, true, true);
   run_post("post f32 blockdiag 96->64->8", 2, 24, 40, 96, 8, 4, true, true);
   run_post("post sp  2x40x64 64->64->64", 2, 40, 64, 64, 64, 64, false);
+  run_hi_only("hi-only 3x40x72 13->32", 3, 40, 72, 13, 32);
+  run_hi_only("hi-only 2x24x40 20->80", 2, 24, 40, 20, 80);
   // the BASELINE layers
+  run_hi_only("conv_pre_1 256^2 13->32", n, 256, 256, 13, 32);
   run_layer("conv_pre_2 256^2 32->32", n, 256, 256, 32, 0, 0, 32, 3, 1, quick);
   run_layer("conv1_1 256^2 32->64 s2", n, 256, 256, 32, 0, 0, 64, 3, 2, quick);
   run_layer("conv1_2 128^2 64->64", n, 128, 128, 64, 0, 0, 64, 3, 1, quick);
