@@ -64,14 +64,22 @@ def test_argument_errors_are_reported_not_thrown():
 def test_packed_weight_image_sizes():
     """size queries are host arithmetic (no GPU): 9 tap blocks per 16-channel chunk, chunks padded to a
     multiple of 4; a 3x3 stride-1 layer over a nearest-upsampled first source packs that source's chunks
-    row-merged: 12 blocks [row-tap 2][parity 2][tx 3] (csrc/conv_sp.hip, UPM)"""
+    tap-merged: 16 blocks [merged tap 4][parity class 4] (csrc/conv_spq.hip; mode 1 = the row-merged form of
+    csrc/conv_sp.hip UPM: 12 blocks [row-tap 2][parity 2][tx 3]; mode 0 = plain)"""
     from disconet_amd import _lib, ops
     lib = _lib.load()
     block = lambda cout: 4 * ((cout + 63) // 64 * 64) * 16
     d = ops.conv_desc(20, 256, 256, 32, 32, 3, math="sp")
     assert lib.dn_spconv_packed_weight_bytes(ctypes.byref(d)) == 4 * 9 * block(32)
     d = ops.conv_desc(20, 32, 32, 512, 256, 3, c1=256, up0=True, math="sp")      # conv5_1
-    assert lib.dn_spconv_packed_weight_bytes(ctypes.byref(d)) == (32 * 12 + 16 * 9) * block(256)
+    assert lib.dn_spconv_packed_weight_bytes(ctypes.byref(d)) == (32 * 16 + 16 * 9) * block(256)
+    try:
+        lib.dn_spconv_set_upmode(1)
+        assert lib.dn_spconv_packed_weight_bytes(ctypes.byref(d)) == (32 * 12 + 16 * 9) * block(256)
+        lib.dn_spconv_set_upmode(0)
+        assert lib.dn_spconv_packed_weight_bytes(ctypes.byref(d)) == 48 * 9 * block(256)
+    finally:
+        lib.dn_spconv_set_upmode(-1)
     d = ops.conv_desc(20, 33, 32, 512, 256, 3, c1=256, up0=True, math="sp")      # odd height: rejected
     assert lib.dn_spconv_packed_weight_bytes(ctypes.byref(d)) == 0 and b"even" in lib.dn_last_error()
     d = ops.conv_desc(20, 32, 32, 24, 64, 3, c1=8, up0=True, math="sp")          # c0 not whole chunks: rejected at pack
