@@ -43,6 +43,9 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3,      # v_mfma_f32_32x32x2_f32
                     "sp": 2500.0}
 EXECUTED_FLOP_FACTOR = {"f32": 1, "f16x3": 3, "sp": 3}
 CONV_KERNELS = ("conv_mfma_kernel", "conv_sp_kernel")
+DTYPE_NAME = {"f32": "f32", "f16x3": "f32 storage; conv products as split-f16 x3 MFMA, f32 accumulate",
+              "sp": "f16 hi+lo pair per value (32 bits; 22-bit significand for |x| >= 0.125, f16 exponent range, "
+                    "lo subnormal below: absolute floor 2^-25); conv products as split-f16 x3 MFMA, f32 accumulate"}
 MATH_LABEL = {"f32": "exact-fp32", "f16x3": "split-f16x3 (fp32 NHWC activations)",
               "sp": "split-f16x3, split-planar activations staged by LDS-DMA"}
 
@@ -83,6 +86,15 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=4,
                     help="also time this many training steps (forward + loss + backward + Adam) of the "
                          "same batch; 0 = skip (reported next to the headline value, never in it)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="--mode agent on ONE GPU: also time rank 0's share of a W-rank agent-sharded run (8 / W "
+                         "agents, peers' maps by device copy) and print projected_speedup = T(unsharded) / T(share)")
+    ap.add_argument("--agent-check", type=int, default=0,
+                    help="--mode agent: replay this many extra steps and compare every step's output checksum with "
+                         "the first (all-gather kernel between the two compute graphs)")
+    ap.add_argument("--no-agent-leg", action="store_true",
+                    help="skip the agent-sharded leg (BASELINE configs[4]) that the default line carries as "
+                         "`agent_sharded` when the GPU count divides 8")
     ap.add_argument("--force-process-group", action="store_true",
                     help="create the RCCL process group even for one rank (exercises the N>1 code path)")
     ap.add_argument("--cpu-baseline-child", nargs=3, metavar=("STATE", "OUT", "THREADS"),
@@ -171,67 +183,159 @@ def cpu_baseline_bounded(state_dict, threads, timeout_s):
                 "sample": "1 scene (5 agents, 256x256x13)", "error": type(e).__name__}, None
 
 
-def agent_sharded_bench(args, world, rank, dist):
-    """BASELINE configs[4]: 8-agent scenes, one agent group per GPU, RCCL all-gather of
-    the intermediate maps as the V2X exchange.  Fixed work (batch 4 of 8-agent scenes)
-    for every N -> "scaling": "strong"."""
+def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
+    """BASELINE configs[4] (the north star's multi-GPU split): 8-agent scenes, the agents sharded across the
+    ranks, ONE RCCL all-gather of the layer-3 maps per step as the V2X exchange, everything else rank-local.
+    Fixed work (batch 4 of 8-agent scenes) for every N -> strong scaling.  One step = dense rebuild of this
+    rank's voxel lists + encoder (hipGraph A) -> all-gather (eager, in stream order) -> fusion of this rank's
+    egos + decoder + heads (hipGraph B): disconet_amd.sharded.GraphedAgentStep.
+
+    emulate_world = W on ONE GPU: time rank 0's share of a W-rank run (8 / W agents; the exchange is a device
+    copy of the peers' maps) next to the unsharded 8-agent step -> projected_speedup = T(8 agents, 1 GPU) /
+    T(share): an upper bound for the W-GPU curve (no link latency, no rank skew).
+    check_steps: replay that many steps and compare a checksum of every step's outputs with the first one's
+    (the collective's kernel runs between our two graphs; outputs must stay bit-identical).
+    Returns the result dict on rank 0, None elsewhere.  Needs an initialised process group unless emulating."""
     from disconet_amd import Config, DiscoNet, ops, sharded
     from disconet_amd.synthetic import make_sparse_scene_batch, make_trans_matrices, randomize_bn_stats
     agents = 8
-    if agents % world:
-        raise SystemExit("--mode agent needs a GPU count that divides 8 agents")
-    if world == 1:
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
-                                device_id=torch.device("cuda", torch.cuda.current_device()))
     torch.manual_seed(0)
     model = DiscoNet(Config(map_hw=MAP_HW), kd_flag=0, num_agent=agents)
     randomize_bn_stats(model)
     model.conv_math = args.math
     model.eval().cuda()
     engine = sharded.HipEngine(model)
-    first, count = sharded.agent_range(agents, world, rank)
     indices, offsets, _ = make_sparse_scene_batch(BATCH, agents, MAP_HW)
-    # this rank's agents: images [first*B, (first+count)*B) of the agent-major stack
-    lo, hi = int(offsets[first * BATCH]), int(offsets[(first + count) * BATCH])
-    my_idx = indices[lo:hi].contiguous().cuda()
-    my_off = (offsets[first * BATCH:(first + count) * BATCH + 1] - lo).to(torch.int32).cuda()
     trans = make_trans_matrices(BATCH, agents).cuda()
     na = torch.full((BATCH, agents), agents, dtype=torch.int64).cuda()
     dims = (MAP_HW, MAP_HW, 13)
 
-    def step():
-        bevs = ops.scatter_dense(my_idx, my_off, count * BATCH, dims)
-        with torch.no_grad():
-            return sharded.forward_agent_sharded(engine, bevs, trans, na, BATCH)
+    def rank_inputs(first, count):
+        # this rank's agents: images [first*B, (first+count)*B) of the agent-major stack
+        lo, hi = int(offsets[first * BATCH]), int(offsets[(first + count) * BATCH])
+        idx = indices[lo:hi].contiguous().cuda()
+        off = (offsets[first * BATCH:(first + count) * BATCH + 1] - lo).to(torch.int32).cuda()
+
+        def make_bevs():
+            if model.conv_math == "sp":
+                return ops.scatter_dense_sp(idx, off, count * BATCH, dims, hi_only=True)
+            return ops.scatter_dense(idx, off, count * BATCH, dims)
+        return make_bevs
+
+    def checksum(out):
+        res, fused = out
+        f = fused.data if isinstance(fused, ops.SpTensor) else fused
+        return (res["cls"].view(torch.int64).sum() + 3 * res["loc"].view(torch.int64).sum()
+                + 5 * f.contiguous().view(torch.int32).sum())
 
     def fence():
         torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    t = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    def time_steps(stepper, steps, warmup):
+        for _ in range(warmup):
+            stepper()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stepper()
+        fence()
+        dt = time.perf_counter() - t0
+        if dist.is_initialized():
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def phase_us(fn, reps=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return round(1e3 * e0.elapsed_time(e1) / reps, 2)
+
+    first, count = sharded.agent_range(agents, world, rank)
+    stepper = sharded.GraphedAgentStep(engine, rank_inputs(first, count), trans, na, BATCH, first, count)
+    elapsed = time_steps(stepper, args.steps, args.warmup)
+    res = None
     if rank == 0:
-        print(json.dumps({
+        res = {
             "metric": "scenes/sec (8-agent 256x256 BEV, agents sharded across GPUs)",
             "value": round(BATCH * args.steps / elapsed, 3), "unit": "scenes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if args.math == "f32" else "f32 storage; conv products as split-f16 x3 MFMA, f32 accumulate",
-            "data": "synthetic",
-            "config": {"workload": "DiscoNet det eval forward, 8-agent scenes, batch 4, 256x256x13 BEV, "
-                                   "%d agent(s) per GPU, RCCL all-gather of the 256x32x32 maps" % count,
+            "scaling": "strong", "vs_baseline": None, "dtype": DTYPE_NAME[args.math], "data": "synthetic",
+            "config": {"workload": "DiscoNet det eval forward (--com disco), 8-agent scenes, batch 4, 256x256x13 BEV, "
+                                   "%d agent(s) per GPU, one RCCL all-gather of the 256x32x32 layer-3 maps per "
+                                   "step (BASELINE configs[4])" % count,
                        "agents": agents, "batch": BATCH, "conv_math": args.math,
-                       "parallelism": "agent-parallel x%d" % world}}), flush=True)
+                       "launch": "hipGraph A (rebuild + encoder) -> all-gather -> hipGraph B (fusion + decoder + heads)",
+                       "parallelism": "agent-parallel x%d" % world},
+            "phases_us": {"graph_a_encode": phase_us(stepper.graph_a), "allgather": phase_us(stepper.exchange),
+                          "graph_b_fuse_decode_heads": phase_us(stepper.graph_b)},
+            "exchanged_bytes_per_rank_per_step": int(stepper.feat_all.numel() * stepper.feat_all.element_size()
+                                                     * (world - 1) // max(world, 1)),
+        }
+    if check_steps > 0:
+        want = checksum(stepper()).clone()
+        sums = torch.zeros(check_steps, dtype=torch.int64, device="cuda")
+        for i in range(check_steps):
+            sums[i] = checksum(stepper())
+        torch.cuda.synchronize()
+        differing = int((sums != want).sum().item())
+        if dist.is_initialized():
+            t = torch.tensor([differing], device="cuda", dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            differing = int(t.item())
+        if rank == 0:
+            res["replay_check"] = {"steps": check_steps, "differing": differing,
+                                   "how": "checksum of cls + loc + fused map after every step (graph A, all-gather, "
+                                          "graph B back to back) vs the first step's"}
+    if emulate_world and world == 1 and rank == 0:
+        W = emulate_world
+        if agents % W:
+            raise SystemExit("--emulate-world must divide 8 agents")
+        full_feat = stepper.feat_all.clone()              # every agent's layer-3 map, from the unsharded step
+        full_out = stepper()
+        full = {"cls": full_out[0]["cls"].clone(), "loc": full_out[0]["loc"].clone()}
+        cnt = agents // W
+        share = sharded.GraphedAgentStep(engine, rank_inputs(0, cnt), trans, na, BATCH, 0, cnt,
+                                         emulate_feat_all=full_feat)
+        t_share = time_steps(share, args.steps, args.warmup)
+        got = share()
+        torch.cuda.synchronize()
+        rows = cnt * BATCH
+        same = bool(torch.equal(got[0]["cls"], full["cls"][:rows]) and torch.equal(got[0]["loc"], full["loc"][:rows]))
+        res["emulated_share"] = {
+            "world": W, "agents_per_rank": cnt, "ms_per_step": round(1e3 * t_share / args.steps, 4),
+            "phases_us": {"graph_a_encode": phase_us(share.graph_a), "exchange_copy": phase_us(share.exchange),
+                          "graph_b_fuse_decode_heads": phase_us(share.graph_b)},
+            "projected_speedup": round(elapsed / t_share, 3),
+            "outputs_equal_unsharded_rows": same,
+            "note": "rank 0's share of a %d-rank run timed on one GPU (peers' maps arrive by a device copy: no "
+                    "link latency, no rank skew); projected_speedup = T(8 agents, 1 GPU) / T(share) bounds the "
+                    "measured curve from above" % W}
+    return res
+
+
+def agent_sharded_bench(args, world, rank, dist):
+    if 8 % world:
+        raise SystemExit("--mode agent needs a GPU count that divides 8 agents")
+    if world == 1 and not dist.is_initialized():
+        import datetime
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                                device_id=torch.device("cuda", torch.cuda.current_device()),
+                                timeout=datetime.timedelta(seconds=120))
+    res = agent_sharded_leg(args, world, rank, dist, emulate_world=args.emulate_world, check_steps=args.agent_check)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     dist.destroy_process_group()
 
 
@@ -581,9 +685,16 @@ def main():
         if outputs_same is not None:
             outputs_same = bool(t[2].item() <= -1.0)
 
-    dtype_name = {"f32": "f32", "f16x3": "f32 storage; conv products as split-f16 x3 MFMA, f32 accumulate",
-                  "sp": "f16 hi+lo pair per value (32 bits, 22-bit significand); conv products as split-f16 x3 "
-                        "MFMA, f32 accumulate"}
+    dtype_name = DTYPE_NAME
+    # the north star's multi-GPU split rides in the same line: BASELINE configs[4], agents sharded across the ranks,
+    # one RCCL all-gather per step (every rank runs it; at N = 1 with rank 0's share of an 8-rank run emulated)
+    agent_res = None
+    if not args.no_agent_leg and args.math == "sp" and 8 % world == 0 and args.in_flight == 1:
+        try:
+            agent_res = agent_sharded_leg(args, world, rank, dist, emulate_world=8 if world == 1 else 0)
+        except Exception as e:      # never lose the headline line to the extra leg
+            agent_res = {"error": repr(e)}
+        torch.cuda.synchronize()
     scenes = world * BATCH * args.steps
     result = {
         "metric": "scenes/sec (5-agent 256x256 BEV)",
@@ -633,6 +744,8 @@ def main():
             result["one_step_at_a_time"] = {"value": result["value"], "ms_per_step": result["ms_per_step"],
                                             "note": "the headline itself: one captured step replayed back to back "
                                                     "on one stream per rank (--in-flight 1, the default)"}
+        if agent_res is not None:
+            result["agent_sharded"] = agent_res
         if timer is not None:
             result["roofline"] = roofline_of(timer, elapsed_events, args.math)
         if world == 1 and not args.no_alt_math:

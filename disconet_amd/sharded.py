@@ -34,11 +34,13 @@ def local_bevs(bevs_all, num_agent, batch_size, world_size, rank):
     return bevs_all[first * batch_size:(first + count) * batch_size]
 
 
-def all_gather_agent_major(x_local, group=None):
+def all_gather_agent_major(x_local, group=None, out=None):
     """[A_local*B, ...] per rank -> [A*B, ...] agent-major on every rank.  Rank
-    order == agent order, so the concatenation IS the agent-major layout."""
+    order == agent order, so the concatenation IS the agent-major layout.
+    `out`: a preallocated result (a static buffer of a captured step)."""
     world = dist.get_world_size(group)
-    out = x_local.new_empty((x_local.shape[0] * world,) + tuple(x_local.shape[1:]))
+    if out is None:
+        out = x_local.new_empty((x_local.shape[0] * world,) + tuple(x_local.shape[1:]))
     x_local = x_local.contiguous()
     try:
         dist.all_gather_into_tensor(out, x_local, group=group)
@@ -62,7 +64,7 @@ class HipEngine:
     def fuse(self, feat_all, trans, num_agent, batch_size, ego_first, ego_count):
         m = self.model
         return m.fuse(feat_all, trans, num_agent, batch_size, m._get_plan(),
-                      ego_first=ego_first, ego_count=ego_count)
+                      ego_first=ego_first, ego_count=ego_count, sp_out=m.conv_math == "sp")
 
     def decode_heads(self, enc_local):
         m = self.model
@@ -91,6 +93,70 @@ def forward_agent_sharded(engine, bevs_local, trans_matrices, num_agent_tensor, 
     enc = list(enc)
     enc[engine.layer] = fused
     return engine.decode_heads(enc), fused
+
+
+class GraphedAgentStep:
+    """One rank's agent-sharded forward as TWO captured hipGraphs around the exchange:
+
+        graph A: dense rebuild of this rank's voxel lists + encoder        (make_bevs, engine.encode)
+        exchange: RCCL all-gather of the layer-`layer` maps, eager, in stream order between the graphs
+                  (the collective's kernel never runs beside one of ours: the compute stream waits for it)
+        graph B: fusion of this rank's egos against all maps + decoder + heads
+
+    Per-rank work at 8 GPUs is 4 images -- ~50 launches of 5-30 us each -- so eager launches from Python
+    would cost more than the kernels; the two replays leave one host call per phase.
+
+    `emulate_feat_all`: single-process emulation of one rank's share (bench.py --emulate-world): a tensor
+    holding ALL agents' layer maps; the exchange becomes a device copy of the peers' maps into the gathered
+    buffer (same bytes landing in HBM, no link latency) and this rank's own rows are overwritten by what
+    graph A just computed.
+    """
+
+    def __init__(self, engine, make_bevs, trans_matrices, num_agent_tensor, batch_size, first, count,
+                 group=None, emulate_feat_all=None):
+        from .graph import GraphedStep
+        self.engine, self.group, self.first, self.count, self.batch = engine, group, first, count, batch_size
+        self.emulated = emulate_feat_all is not None
+        layer = engine.layer
+        with torch.no_grad():
+            self.graph_a = GraphedStep(lambda: engine.encode(make_bevs()))
+        self.enc = list(self.graph_a.outputs)
+        x_local = self.enc[layer]
+        world = 1 if (self.emulated or not (dist.is_available() and dist.is_initialized())) else dist.get_world_size(group)
+        n_all = engine.agent_num * batch_size
+        assert x_local.shape[0] * (engine.agent_num // count) == n_all
+        self.feat_all = x_local.new_empty((n_all,) + tuple(x_local.shape[1:]))
+        self.peers = emulate_feat_all
+        self.world = world
+        dev = x_local.device
+        trans = trans_matrices.to(device=dev, dtype=torch.float32).contiguous()
+        num_agent = num_agent_tensor[:, 0].to(device=dev, dtype=torch.int32).contiguous()
+        self.exchange()                       # the gathered buffer holds real maps before graph B's warm-up
+
+        def fuse_decode():
+            fused = engine.fuse(self.feat_all, trans, num_agent, batch_size, first, count)
+            enc = list(self.enc)
+            enc[layer] = fused
+            return engine.decode_heads(enc), fused
+
+        with torch.no_grad():
+            self.graph_b = GraphedStep(fuse_decode)
+
+    def exchange(self):
+        x_local = self.enc[self.engine.layer]
+        if self.emulated:
+            self.feat_all.copy_(self.peers)                      # the peers' maps arriving
+            lo = self.first * self.batch
+            self.feat_all[lo:lo + x_local.shape[0]].copy_(x_local)
+        elif self.count == self.engine.agent_num and not (dist.is_available() and dist.is_initialized()):
+            self.feat_all.copy_(x_local)                         # one process owns every agent: nothing to exchange
+        else:
+            all_gather_agent_major(x_local, self.group, out=self.feat_all)
+
+    def __call__(self):
+        self.graph_a()
+        self.exchange()
+        return self.graph_b()
 
 
 def average_gradients_(flat_grad):

@@ -76,3 +76,43 @@ def test_hip_engine_single_rank_world():
         assert torch.equal(got["cls"], want["cls"]) and torch.equal(got["loc"], want["loc"])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [8, 4])
+def test_graphed_emulated_share_equals_unsharded_rows(world):
+    """bench.py --mode agent --emulate-world: one rank's share of a `world`-rank agent-sharded run (its agents
+    through graph A, the peers' maps by device copy, its egos through graph B) must be the matching rows of
+    the unsharded 8-agent forward, bit for bit -- for every rank of the emulated world."""
+    from disconet_amd import Config, DiscoNet, ops, sharded
+    from disconet_amd.synthetic import make_sparse_scene_batch, make_trans_matrices
+    A, B, hw = 8, 2, 128
+    torch.manual_seed(5)
+    m = DiscoNet(Config(map_hw=hw), kd_flag=0, num_agent=A).eval().cuda()
+    engine = sharded.HipEngine(m)
+    indices, offsets, _ = make_sparse_scene_batch(B, A, hw)
+    trans = make_trans_matrices(B, A, jitter_seed=3).cuda()
+    na = torch.full((B, A), A, dtype=torch.int64).cuda()
+    dims = (hw, hw, 13)
+
+    def inputs(first, count):
+        lo, hi = int(offsets[first * B]), int(offsets[(first + count) * B])
+        idx = indices[lo:hi].contiguous().cuda()
+        off = (offsets[first * B:(first + count) * B + 1] - lo).to(torch.int32).cuda()
+        return lambda: ops.scatter_dense_sp(idx, off, count * B, dims, hi_only=True)
+
+    with torch.no_grad():
+        want = m(ops.scatter_dense_sp(indices.cuda(), offsets.cuda(), A * B, dims), trans, na, B)
+    full = sharded.GraphedAgentStep(engine, inputs(0, A), trans, na, B, 0, A)      # no process group: local exchange
+    res, _ = full()
+    torch.cuda.synchronize()
+    assert torch.equal(res["cls"], want["cls"]) and torch.equal(res["loc"], want["loc"])
+    feat_all = full.feat_all.clone()
+    cnt = A // world
+    for r in (0, world - 1, world // 2):
+        share = sharded.GraphedAgentStep(engine, inputs(r * cnt, cnt), trans, na, B, r * cnt, cnt,
+                                         emulate_feat_all=feat_all)
+        for _ in range(2):          # replayed: the second replay must reproduce the first
+            got, _ = share()
+        torch.cuda.synchronize()
+        rows = slice(r * cnt * B, (r + 1) * cnt * B)
+        assert torch.equal(got["cls"], want["cls"][rows]) and torch.equal(got["loc"], want["loc"][rows]), (world, r)
