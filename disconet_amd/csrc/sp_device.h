@@ -5,7 +5,10 @@
 #include <hip/hip_runtime.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef DN_F32X4_DEFINED
+#define DN_F32X4_DEFINED
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
