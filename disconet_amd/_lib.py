@@ -94,6 +94,9 @@ SIGNATURES = {
     "dn_disco_fuse_mlp": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(FuseMlpParams), c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    "dn_disco_fuse_warp": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(FuseMlpParams), c_int, c_int,
+                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
     # ---- include/disconet_seg.h ----
     "dn_sp_maxpool2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dn_sp_upsample2_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

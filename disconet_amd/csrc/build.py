@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["common.hip", "conv_mfma.hip", "conv_sp.hip", "conv_spq.hip", "voxel.hip", "warp.hip", "fuse_tail.hip", "fuse_mlp.hip", "decode.hip",
+SOURCES = ["common.hip", "conv_mfma.hip", "conv_sp.hip", "conv_spq.hip", "voxel.hip", "warp.hip", "fuse_tail.hip", "fuse_mlp.hip", "fuse_warp.hip", "decode.hip",
            "conv_wgrad.hip", "train_ops.hip", "seg_ops.hip"]
 LIB_PATH = os.path.join(os.path.dirname(HERE), "libdisconet_hip.so")
 
@@ -17,7 +17,7 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(HERE, s) for s in SOURCES] + [
-        os.path.join(HERE, "dn_internal.h"), os.path.join(HERE, "sp_layout.h"), os.path.join(HERE, "sp_device.h"), os.path.join(ROOT, "include", "disconet_hip.h"),
+        os.path.join(HERE, "dn_internal.h"), os.path.join(HERE, "sp_layout.h"), os.path.join(HERE, "sp_device.h"), os.path.join(HERE, "warp_device.h"), os.path.join(ROOT, "include", "disconet_hip.h"),
         os.path.join(ROOT, "include", "disconet_train.h"), os.path.join(ROOT, "include", "disconet_seg.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -33,7 +33,8 @@ hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
 extern "C" int dn_version(void) { return 110; }  // 0.1.1
 
 extern "C" unsigned dn_sp_range_flags(int reset) {
-  return dn::range_flags_conv_sp(reset != 0) | dn::range_flags_conv_spq(reset != 0) | dn::range_flags_fuse_mlp(reset != 0);
+  return dn::range_flags_conv_sp(reset != 0) | dn::range_flags_conv_spq(reset != 0) | dn::range_flags_fuse_mlp(reset != 0) |
+         dn::range_flags_fuse_warp(reset != 0);
 }
 
 extern "C" const char* dn_last_error(void) { return dn::err_buf(); }

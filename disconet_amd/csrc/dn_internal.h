@@ -51,6 +51,7 @@ int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const vo
 unsigned range_flags_conv_sp(bool reset);
 unsigned range_flags_conv_spq(bool reset);
 unsigned range_flags_fuse_mlp(bool reset);
+unsigned range_flags_fuse_warp(bool reset);
 
 }  // namespace dn
 

@@ -287,6 +287,9 @@ class DiscoNet(nn.Module):
         # one-launch attention MLP + softmax + weighted sum (csrc/fuse_mlp.hip) instead of
         # two 1x1 conv launches + the tail kernel (split-f16 engines, C in {64, 128, 256})
         self.fuse_mlp = os.environ.get("DISCONET_FUSE_MLP", "1") != "0"
+        # ... and the pose warp inside that launch as well (csrc/fuse_warp.hip): the warped neighbour maps are
+        # re-derived tile by tile in LDS and never written.  DISCONET_FUSE_WARP=0: warp kernel + fuse_mlp.
+        self.fuse_warp = os.environ.get("DISCONET_FUSE_WARP", "1") != "0"
         # run the encoder levels above the exchanged one beside the fusion block on a second HIP stream:
         # REFUSED unless DISCONET_UNSAFE_OVERLAP=1 (the property below).  A kernel that shares a SIMD with
         # the split-f16 conv kernels has been observed to compute with corrupted VGPR lanes (DESIGN.md
@@ -351,7 +354,7 @@ class DiscoNet(nn.Module):
     def _signature(self):
         if self.conv_math not in ops.MATH_MODES:
             raise ValueError("conv_math must be one of %s" % sorted(ops.MATH_MODES))
-        return (self.conv_math, self.fuse_1x1, self.fuse_mlp) + tuple((t.data_ptr(), t._version) for t in
+        return (self.conv_math, self.fuse_1x1, self.fuse_mlp, self.fuse_warp) + tuple((t.data_ptr(), t._version) for t in
                                          list(self.parameters()) + list(self.buffers()))
 
     def _build_plan(self):
@@ -502,6 +505,12 @@ class DiscoNet(nn.Module):
         B = batch_size
         map_bytes = 4.0 * h * w * c
         pairs = B * E * (A - 1)
+        if "_fuse_mlp" in P and self.fuse_warp and A <= 8:
+            # one launch, no `warped` tensor: every agent's map read (L2), the served egos' fused maps written
+            flops = 2.0 * B * E * h * w * (128.0 * c * (2 + (A - 1)) + A * (128 * 32 + 32 * 8 + 8))
+            with region("fuse_warp", "disco_fuse_warp_kernel", flops, map_bytes * (n + E * B)):
+                return ops.disco_fuse_warp(feat, trans_matrices, num_agent, P["_fuse_mlp"], B, A, self.only_v2i,
+                                           want_weights, ego_first, E, sp_out=sp_out)
         warped = torch.empty((B, E, max(A - 1, 0), h, w, c), dtype=torch.float32,
                              device=feat.device)
         with region("warp", "warp_neighbors_kernel", 0.0, map_bytes * (n + pairs)):

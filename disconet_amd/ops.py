@@ -507,6 +507,28 @@ def disco_fuse_mlp(feat, warped, num_agent, params, batch, agents, only_v2i=Fals
     return (res, weights) if want_weights else res
 
 
+def disco_fuse_warp(feat, trans, num_agent, params, batch, agents, only_v2i=False, want_weights=False,
+                    ego_first=0, ego_count=None, sp_out=False):
+    """Pose warp + attention MLP + agent softmax + weighted sum in ONE launch (no `warped` tensor).
+    feat [A*B, h, w, C] NHWC (all agents), trans [B, A, A, 4, 4]; -> SpTensor (sp_out) or float32 NHWC
+    [E*B, h, w, C] (+ weights [B, E, A, h*w] when want_weights)."""
+    _need_gpu(feat, num_agent, trans)
+    _f32c(feat, "feat")
+    _f32c(trans, "trans_matrices")
+    ego_count = agents if ego_count is None else ego_count
+    n, h, w, c = feat.shape
+    out_sp = SpTensor(ego_count * batch, h, w, c, device=feat.device) if sp_out else None
+    out = None if sp_out else torch.empty((ego_count * batch, h, w, c), dtype=torch.float32, device=feat.device)
+    weights = (torch.zeros((batch, ego_count, agents, h * w), dtype=torch.float32, device=feat.device)
+               if want_weights else None)
+    check(_lib.load().dn_disco_fuse_warp(_ptr(feat), _ptr(trans), _ptr(num_agent), ctypes.byref(params),
+                                         batch, agents, h, w, c, int(only_v2i), ego_first, ego_count,
+                                         _ptr(out_sp.data) if sp_out else None, _ptr(out), _ptr(weights),
+                                         _stream()), "dn_disco_fuse_warp")
+    res = out_sp if sp_out else out
+    return (res, weights) if want_weights else res
+
+
 def make_tail_params(tensors):
     """tensors: dict name -> float32 device tensor for every dn_mlp_tail_params field."""
     p = MlpTailParams()

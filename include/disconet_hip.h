@@ -315,6 +315,21 @@ int dn_disco_fuse_mlp(const float* feat, const float* warped, const int32_t* num
                       float* fused_nhwc, float* weights_out, void* stream);
 
 /* ------------------------------------------------------------------------
+ * K4 + K5 + K6 in ONE launch (disconet_amd/csrc/fuse_warp.hip): dn_warp_neighbors and
+ * dn_disco_fuse_mlp fused -- the warped neighbour maps are re-derived tile by tile in LDS (rotated
+ * block of an 8 x 4 pixel tile, then the translation blend straight into the MFMA operands) and never
+ * written: no `warped` tensor.  Same semantics, neighbour order, ego range, only_v2i and outputs as
+ * dn_disco_fuse_mlp; feat [A*B][h][w][c] float32 NHWC (all agents), trans [B][A][A][4][4], p from
+ * dn_fuse_mlp_pack.  c in {64, 128, 256}, agents <= 8.
+ * Replaces feature_transformation + PixelWeightedFusionSoftmax.forward + the fusion loop body of
+ * upstream:coperception/models/det/DiscoNet.py :: DiscoNet.forward.
+ * ------------------------------------------------------------------------ */
+int dn_disco_fuse_warp(const float* feat, const float* trans, const int32_t* num_agent,
+                       const dn_fuse_mlp_params* p, int batch, int agents, int h, int w, int c,
+                       int only_v2i, int ego_first, int ego_count, void* fused_sp, float* fused_nhwc,
+                       float* weights_out, void* stream);
+
+/* ------------------------------------------------------------------------
  * Detection decode (first step after the hot path).
  * Replaces the dense part of upstream:coperception/utils/postprocess.py that
  * CoDetModule.predict_all runs on the CPU: foreground probability = softmax of
