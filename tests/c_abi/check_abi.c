@@ -3,7 +3,9 @@
  *   gcc -std=c11 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tests/c_abi/check_abi.c \
  *       -L disconet_amd -ldisconet_hip -L /opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,... -o check_abi
  *   ./check_abi          error behaviour only (no GPU needed)
- *   ./check_abi --gpu    + a 3x3 conv (both math modes) and the voxelizer against C loops
+ *   ./check_abi --gpu    + a 3x3 conv (both math modes), the voxelizer, the split-planar engine (plain and over an
+ *                        upsampled + concatenated source), the hi-only occupancy form, the range flags, the pose warp
+ *                        and both forms of the fusion launch against C loops
  */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -115,10 +117,247 @@ static int gpu_voxel(void) {
   return 0;
 }
 
+/* ---- the inference engine's default path: dn_spconv_pack_weights -> dn_spconv2d -> dn_sp_to_nhwc, plain and
+ * over cat([upsample x2 (src0), src1]) (the tap-merged image / kernel), against C loops ---- */
+static int gpu_spconv(int up) {
+  const int n = 2, h = 16, w = 40, c0 = up ? 32 : 24, c1 = up ? 16 : 0, cin = c0 + c1, cout = 40;
+  const int h0 = up ? h / 2 : h, w0 = up ? w / 2 : w;
+  dn_conv_desc d;
+  memset(&d, 0, sizeof d);
+  d.n_images = n; d.h_in = h; d.w_in = w; d.c0 = c0; d.c1 = c1; d.up0 = up; d.c_out = cout; d.ksize = 3; d.stride = 1;
+  d.relu = 1; d.ld0 = c0; d.ld1 = c1; d.ldo = cout; d.math = 2;
+  const size_t n0 = (size_t)n * h0 * w0 * c0, n1 = (size_t)n * h * w * c1, ny = (size_t)n * h * w * cout, nw = (size_t)cout * cin * 9;
+  float *x0 = malloc(n0 * 4), *x1 = malloc((n1 + 1) * 4), *wt = malloc(nw * 4), *bias = malloc(cout * 4), *y = malloc(ny * 4), *ref = malloc(ny * 4);
+  unsigned s = 11 + up;
+  for (size_t i = 0; i < n0; ++i) x0[i] = frand(&s);
+  for (size_t i = 0; i < n1; ++i) x1[i] = frand(&s);
+  for (size_t i = 0; i < nw; ++i) wt[i] = frand(&s) * 0.08f;
+  for (int i = 0; i < cout; ++i) bias[i] = frand(&s) * 0.1f;
+  for (int im = 0; im < n; ++im) for (int oy = 0; oy < h; ++oy) for (int ox = 0; ox < w; ++ox) for (int co = 0; co < cout; ++co) {
+    double acc = bias[co];
+    for (int dy = 0; dy < 3; ++dy) for (int dx = 0; dx < 3; ++dx) {
+      const int iy = oy + dy - 1, ix = ox + dx - 1;
+      if (iy < 0 || iy >= h || ix < 0 || ix >= w) continue;
+      const int sy = up ? iy / 2 : iy, sx = up ? ix / 2 : ix;
+      for (int ci = 0; ci < c0; ++ci)
+        acc += (double)x0[((size_t)(im * h0 + sy) * w0 + sx) * c0 + ci] * wt[((size_t)co * cin + ci) * 9 + dy * 3 + dx];
+      for (int ci = 0; ci < c1; ++ci)
+        acc += (double)x1[((size_t)(im * h + iy) * w + ix) * c1 + ci] * wt[((size_t)co * cin + c0 + ci) * 9 + dy * 3 + dx];
+    }
+    ref[((size_t)(im * h + oy) * w + ox) * cout + co] = acc > 0 ? (float)acc : 0.f;
+  }
+  float *dx0, *dx1 = NULL, *dw, *db, *dsc, *dsh, *dy_;
+  void *sp0, *sp1 = NULL, *spo, *pk;
+  const size_t pkb = dn_spconv_packed_weight_bytes(&d);
+  CHECK(pkb > 0, "sp packed size: %s", dn_last_error());
+  HIP(hipMalloc((void**)&dx0, n0 * 4)); HIP(hipMalloc((void**)&dw, nw * 4)); HIP(hipMalloc((void**)&db, cout * 4));
+  HIP(hipMalloc((void**)&dsc, cout * 4)); HIP(hipMalloc((void**)&dsh, cout * 4)); HIP(hipMalloc((void**)&dy_, ny * 4));
+  HIP(hipMalloc(&sp0, dn_sp_tensor_bytes(n, h0, w0, c0))); HIP(hipMalloc(&spo, dn_sp_tensor_bytes(n, h, w, cout))); HIP(hipMalloc(&pk, pkb));
+  HIP(hipMemcpy(dx0, x0, n0 * 4, hipMemcpyHostToDevice)); HIP(hipMemcpy(dw, wt, nw * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(db, bias, cout * 4, hipMemcpyHostToDevice));
+  CHECK(dn_sp_from_nhwc(dx0, n, h0, w0, c0, c0, sp0, NULL) == DN_OK, "from_nhwc: %s", dn_last_error());
+  if (c1) {
+    HIP(hipMalloc((void**)&dx1, n1 * 4)); HIP(hipMalloc(&sp1, dn_sp_tensor_bytes(n, h, w, c1)));
+    HIP(hipMemcpy(dx1, x1, n1 * 4, hipMemcpyHostToDevice));
+    CHECK(dn_sp_from_nhwc(dx1, n, h, w, c1, c1, sp1, NULL) == DN_OK, "from_nhwc: %s", dn_last_error());
+  }
+  const float wmul = 4096.f;   /* lifts |w| <= 0.08 out of the f16 subnormal range; undone in the scale */
+  CHECK(dn_spconv_pack_weights(&d, dw, wmul, pk, NULL) == DN_OK, "sp pack: %s", dn_last_error());
+  CHECK(dn_fold_bn(db, NULL, NULL, NULL, NULL, 0.f, cout, dsc, dsh, NULL) == DN_OK, "fold: %s", dn_last_error());
+  float* hsc = malloc(cout * 4);
+  HIP(hipMemcpy(hsc, dsc, cout * 4, hipMemcpyDeviceToHost));
+  for (int i = 0; i < cout; ++i) hsc[i] /= wmul;
+  HIP(hipMemcpy(dsc, hsc, cout * 4, hipMemcpyHostToDevice));
+  CHECK(dn_spconv2d(&d, sp0, sp1, pk, dsc, dsh, spo, NULL) == DN_OK, "spconv: %s", dn_last_error());
+  CHECK(dn_sp_to_nhwc(spo, n, h, w, cout, cout, dy_, NULL) == DN_OK, "to_nhwc: %s", dn_last_error());
+  HIP(hipDeviceSynchronize());
+  HIP(hipMemcpy(y, dy_, ny * 4, hipMemcpyDeviceToHost));
+  double err = 0;
+  for (size_t i = 0; i < ny; ++i) { const double e = fabs((double)y[i] - ref[i]); if (e > err) err = e; }
+  printf("C ABI spconv 3x3 %s: max abs err %.3e, range flags %u\n", up ? "over cat(up2(src0), src1)" : "plain", err,
+         dn_sp_range_flags(0));
+  CHECK(err <= 1e-4, "spconv error too large");
+  CHECK(dn_sp_range_flags(1) == 0, "range flags set on O(1) data");
+  return 0;
+}
+
+/* ---- hi-only occupancy planes: dn_scatter_dense_sp_hi + dn_spconv2d(math = 3) == the full SP form, bit for bit;
+ * and the range flag: a value above 65504 through dn_sp_from_nhwc must raise bit 0 ---- */
+static int gpu_hi_only_and_flags(void) {
+  const int n = 2, X = 24, Y = 40, Z = 13, cout = 32, nidx = 900;
+  int32_t* idx = malloc((size_t)nidx * 12);
+  int32_t off[3] = {0, 400, nidx};
+  unsigned s = 5;
+  for (int i = 0; i < nidx; ++i) {
+    idx[3 * i] = (int)((frand(&s) * 0.5f + 0.5f) * X) % X; idx[3 * i + 1] = (int)((frand(&s) * 0.5f + 0.5f) * Y) % Y;
+    idx[3 * i + 2] = (int)((frand(&s) * 0.5f + 0.5f) * Z) % Z;
+  }
+  const int dims[3] = {X, Y, Z};
+  dn_conv_desc d;
+  memset(&d, 0, sizeof d);
+  d.n_images = n; d.h_in = X; d.w_in = Y; d.c0 = Z; d.c_out = cout; d.ksize = 3; d.stride = 1; d.relu = 1; d.math = 2;
+  const size_t nw = (size_t)cout * Z * 9, full_b = dn_sp_tensor_bytes(n, X, Y, Z), ob = dn_sp_tensor_bytes(n, X, Y, cout);
+  float *wt = malloc(nw * 4), *sc = malloc(cout * 4), *sh = malloc(cout * 4);
+  for (size_t i = 0; i < nw; ++i) wt[i] = frand(&s) * 0.2f;
+  for (int i = 0; i < cout; ++i) { sc[i] = 1.f / 1024.f; sh[i] = frand(&s) * 0.1f; }
+  int32_t *didx, *doff; float *dw, *dsc, *dsh; void *spf, *sph, *pk, *o1, *o2;
+  HIP(hipMalloc((void**)&didx, (size_t)nidx * 12)); HIP(hipMalloc((void**)&doff, 12)); HIP(hipMalloc((void**)&dw, nw * 4));
+  HIP(hipMalloc((void**)&dsc, cout * 4)); HIP(hipMalloc((void**)&dsh, cout * 4));
+  HIP(hipMalloc(&spf, full_b)); HIP(hipMalloc(&sph, full_b / 2)); HIP(hipMalloc(&o1, ob)); HIP(hipMalloc(&o2, ob));
+  HIP(hipMalloc(&pk, dn_spconv_packed_weight_bytes(&d)));
+  HIP(hipMemcpy(didx, idx, (size_t)nidx * 12, hipMemcpyHostToDevice)); HIP(hipMemcpy(doff, off, 12, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(dw, wt, nw * 4, hipMemcpyHostToDevice)); HIP(hipMemcpy(dsc, sc, cout * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(dsh, sh, cout * 4, hipMemcpyHostToDevice));
+  CHECK(dn_scatter_dense_sp(didx, doff, n, nidx, dims, spf, NULL) == DN_OK, "scatter sp: %s", dn_last_error());
+  CHECK(dn_scatter_dense_sp_hi(didx, doff, n, nidx, dims, sph, NULL) == DN_OK, "scatter sp hi: %s", dn_last_error());
+  CHECK(dn_spconv_pack_weights(&d, dw, 1024.f, pk, NULL) == DN_OK, "pack: %s", dn_last_error());
+  CHECK(dn_spconv2d(&d, spf, NULL, pk, dsc, dsh, o1, NULL) == DN_OK, "spconv full: %s", dn_last_error());
+  d.math = 3;
+  CHECK(dn_spconv2d(&d, sph, NULL, pk, dsc, dsh, o2, NULL) == DN_OK, "spconv hi-only: %s", dn_last_error());
+  HIP(hipDeviceSynchronize());
+  unsigned char *h1 = malloc(ob), *h2 = malloc(ob);
+  HIP(hipMemcpy(h1, o1, ob, hipMemcpyDeviceToHost)); HIP(hipMemcpy(h2, o2, ob, hipMemcpyDeviceToHost));
+  CHECK(memcmp(h1, h2, ob) == 0, "hi-only conv differs from the full form");
+  printf("C ABI hi-only occupancy planes: conv output bit-equal to the full form\n");
+  /* range guard */
+  CHECK(dn_sp_range_flags(1) == 0, "flags not clean before the probe");
+  float big[16] = {0}; big[3] = 70000.f; big[9] = 20000.f;
+  float* dbig; void* spb;
+  HIP(hipMalloc((void**)&dbig, sizeof big)); HIP(hipMalloc(&spb, dn_sp_tensor_bytes(1, 1, 1, 16)));
+  HIP(hipMemcpy(dbig, big, sizeof big, hipMemcpyHostToDevice));
+  CHECK(dn_sp_from_nhwc(dbig, 1, 1, 1, 16, 16, spb, NULL) == DN_OK, "from_nhwc: %s", dn_last_error());
+  const unsigned f = dn_sp_range_flags(1);
+  CHECK(f == 3u, "range flags after splitting 70000: %u (want 3)", f);
+  CHECK(dn_sp_range_flags(0) == 0, "flags not cleared by reset");
+  printf("C ABI range guard: clamp reported (flags 3), cleared by reset\n");
+  return 0;
+}
+
+/* ---- fusion block on a small scene: dn_warp_neighbors + dn_disco_fuse_mlp and the one-launch dn_disco_fuse_warp
+ * against a C restatement (two bilinear passes with zero padding, 4-layer MLP in double, exp / sum / weighted sum) ---- */
+static float bil(const float* img, int h, int w, int c, float gx, float gy, int ch) {
+  const float ix = ((gx + 1.f) * w - 1.f) * 0.5f, iy = ((gy + 1.f) * h - 1.f) * 0.5f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx1 = ix - fx, wy1 = iy - fy;
+  float acc = 0.f;
+  for (int k = 0; k < 4; ++k) {
+    const int x = x0 + (k & 1), y = y0 + (k >> 1);
+    if (x < 0 || x >= w || y < 0 || y >= h) continue;
+    acc += img[((size_t)y * w + x) * c + ch] * ((k & 1) ? wx1 : 1.f - wx1) * ((k >> 1) ? wy1 : 1.f - wy1);
+  }
+  return acc;
+}
+
+static int gpu_fusion(void) {
+  enum { A = 3, B = 1, H = 8, W = 16, C = 64, HW = H * W };
+  unsigned s = 21;
+  float* feat = malloc((size_t)A * B * HW * C * 4);
+  for (size_t i = 0; i < (size_t)A * B * HW * C; ++i) { const float v = frand(&s); feat[i] = v > 0 ? v : 0.f; }
+  float trans[B][A][A][16];
+  for (int i = 0; i < A; ++i) for (int j = 0; j < A; ++j) {
+    const float th = 0.2f * (j - i), tx = 3.f * (j - i), ty = -2.f * (j - i);
+    float* m = trans[0][i][j];
+    memset(m, 0, 64);
+    m[0] = cosf(th); m[1] = -sinf(th); m[4] = sinf(th); m[5] = cosf(th); m[3] = tx; m[7] = ty; m[10] = 1.f; m[15] = 1.f;
+  }
+  float w1[128 * 2 * C], b1[128], w2[32 * 128], b2[32], w3[8 * 32], b3[8], w4[8], b4[1];
+  for (int i = 0; i < 128 * 2 * C; ++i) w1[i] = frand(&s) * 0.06f;   /* amplitudes keep s_k = O(1): exp() stays finite */
+  for (int i = 0; i < 32 * 128; ++i) w2[i] = frand(&s) * 0.08f;
+  for (int i = 0; i < 8 * 32; ++i) w3[i] = frand(&s) * 0.4f;
+  for (int i = 0; i < 8; ++i) { w4[i] = frand(&s) * 1.5f; b3[i] = frand(&s) * 0.1f; }
+  for (int i = 0; i < 128; ++i) b1[i] = frand(&s) * 0.1f;
+  for (int i = 0; i < 32; ++i) b2[i] = frand(&s) * 0.1f;
+  b4[0] = 0.05f;
+  /* reference: warped maps, then the fusion of every ego */
+  float* warped = calloc((size_t)A * (A - 1) * HW * C, 4);
+  float* rot = malloc((size_t)HW * C * 4);
+  for (int i = 0; i < A; ++i) for (int j = 0, jj = 0; j < A; ++j) {
+    if (j == i) continue;
+    const float* m = trans[0][i][j];
+    const float* src = feat + (size_t)j * HW * C;
+    const float xt = (4.f * m[3]) / 128.f, yt = -(4.f * m[7]) / 128.f;
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+      const float bx = (2.f * x + 1.f) / W - 1.f, by = (2.f * y + 1.f) / H - 1.f;
+      for (int ch = 0; ch < C; ++ch) rot[((size_t)y * W + x) * C + ch] = bil(src, H, W, C, m[0] * bx + m[1] * by, m[4] * bx + m[5] * by, ch);
+    }
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+      const float bx = (2.f * x + 1.f) / W - 1.f, by = (2.f * y + 1.f) / H - 1.f;
+      for (int ch = 0; ch < C; ++ch)
+        warped[(((size_t)i * (A - 1) + jj) * HW + (size_t)y * W + x) * C + ch] = bil(rot, H, W, C, bx + xt, by + yt, ch);
+    }
+    ++jj;
+  }
+  float* ref = malloc((size_t)A * HW * C * 4);
+  for (int i = 0; i < A; ++i) for (int p = 0; p < HW; ++p) {
+    const float* ego = feat + ((size_t)i * HW + p) * C;
+    const float* nb[A];
+    nb[0] = ego;
+    for (int jj = 0; jj < A - 1; ++jj) nb[1 + jj] = warped + (((size_t)i * (A - 1) + jj) * HW + p) * C;
+    double e[A], den = 0;
+    for (int k = 0; k < A; ++k) {
+      double h1[128], h2[32], h3[8], sk = b4[0];
+      for (int u = 0; u < 128; ++u) {
+        double acc = b1[u];
+        for (int ch = 0; ch < C; ++ch) acc += (double)w1[u * 2 * C + ch] * ego[ch] + (double)w1[u * 2 * C + C + ch] * nb[k][ch];
+        h1[u] = acc > 0 ? acc : 0;
+      }
+      for (int u = 0; u < 32; ++u) { double acc = b2[u]; for (int v = 0; v < 128; ++v) acc += w2[u * 128 + v] * h1[v]; h2[u] = acc > 0 ? acc : 0; }
+      for (int u = 0; u < 8; ++u) { double acc = b3[u]; for (int v = 0; v < 32; ++v) acc += w3[u * 32 + v] * h2[v]; h3[u] = acc > 0 ? acc : 0; }
+      for (int u = 0; u < 8; ++u) sk += w4[u] * h3[u];
+      e[k] = exp(sk > 0 ? sk : 0);
+      den += e[k];
+    }
+    for (int ch = 0; ch < C; ++ch) {
+      double acc = 0;
+      for (int k = 0; k < A; ++k) acc += e[k] / den * nb[k][ch];
+      ref[((size_t)i * HW + p) * C + ch] = (float)acc;
+    }
+  }
+  /* device side */
+  float *dfeat, *dtrans, *dwarp, *dw1, *dw2, *dw3, *dv, *dout1, *dout2;
+  int32_t* dna; void* dpk;
+  const int32_t na = A;
+  HIP(hipMalloc((void**)&dfeat, (size_t)A * HW * C * 4)); HIP(hipMalloc((void**)&dtrans, sizeof trans)); HIP(hipMalloc((void**)&dna, 4));
+  HIP(hipMalloc((void**)&dwarp, (size_t)A * (A - 1) * HW * C * 4)); HIP(hipMalloc((void**)&dw1, sizeof w1)); HIP(hipMalloc((void**)&dw2, sizeof w2));
+  HIP(hipMalloc((void**)&dw3, sizeof w3)); HIP(hipMalloc(&dpk, dn_fuse_mlp_packed_bytes(C)));
+  HIP(hipMalloc((void**)&dout1, (size_t)A * HW * C * 4)); HIP(hipMalloc((void**)&dout2, (size_t)A * HW * C * 4));
+  HIP(hipMemcpy(dfeat, feat, (size_t)A * HW * C * 4, hipMemcpyHostToDevice)); HIP(hipMemcpy(dtrans, trans, sizeof trans, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(dna, &na, 4, hipMemcpyHostToDevice)); HIP(hipMemcpy(dw1, w1, sizeof w1, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(dw2, w2, sizeof w2, hipMemcpyHostToDevice)); HIP(hipMemcpy(dw3, w3, sizeof w3, hipMemcpyHostToDevice));
+  const float m1 = 16384.f, m2 = 16384.f, m3 = 8192.f;     /* powers of two lifting the weights; undone in s1..s3 */
+  CHECK(dn_fuse_mlp_pack(dw1, dw2, dw3, C, m1, m2, m3, dpk, NULL) == DN_OK, "mlp pack: %s", dn_last_error());
+  float vec[128 + 128 + 32 + 32 + 8 + 8 + 8 + 4];   /* s1 t1 s2 t2 s3 t3 w4 b4 (no BatchNorm: scale = 1 / wmul, shift = bias) */
+  float *s1 = vec, *t1 = vec + 128, *s2 = vec + 256, *t2 = vec + 288, *s3 = vec + 320, *t3 = vec + 328, *pw4 = vec + 336, *pb4 = vec + 344;
+  for (int i = 0; i < 128; ++i) { s1[i] = 1.f / m1; t1[i] = b1[i]; }
+  for (int i = 0; i < 32; ++i) { s2[i] = 1.f / m2; t2[i] = b2[i]; }
+  for (int i = 0; i < 8; ++i) { s3[i] = 1.f / m3; t3[i] = b3[i]; pw4[i] = w4[i]; }
+  pb4[0] = b4[0];
+  HIP(hipMalloc((void**)&dv, sizeof vec)); HIP(hipMemcpy(dv, vec, sizeof vec, hipMemcpyHostToDevice));
+  dn_fuse_mlp_params prm = {dpk, dv, dv + 128, dv + 256, dv + 288, dv + 320, dv + 328, dv + 336, dv + 344};
+  CHECK(dn_warp_neighbors(dfeat, dtrans, dna, B, A, H, W, C, 0, 0, A, dwarp, NULL) == DN_OK, "warp: %s", dn_last_error());
+  CHECK(dn_disco_fuse_mlp(dfeat, dwarp, dna, &prm, B, A, HW, C, 0, 0, A, NULL, dout1, NULL, NULL) == DN_OK, "fuse_mlp: %s", dn_last_error());
+  CHECK(dn_disco_fuse_warp(dfeat, dtrans, dna, &prm, B, A, H, W, C, 0, 0, A, NULL, dout2, NULL, NULL) == DN_OK, "fuse_warp: %s", dn_last_error());
+  HIP(hipDeviceSynchronize());
+  float *hw_ = malloc((size_t)A * (A - 1) * HW * C * 4), *o1 = malloc((size_t)A * HW * C * 4), *o2 = malloc((size_t)A * HW * C * 4);
+  HIP(hipMemcpy(hw_, dwarp, (size_t)A * (A - 1) * HW * C * 4, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(o1, dout1, (size_t)A * HW * C * 4, hipMemcpyDeviceToHost)); HIP(hipMemcpy(o2, dout2, (size_t)A * HW * C * 4, hipMemcpyDeviceToHost));
+  double ew = 0, e1 = 0, e2 = 0;
+  for (size_t i = 0; i < (size_t)A * (A - 1) * HW * C; ++i) { const double e = fabs((double)hw_[i] - warped[i]); if (e > ew) ew = e; }
+  for (size_t i = 0; i < (size_t)A * HW * C; ++i) {
+    double e = fabs((double)o1[i] - ref[i]); if (e > e1) e1 = e;
+    e = fabs((double)o2[i] - ref[i]); if (e > e2) e2 = e;
+  }
+  printf("C ABI fusion: warp max abs err %.3e, warp + fuse_mlp %.3e, one-launch fuse_warp %.3e\n", ew, e1, e2);
+  CHECK(ew <= 1e-5 && e1 <= 1e-4 && e2 <= 1e-4, "fusion error too large");
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (errors_only()) return 1;
   if (argc > 1 && strcmp(argv[1], "--gpu") == 0) {
     if (gpu_conv(0) || gpu_conv(1) || gpu_voxel()) return 1;
+    if (gpu_spconv(0) || gpu_spconv(1) || gpu_hi_only_and_flags() || gpu_fusion()) return 1;
   }
   printf("OK\n");
   return 0;
