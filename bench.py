@@ -154,8 +154,11 @@ def cpu_baseline(state_dict, threads):
             t0 = time.perf_counter()
             ref(b4[0], b4[1], b4[2], BATCH)
             dt4 = time.perf_counter() - t0
-        base["batch_%d" % BATCH] = {"value": round(BATCH / dt4, 4), "unit": "scenes/s",
-                                    "sample": "one forward of %d scenes (the bench's batch), no warm-up repeat" % BATCH}
+        # like for like with the GPU step: the headline CPU figure is the bench's own batch; batch 1 beside it
+        base["batch_1"] = {"value": base["value"], "unit": "scenes/s", "sample": base["sample"]}
+        base["value"] = round(BATCH / dt4, 4)
+        base["sample"] = ("one forward of %d scenes (5 agents, 256x256x13: the bench's batch), eval fwd, fp32, after the "
+                          "batch-1 runs as warm-up; torch-CPU oracle (reference source not in the mount)" % BATCH)
     return base, (bevs, trans, na, out)
 
 
@@ -610,13 +613,23 @@ def main():
                           if f.endswith("_rocprof_conv_%s.json" % math))[-1]
             rp = json.load(open(os.path.join(ROOT, "profiles", prof)))
             rp_ms = rp["conv_ms_per_step"]
+            from disconet_amd import _lib as _dl
+            live_launches = launches / args.steps
+            fresh = (rp.get("dn_version") == _dl.load().dn_version() and abs(rp["launches_per_step"] - live_launches) < 0.5)
+            if not fresh:       # a kernel changed since the profile was committed: do not quote its durations
+                raise KeyError("stale")
             rocprof = {"conv_ms_per_step": round(rp_ms, 4), "avg_launch_us": round(rp["avg_launch_us"], 2),
                        "achieved": round(flops / args.steps / (rp_ms * 1e-3) / 1e12, 3),
                        "frac": round(flops / args.steps / (rp_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[math], 4),
                        "source": "profiles/" + prof,
                        "note": "kernel durations from rocprofv3 --kernel-trace over `python bench.py` (hipGraph replay); "
                                "must agree with kernel_ms_per_step (HIP events, eager) measured live"}
-        except (OSError, IndexError, KeyError, ValueError):
+        except KeyError as e:
+            if e.args and e.args[0] == "stale":
+                rocprof = {"stale": True, "source": "profiles/" + prof,
+                           "note": "the committed rocprofv3 summary was taken with another build of the library "
+                                   "(dn_version / launches per step differ from this run): not quoted"}
+        except (OSError, IndexError, ValueError):
             pass
         roof = {
             "kernel": "%s (%s MFMA implicit-GEMM conv, all %d launches/step)"

@@ -602,6 +602,7 @@ class DiscoNet(nn.Module):
         x8, x7, x6, x5 = self.decode(enc, P)
 
         result = self.heads(x8, P)
+        ops.check_sp_range("DiscoNet.forward")      # DN_SP_CHECK=1 only: one blocking flag read per forward
         if self.kd_flag == 1:
             # NCHW-shaped, channels-last-strided views of the NHWC buffers
             nchw = lambda t: ops.as_nhwc(t).permute(0, 3, 1, 2)

@@ -244,6 +244,28 @@ class SpTensor:
         return t
 
 
+def sp_range_flags(reset=True):
+    """Sticky range flags of the split-f16 engines on the current device (include/disconet_hip.h ::
+    dn_sp_range_flags): bit 1 = a value above 2^14 was stored as an f16 hi/lo pair, bit 0 = a value was clamped
+    to +-65504 (results no longer follow the fp32 reference).  Blocking: validation time, not per step."""
+    return int(_lib.load().dn_sp_range_flags(1 if reset else 0))
+
+
+def check_sp_range(what="forward"):
+    """DN_SP_CHECK=1: turn a raised clamp flag into an error (and a near-limit flag into a warning)."""
+    import os
+    if os.environ.get("DN_SP_CHECK", "0") != "1":
+        return
+    flags = sp_range_flags(reset=True)
+    if flags & 1:
+        raise _lib.DnError("%s: a value was clamped to +-65504 by the split-f16 (hi + lo binary16) activation format; "
+                           "the outputs do not follow the fp32 reference.  Rescale the layer (fold a power of two into "
+                           "its BatchNorm) or run conv_math = 'f32'." % what)
+    if flags & 2:
+        import warnings
+        warnings.warn("%s: activations above 2^14 were stored as f16 hi/lo pairs (limit 65504)" % what)
+
+
 def as_sp(x):
     return x if isinstance(x, SpTensor) else SpTensor.from_nhwc(x)
 

@@ -201,3 +201,63 @@ def test_split_planar_bevs_input_equals_dense_input():
     assert torch.equal(dense["cls"], sp["cls"]) and torch.equal(dense["loc"], sp["loc"])
     # hi-only occupancy planes (half the bytes, 2 MFMAs per product in conv_pre_1): the dropped terms are exact zeros
     assert torch.equal(hi["cls"], sp["cls"]) and torch.equal(hi["loc"], sp["loc"])
+
+
+def _trained_like(ref):
+    """A network with the statistics of a trained checkpoint rather than of an initialiser: BatchNorm gains up to 4,
+    a stage whose activations reach ~1e3 and a layer with |w| ~ 1e-4 that brings them back."""
+    with torch.no_grad():
+        e, d = ref.u_encoder, ref.decoder
+        e.bn_pre_2.weight.mul_(4.0)
+        e.bn1_1.weight.mul_(3.0)
+        e.conv1_1.weight.mul_(60.0); e.conv1_1.bias.mul_(60.0)          # x1 activations up to ~1e3
+        e.conv1_2.weight.mul_(1.5e-3); e.conv1_2.bias.mul_(0.1)          # |w| ~ 1e-4
+        e.bn1_2.weight.mul_(2.0)
+        d.bn7_1.weight.mul_(4.0); d.bn7_1.running_var.mul_(16.0)
+        d.conv6_2.weight.mul_(20.0); d.bn6_2.running_var.mul_(400.0)
+    return ref
+
+
+@pytest.mark.parametrize("math", MATHS)
+def test_model_with_trained_like_statistics(math):
+    """The split-f16 format has the f16 exponent range: parity must hold away from O(1) data as well, and the
+    range flags must stay clear below 2^14 (include/disconet_hip.h :: dn_sp_range_flags)."""
+    from disconet_amd import ops
+    c = cases.MODEL_CASES["cfg1_f1"]
+    ref = _trained_like(cases.ref_model(c["map_hw"], c["agents"]))
+    bevs, trans, na = cases.model_inputs("cfg1_f1")
+    with torch.no_grad():
+        res, x8, x7, x6, x5, fused = ref(bevs, trans, na, c["batch"])
+        enc = ref.u_encoder(bevs.permute(0, 1, 4, 2, 3))
+        big = torch.relu(ref.u_encoder.bn1_1(ref.u_encoder.conv1_1(enc[0])))     # conv1_1's output, the large stage
+    assert 200.0 < big.abs().max().item() < 1.6e4, big.abs().max().item()
+    assert ref.u_encoder.conv1_2.weight.abs().max().item() < 1e-3
+    want = {"cls": res["cls"], "loc": res["loc"], "x8": x8, "x5": x5, "fused": fused}
+    ops.sp_range_flags(reset=True)
+    m = _product(ref, c["map_hw"], c["agents"], math=math)
+    got = _gpu_outputs(m, bevs, trans, na, c["batch"])
+    for name in want:
+        scale = max(1.0, want[name].abs().max().item())
+        err = (got[name] - want[name]).abs().max().item()
+        assert err <= TOL * scale, "%s max abs err %.3e (scale %.3g)" % (name, err, scale)
+    assert ops.sp_range_flags(reset=True) == 0
+
+
+def test_range_guard_reports_a_clamped_activation(monkeypatch):
+    """an activation beyond 65504 cannot be stored as an f16 hi/lo pair: the sticky flag is raised and, with
+    DN_SP_CHECK=1, the forward refuses to return numbers that no longer follow the reference"""
+    from disconet_amd import ops
+    from disconet_amd._lib import DnError
+    c = cases.MODEL_CASES["cfg1_f1"]
+    ref = cases.ref_model(c["map_hw"], c["agents"])
+    with torch.no_grad():
+        ref.u_encoder.conv_pre_2.weight.mul_(3.0e5)
+    bevs, trans, na = cases.model_inputs("cfg1_f1")
+    m = _product(ref, c["map_hw"], c["agents"], math="sp")
+    ops.sp_range_flags(reset=True)
+    _gpu_outputs(m, bevs, trans, na, c["batch"])
+    assert ops.sp_range_flags(reset=False) & 1
+    monkeypatch.setenv("DN_SP_CHECK", "1")
+    with pytest.raises(DnError, match="clamped"):
+        _gpu_outputs(m, bevs, trans, na, c["batch"])
+    assert ops.sp_range_flags(reset=True) == 0

@@ -1,6 +1,6 @@
 """Per-layer table of one bench step from a rocprofv3 kernel trace of the default command (graph replay):
 launch order -> layer name, duration, algorithmic GFLOP (true channel counts), TFLOP/s.
-    python tools/layers_from_trace.py gpurun_out/r02prof/kernel_trace.csv > profiles/r02_bench_layers.txt"""
+    python tools/layers_from_trace.py gpurun_out/r03prof/kernel_trace.csv > profiles/r03_bench_layers.txt"""
 import csv
 import sys
 
@@ -20,20 +20,26 @@ rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Time
 starts = [i for i, r in enumerate(rows) if "zero_fill_kernel" in r["Kernel_Name"]]
 skip = 4                                       # the bench ends with an eager check step and extras: go back a few
 sel = rows[starts[-skip]:starts[-skip + 1]]
-conv = [r for r in sel if "conv_sp_kernel" in r["Kernel_Name"]]
+def is_conv(r):
+    return "conv_sp_kernel" in r["Kernel_Name"] or "conv_spq_kernel" in r["Kernel_Name"]
+
+
+conv = [r for r in sel if is_conv(r)]
 assert len(conv) == len(LAYERS), (len(conv), len(LAYERS))
-print("%-30s %9s %10s %9s   %s" % ("layer", "us", "GFLOP", "TFLOP/s", "kernel configuration <KS,S,TH,TW,BN,TG,CA,WM,WN,WTM,WTN,POST,ABL,BSTAT,UPM>"))
+print("%-30s %9s %10s %9s   %s" % ("layer", "us", "GFLOP", "TFLOP/s", "kernel configuration <KS,S,TH,TW,BN,TG,CA,WM,WN,WTM,WTN,POST,ABL,BSTAT,UPM,AHI>"))
 tot_us = tot_gf = 0.0
 for i, (r, (name, px, cin, cout, k)) in enumerate(zip(conv, LAYERS)):
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     gf = (2.0 * N * px * cout * cin * k * k + EXTRA.get(i, 0.0)) / 1e9
-    cfg = r["Kernel_Name"].split("conv_sp_kernel<")[1].split(">")[0].replace(" ", "")
-    print("%-30s %9.1f %10.2f %9.1f   <%s>" % (name, us, gf, gf / (us * 1e-6) / 1e3, cfg))
+    kn = r["Kernel_Name"]
+    cfg = ("quad-merged BN=" + kn.split("conv_spq_kernel<")[1].split(">")[0]) if "conv_spq_kernel" in kn else \
+        "<" + kn.split("conv_sp_kernel<")[1].split(">")[0].replace(" ", "") + ">"
+    print("%-30s %9.1f %10.2f %9.1f   %s" % (name, us, gf, gf / (us * 1e-6) / 1e3, cfg))
     tot_us += us
     tot_gf += gf
 print("%-30s %9.1f %10.2f %9.1f" % ("all conv launches", tot_us, tot_gf, tot_gf / (tot_us * 1e-6) / 1e3))
 for r in sel:
-    if "conv_sp_kernel" not in r["Kernel_Name"]:
+    if not is_conv(r):
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         nm = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
         nm = nm.split("<")[0].split("(")[0] if not nm.startswith("at::") else "torch elementwise (num_agent cast)"

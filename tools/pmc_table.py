@@ -22,7 +22,11 @@ def short(n):
     m = re.search(r'conv_(mfma|sp)_kernel<([^>]*)>', n)
     if m:
         return ('sp<' if m.group(1) == 'sp' else 'conv<') + m.group(2).replace(' ', '').replace('(anonymousnamespace)::', '')[:28] + '>'
-    return n.split('(')[0][-34:]
+    m = re.search(r'conv_spq_kernel<([^>]*)>', n)
+    if m:
+        return 'spq<BN=%s>' % m.group(1)
+    n = n.replace('(anonymous namespace)::', '').replace('void ', '')
+    return n.split('(')[0].split('<')[0][-34:]
 
 
 def main(d, last):

@@ -12,7 +12,7 @@ import sys
 def per_dispatch(path, counter, kernel):
     out = {}
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and kernel in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in kernel.split(",")):
             k = int(r["Dispatch_Id"])
             out[k] = out.get(k, 0.0) + float(r["Counter_Value"])
     return [out[k] for k in sorted(out)]
@@ -26,11 +26,11 @@ def main(d, math, kernel, steps=3):
     fetch, write = fetch[-launches:], write[-launches:]
     fb, wb = 2 * 1024 * sum(fetch), 1024 * sum(write)
     print(json.dumps({
-        "round": 2, "kernel": kernel, "conv_math": math, "launches_per_step": launches,
+        "round": 3, "kernel": kernel, "conv_math": math, "launches_per_step": launches,
         "fetch_bytes_per_step": fb, "write_bytes_per_step": wb,
         "hbm_bytes_per_launch": (fb + wb) / launches,
         "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over the eager bench "
-                "(tools/r02_profile.sh); FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; "
+                "(tools/r03_profile.sh); FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; "
                 "WRITE_SIZE as reported; last step's launches"}, indent=1))
 
 
