@@ -20,8 +20,10 @@
 //       blend:   wave w blends k-step w of the phase for its 32 pixels from LDS (the translation pass), splits
 //                the 8 channels of each lane into hi / lo f16 and publishes the two 16-byte B fragments in LDS;
 //       mfma:    every wave multiplies the phase's four fragment pairs by ITS 32 units' weights (12 MFMAs);
-//     pipelined over stages s = (neighbour, phase): rotate(s + 2), blend(s + 1) and mfma(s) between two
-//     barriers, rotated blocks and fragments double-buffered -- one barrier per stage;
+//     pipelined over stages s = (neighbour, phase): between two barriers every wave blends stage s + 1, multiplies
+//     stage s, writes the rotated block of stage s + 2 (whose source-tap loads were issued a stage earlier and
+//     waited in registers: they come from far L2 / MALL) and issues the loads of stage s + 3; rotated blocks and
+//     fragments double-buffered -- one barrier per stage;
 //   * a slot's tail (layers 2-4): every wave turns its 32 layer-1 units into two k-steps of layer 2 and leaves a
 //     PARTIAL 32 x 32 accumulator in LDS; after the next barrier all waves add the four partials (fixed order)
 //     and finish layers 3, 4 and exp redundantly -- no second hand-off;
@@ -164,19 +166,50 @@ __global__ void __launch_bounds__(256, 2) disco_fuse_warp_kernel(const FuseWarpA
     ps.src = a.feat + ((size_t)j * a.batch + b) * hw * C;
     return ps;
   };
-  // rotate: R(q) for the FQ pixels of the block, channels [64 ph, 64 ph + 64), into rot_s[buf]
-  auto rotate = [&](int s, int buf) {
+  // rotate: R(q) for the FQ pixels of the block, channels [64 ph, 64 ph + 64), into rot_s[buf] -- in two halves so
+  // that the 16 tap loads of a thread (far L2 / MALL: ~1 us) are in flight during a whole stage of the pipeline:
+  //   rotate_issue(s, v):        the clamped tap loads of this thread's (up to) 4 block pixels into registers
+  //   rotate_commit(s, buf, v):  sample_src's blend (same masked weights, same order) and the LDS write
+  constexpr int RIT = (FQ * 16 + 255) / 256;
+  struct RotTaps {
+    f32x4 v[RIT][4];
+  };
+  auto rot_taps_of = [&](const Pose& ps, int idx) {
+    const int q = min(idx >> 4, FQ - 1);
+    const int qx = ps.qx0 + q % FQ_W, qy = ps.qy0 + q / FQ_W;
+    const float qbx = (2.f * qx + 1.f) / a.w - 1.f;
+    const float qby = (2.f * qy + 1.f) / a.h - 1.f;
+    return bilinear_taps(ps.r00 * qbx + ps.r01 * qby, ps.r10 * qbx + ps.r11 * qby, a.w, a.h);
+  };
+  auto rotate_issue = [&](int s, RotTaps& rt) {
     const int k = 1 + s / NPH, ph = s % NPH;
     const Pose ps = pose_of(k);
     const SrcImage src = make_src_image(ps.src, (size_t)hw * C * 4);
-    const int l = tid & 15;
-    for (int idx = tid; idx < FQ * 16; idx += 256) {
-      const int q = idx >> 4;
-      const int qx = ps.qx0 + q % FQ_W, qy = ps.qy0 + q / FQ_W;
-      const float qbx = (2.f * qx + 1.f) / a.w - 1.f;
-      const float qby = (2.f * qy + 1.f) / a.h - 1.f;
-      const Bilinear t1 = bilinear_taps(ps.r00 * qbx + ps.r01 * qby, ps.r10 * qbx + ps.r11 * qby, a.w, a.h);
-      rot_s[buf][q][l] = sample_src(src, t1, a.w, a.h, C, ph * 16 + l);
+    const unsigned lane_off = 16u * (ph * 16 + (tid & 15));
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      const Bilinear b = rot_taps_of(ps, tid + 256 * it);
+      const int x0 = min(max(b.x0, 0), a.w - 1), x1 = min(max(b.x0 + 1, 0), a.w - 1);
+      const int y0 = min(max(b.y0, 0), a.h - 1), y1 = min(max(b.y0 + 1, 0), a.h - 1);
+      rt.v[it][0] = ldb4(src, (unsigned)((y0 * a.w + x0) * C) * 4u + lane_off);
+      rt.v[it][1] = ldb4(src, (unsigned)((y0 * a.w + x1) * C) * 4u + lane_off);
+      rt.v[it][2] = ldb4(src, (unsigned)((y1 * a.w + x0) * C) * 4u + lane_off);
+      rt.v[it][3] = ldb4(src, (unsigned)((y1 * a.w + x1) * C) * 4u + lane_off);
+    }
+  };
+  auto rotate_commit = [&](int s, int buf, const RotTaps& rt) {
+    const Pose ps = pose_of(1 + s / NPH);
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      const int idx = tid + 256 * it;
+      const Bilinear b = rot_taps_of(ps, idx);
+      const bool x0ok = b.x0 >= 0 && b.x0 < a.w, x1ok = b.x0 + 1 >= 0 && b.x0 + 1 < a.w;
+      const bool y0ok = b.y0 >= 0 && b.y0 < a.h, y1ok = b.y0 + 1 >= 0 && b.y0 + 1 < a.h;
+      f32x4 acc = rt.v[it][0] * ((y0ok && x0ok) ? b.w_nw : 0.f);     // order of torch's CPU kernel: nw, ne, sw, se
+      acc += rt.v[it][1] * ((y0ok && x1ok) ? b.w_ne : 0.f);
+      acc += rt.v[it][2] * ((y1ok && x0ok) ? b.w_sw : 0.f);
+      acc += rt.v[it][3] * ((y1ok && x1ok) ? b.w_se : 0.f);
+      if (idx < FQ * 16) rot_s[buf][idx >> 4][tid & 15] = acc;
     }
   };
   // blend: the translation pass for this lane's pixel, channels of k-step `wave` of the phase, octet lh
@@ -311,27 +344,31 @@ __global__ void __launch_bounds__(256, 2) disco_fuse_warp_kernel(const FuseWarpA
   }
   int pending_tail = 0;        // list slot whose partials sit in red_s
 
-  // ---- pass 1b: the neighbours.  Stage pipeline: prologue rotate(0) | rotate(1), blend(0) |, then per stage
-  // barrier; rotate(s + 2); blend(s + 1); mfma(s)
+  // ---- pass 1b: the neighbours.  Stage pipeline (one barrier per stage): after barrier(s) every wave blends
+  // stage s + 1 from its rotated block into fragments, multiplies stage s, commits the rotated block of stage
+  // s + 2 (its tap loads were issued a stage ago) and issues the tap loads of stage s + 3.
+  RotTaps rt;
   if (n_stages > 0) {
-    rotate(0, 0);
+    rotate_issue(0, rt);
+    rotate_commit(0, 0, rt);
+    if (n_stages > 1) rotate_issue(1, rt);
     __syncthreads();                 // rot[0] complete (and the tail partials of slot 0)
     tail_finish(0);
     pending_tail = -1;
-    if (n_stages > 1) rotate(1, 1);
     {
       f32x4 v0, v1;
       blend(0, 0, v0, v1);
       publish(0, v0, v1);
     }
+    if (n_stages > 1) rotate_commit(1, 1, rt);
+    if (n_stages > 2) rotate_issue(2, rt);
     for (int s = 0; s < n_stages; ++s) {
       const int k = 1 + s / NPH, ph = s % NPH;
-      half8 wh[4], wl[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { wh[u] = w1frag(1, ph * 4 + u, 0); wl[u] = w1frag(1, ph * 4 + u, 1); }
       __syncthreads();               // frag[s & 1] and rot[(s + 1) & 1] complete; blend(s), mfma(s - 1) done everywhere
       if (pending_tail >= 0) { tail_finish(pending_tail); pending_tail = -1; }
-      if (s + 2 < n_stages) rotate(s + 2, s & 1);
+      half8 wh[4], wl[4];            // this stage's weight fragments (L2): in flight under the blend
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { wh[u] = w1frag(1, ph * 4 + u, 0); wl[u] = w1frag(1, ph * 4 + u, 1); }
       if (s + 1 < n_stages) {
         f32x4 v0, v1;
         blend(s + 1, (s + 1) & 1, v0, v1);
@@ -349,6 +386,8 @@ __global__ void __launch_bounds__(256, 2) disco_fuse_warp_kernel(const FuseWarpA
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], fl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], fh, acc, 0, 0, 0);
       }
+      if (s + 2 < n_stages) rotate_commit(s + 2, s & 1, rt);     // rot[s & 1] was last read by blend(s), a barrier ago
+      if (s + 3 < n_stages) rotate_issue(s + 3, rt);
       if (ph == NPH - 1) {             // the slot's layer 1 is complete: leave the layer-2 partial for the next barrier
         if (NPH == 1) __syncthreads(); // one-stage slots: the previous slot's partials may still be being read
         f32x16 sum;
@@ -380,7 +419,9 @@ __global__ void __launch_bounds__(256, 2) disco_fuse_warp_kernel(const FuseWarpA
     }
   }
   if (n_stages > 0) {
-    rotate(0, 0);
+    rotate_issue(0, rt);
+    rotate_commit(0, 0, rt);
+    if (n_stages > 1) rotate_issue(1, rt);
     for (int k = 1; k < n; ++k) {
       const float wk = ek_s[k][li] / den;
       if (a.weights_out && pvalid && lh == 0 && wave == 0)
@@ -389,11 +430,12 @@ __global__ void __launch_bounds__(256, 2) disco_fuse_warp_kernel(const FuseWarpA
       for (int ph = 0; ph < NPH; ++ph) {
         const int s = (k - 1) * NPH + ph;
         __syncthreads();               // rot[s & 1] complete; blend(s - 1) done everywhere
-        if (s + 1 < n_stages) rotate(s + 1, (s + 1) & 1);
         f32x4 v0, v1;
         blend(s, s & 1, v0, v1);
         f0[ph] += v0 * wk;
         f1[ph] += v1 * wk;
+        if (s + 1 < n_stages) rotate_commit(s + 1, (s + 1) & 1, rt);   // last read by blend(s - 1), a barrier ago
+        if (s + 2 < n_stages) rotate_issue(s + 2, rt);
       }
     }
   }
