@@ -92,6 +92,9 @@ def parse():
     ap.add_argument("--agent-check", type=int, default=0,
                     help="--mode agent: replay this many extra steps and compare every step's output checksum with "
                          "the first (all-gather kernel between the two compute graphs)")
+    ap.add_argument("--no-pg", action="store_true",
+                    help="--mode agent on one GPU: no process group at all (the exchange is a local copy): isolates "
+                         "the compute graphs from the collective in --agent-check")
     ap.add_argument("--no-agent-leg", action="store_true",
                     help="skip the agent-sharded leg (BASELINE configs[4]) that the default line carries as "
                          "`agent_sharded` when the GPU count divides 8")
@@ -226,10 +229,11 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
         return make_bevs
 
     def checksum(out):
+        """three order-independent checksums: cls, loc, the fused layer-3 map"""
         res, fused = out
         f = fused.data if isinstance(fused, ops.SpTensor) else fused
-        return (res["cls"].view(torch.int64).sum() + 3 * res["loc"].view(torch.int64).sum()
-                + 5 * f.contiguous().view(torch.int32).sum())
+        return torch.stack([res["cls"].view(torch.int64).sum(), res["loc"].view(torch.int64).sum(),
+                            f.contiguous().view(torch.int32).sum().to(torch.int64)])
 
     def fence():
         torch.cuda.synchronize()
@@ -288,17 +292,26 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
         }
     if check_steps > 0:
         want = checksum(stepper()).clone()
-        sums = torch.zeros(check_steps, dtype=torch.int64, device="cuda")
+        sums = torch.zeros((check_steps, 3), dtype=torch.int64, device="cuda")
+        enc_sums = torch.zeros(check_steps, dtype=torch.int64, device="cuda")
+        x3 = stepper.enc[engine.layer]
+        enc_want = None
         for i in range(check_steps):
             sums[i] = checksum(stepper())
+            enc_sums[i] = (x3.data if isinstance(x3, ops.SpTensor) else x3).contiguous().view(torch.int32).sum()
         torch.cuda.synchronize()
-        differing = int((sums != want).sum().item())
+        per_part = (sums != want).sum(0).tolist()
+        enc_diff = int((enc_sums != enc_sums[0]).sum().item())
+        differing = int((sums != want).any(1).sum().item())
         if dist.is_initialized():
             t = torch.tensor([differing], device="cuda", dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             differing = int(t.item())
         if rank == 0:
             res["replay_check"] = {"steps": check_steps, "differing": differing,
+                                   "differing_by_output": {"cls": per_part[0], "loc": per_part[1], "fused": per_part[2],
+                                                           "encoder_layer3_map": enc_diff},
+                                   "exchange": "local copy (no process group)" if not dist.is_initialized() else "RCCL all-gather",
                                    "how": "checksum of cls + loc + fused map after every step (graph A, all-gather, "
                                           "graph B back to back) vs the first step's"}
     if emulate_world and world == 1 and rank == 0:
@@ -331,7 +344,7 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
 def agent_sharded_bench(args, world, rank, dist):
     if 8 % world:
         raise SystemExit("--mode agent needs a GPU count that divides 8 agents")
-    if world == 1 and not dist.is_initialized():
+    if world == 1 and not dist.is_initialized() and not args.no_pg:
         import datetime
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
                                 device_id=torch.device("cuda", torch.cuda.current_device()),
@@ -339,7 +352,8 @@ def agent_sharded_bench(args, world, rank, dist):
     res = agent_sharded_leg(args, world, rank, dist, emulate_world=args.emulate_world, check_steps=args.agent_check)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    dist.destroy_process_group()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def seg_bench(args, world, rank, dist, use_pg):
@@ -515,6 +529,7 @@ def main():
     na = torch.full((BATCH, AGENTS), AGENTS, dtype=torch.int64).cuda()
     dims = (MAP_HW, MAP_HW, 13)
     n_img = AGENTS * BATCH
+    na_live = na[:, 0].to(torch.int32).contiguous()     # the kernels' [B] live-agent counts, cast once (plan time)
 
     def step():
         # dense rebuild of the batch (K1/a2) in the layout the conv engine of the chosen mode reads
@@ -523,7 +538,7 @@ def main():
         else:
             bevs = ops.scatter_dense(indices, offsets, n_img, dims)
         with torch.no_grad():
-            return model(bevs, trans, na, BATCH)
+            return model(bevs, trans, na_live, BATCH)
 
     def fence():
         torch.cuda.synchronize()

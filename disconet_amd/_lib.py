@@ -103,6 +103,10 @@ SIGNATURES = {
     "dn_seg_label_count": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "dn_seg_ce_loss": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                c_void_p]),
+    "dn_maxpool2_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dn_maxpool2_nhwc_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dn_upsample2_bilinear_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dn_upsample2_bilinear_nhwc_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     # ---- include/disconet_train.h ----
     "dn_conv_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "dn_conv_wgrad": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

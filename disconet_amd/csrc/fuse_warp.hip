@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(256, 2) disco_fuse_warp_kernel(const FuseWarpA
   __shared__ float red_s[4][16][64];                                       // layer-2 partials: [wave][reg][lane]
   __shared__ float ek_s[FW_MAX_AGENTS][32];                                // exp(s_k) per list slot and pixel
   __shared__ int jl_s[FW_MAX_AGENTS];
+  __shared__ __attribute__((aligned(16))) float pose_s[FW_MAX_AGENTS][8];                               // r00 r01 r10 r11 xt yt, (qx0, qy0) as int bits
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -146,24 +147,34 @@ __global__ void __launch_bounds__(256, 2) disco_fuse_warp_kernel(const FuseWarpA
     int qx0, qy0;
     const float* src;
   };
-  auto pose_of = [&](int k) {
+  // computed once per workgroup (thread k - 1 for list slot k) into pose_s: a stage reads it from LDS instead of
+  // chasing jl_s -> trans -> 6 dependent global loads three times per stage
+  auto pose_build = [&](int k) {
     const int j = jl_s[k];
     const float* m = a.trans + (((size_t)b * a.agents + i) * a.agents + j) * 16;
-    Pose ps;
-    ps.r00 = m[0]; ps.r01 = m[1]; ps.r10 = m[4]; ps.r11 = m[5];
-    ps.xt = (4.f * m[3]) / 128.f;
-    ps.yt = -(4.f * m[7]) / 128.f;
+    const float xt = (4.f * m[3]) / 128.f, yt = -(4.f * m[7]) / 128.f;
     // north-west q of the tile: the smallest x0(p) - (p - tile origin) over the tile's columns / rows
     int qx = 1 << 30, qy = 1 << 30;
 #pragma unroll
     for (int kk = 0; kk < FT_W; ++kk) {
-      const Bilinear t = bilinear_taps((2.f * (tile_x0 + kk) + 1.f) / a.w - 1.f + ps.xt,
-                                       (2.f * (tile_y0 + (kk < FT_H ? kk : 0)) + 1.f) / a.h - 1.f + ps.yt, a.w, a.h);
+      const Bilinear t = bilinear_taps((2.f * (tile_x0 + kk) + 1.f) / a.w - 1.f + xt,
+                                       (2.f * (tile_y0 + (kk < FT_H ? kk : 0)) + 1.f) / a.h - 1.f + yt, a.w, a.h);
       qx = min(qx, t.x0 - kk);
       if (kk < FT_H) qy = min(qy, t.y0 - kk);
     }
-    ps.qx0 = qx; ps.qy0 = qy;
-    ps.src = a.feat + ((size_t)j * a.batch + b) * hw * C;
+    pose_s[k][0] = m[0]; pose_s[k][1] = m[1]; pose_s[k][2] = m[4]; pose_s[k][3] = m[5];
+    pose_s[k][4] = xt; pose_s[k][5] = yt;
+    pose_s[k][6] = __int_as_float(qx); pose_s[k][7] = __int_as_float(qy);
+  };
+  if (tid >= 1 && tid < n) pose_build(tid);
+  __syncthreads();
+  auto pose_of = [&](int k) {
+    Pose ps;
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(&pose_s[k][0]), p1 = *reinterpret_cast<const f32x4*>(&pose_s[k][4]);
+    ps.r00 = p0[0]; ps.r01 = p0[1]; ps.r10 = p0[2]; ps.r11 = p0[3];
+    ps.xt = p1[0]; ps.yt = p1[1];
+    ps.qx0 = __float_as_int(p1[2]); ps.qy0 = __float_as_int(p1[3]);
+    ps.src = a.feat + ((size_t)jl_s[k] * a.batch + b) * hw * C;
     return ps;
   };
   // rotate: R(q) for the FQ pixels of the block, channels [64 ph, 64 ph + 64), into rot_s[buf] -- in two halves so

@@ -169,6 +169,140 @@ __global__ void seg_ce_kernel(const float* __restrict__ logits, const int32_t* _
   if (threadIdx.x == 0) atomicAdd(loss, part[0]);
 }
 
+// ---- training forms on fp32 NHWC maps (the UNet's backward; include/disconet_train.h conventions) ----------
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+// nn.MaxPool2d(2): y[n][h/2][w/2][c]; one thread per (output pixel, 4 channels)
+__global__ void maxpool2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int c4n, long total) {
+  const int ho = h >> 1, wo = w >> 1;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c4 = idx % c4n;
+    long r = idx / c4n;
+    const int ox = r % wo; r /= wo;
+    const int oy = r % ho;
+    const long n = r / ho;
+    const float* s = x + (((n * h + 2 * oy) * w + 2 * ox) * (long)c4n + c4) * 4;
+    f32x4s best = *reinterpret_cast<const f32x4s*>(s);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const f32x4s v = *reinterpret_cast<const f32x4s*>(s + ((long)(k >> 1) * w + (k & 1)) * c4n * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) best[e] = (v[e] > best[e] || v[e] != v[e]) ? v[e] : best[e];   // ATen: val > max || isnan(val)
+    }
+    *reinterpret_cast<f32x4s*>(y + idx * 4) = best;
+  }
+}
+
+// backward of the above: dx[2oy + i][2ox + j] = dy[oy][ox] at the window's arg-max -- the FIRST maximum in scan
+// order (0,0) (0,1) (1,0) (1,1), as ATen's forward records it (strict >), so the zero windows of post-ReLU maps
+// route their gradient to the top-left pixel exactly like torch -- and 0 at the other three.  Every dx element is
+// written exactly once: no zero fill, no atomics, deterministic.  dy: pixel stride ld_dy (a channel slice is fine).
+__global__ void maxpool2_nhwc_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int ld_dy,
+                                         float* __restrict__ dx, int h, int w, int c4n, long total) {
+  const int ho = h >> 1, wo = w >> 1;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c4 = idx % c4n;
+    long r = idx / c4n;
+    const int ox = r % wo; r /= wo;
+    const int oy = r % ho;
+    const long n = r / ho;
+    const long base = (((n * h + 2 * oy) * w + 2 * ox) * (long)c4n + c4) * 4;
+    f32x4s v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4s*>(x + base + ((long)(k >> 1) * w + (k & 1)) * c4n * 4);
+    const f32x4s g = *reinterpret_cast<const f32x4s*>(dy + ((n * ho + oy) * wo + ox) * (long)ld_dy + c4 * 4);
+    int arg[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float best = v[0][e];
+      arg[e] = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (v[k][e] > best || v[k][e] != v[k][e]) { best = v[k][e]; arg[e] = k; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4s o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = arg[e] == k ? g[e] : 0.f;
+      *reinterpret_cast<f32x4s*>(dx + base + ((long)(k >> 1) * w + (k & 1)) * c4n * 4) = o;
+    }
+  }
+}
+
+// nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True): ATen's arithmetic (cf. sp_upsample2_kernel)
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ inline Lerp lerp_of(int o, int in, float scale) {
+  const float f = scale * o;
+  Lerp t;
+  t.i0 = (int)f;
+  t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
+  t.l1 = f - t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+
+__global__ void upsample2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int c4n, long total) {
+  const int ho = 2 * h, wo = 2 * w;
+  const float sy = ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f, sx = wo > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.f;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c4 = idx % c4n;
+    long r = idx / c4n;
+    const int ox = r % wo; r /= wo;
+    const int oy = r % ho;
+    const long n = r / ho;
+    const Lerp ty = lerp_of(oy, h, sy), tx = lerp_of(ox, w, sx);
+    auto at = [&](int yy, int xx) { return *reinterpret_cast<const f32x4s*>(x + (((n * h + yy) * w + xx) * (long)c4n + c4) * 4); };
+    const f32x4s a = at(ty.i0, tx.i0), b = at(ty.i0, tx.i1), cc = at(ty.i1, tx.i0), d = at(ty.i1, tx.i1);
+    *reinterpret_cast<f32x4s*>(y + idx * 4) = ty.l0 * (tx.l0 * a + tx.l1 * b) + ty.l1 * (tx.l0 * cc + tx.l1 * d);
+  }
+}
+
+// backward, GATHER form: input pixel (iy, ix) collects dy[oy][ox] * wy(oy -> iy) * wx(ox -> ix) over the output
+// rows / columns whose taps reach it -- o in [2 i - 2, 2 i + 2] covers every o with i0(o) or i1(o) == i for a x2
+// align_corners map (i0(o) = floor(o (in - 1) / (2 in - 1)) lies in {ceil(o / 2) - 1, floor(o / 2)}) -- each weight
+// re-derived with the forward's arithmetic, summed in a fixed order: deterministic, no atomics, no zero fill.
+__global__ void upsample2_nhwc_bwd_kernel(const float* __restrict__ dy, int ld_dy, float* __restrict__ dx, int h, int w,
+                                          int c4n, long total) {
+  const int ho = 2 * h, wo = 2 * w;
+  const float sy = ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f, sx = wo > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.f;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c4 = idx % c4n;
+    long r = idx / c4n;
+    const int ix = r % w; r /= w;
+    const int iy = r % h;
+    const long n = r / h;
+    float wy[5], wx[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int oy = 2 * iy - 2 + k, ox = 2 * ix - 2 + k;
+      wy[k] = wx[k] = 0.f;
+      if (oy >= 0 && oy < ho) {
+        const Lerp t = lerp_of(oy, h, sy);
+        wy[k] = (t.i0 == iy ? t.l0 : 0.f) + (t.i1 == iy ? t.l1 : 0.f);
+      }
+      if (ox >= 0 && ox < wo) {
+        const Lerp t = lerp_of(ox, w, sx);
+        wx[k] = (t.i0 == ix ? t.l0 : 0.f) + (t.i1 == ix ? t.l1 : 0.f);
+      }
+    }
+    f32x4s acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      const int oy = 2 * iy - 2 + ky;
+      if (wy[ky] == 0.f) continue;
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        const int ox = 2 * ix - 2 + kx;
+        if (wx[kx] == 0.f) continue;
+        const f32x4s g = *reinterpret_cast<const f32x4s*>(dy + ((n * ho + oy) * wo + ox) * (long)ld_dy + c4 * 4);
+        acc += g * (wy[ky] * wx[kx]);
+      }
+    }
+    *reinterpret_cast<f32x4s*>(dx + idx * 4) = acc;
+  }
+}
+
 inline int blocks_for(long total) { return (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384); }
 
 }  // namespace
@@ -222,4 +356,49 @@ extern "C" int dn_seg_ce_loss(const float* logits, const int32_t* labels, long p
     hipLaunchKernelGGL(seg_ce_kernel<0>, dim3(blocks), dim3(256), 0, s, logits, labels, pixels, classes, ld, grad_scale,
                        counts, loss_sum, dlogits);
   return dn::check_launch("seg_ce_kernel");
+}
+
+// ---- fp32 NHWC training forms (disconet_seg.h) ----
+namespace {
+int check_nhwc(const char* what, const void* a, const void* b, int n, int h, int w, int c) {
+  DN_REQUIRE(a && b && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "%s: bad arguments (c must be a multiple of 4)", what);
+  DN_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0, "%s: buffers must be 16-byte aligned", what);
+  return DN_OK;
+}
+}  // namespace
+
+extern "C" int dn_maxpool2_nhwc(const float* x, int n_images, int h, int w, int c, float* y, void* stream) {
+  if (int rc = check_nhwc("maxpool2_nhwc", x, y, n_images, h, w, c)) return rc;
+  DN_REQUIRE(h % 2 == 0 && w % 2 == 0, "maxpool2_nhwc: %d x %d is not even", h, w);
+  const long total = (long)n_images * (h / 2) * (w / 2) * (c / 4);
+  hipLaunchKernelGGL(maxpool2_nhwc_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, h, w, c / 4, total);
+  return dn::check_launch("maxpool2_nhwc_kernel");
+}
+
+extern "C" int dn_maxpool2_nhwc_backward(const float* x, const float* dy, int ld_dy, int n_images, int h, int w, int c,
+                                         float* dx, void* stream) {
+  if (int rc = check_nhwc("maxpool2_nhwc_backward", x, dx, n_images, h, w, c)) return rc;
+  DN_REQUIRE(dy && ld_dy >= c && ld_dy % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && h % 2 == 0 && w % 2 == 0,
+             "maxpool2_nhwc_backward: bad gradient view / odd map");
+  const long total = (long)n_images * (h / 2) * (w / 2) * (c / 4);
+  hipLaunchKernelGGL(maxpool2_nhwc_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, ld_dy, dx, h,
+                     w, c / 4, total);
+  return dn::check_launch("maxpool2_nhwc_bwd_kernel");
+}
+
+extern "C" int dn_upsample2_bilinear_nhwc(const float* x, int n_images, int h, int w, int c, float* y, void* stream) {
+  if (int rc = check_nhwc("upsample2_bilinear_nhwc", x, y, n_images, h, w, c)) return rc;
+  const long total = (long)n_images * (2 * h) * (2 * w) * (c / 4);
+  hipLaunchKernelGGL(upsample2_nhwc_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, h, w, c / 4, total);
+  return dn::check_launch("upsample2_nhwc_kernel");
+}
+
+extern "C" int dn_upsample2_bilinear_nhwc_backward(const float* dy, int ld_dy, int n_images, int h, int w, int c, float* dx,
+                                                   void* stream) {
+  if (int rc = check_nhwc("upsample2_bilinear_nhwc_backward", dy, dx, n_images, h, w, c)) return rc;
+  DN_REQUIRE(ld_dy >= c && ld_dy % 4 == 0, "upsample2_bilinear_nhwc_backward: bad gradient view");
+  const long total = (long)n_images * h * w * (c / 4);
+  hipLaunchKernelGGL(upsample2_nhwc_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, dx, h, w,
+                     c / 4, total);
+  return dn::check_launch("upsample2_nhwc_bwd_kernel");
 }

@@ -159,6 +159,10 @@ class _ConvLayer:
             # sync + allocation: not inside a hipGraph capture)
             self.weight = weight.detach()
             self.packed_sig = (up_split[0], up_split[1], 1) if up_split is not None else (c_in, 0, 0)
+        elif math == 1:   # split-f16 on the NHWC engine: the same power-of-two lift (the lo halves of |w| ~ 1e-4
+            wmul = ops._pow2_lift(weight)      # would otherwise be f16 subnormals: 6e-4 relative error)
+            self.packed = ops.pack_conv_weights(d, weight.detach() * wmul)
+            self.scale = (self.scale / wmul).contiguous()
         else:
             self.packed = ops.pack_conv_weights(d, weight)
         self.c_in, self.c_out, self.ksize, self.stride, self.relu = c_in, c_out, ksize, stride, relu
@@ -213,9 +217,10 @@ class _ConvPostLayer:
             # `scale`/`shift` may belong to another layer of the plan: scale copies, never in place
             self.scale, self.scale2 = (scale / wmul).contiguous(), (scale2 / wmul2).contiguous()
         else:
-            self.packed = ops.pack_conv_weights(d, weight)
-            self.packed2 = ops.pack_post1x1_weights(w2)
-            self.scale, self.scale2 = scale.contiguous(), scale2.contiguous()
+            wmul, wmul2 = ops._pow2_lift(weight), ops._pow2_lift(w2)
+            self.packed = ops.pack_conv_weights(d, weight.detach() * wmul)
+            self.packed2 = ops.pack_post1x1_weights(w2.detach() * wmul2)
+            self.scale, self.scale2 = (scale / wmul).contiguous(), (scale2 / wmul2).contiguous()
         self.shift, self.shift2 = shift.contiguous(), shift2.contiguous()
 
     def run(self, src0):
@@ -564,7 +569,7 @@ class DiscoNet(nn.Module):
             raise ValueError("bevs has %d images, expected num_agent*batch_size = %d"
                              % (bevs.shape[0], A * batch_size))
         trans = trans_matrices.to(device=bevs.device, dtype=torch.float32).contiguous()
-        num_agent = num_agent_tensor[:, 0].to(device=bevs.device, dtype=torch.int32).contiguous()
+        num_agent = ops.live_agent_counts(num_agent_tensor, bevs.device)
 
         if self.overlap_streams and self.layer < 4:
             # The encoder groups above the exchanged level do not depend on the fusion: they run on a

@@ -551,6 +551,18 @@ def disco_fuse_warp(feat, trans, num_agent, params, batch, agents, only_v2i=Fals
     return (res, weights) if want_weights else res
 
 
+def live_agent_counts(num_agent_tensor, device):
+    """The kernels' [B] int32 live-agent counts from the reference's num_agent_tensor [B, A] (column 0 is the
+    count).  A 1-D int32 tensor already on the device is taken as is -- no cast / gather kernel inside the step
+    (pass `num_agent_tensor[:, 0].int().contiguous()` once, outside a captured step)."""
+    t = num_agent_tensor
+    if t.dim() == 1 and t.dtype == torch.int32 and t.device == torch.device(device) and t.is_contiguous():
+        return t
+    if t.dim() == 1:
+        return t.to(device=device, dtype=torch.int32).contiguous()
+    return t[:, 0].to(device=device, dtype=torch.int32).contiguous()
+
+
 def make_tail_params(tensors):
     """tensors: dict name -> float32 device tensor for every dn_mlp_tail_params field."""
     p = MlpTailParams()

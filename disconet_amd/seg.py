@@ -21,7 +21,8 @@ torch modules that are never called; the eval forward packs them once and runs
     fusion at x4              dn_warp_neighbors + attention MLP + dn_disco_fuse_tail (C = 512)
     cross entropy (SegModule) dn_seg_ce_loss: value + d/d(logits)
 
-There is no torch / CPU fallback.  Training (the UNet's backward) is not built: train() raises.
+There is no torch / CPU fallback.  Training: SegModule.step (seg_train.py: the detector's training engine + the
+UNet's max-pool / bilinear-upsample backward kernels).
 """
 import torch
 import torch.nn as nn
@@ -81,9 +82,9 @@ class SegDiscoNet(nn.Module):
         return super().load_state_dict(cleaned, strict=strict, **kw)
 
     def train(self, mode=True):
-        if mode:
-            raise NotImplementedError("SegDiscoNet: only the eval forward and the loss kernel are built on "
-                                      "the MI355X path (the UNet backward is a next step, DESIGN.md)")
+        """train(): SegModule.step / SegTrainStep run the explicit HIP training graph (seg_train.py); the module's
+        own forward() stays the eval plan -- a train()-mode forward() through autograd is not provided."""
+        self._plan = None
         return super().train(mode)
 
     # ------------------------------------------------------------------
@@ -145,7 +146,8 @@ class SegDiscoNet(nn.Module):
 
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size=None):
         if self.training:
-            raise NotImplementedError("SegDiscoNet: eval() only")
+            raise NotImplementedError("SegDiscoNet.forward in train() mode: use SegModule.step (disconet_amd/seg_train.py), "
+                                      "the explicit HIP training step; forward() is the eval plan")
         if isinstance(bevs, ops.SpTensor):
             x, dev = bevs, bevs.device
         else:
@@ -192,8 +194,18 @@ class SegModule:
     """upstream:coperception/utils/SegModule.py :: SegModule, the evaluation half: forward + the
     per-pixel cross entropy on the HIP path (value and gradient w.r.t. the logits)."""
 
-    def __init__(self, model):
+    def __init__(self, model, optimizer=None, lr=1e-3):
         self.model = model
+        self._optimizer, self._lr, self._trainer = optimizer, lr, None
+
+    def step(self, data, batch_size=None):
+        """upstream SegModule.step: one training step (train-mode forward with batch statistics, cross entropy,
+        explicit HIP reverse pass, Adam) -> {"loss": float}.  The training engine is built on first use (its flat
+        parameter buffer re-points the module's Parameters: build after the model is on the GPU)."""
+        if self._trainer is None:
+            from .seg_train import SegTrainStep
+            self._trainer = SegTrainStep(self.model, self._optimizer, self._lr)
+        return self._trainer.step(data, batch_size)
 
     def loss(self, logits, labels, want_grad=True):
         """logits [N, classes, H, W] (the model's NCHW-shaped, channels-last view), labels [N, H, W]

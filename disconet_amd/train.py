@@ -129,7 +129,7 @@ class TrainEngine:
         self.step_count = 0
         self.generation = 0          # bumped by every forward(): the saved activations belong to it
         self._overlap_streams = False
-        params = _param_order(model)
+        params = self._param_order(model)
         dev = params[0].device
         if dev.type != "cuda":
             raise ops._lib.DnError("TrainEngine needs the model on the GPU; there is no CPU path")
@@ -151,6 +151,9 @@ class TrainEngine:
         self._graph()
 
     # ------------------------------------------------------------------
+    def _param_order(self, model):      # subclasses (the segmentation variant) order their own parameters
+        return _param_order(model)
+
     def _side_stream(self, dev):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=dev)
@@ -202,15 +205,28 @@ class TrainEngine:
         d = ops.conv_desc(n, h_in, w_in, c0, c_out, ksize, stride, False, c1=c1, up0=up0,
                           ld0=src0.stride(2), ld1=src1.stride(2) if src1 is not None else None,
                           ldo=out.stride(2) if out is not None else None, math=self._math())
-        packed = ops.pack_conv_weights(d, w)
         dev = src0.device
-        one = self._const(dev, c_out, 1.0)
+        wmul = self._wmul_of(w) if d.math == 1 else 1.0
+        packed = ops.pack_conv_weights(d, w if wmul == 1.0 else w.detach() * wmul)
+        one = self._const(dev, c_out, 1.0 / wmul)
         shift = bias if bias is not None else self._const(dev, c_out, 0.0)
         if out is None:
             ho, wo = ops.conv_out_hw(d)
             out = torch.empty((n, ho, wo, c_out), dtype=torch.float32, device=dev)
         ops.conv2d(d, src0, packed, one, shift, src1=src1, out=out)
         return out, d
+
+    def _wmul_of(self, w):
+        """power-of-two lift of a layer's weights for the split-f16 forward (ops._pow2_lift: keeps the lo halves
+        of small weights out of the f16 subnormal range; 1 / wmul rides in the conv's scale vector).  The max |w|
+        behind it is read back from the device: cached per weight tensor, refreshed every 64 optimizer steps."""
+        key = (w.data_ptr(), tuple(w.shape))
+        cache = self.__dict__.setdefault("_wmul_cache", {})
+        hit = cache.get(key)
+        if hit is None or self.step_count - hit[1] >= 64:
+            hit = (ops._pow2_lift(w), self.step_count)
+            cache[key] = hit
+        return hit[0]
 
     def _const(self, dev, n, val, cache={}):
         key = (str(dev), n, val)

@@ -141,6 +141,45 @@ def add_rows(a, b):
     return a
 
 
+# ---- UNet pieces of the segmentation variant (include/disconet_seg.h) -----------------------
+def maxpool2(x):
+    """nn.MaxPool2d(2) on a dense NHWC map"""
+    _need_gpu(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+    check(_lib.load().dn_maxpool2_nhwc(_ptr(x), n, h, w, c, _ptr(y), _stream()), "dn_maxpool2_nhwc")
+    return y
+
+
+def maxpool2_backward(x, dy):
+    """x: the pooled map's INPUT [n, h, w, c] dense; dy [n, h/2, w/2, c] (may be a channel slice) -> dx dense"""
+    _need_gpu(x, dy)
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.load().dn_maxpool2_nhwc_backward(_ptr(x), _ptr(dy), _ld(dy), n, h, w, c, _ptr(dx), _stream()),
+          "dn_maxpool2_nhwc_backward")
+    return dx
+
+
+def upsample2_bilinear(x):
+    """nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) on a dense NHWC map"""
+    _need_gpu(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.float32, device=x.device)
+    check(_lib.load().dn_upsample2_bilinear_nhwc(_ptr(x), n, h, w, c, _ptr(y), _stream()), "dn_upsample2_bilinear_nhwc")
+    return y
+
+
+def upsample2_bilinear_backward(dy):
+    """dy [n, 2h, 2w, c] (may be a channel slice) -> dx [n, h, w, c] dense"""
+    _need_gpu(dy)
+    n, h2, w2, c = dy.shape
+    dx = torch.empty((n, h2 // 2, w2 // 2, c), dtype=torch.float32, device=dy.device)
+    check(_lib.load().dn_upsample2_bilinear_nhwc_backward(_ptr(dy), _ld(dy), n, h2 // 2, w2 // 2, c, _ptr(dx),
+                                                          _stream()), "dn_upsample2_bilinear_nhwc_backward")
+    return dx
+
+
 # ---- fusion, training form ----------------------------------------------------------------
 def pair_add_ego(z1, e, ego_image):
     n_pairs, rows, c = z1.shape[0], z1[0].numel() // z1.shape[-1], z1.shape[-1]

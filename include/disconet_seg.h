@@ -50,6 +50,21 @@ int dn_seg_label_count(const int32_t* labels, long pixels, int classes, int32_t*
 int dn_seg_ce_loss(const float* logits, const int32_t* labels, long pixels, int classes, int ld,
                    float grad_scale, const int32_t* counts, double* loss_sum, float* dlogits, void* stream);
 
+/* ---- training forms on float32 NHWC maps (SegModule.step: the UNet's reverse pass; conventions of
+ * disconet_train.h -- a gradient argument may be a channel slice of a wider map: pointer at its first
+ * channel + the pixel stride ld in floats).  c % 4 == 0, 16-byte aligned buffers. ---- */
+/* nn.MaxPool2d(2): x [n][h][w][c] -> y [n][h/2][w/2][c] */
+int dn_maxpool2_nhwc(const float* x, int n_images, int h, int w, int c, float* y, void* stream);
+/* its backward: dx [n][h][w][c] = dy routed to each window's FIRST maximum in scan order (ATen's recorded
+ * index), zero elsewhere; every element written once (no zero fill, deterministic). */
+int dn_maxpool2_nhwc_backward(const float* x, const float* dy, int ld_dy, int n_images, int h, int w, int c,
+                              float* dx, void* stream);
+/* nn.Upsample(x2, bilinear, align_corners=True): x [n][h][w][c] -> y [n][2h][2w][c] */
+int dn_upsample2_bilinear_nhwc(const float* x, int n_images, int h, int w, int c, float* y, void* stream);
+/* its backward in gather form: dy [n][2h][2w] (stride ld_dy) -> dx [n][h][w][c]; fixed summation order. */
+int dn_upsample2_bilinear_nhwc_backward(const float* dy, int ld_dy, int n_images, int h, int w, int c,
+                                        float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
