@@ -473,6 +473,28 @@ def seg_bench(args, world, rank, dist, use_pg):
             "sample": "1 scene (5 agents, 256x256x13), eval fwd, fp32, best of 2 after 1 warm-up; torch-CPU "
                       "oracle (reference source not in the mount)",
             "parity_max_abs_err": float((got.cpu() - want).abs().max())}
+    if world == 1 and args.train_steps > 0:
+        # SegModule.step on the same batch (train() mode: batch statistics, cross entropy, explicit HIP reverse
+        # pass through the UNet and the fusion, Adam) -- reported beside the headline value, never in it
+        try:
+            tmodel = SegDiscoNet(num_agent=AGENTS).cuda()
+            tmod = SegModule(tmodel, lr=1e-3)
+            x = ops.scatter_dense(indices, offsets, n_img, dims).view(n_img, MAP_HW, MAP_HW, 13)
+            tdata = {"bev_seq": x, "trans_matrices": trans, "num_agent": na, "labels": labels}
+            first = tmod.step(tdata, BATCH)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.train_steps):
+                last = tmod.step(tdata, BATCH)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.train_steps
+            result["train_step"] = {"ms_per_step": round(1e3 * dt, 3), "scenes_per_s": round(BATCH / dt, 2),
+                                    "steps": args.train_steps, "batch_per_gpu": BATCH,
+                                    "loss_first": round(first["loss"], 5), "loss_last": round(last["loss"], 5),
+                                    "note": "SegModule.step: train() forward + cross entropy + explicit HIP backward + Adam, "
+                                            "eager launches, wall clock"}
+        except Exception as e:
+            result["train_step"] = {"error": repr(e)}
     print(json.dumps(result), flush=True)
 
 

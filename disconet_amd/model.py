@@ -293,8 +293,11 @@ class DiscoNet(nn.Module):
         # two 1x1 conv launches + the tail kernel (split-f16 engines, C in {64, 128, 256})
         self.fuse_mlp = os.environ.get("DISCONET_FUSE_MLP", "1") != "0"
         # ... and the pose warp inside that launch as well (csrc/fuse_warp.hip): the warped neighbour maps are
-        # re-derived tile by tile in LDS and never written.  DISCONET_FUSE_WARP=0: warp kernel + fuse_mlp.
-        self.fuse_warp = os.environ.get("DISCONET_FUSE_WARP", "1") != "0"
+        # re-derived tile by tile in LDS and never written.  Opt-in (DISCONET_FUSE_WARP=1): it removes the 84 MB
+        # `warped` tensor but measures 225 us against 137 us for warp + fuse_mlp at the BASELINE shape -- the
+        # block is bound by gather latency, not bytes, and the fused form derives every warped value twice
+        # (DESIGN.md 3.4).
+        self.fuse_warp = os.environ.get("DISCONET_FUSE_WARP", "0") == "1"
         # run the encoder levels above the exchanged one beside the fusion block on a second HIP stream:
         # REFUSED unless DISCONET_UNSAFE_OVERLAP=1 (the property below).  A kernel that shares a SIMD with
         # the split-f16 conv kernels has been observed to compute with corrupted VGPR lanes (DESIGN.md
