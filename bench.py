@@ -271,6 +271,10 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
     first, count = sharded.agent_range(agents, world, rank)
     stepper = sharded.GraphedAgentStep(engine, rank_inputs(first, count), trans, na, BATCH, first, count)
     elapsed = time_steps(stepper, args.steps, args.warmup)
+    # per-phase times on EVERY rank (the exchange is a collective: all ranks must call it the same number of times)
+    phases = {"graph_a_encode": phase_us(stepper.graph_a), "allgather": phase_us(stepper.exchange),
+              "graph_b_fuse_decode_heads": phase_us(stepper.graph_b)}
+    fence()
     res = None
     if rank == 0:
         res = {
@@ -285,8 +289,7 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
                        "agents": agents, "batch": BATCH, "conv_math": args.math,
                        "launch": "hipGraph A (rebuild + encoder) -> all-gather -> hipGraph B (fusion + decoder + heads)",
                        "parallelism": "agent-parallel x%d" % world},
-            "phases_us": {"graph_a_encode": phase_us(stepper.graph_a), "allgather": phase_us(stepper.exchange),
-                          "graph_b_fuse_decode_heads": phase_us(stepper.graph_b)},
+            "phases_us": phases,
             "exchanged_bytes_per_rank_per_step": int(stepper.feat_all.numel() * stepper.feat_all.element_size()
                                                      * (world - 1) // max(world, 1)),
         }

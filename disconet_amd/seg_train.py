@@ -30,6 +30,11 @@ class SegTrainEngine(TrainEngine):
     def _param_order(self, model):
         return list(model.parameters())
 
+    def _math(self):
+        # forward convs of the training step: split-f16 on the NHWC engine (the eval plan's arithmetic; "f32" =
+        # exact-fp32 MFMA, set model.train_math); data and weight gradients are always exact fp32 (train.py)
+        return ops.nhwc_math(getattr(self.model, "train_math", "f16x3"))
+
     def _graph(self):
         m = self.model
         L = {}
