@@ -218,3 +218,29 @@ def run_seg_ref(case, model=None):
 def seg_subsample(name, t):
     t = t.detach().cpu().numpy()
     return t[:, :, ::7, ::5] if name == "logits" else t[:, ::5, ::3, ::3]
+
+
+SEG_GOLDEN_GRAD_TENSORS = [
+    "inc.double_conv.0.weight", "down2.maxpool_conv.1.double_conv.4.weight", "down3.maxpool_conv.1.double_conv.3.weight",
+    "down4.maxpool_conv.1.double_conv.0.weight", "up1.conv.double_conv.0.weight", "up3.conv.double_conv.3.weight",
+    "up4.conv.double_conv.1.bias", "pixel_weighted_fusion.conv1_1.weight", "pixel_weighted_fusion.bn1_2.weight",
+    "outc.conv.weight",
+]
+
+
+def oracle_seg_train_fp64(case, ref):
+    """the seg oracle's training forward / backward in float64 (fp32 warp grids): -> (loss, grads)"""
+    import copy
+    import torch.nn.functional as F
+    from oracle.seg_ref import seg_loss
+    c = SEG_CASES[case]
+    x, trans, na, labels = seg_inputs(case)
+    ref64 = copy.deepcopy(ref).double().train()
+    orig = F.grid_sample
+    F.grid_sample = lambda inp, grid, **kw: orig(inp, grid.to(inp.dtype), **kw)
+    try:
+        loss = seg_loss(ref64(x.double(), trans, na, c["batch"]), labels)
+        loss.backward()
+    finally:
+        F.grid_sample = orig
+    return float(loss.detach()), {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}

@@ -95,10 +95,29 @@ def main():
         print("seg", case, {k: tuple(v.shape) for k, v in outs.items()}, "loss", loss)
     np.savez_compressed(os.path.join(HERE, "seg_cases.npz"), **store)
 
+    seg_train_golden()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
+def seg_train_golden():
+    """7. segmentation training step (float64 oracle): loss and strided gradient slices.
+    `python tests/golden/make_golden.py seg_train` regenerates this fixture alone."""
+    store = {}
+    for case, c in cases.SEG_CASES.items():
+        ref = cases.seg_ref_model(c["agents"])
+        loss, grads = cases.oracle_seg_train_fp64(case, ref)
+        store["%s/loss" % case] = np.float64(loss)
+        for n in cases.SEG_GOLDEN_GRAD_TENSORS:
+            store["%s/%s" % (case, n)] = cases.grad_slice(grads[n])
+            store["%s/%s/absmax" % (case, n)] = np.float64(grads[n].abs().max())
+        print("seg train", case, loss)
+    np.savez_compressed(os.path.join(HERE, "seg_train_step.npz"), **store)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "seg_train":
+        seg_train_golden()
+    else:
+        main()

@@ -81,6 +81,16 @@ def test_seg_train_step_matches_oracle(case, monkeypatch):
     assert abs(out["loss"] - l_ref) < 2e-5 * abs(l_ref), (out, l_ref)
 
     eng = mod._trainer.engine
+    # the committed float64 golden (tests/golden/seg_train_step.npz): loss and gradient slices
+    import os
+    import numpy as np
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "seg_train_step.npz"))
+    assert abs(out["loss"] - float(gold["%s/loss" % case])) < 2e-5 * abs(float(gold["%s/loss" % case]))
+    named = dict(model.named_parameters())
+    for n in cases.SEG_GOLDEN_GRAD_TENSORS:
+        got = cases.grad_slice(eng.g(named[n]).cpu())
+        scale = float(gold["%s/%s/absmax" % (case, n)])
+        assert abs(got - gold["%s/%s" % (case, n)]).max() < 0.05 * scale, n      # ~1 % fp32 noise floor
     ref_named = dict(ref.named_parameters())
     gmax = max(float(g.abs().max()) for g in g64.values())
     rows = {}

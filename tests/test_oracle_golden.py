@@ -129,3 +129,16 @@ def test_training_step_golden(golden_dir, case, tag):
         want = g["%s/%s/%s" % (case, tag, n)]
         scale = float(g["%s/%s/%s/absmax" % (case, tag, n)])
         assert abs(cases.grad_slice(grads[n]) - want).max() <= 1e-7 * scale, n
+
+
+def test_seg_training_step_golden(golden_dir):
+    """the seg oracle's float64 training forward / backward (oracle/seg_ref.py through F.cross_entropy; what
+    oracle/seg_train_ref.py steps) against tests/golden/seg_train_step.npz: loss and gradient slices"""
+    g = np.load(os.path.join(golden_dir, "seg_train_step.npz"))
+    case = "seg_a2"
+    ref = cases.seg_ref_model(cases.SEG_CASES[case]["agents"])
+    loss, grads = cases.oracle_seg_train_fp64(case, ref)
+    assert abs(loss - float(g["%s/loss" % case])) <= 1e-9 * abs(loss)
+    for n in cases.SEG_GOLDEN_GRAD_TENSORS:
+        scale = float(g["%s/%s/absmax" % (case, n)])
+        assert abs(cases.grad_slice(grads[n]) - g["%s/%s" % (case, n)]).max() <= 1e-7 * scale, n
