@@ -46,6 +46,8 @@ struct SpArgs {
   int up0, c_out, cog, relu;   // cog = chunks of the output tensor
   int ngroups;                 // A groups (CA chunks each) of the K loop
   int tiles_x, tiles_y, total_items, xcd_order;
+  int n_cb;                    // channel blocks; reciprocals of the work-item decode's divisors (sp_device.h :: fdivmod)
+  float rcp_ncb, rcp_tx, rcp_ty;
   int cout_pad, wpk_bytes;
   // fused 1x1 stage
   const unsigned char* w2;     // [2 n-tiles][4 k-steps][2 parts][2 h][32 n] x 16 B
@@ -166,7 +168,7 @@ conv_sp_kernel(const SpArgs a) {
   // ---- work items (channel block, image, tile_y, tile_x), XCD-aware order as in conv_mfma.hip
   const int G = gridDim.x;
   const int spatial_items = a.n_images * a.tiles_y * a.tiles_x;
-  const int n_cb = a.total_items / spatial_items;
+  const int n_cb = a.n_cb;
   const int sp_full = spatial_items & ~7;
   auto decode = [&](int item) {
     TileCoord tc;
@@ -176,18 +178,19 @@ conv_sp_kernel(const SpArgs a) {
       spi = item % spatial_items;
     } else if (item < sp_full * n_cb) {
       const int j = item >> 3;
-      cb = j % n_cb;
-      spi = (item & 7) * (sp_full >> 3) + j / n_cb;
+      const int jq = fdivmod(j, n_cb, a.rcp_ncb, cb);
+      spi = (item & 7) * (sp_full >> 3) + jq;
     } else {
-      const int r = item - sp_full * n_cb, rem = spatial_items - sp_full;
+      const int r = item - sp_full * n_cb, rem = spatial_items - sp_full;   // the last < 8 spatial items: rare
       cb = r / rem;
       spi = sp_full + r % rem;
     }
     tc.n0 = cb * BN;
-    tc.ox0 = (spi % a.tiles_x) * TW;
-    spi /= a.tiles_x;
-    tc.oy0 = (spi % a.tiles_y) * TH;
-    tc.img = spi / a.tiles_y;
+    int tx, ty;
+    spi = fdivmod(spi, a.tiles_x, a.rcp_tx, tx);
+    tc.img = fdivmod(spi, a.tiles_y, a.rcp_ty, ty);
+    tc.ox0 = tx * TW;
+    tc.oy0 = ty * TH;
     return tc;
   };
 
@@ -223,24 +226,39 @@ conv_sp_kernel(const SpArgs a) {
     asm volatile("" : "+v"(v));
     return v;
   };
-  // per-lane source offsets of the A pieces this lane moves: piece (it * NW + wave) * 64 + lane
+  // per-lane source offsets of the A pieces this lane moves: piece (it * NW + wave) * 64 + lane.  Which patch
+  // pixel (row r, column cc) and quarter plane cq a piece is does not depend on the tile: decoded ONCE per launch
+  // into one packed register per piece (r | cc + 1 << 8 | cq << 16 | valid << 31) -- the two constant divisions and
+  // the column map per piece were ~half of the per-tile instruction stream of the short-K layers.
+  // A tile then only adds its origin, tests the image bounds and forms the offset.
+  unsigned piece_map[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int piece = (it * NW + wave) * 64 + lane;
+    const int cq = piece / NPIX, pp = piece % NPIX;   // cq = cu * 4 + q
+    const int r = pp / P::PITCH, cc = sp::patch_col_of<KS, STRIDE, TH, TW>(pp % P::PITCH);
+    const bool valid = piece < T::A_PIECES && cc >= 0;   // (pad pieces decode to in-range but meaningless fields)
+    piece_map[it] = (unsigned)r | ((unsigned)(cc + 1) << 8) | ((unsigned)cq << 16) | (valid ? 0x80000000u : 0u);
+  }
   auto setup_voff_a = [&](const TileCoord& tc, bool from1) {
-    const int t = opaque(tid);
     const int iy0 = tc.oy0 * STRIDE - KS / 2, ix0 = tc.ox0 * STRIDE - KS / 2;
     const unsigned plane = from1 ? plane1 : plane0;
     const int ws = from1 ? a.w_in : ws0;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-      const int piece = (it * NW + (t >> 6)) * 64 + (t & 63);
-      const int cq = piece / NPIX, pp = piece % NPIX;   // cq = cu * 4 + q
-      const int r = pp / P::PITCH, cc = sp::patch_col_of<KS, STRIDE, TH, TW>(pp % P::PITCH);
+      unsigned pm = piece_map[it];
+      asm volatile("" : "+v"(pm));          // unpack per tile: keeps ONE register per piece live across the K loop
+      const int r = pm & 0xff, cc = (int)((pm >> 8) & 0xff) - 1, cq = (pm >> 16) & 0xff;
       const int iy = iy0 + r, ix = ix0 + cc;
-      const bool ok = piece < T::A_PIECES && cc >= 0 && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;   // (piece % NPIX etc. of a pad piece are in range but meaningless: `ok` is false)
+      const bool ok = (int)pm < 0 && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
       const int sy = (!from1 && a.up0) ? (iy >> 1) : iy, sx = (!from1 && a.up0) ? (ix >> 1) : ix;
       voff_a[it] = ok ? (unsigned)cq * plane + (unsigned)(sy * ws + sx) * 16u : OOB;
     }
   };
+  int voffb_n0 = -1;       // the channel block voff_b was formed for (it only depends on the tile through n0)
   auto setup_voff_b = [&](const TileCoord& tc) {
+    if (tc.n0 == voffb_n0) return;
+    voffb_n0 = tc.n0;
     const int t = opaque(tid);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
@@ -1102,8 +1120,11 @@ int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   a.tiles_y = (a.h_out + TH - 1) / TH;
   const long total = (long)a.n_images * a.tiles_y * a.tiles_x * ((d.c_out + BN - 1) / BN);
   DN_REQUIRE(total < (1L << 31), "spconv: too many tiles (%ld)", total);
+  DN_REQUIRE(total < (1L << 22), "spconv: too many work items for the reciprocal decode (%ld)", total);
   a.total_items = (int)total;
   a.xcd_order = 1;
+  a.n_cb = (d.c_out + BN - 1) / BN;
+  a.rcp_ncb = 1.0f / (float)a.n_cb; a.rcp_tx = 1.0f / (float)a.tiles_x; a.rcp_ty = 1.0f / (float)a.tiles_y;
   const long resident = (long)occupancy * kCUs;
   dim3 grid((unsigned)(total > resident ? resident : total));
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), lds_bytes, stream, a);

@@ -56,6 +56,8 @@ struct SpqArgs {
   int c_out, cog, relu;
   int tiles_x, tiles_y, total_items;
   int cout_pad, wpk_bytes;
+  int n_cb;                    // channel blocks; reciprocals of the work-item decode's divisors (sp_device.h :: fdivmod)
+  float rcp_ncb, rcp_tx, rcp_ty;
 };
 
 struct QTile {
@@ -94,25 +96,26 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
   // ---- work items (channel block, image, tile_y, tile_x), XCD-aware order as in conv_sp_kernel
   const int G = gridDim.x;
   const int spatial_items = a.n_images * a.tiles_y * a.tiles_x;
-  const int n_cb = a.total_items / spatial_items;
+  const int n_cb = a.n_cb;
   const int sp_full = spatial_items & ~7;
   auto decode = [&](int item) {
     QTile tc;
     int cb, spi;
     if (item < sp_full * n_cb) {
       const int j = item >> 3;
-      cb = j % n_cb;
-      spi = (item & 7) * (sp_full >> 3) + j / n_cb;
+      const int jq = fdivmod(j, n_cb, a.rcp_ncb, cb);
+      spi = (item & 7) * (sp_full >> 3) + jq;
     } else {
-      const int r = item - sp_full * n_cb, rem = spatial_items - sp_full;
+      const int r = item - sp_full * n_cb, rem = spatial_items - sp_full;   // the last < 8 spatial items: rare
       cb = r / rem;
       spi = sp_full + r % rem;
     }
     tc.n0 = cb * BN;
-    tc.ox0 = (spi % a.tiles_x) * QTW;
-    spi /= a.tiles_x;
-    tc.oy0 = (spi % a.tiles_y) * QTH;
-    tc.img = spi / a.tiles_y;
+    int tx, ty;
+    spi = fdivmod(spi, a.tiles_x, a.rcp_tx, tx);
+    tc.img = fdivmod(spi, a.tiles_y, a.rcp_ty, ty);
+    tc.ox0 = tx * QTW;
+    tc.oy0 = ty * QTH;
     return tc;
   };
 
@@ -159,26 +162,38 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
     asm volatile("" : "+v"(v));
     return v;
   };
-  // per-lane source offsets of the patch pieces this lane moves: LDS piece (it * NW + wave) * 64 + lane
+  // per-lane source offsets of the patch pieces this lane moves: LDS piece (it * NW + wave) * 64 + lane.  The piece's
+  // patch pixel (r, cc) and quarter plane are tile-independent: decoded once per launch into one packed register
+  // (r | cc << 8 | cq << 16 | valid << 31), as in conv_sp_kernel; a tile adds its origin and tests the image bounds.
+  unsigned piece_map[QA_IT];
+#pragma unroll
+  for (int it = 0; it < QA_IT; ++it) {
+    const int piece = (it * QNW + wave) * 64 + lane;
+    const int cq = piece / QNPIX, pp = piece % QNPIX;
+    const int r = pp / QPITCH, pos = pp % QPITCH;
+    const int cc = pos < QHALF ? 2 * pos : 2 * (pos - QHALF) + 1;
+    piece_map[it] = (unsigned)r | ((unsigned)cc << 8) | ((unsigned)cq << 16) | (piece < QA_PIECES ? 0x80000000u : 0u);
+  }
   auto setup_voff_a = [&](const QTile& tc, bool from1) {
-    const int t = opaque(tid);
     const int iy0 = tc.oy0 - 1, ix0 = tc.ox0 - 1;
     const unsigned plane = from1 ? plane1 : plane0;
     const int ws = from1 ? a.w : ws0;
 #pragma unroll
     for (int it = 0; it < QA_IT; ++it) {
-      const int piece = (it * QNW + (t >> 6)) * 64 + (t & 63);
-      const int cq = piece / QNPIX, pp = piece % QNPIX;
-      const int r = pp / QPITCH, pos = pp % QPITCH;
-      const int cc = pos < QHALF ? 2 * pos : 2 * (pos - QHALF) + 1;
+      unsigned pm = piece_map[it];
+      asm volatile("" : "+v"(pm));
+      const int r = pm & 0xff, cc = (pm >> 8) & 0xff, cq = (pm >> 16) & 0xff;
       const int iy = iy0 + r, ix = ix0 + cc;
-      const bool ok = piece < QA_PIECES && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
+      const bool ok = (int)pm < 0 && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
       const int sy = from1 ? iy : (iy >> 1), sx = from1 ? ix : (ix >> 1);
       voff_a[it] = ok ? (unsigned)cq * plane + (unsigned)(sy * ws + sx) * 16u : OOB;
     }
   };
   // weight pieces: LDS piece -> (block of the step, quarter, channel); the same map serves both step kinds
+  int voffb_n0 = -1;
   auto setup_voff_b = [&](const QTile& tc) {
+    if (tc.n0 == voffb_n0) return;
+    voffb_n0 = tc.n0;
     const int t = opaque(tid);
 #pragma unroll
     for (int it = 0; it < T::B_IT0; ++it) {
@@ -506,8 +521,10 @@ int launch_spq(SpqArgs& a, hipStream_t stream) {
   a.tiles_x = (a.w + QTW - 1) / QTW;
   a.tiles_y = (a.h + QTH - 1) / QTH;
   const long total = (long)a.n_images * a.tiles_y * a.tiles_x * ((a.c_out + BN - 1) / BN);
-  DN_REQUIRE(total < (1L << 31), "spconv (quad-merged): too many tiles (%ld)", total);
+  DN_REQUIRE(total < (1L << 22), "spconv (quad-merged): too many tiles (%ld)", total);
   a.total_items = (int)total;
+  a.n_cb = (a.c_out + BN - 1) / BN;
+  a.rcp_ncb = 1.0f / (float)a.n_cb; a.rcp_tx = 1.0f / (float)a.tiles_x; a.rcp_ty = 1.0f / (float)a.tiles_y;
   const long resident = 2L * kCUs;
   dim3 grid((unsigned)(total > resident ? resident : total));
   hipLaunchKernelGGL(kern, grid, dim3(QNT), T::LDS_BYTES, stream, a);

@@ -23,6 +23,18 @@ __device__ inline void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// x / d and x % d for a work-item index (0 <= x < 2^22, d >= 1) through the float reciprocal the host put into the
+// kernel arguments: the work-item decode runs once per tile and runtime integer division costs ~35 instructions
+// apiece.  q = trunc(x * rcp) is off by at most one for quotients below 2^20; corrected either way.
+__device__ inline int fdivmod(int x, int d, float rcp, int& rem) {
+  int q = (int)((float)x * rcp);
+  int r = x - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+  rem = r;
+  return q;
+}
+
 // One LDS-DMA instruction: 64 lanes x 16 bytes, global (per-lane voff + scalar soff) -> LDS at
 // lds + 16 * lane (wave-uniform base through M0).  An out-of-range voff writes zeros.  A plain
 // __device__ function, not a lambda: the builtin inside a lambda makes hipcc's HOST pass drop the
@@ -54,15 +66,17 @@ inline unsigned sp_range_flags_here(bool reset) {   // host: this translation un
 
 // x -> (hi, lo) halves, 4 values -> two dword pairs.  amax: running max |x| of what this lane has split
 // (note_range() reports it once per epilogue).
+// Vector form on purpose: gfx950 has v_cvt_pk_f16_f32 (two fp32 -> packed halves, round to nearest even, the scalar
+// conversion's result) and v_med3_f32 / v_max3_f32 -- 18 VALU instructions per 4 values against ~30 for the
+// element-wise form; every epilogue of the short-K layers runs this for each of its outputs.
 __device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo, float& amax) {
-  half4 h, l;
+  amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
+  amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
+  f32x4 x;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    amax = fmaxf(amax, fabsf(v[e]));
-    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
-    h[e] = (_Float16)x;
-    l[e] = (_Float16)(x - (float)h[e]);
-  }
+  for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+  const half4 h = __builtin_convertvector(x, half4);
+  const half4 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), half4);
   hi = __builtin_bit_cast(u32x2, h);
   lo = __builtin_bit_cast(u32x2, l);
 }
