@@ -109,6 +109,7 @@ SIGNATURES = {
     "dn_upsample2_bilinear_nhwc_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     # ---- include/disconet_train.h ----
     "dn_conv_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
+    "dn_reduce_workspace_bytes": (c_size_t, [c_int, c_long, c_int]),
     "dn_conv_wgrad": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_int, c_int, c_void_p]),
     "dn_conv_dgrad_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,

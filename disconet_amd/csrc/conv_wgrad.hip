@@ -183,17 +183,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   }
 
   // four waves -> one block: LDS reduction, then the slice's partial goes out row-major
+  // (the waves add in wave order, one after the other: a fixed summation order -- round 2 used LDS float atomics,
+  // whose arrival order made the weight gradients differ from run to run in the last bits)
   float* R = smem;
-  for (int i = tid; i < T::R_FLOATS; i += 256) R[i] = 0.f;
-  __syncthreads();
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+      for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = lh * 4 + (r & 3) + 8 * (r >> 2);
-      atomicAdd(&R[t * 1024 + i * 32 + li], acc[t][r]);
+        for (int r = 0; r < 16; ++r) {
+          const int i = lh * 4 + (r & 3) + 8 * (r >> 2);
+          float* slot = &R[t * 1024 + i * 32 + li];
+          *slot = (wv == 0 ? 0.f : *slot) + acc[t][r];
+        }
     }
-  __syncthreads();
+    __syncthreads();
+  }
   float* out = a.partial + ((size_t)(slice * a.n_cot + cot) * a.n_cit + cit) * T::R_FLOATS;
   for (int i = tid * 4; i < T::R_FLOATS; i += 1024)
     *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(&R[i]);

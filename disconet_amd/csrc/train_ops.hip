@@ -28,17 +28,22 @@ __device__ inline int lanes_for(int c) {   // power-of-two channel lanes per row
   return t;
 }
 
+// loss VALUES only (det_loss_kernel, kd_kl_kernel): one f64 atomic per workgroup; the reported scalar may differ in
+// its last bits between runs, no gradient or parameter depends on it
 __device__ inline void atomic_add_f64(double* p, double v) { atomicAdd(p, v); }
 
 // ---------------------------------------------------------------------------------
-// per-(group, channel) sums of up to two quantities over the rows of a group
+// per-(group, channel) sums of up to two quantities over the rows of a group -- DETERMINISTIC: the rows a thread
+// adds, the order in which a workgroup adds its threads' partials (LDS, by row-lane index) and the order in which
+// the workgroups' partials are added (fold_partials_kernel, by block index) are all fixed by the launch shape,
+// so two runs of a training step produce the same bits (round 2 used f64 atomics in LDS and in global memory).
 // ---------------------------------------------------------------------------------
-// F(row_in_group, c, &q0, &q1) yields the two addends; grid = (blocks per group, groups)
+// F(row_in_group, c, &q0, &q1) yields the two addends; grid = (blocks per group, groups).  The workgroup's partial
+// goes to part_g[blockIdx.x * NQ * c + q * c + channel].
+constexpr int kRedSlots = 2048;     // ty_n * c <= 2048 for every launch shape (c <= kMaxC)
 template <int NQ, class F>
-__device__ inline void group_channel_sums(int c, long rows_per_group, double* sums_g, F f) {
-  __shared__ double acc[2][kMaxC];
-  for (int i = threadIdx.x; i < NQ * kMaxC; i += blockDim.x) acc[i / kMaxC][i % kMaxC] = 0.0;
-  __syncthreads();
+__device__ inline void group_channel_sums(int c, long rows_per_group, double* part_g, F f) {
+  __shared__ double red[2][kRedSlots];
   const int tx_n = lanes_for(c), ty_n = blockDim.x / tx_n;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
   const long chunk = (rows_per_group + gridDim.x - 1) / gridDim.x;
@@ -52,20 +57,23 @@ __device__ inline void group_channel_sums(int c, long rows_per_group, double* su
       s0 += q0;
       if (NQ > 1) s1 += q1;
     }
-    atomic_add_f64(&acc[0][cc], s0);
-    if (NQ > 1) atomic_add_f64(&acc[1][cc], s1);
+    red[0][ty * c + cc] = s0;
+    if (NQ > 1) red[1][ty * c + cc] = s1;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NQ * c; i += blockDim.x)
-    atomic_add_f64(&sums_g[i], acc[i / c][i % c]);
+  double* out = part_g + (size_t)blockIdx.x * NQ * c;
+  for (int i = threadIdx.x; i < NQ * c; i += blockDim.x) {
+    const int q = i / c, cc = i % c;
+    double t = 0.0;
+    for (int y = 0; y < ty_n; ++y) t += red[q][y * c + cc];
+    out[i] = t;
+  }
 }
 
 // float4 form: lanes over groups of 4 channels (c % 4 == 0, 16-byte aligned rows)
 template <int NQ, class F>
-__device__ inline void group_channel_sums_v4(int c, long rows_per_group, double* sums_g, F f) {
-  __shared__ double acc[2][kMaxC];
-  for (int i = threadIdx.x; i < NQ * kMaxC; i += blockDim.x) acc[i / kMaxC][i % kMaxC] = 0.0;
-  __syncthreads();
+__device__ inline void group_channel_sums_v4(int c, long rows_per_group, double* part_g, F f) {
+  __shared__ double red[2][kRedSlots];
   const int c4n = c >> 2;
   const int tx_n = lanes_for(c4n), ty_n = blockDim.x / tx_n;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
@@ -85,13 +93,30 @@ __device__ inline void group_channel_sums_v4(int c, long rows_per_group, double*
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      atomic_add_f64(&acc[0][4 * c4 + e], s0[e]);
-      if (NQ > 1) atomic_add_f64(&acc[1][4 * c4 + e], s1[e]);
+      red[0][ty * c + 4 * c4 + e] = s0[e];
+      if (NQ > 1) red[1][ty * c + 4 * c4 + e] = s1[e];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NQ * c; i += blockDim.x)
-    atomic_add_f64(&sums_g[i], acc[i / c][i % c]);
+  double* out = part_g + (size_t)blockIdx.x * NQ * c;
+  for (int i = threadIdx.x; i < NQ * c; i += blockDim.x) {
+    const int q = i / c, cc = i % c;
+    double t = 0.0;
+    for (int y = 0; y < ty_n; ++y) t += red[q][y * c + cc];
+    out[i] = t;
+  }
+}
+
+// sums[g][i] = sum over the group's blocks, in block order, of part[g][blk][i]   (i < per = NQ * c)
+__global__ void fold_partials_kernel(const double* __restrict__ part, int n_blocks, int per, int n_groups,
+                                     double* __restrict__ sums) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_groups * per) return;
+  const int g = idx / per, i = idx % per;
+  const double* p = part + (size_t)g * n_blocks * per + i;
+  double t = 0.0;
+  for (int b = 0; b < n_blocks; ++b) t += p[(size_t)b * per];
+  sums[idx] = t;
 }
 
 __device__ inline f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -106,7 +131,7 @@ bn_stats_v4_kernel(const float* __restrict__ z, long rows_per_group, int c, int 
                    double* __restrict__ sums) {
   const int g = blockIdx.y;
   const float* zg = z + (size_t)g * rows_per_group * ldz;
-  group_channel_sums_v4<2>(c, rows_per_group, sums + (size_t)g * 2 * c,
+  group_channel_sums_v4<2>(c, rows_per_group, sums + (size_t)g * gridDim.x * 2 * c,
                            [&](long r, int c4, f32x4& q0, f32x4& q1) {
                              q0 = ldv4(zg + r * ldz + 4 * c4);
                              q1 = q0 * q0;
@@ -137,7 +162,7 @@ bn_stats_kernel(const float* __restrict__ z, long rows_per_group, int c, int ldz
                 double* __restrict__ sums) {
   const int g = blockIdx.y;
   const float* zg = z + (size_t)g * rows_per_group * ldz;
-  group_channel_sums<2>(c, rows_per_group, sums + (size_t)g * 2 * c,
+  group_channel_sums<2>(c, rows_per_group, sums + (size_t)g * gridDim.x * 2 * c,
                         [&](long r, int cc, float& q0, float& q1) {
                           const float v = zg[r * ldz + cc];
                           q0 = v;
@@ -240,7 +265,7 @@ bn_bwd_reduce_v4_kernel(GradSrc src, const float* __restrict__ z, const float* _
                         double* __restrict__ sums) {
   const int g = blockIdx.y, c = src.c;
   const long base = (long)g * rows_per_group;
-  group_channel_sums_v4<2>(c, rows_per_group, sums + (size_t)g * 2 * c,
+  group_channel_sums_v4<2>(c, rows_per_group, sums + (size_t)g * gridDim.x * 2 * c,
                            [&](long r, int c4, f32x4& q0, f32x4& q1) {
                              q0 = src.v4(base + r, c4);
                              const f32x4 zh = (ldv4(z + (base + r) * c + 4 * c4) - ldv4(mean + g * c + 4 * c4)) *
@@ -280,7 +305,7 @@ bn_bwd_reduce_kernel(GradSrc src, const float* __restrict__ z, const float* __re
                      double* __restrict__ sums) {
   const int g = blockIdx.y, c = src.c;
   const long base = (long)g * rows_per_group;
-  group_channel_sums<2>(c, rows_per_group, sums + (size_t)g * 2 * c,
+  group_channel_sums<2>(c, rows_per_group, sums + (size_t)g * gridDim.x * 2 * c,
                         [&](long r, int cc, float& q0, float& q1) {
                           const float gr = src(base + r, cc);
                           const float rstd = 1.f / sqrtf(var[g * c + cc] + eps);
@@ -591,20 +616,27 @@ int blocks_per_group(long rows_per_group, int n_groups) {
 
 }  // namespace
 
+// doubles of workspace a per-channel reduction needs: the folded sums + every workgroup's partial
+extern "C" size_t dn_reduce_workspace_bytes(int n_groups, long rows_per_group, int c) {
+  if (n_groups <= 0 || rows_per_group <= 0 || c <= 0) return 0;
+  return sizeof(double) * 2 * c * n_groups * (size_t)(1 + blocks_per_group(rows_per_group, n_groups));
+}
+
 extern "C" int dn_bn_train_stats(const float* z, int n_groups, long rows_per_group, int c, int ldz,
                                  double* sums, float* mean, float* var, void* stream) {
   DN_REQUIRE(z && sums && mean && var, "bn stats: null pointer");
   DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0 && c <= kMaxC && ldz >= c,
              "bn stats: bad shape (groups %d rows %ld c %d ld %d)", n_groups, rows_per_group, c, ldz);
   hipStream_t s = (hipStream_t)stream;
-  if (dn::zero_fill(sums, sizeof(double) * 2 * c * n_groups, s) != hipSuccess)
-    return dn::fail(DN_ERR_LAUNCH, "bn stats: memset failed");
+  // workspace: [n_groups][2 c] folded sums, then the workgroups' partials [n_groups][blocks][2 c]
+  const int nblk = blocks_per_group(rows_per_group, n_groups);
+  double* part = sums + (size_t)2 * c * n_groups;
   if (vec4_ok(c, {ldz}, {z}))
-    hipLaunchKernelGGL(bn_stats_v4_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
-                       dim3(256), 0, s, z, rows_per_group, c, ldz, sums);
+    hipLaunchKernelGGL(bn_stats_v4_kernel, dim3(nblk, n_groups), dim3(256), 0, s, z, rows_per_group, c, ldz, part);
   else
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
-                       dim3(256), 0, s, z, rows_per_group, c, ldz, sums);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, n_groups), dim3(256), 0, s, z, rows_per_group, c, ldz, part);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((n_groups * 2 * c + 255) / 256), dim3(256), 0, s, part, nblk, 2 * c,
+                     n_groups, sums);
   const int n = n_groups * c;
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sums, n, c,
                      rows_per_group, mean, var);
@@ -652,18 +684,24 @@ extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const
              "bn backward: bad shape");
   hipStream_t s = (hipStream_t)stream;
   const long rows_per_group = (long)images_per_group * h * w;
-  if (dn::zero_fill(sums, sizeof(double) * 2 * c * n_groups, s) != hipSuccess)
-    return dn::fail(DN_ERR_LAUNCH, "bn backward: memset failed");
   GradSrc src{dy_a, dy_b, y, ld_a, up_a, ld_b, relu, h, w, c};
   const long total = (long)n_groups * rows_per_group * c;
+  const int nblk = blocks_per_group(rows_per_group, n_groups);
+  double* part = sums + (size_t)2 * c * n_groups;      // workspace layout: see dn_bn_train_stats
+  auto fold = [&] {
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((n_groups * 2 * c + 255) / 256), dim3(256), 0, s, part, nblk, 2 * c,
+                       n_groups, sums);
+  };
   if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz})) {
-    hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
-                       dim3(256), 0, s, src, z, mean, var, eps, rows_per_group, sums);
+    hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel, dim3(nblk, n_groups), dim3(256), 0, s, src, z, mean, var, eps,
+                       rows_per_group, part);
+    fold();
     hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z,
                        mean, var, gamma, eps, rows_per_group, sums, total / 4, dz);
   } else {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_per_group(rows_per_group, n_groups), n_groups),
-                       dim3(256), 0, s, src, z, mean, var, eps, rows_per_group, sums);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, n_groups), dim3(256), 0, s, src, z, mean, var, eps,
+                       rows_per_group, part);
+    fold();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, src, z, mean,
                        var, gamma, eps, rows_per_group, sums, total, dz);
   }
@@ -677,14 +715,13 @@ extern "C" int dn_channel_sum(const float* x, long rows, int c, int ld, double* 
   DN_REQUIRE(x && sums && out, "channel sum: null pointer");
   DN_REQUIRE(rows > 0 && c > 0 && c <= kMaxC && ld >= c, "channel sum: bad shape");
   hipStream_t s = (hipStream_t)stream;
-  if (dn::zero_fill(sums, sizeof(double) * c, s) != hipSuccess)
-    return dn::fail(DN_ERR_LAUNCH, "channel sum: memset failed");
+  const int nblk = blocks_per_group(rows, 1);
+  double* part = sums + c;                              // [c] folded sums, then the workgroups' partials [blocks][c]
   if (vec4_ok(c, {ld}, {x}))
-    hipLaunchKernelGGL(channel_sum_v4_kernel, dim3(blocks_per_group(rows, 1)), dim3(256), 0, s, x, rows,
-                       c, ld, sums);
+    hipLaunchKernelGGL(channel_sum_v4_kernel, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
   else
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(blocks_per_group(rows, 1)), dim3(256), 0, s, x, rows, c,
-                       ld, sums);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((c + 255) / 256), dim3(256), 0, s, part, nblk, c, 1, sums);
   hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, s, sums, c, out,
                      accumulate);
   return dn::check_launch("channel_sum_kernel");

@@ -66,7 +66,7 @@ def bn_stats(z, n_groups=1):
     assert rows % n_groups == 0
     mean = torch.empty((n_groups, c), dtype=torch.float32, device=z.device)
     var = torch.empty_like(mean)
-    sums = _ws(z.device, 16 * c * n_groups)
+    sums = _ws(z.device, _lib.load().dn_reduce_workspace_bytes(n_groups, rows // n_groups, c))
     check(_lib.load().dn_bn_train_stats(_ptr(z), n_groups, rows // n_groups, c, c, _ptr(sums),
                                         _ptr(mean), _ptr(var), _stream()), "dn_bn_train_stats")
     return mean, var
@@ -102,7 +102,7 @@ def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_
     n_groups = mean.shape[0]
     assert n % n_groups == 0
     dz = torch.empty_like(z) if out is None else out
-    sums = _ws(z.device, 16 * c * n_groups)
+    sums = _ws(z.device, _lib.load().dn_reduce_workspace_bytes(n_groups, (n // n_groups) * h * w, c))
     check(_lib.load().dn_bn_train_backward(
         _ptr(dy_a), _ld(dy_a), int(bool(up_a)), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0,
         _ptr(y), _ptr(z), _ptr(mean), _ptr(var), _ptr(gamma), float(eps), int(relu), n_groups, h, w,
@@ -116,7 +116,7 @@ def channel_sum(x, out, accumulate=False):
     _need_gpu(x, out)
     c = x.shape[-1]
     rows = x.numel() // c
-    sums = _ws(x.device, 8 * c)
+    sums = _ws(x.device, _lib.load().dn_reduce_workspace_bytes(1, rows, c))
     check(_lib.load().dn_channel_sum(_ptr(x), rows, c, _ld(x), _ptr(sums), _ptr(out),
                                      int(bool(accumulate)), _stream()), "dn_channel_sum")
     return out

@@ -33,6 +33,8 @@ extern "C" {
  * weight (the attention MLP's [W_ego | W_nbr]) can be written in place.  Slices are summed
  * in a fixed order: deterministic.  accumulate != 0 adds to dw. */
 size_t dn_conv_wgrad_workspace(const dn_conv_desc* d);
+/* workspace of the per-channel reductions below (dn_bn_train_stats, dn_bn_train_backward, dn_channel_sum) */
+size_t dn_reduce_workspace_bytes(int n_groups, long rows_per_group, int c);
 int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz,
                   void* workspace, float* dw, int dw_cin_total, int accumulate, void* stream);
 
@@ -48,7 +50,9 @@ int dn_conv_dgrad_weights(const float* w_oihw, int c_out, int cin_total, int ci_
 /* Statistics over `rows_per_group` pixels for each of `n_groups` consecutive groups of rows
  * (n_groups = 1: nn.BatchNorm2d over the batch; n_groups = calls: the attention MLP's BN
  * layers, which see one (ego, neighbour) pair of 1 x C x 32 x 32 per call).
- * sums: workspace of n_groups * 2 * c doubles.  var is the biased variance. */
+ * sums: workspace of dn_reduce_workspace_bytes(n_groups, rows_per_group, c) bytes (the folded sums and every
+ * workgroup's partial: the per-channel sums are DETERMINISTIC -- fixed thread, workgroup and fold order, no
+ * atomics).  var is the biased variance. */
 int dn_bn_train_stats(const float* z, int n_groups, long rows_per_group, int c, int ldz,
                       double* sums, float* mean, float* var, void* stream);
 
@@ -69,14 +73,14 @@ int dn_bn_update_running(const float* mean, const float* var, int n_groups, long
  *   g = (dy_a + dy_b) * (y > 0)      dbeta = sum g      dgamma = sum g * zhat
  *   dz = gamma * rstd * (g - mean(g) - zhat * mean(g * zhat))       (means per group)
  * dgamma / dbeta are summed over groups and ADDED when accumulate != 0.
- * sums: workspace of n_groups * 2 * c doubles. */
+ * sums: workspace of dn_reduce_workspace_bytes(n_groups, images_per_group * h * w, c) bytes. */
 int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
                          const float* y, const float* z, const float* mean, const float* var,
                          const float* gamma, float eps, int relu, int n_groups, int h, int w,
                          int images_per_group, int c, double* sums, float* dz, float* dgamma,
                          float* dbeta, int accumulate, void* stream);
 
-/* out[c] (+)= sum over rows of x[row][c] (bias gradients); sums: c doubles */
+/* out[c] (+)= sum over rows of x[row][c] (bias gradients); sums: dn_reduce_workspace_bytes(1, rows, c) bytes */
 int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, float* out,
                    int accumulate, void* stream);
 

@@ -152,3 +152,10 @@ def test_seg_train_step_at_baseline_size_properties():
     assert float(eng.flat_g.abs().max()) > 0
     assert not torch.equal(rm0, model.inc.double_conv[1].running_mean)
     assert int(model.up4.conv.double_conv[4].num_batches_tracked) == 3
+    # determinism: the same three steps from the same start give the same bits (no atomics on the gradient path)
+    torch.manual_seed(0)
+    model2 = SegDiscoNet(num_agent=A).cuda()
+    mod2 = SegModule(model2, lr=1e-3)
+    losses2 = [mod2.step(data, B)["loss"] for _ in range(3)]
+    assert torch.equal(mod2._trainer.engine.flat_g, eng.flat_g) and torch.equal(mod2._trainer.engine.flat_p, eng.flat_p)
+    assert abs(losses2[2] - losses[2]) <= 1e-12 * abs(losses[2])

@@ -490,12 +490,15 @@ def test_kd_train_step_at_baseline_size_properties():
     for out in (plain, zero_kd, with_kd):
         assert all(v == v and abs(v) != float("inf") for v in out.values()), out
     assert zero_kd["kd_loss"] == 0.0 and with_kd["kd_loss"] > 0.0
-    # a zeroed teacher term vanishes: what is left between the two runs is the run-to-run noise of the
-    # backward's atomics (BatchNorm / bias sums); the live KD term moves the gradient far beyond it
+    # the backward is deterministic (fixed-order per-channel sums and wave reductions since round 3; rigid poses take
+    # the gather form of the warp backward): the same step twice gives the same bits ...
+    plain2, g_plain2 = grads_of(0, 0.0)
+    assert torch.equal(g_plain, g_plain2)
+    # ... a zeroed teacher term adds exact zeros to the decoder's gradients, and the live KD term moves them
     gmax = float(g_plain.abs().max())
     noise = float((g_plain - g_zero).abs().max())
-    assert noise <= 1e-5 * gmax
-    assert float((g_kd - g_plain).abs().max()) > max(20 * noise, 1e-4 * gmax)
+    assert noise <= 1e-6 * gmax
+    assert float((g_kd - g_plain).abs().max()) > 1e-4 * gmax
     # training moves the loss down
     model.load_state_dict(state)
     mod = CoDetModule(model, teacher, kd_flag=1, lr=1e-3)
