@@ -546,7 +546,7 @@ int spq_pack_weights(const float* weight_oihw, void* packed, int c_out, int c_in
   return check_launch("spq_pack_weights_kernel");
 }
 
-// bn: 32 or 64 output channels per workgroup; 0 = choose (enough work items for two workgroups on every CU)
+// bn: 32 or 64 output channels per workgroup; 0 = choose
 int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed, size_t packed_bytes,
              const float* scale, const float* shift, void* out, int cout_pad, int bn, hipStream_t stream) {
   SpqArgs a;
@@ -559,7 +559,9 @@ int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const vo
   a.tiles_x = a.tiles_y = a.total_items = 0;
   if (bn == 0) {
     const long tiles = (long)d->n_images * ((d->h_in + QTH - 1) / QTH) * ((d->w_in + QTW - 1) / QTW);
-    bn = (d->c_out > 32 && tiles * ((d->c_out + 63) / 64) >= 2L * kCUs) ? 64 : 32;
+    // BN = 64 halves the patch traffic per MAC but needs >= two full rounds of 64-wide items (measured: conv7_1
+    // 1280 items: 129 vs 153 us; conv6_1 640 items: 146 vs 142 us; conv5_1 320 items: 174 vs 171 us)
+    bn = (d->c_out > 32 && tiles * ((d->c_out + 63) / 64) >= 4L * kCUs) ? 64 : 32;
   }
   if (bn == 64) return launch_spq<64>(a, stream);
   return launch_spq<32>(a, stream);
