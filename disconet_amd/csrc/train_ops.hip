@@ -107,16 +107,20 @@ __device__ inline void group_channel_sums_v4(int c, long rows_per_group, double*
   }
 }
 
-// sums[g][i] = sum over the group's blocks, in block order, of part[g][blk][i]   (i < per = NQ * c)
-__global__ void fold_partials_kernel(const double* __restrict__ part, int n_blocks, int per, int n_groups,
-                                     double* __restrict__ sums) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// sums[g][i] = sum over the group's blocks of part[g][blk][i]   (i < per = NQ * c), in a FIXED order: one wavefront
+// per output; lane l adds blocks l, l + 64, l + 128, ... in that order, then the 64 lane sums go through a xor
+// butterfly (a fixed tree).  (A single thread walking up to 2048 partials was a 1 ms serial chain per reduction.)
+__global__ void __launch_bounds__(256) fold_partials_kernel(const double* __restrict__ part, int n_blocks, int per,
+                                                            int n_groups, double* __restrict__ sums) {
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (idx >= n_groups * per) return;
   const int g = idx / per, i = idx % per;
   const double* p = part + (size_t)g * n_blocks * per + i;
   double t = 0.0;
-  for (int b = 0; b < n_blocks; ++b) t += p[(size_t)b * per];
-  sums[idx] = t;
+  for (int b = lane; b < n_blocks; b += 64) t += p[(size_t)b * per];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  if (lane == 0) sums[idx] = t;
 }
 
 __device__ inline f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -635,7 +639,7 @@ extern "C" int dn_bn_train_stats(const float* z, int n_groups, long rows_per_gro
     hipLaunchKernelGGL(bn_stats_v4_kernel, dim3(nblk, n_groups), dim3(256), 0, s, z, rows_per_group, c, ldz, part);
   else
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, n_groups), dim3(256), 0, s, z, rows_per_group, c, ldz, part);
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((n_groups * 2 * c + 255) / 256), dim3(256), 0, s, part, nblk, 2 * c,
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((n_groups * 2 * c + 3) / 4), dim3(256), 0, s, part, nblk, 2 * c,
                      n_groups, sums);
   const int n = n_groups * c;
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sums, n, c,
@@ -689,7 +693,7 @@ extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const
   const int nblk = blocks_per_group(rows_per_group, n_groups);
   double* part = sums + (size_t)2 * c * n_groups;      // workspace layout: see dn_bn_train_stats
   auto fold = [&] {
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((n_groups * 2 * c + 255) / 256), dim3(256), 0, s, part, nblk, 2 * c,
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((n_groups * 2 * c + 3) / 4), dim3(256), 0, s, part, nblk, 2 * c,
                        n_groups, sums);
   };
   if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz})) {
@@ -721,7 +725,7 @@ extern "C" int dn_channel_sum(const float* x, long rows, int c, int ld, double* 
     hipLaunchKernelGGL(channel_sum_v4_kernel, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
   else
     hipLaunchKernelGGL(channel_sum_kernel, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((c + 255) / 256), dim3(256), 0, s, part, nblk, c, 1, sums);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, nblk, c, 1, sums);
   hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, s, sums, c, out,
                      accumulate);
   return dn::check_launch("channel_sum_kernel");

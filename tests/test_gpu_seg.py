@@ -128,7 +128,11 @@ def test_seg_at_baseline_size_properties():
     assert torch.equal(a, b)
 
 
-def test_seg_train_mode_fails_loudly():
+def test_seg_forward_in_train_mode_fails_loudly():
+    """training runs through SegModule.step (the explicit HIP training graph, tests/test_gpu_seg_train.py); the module's
+    forward() is the eval plan and refuses train() mode instead of silently using running statistics"""
     from disconet_amd import SegDiscoNet
-    with pytest.raises(NotImplementedError):
-        SegDiscoNet().train()
+    m = SegDiscoNet(num_agent=2).cuda().train()
+    x = torch.zeros(2, 13, 32, 32).cuda()
+    with pytest.raises(NotImplementedError, match="SegModule.step"):
+        m(x, torch.eye(4).repeat(1, 2, 2, 1, 1).cuda(), torch.full((1, 2), 2).cuda(), 1)
