@@ -73,6 +73,8 @@ SIGNATURES = {
     "dn_spconv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_float, c_void_p, c_void_p]),
     "dn_spconv2d": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p]),
+    "dn_spconv2d_dual": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_int, c_void_p]),
     "dn_sp_post1x1_packed_bytes": (c_size_t, []),
     "dn_sp_post1x1_pack_weights": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "dn_sp_post1x1_pack_heads": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),

@@ -453,6 +453,10 @@ conv_sp_kernel(const SpArgs a) {
           v[e] = co + e < c_lim ? v[e] : 0.f;
         }
       }
+      if constexpr (POST == 0) {   // optional second output: the same values as fp32 NHWC rows (the exchanged level)
+        if (a.out_b != nullptr && inside && co < c_lim)
+          *reinterpret_cast<f32x4*>(a.out_b + (((size_t)img * a.h_out + oy) * a.w_out + ox) * a.ldo_b + co) = v;
+      }
       split4(v, hi[g], lo[g], amax);
     }
 #pragma unroll
@@ -1275,14 +1279,37 @@ extern "C" int dn_spconv_set_upmode(int mode) {
   return DN_OK;
 }
 
+namespace {
+int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed, const float* scale,
+                  const float* shift, void* out, float* out_nhwc, int ld_nhwc, void* stream);
+}
+
 extern "C" int dn_spconv2d(const dn_conv_desc* d, const void* src0, const void* src1,
                            const void* packed, const float* scale, const float* shift, void* out,
                            void* stream) {
+  return spconv2d_impl(d, src0, src1, packed, scale, shift, out, nullptr, 0, stream);
+}
+
+extern "C" int dn_spconv2d_dual(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed,
+                                const float* scale, const float* shift, void* out_sp, float* out_nhwc, int ld_nhwc,
+                                void* stream) {
+  DN_REQUIRE(d && out_nhwc && ld_nhwc >= d->c_out && ld_nhwc % 4 == 0 && d->c_out % 4 == 0 &&
+                 (reinterpret_cast<uintptr_t>(out_nhwc) & 15) == 0,
+             "spconv dual: the fp32 NHWC output needs c_out %% 4 == 0, ld >= c_out, ld %% 4 == 0, 16-byte alignment");
+  return spconv2d_impl(d, src0, src1, packed, scale, shift, out_sp, out_nhwc, ld_nhwc, stream);
+}
+
+namespace {
+int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed, const float* scale,
+                  const float* shift, void* out, float* out_nhwc, int ld_nhwc, void* stream) {
   if (int rc = validate(d)) return rc;
   DN_REQUIRE(src0 && packed && scale && shift && out, "spconv: null pointer");
   DN_REQUIRE(d->c1 == 0 || src1, "spconv: c1 > 0 but src1 is null");
   SpArgs a;
   if (int rc = fill_args(d, src0, src1, packed, scale, shift, out, a)) return rc;
+  a.out_b = out_nhwc; a.ldo_b = ld_nhwc;      // POST 0: optional fp32 NHWC copy of the output
+  DN_REQUIRE(!out_nhwc || (up_mode(*d) != 2 && g_sp_force < 100),
+             "spconv dual: not available on the tap-merged up-conv kernel");
   hipStream_t s = (hipStream_t)stream;
   if (up_mode(*d) == 2) {   // the packed image is the quad-merged one: conv_spq.hip (tools: 20 / 21 force BN = 32 / 64)
     DN_REQUIRE(a.c1g == 0 || d->c0 % 16 == 0, "spconv: concat needs c0 %% 16 == 0");
@@ -1351,6 +1378,7 @@ extern "C" int dn_spconv2d(const dn_conv_desc* d, const void* src0, const void* 
   }
   return dn::fail(DN_ERR_UNSUPPORTED, "spconv: no tile configuration");
 }
+}  // namespace
 
 extern "C" int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p, const void* src0,
                                    const void* src1, const void* packed, const float* scale,

@@ -167,7 +167,8 @@ class _ConvLayer:
             self.packed = ops.pack_conv_weights(d, weight)
         self.c_in, self.c_out, self.ksize, self.stride, self.relu = c_in, c_out, ksize, stride, relu
 
-    def run(self, src0, src1=None, up0=False):
+    def run(self, src0, src1=None, up0=False, nhwc_copy=False):
+        """nhwc_copy (SP engine, not on an upsampled source): -> (SpTensor, float32 NHWC copy from the same launch)"""
         n, h0, w0, c0 = src0.shape
         h_in, w_in = (h0 * 2, w0 * 2) if up0 else (h0, w0)
         c1 = src1.shape[3] if src1 is not None else 0
@@ -187,7 +188,8 @@ class _ConvLayer:
             # split-planar engine: NHWC inputs (the voxel grid, the fused map) are split once here
             src0, src1 = ops.as_sp(src0), (ops.as_sp(src1) if src1 is not None else None)
             with region(self.name, "conv_sp_kernel", flops, nbytes):
-                return ops.sp_conv2d(d, src0, self.packed, self.scale, self.shift, src1=src1)
+                return ops.sp_conv2d(d, src0, self.packed, self.scale, self.shift, src1=src1,
+                                     nhwc_copy=nhwc_copy and not up0 and self.c_out % 4 == 0)
         src0, src1 = ops.as_nhwc(src0), (ops.as_nhwc(src1) if src1 is not None else None)
         out = torch.empty((n, ho, wo, self.c_out), dtype=torch.float32, device=src0.device)
         with region(self.name, "conv_mfma_kernel", flops, nbytes):
@@ -476,28 +478,35 @@ class DiscoNet(nn.Module):
             x = x.float().contiguous()
         return x
 
-    def _enc_group(self, k, x, P):
-        """encoder group k: its last layer's output is the pyramid level e[k]"""
+    def _enc_group(self, k, x, P, nhwc_copy=False):
+        """encoder group k: its last layer's output is the pyramid level e[k].  nhwc_copy (SP engine): the last
+        layer also writes the level as fp32 NHWC from its epilogue (the exchanged level: no dn_sp_to_nhwc pass);
+        returns (level, nhwc copy or None)."""
+        dual = nhwc_copy and self.conv_math == "sp"
+        unpack = lambda r: r if isinstance(r, tuple) else (r, None)
         if k == 0:
-            return P["conv_pre_2"].run(P["conv_pre_1"].run(x))
+            return unpack(P["conv_pre_2"].run(P["conv_pre_1"].run(x), nhwc_copy=dual))
         if k == 1:
             if "conv1_2_3d" in P:
-                return P["conv1_2_3d"].run(P["conv1_1"].run(x))[0]
-            return P["conv3d_1"].run(P["conv1_2"].run(P["conv1_1"].run(x)))
+                return P["conv1_2_3d"].run(P["conv1_1"].run(x))[0], None
+            return unpack(P["conv3d_1"].run(P["conv1_2"].run(P["conv1_1"].run(x)), nhwc_copy=dual))
         if k == 2:
-            return P["conv3d_2"].run(P["conv2_2"].run(P["conv2_1"].run(x)))
-        return P["conv%d_2" % k].run(P["conv%d_1" % k].run(x))
+            return unpack(P["conv3d_2"].run(P["conv2_2"].run(P["conv2_1"].run(x)), nhwc_copy=dual))
+        return unpack(P["conv%d_2" % k].run(P["conv%d_1" % k].run(x), nhwc_copy=dual))
 
     def encode(self, bevs, P):
         x = self._enc_input(bevs)
         enc = []
+        flat = None
         for k in range(5):
-            x = self._enc_group(k, x, P)
+            x, copy = self._enc_group(k, x, P, nhwc_copy=(k == self.layer and "compress" not in P))
+            flat = copy if k == self.layer else flat
             enc.append(x)
         if "compress" in P:
             enc[3] = P["decompress"].run(P["compress"].run(enc[3]))
-        # the exchanged level leaves the conv engine (fusion kernels, the agent all-gather): fp32 NHWC
-        enc[self.layer] = ops.as_nhwc(enc[self.layer])
+        # the exchanged level leaves the conv engine (fusion kernels, the agent all-gather): fp32 NHWC, written by the
+        # producing conv's own epilogue where that form exists, else converted
+        enc[self.layer] = flat if flat is not None else ops.as_nhwc(enc[self.layer])
         return enc
 
     def fuse(self, feat, trans_matrices, num_agent, batch_size, P, want_weights=False,
@@ -582,7 +591,7 @@ class DiscoNet(nn.Module):
             x = self._enc_input(bevs)
             enc = []
             for k in range(self.layer + 1):
-                x = self._enc_group(k, x, P)
+                x, _ = self._enc_group(k, x, P)
                 enc.append(x)
             main = torch.cuda.current_stream()
             side = self._side_stream(bevs.device)
@@ -590,7 +599,7 @@ class DiscoNet(nn.Module):
             with torch.cuda.stream(side):
                 up = x
                 for k in range(self.layer + 1, 5):
-                    up = self._enc_group(k, up, P)
+                    up, _ = self._enc_group(k, up, P)
                     enc.append(up)
             feat = ops.as_nhwc(enc[self.layer])
             if "compress" in P and self.layer != 3:

@@ -299,12 +299,24 @@ def sp_pack_conv_weights(d, weight):
     return packed, wmul
 
 
-def sp_conv2d(d, src0, packed, scale, shift, src1=None, out=None):
-    """SP conv: src0 / src1 SpTensors -> SpTensor [n_images, h_out, w_out, c_out]"""
+def sp_conv2d(d, src0, packed, scale, shift, src1=None, out=None, nhwc_copy=False):
+    """SP conv: src0 / src1 SpTensors -> SpTensor [n_images, h_out, w_out, c_out].
+    nhwc_copy: also return the output as a float32 NHWC tensor written by the same launch (dn_spconv2d_dual)
+    -> (SpTensor, tensor)."""
     _need_gpu(src0, packed, scale, shift, src1)
     ho, wo = conv_out_hw(d)
     if out is None:
         out = SpTensor(d.n_images, ho, wo, d.c_out, device=src0.device)
+    if nhwc_copy:
+        if src1 is not None and src1.hi_only:
+            raise _lib.DnError("sp_conv2d: only source 0 may be a hi-only SP tensor")
+        if src0.hi_only:
+            d.math = 3
+        flat = torch.empty((d.n_images, ho, wo, d.c_out), dtype=torch.float32, device=src0.device)
+        check(_lib.load().dn_spconv2d_dual(ctypes.byref(d), _ptr(src0.data), _ptr(src1.data) if src1 is not None else None,
+                                           _ptr(packed), _ptr(scale), _ptr(shift), _ptr(out.data), _ptr(flat), d.c_out,
+                                           _stream()), "dn_spconv2d_dual")
+        return out, flat
     if src1 is not None and src1.hi_only:
         raise _lib.DnError("sp_conv2d: only source 0 may be a hi-only SP tensor")
     if src0.hi_only:

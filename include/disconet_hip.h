@@ -208,6 +208,13 @@ int dn_spconv_pack_weights(const dn_conv_desc* d, const float* weight_oihw, floa
 int dn_spconv2d(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp,
                 const void* packed, const float* scale, const float* shift, void* out_sp,
                 void* stream);
+/* The same conv with a SECOND copy of its output as float32 NHWC rows [n][h_out][w_out][ld_nhwc] (first c_out
+ * columns; c_out % 4 == 0), written from the same epilogue registers before the f16 split: the level a
+ * consumer outside the conv engine reads (the fusion kernels' maps, the agent all-gather) needs no
+ * dn_sp_to_nhwc pass.  Not available on the tap-merged up-conv kernel (up0 = 1 layers). */
+int dn_spconv2d_dual(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp, const void* packed,
+                     const float* scale, const float* shift, void* out_sp, float* out_nhwc, int ld_nhwc,
+                     void* stream);
 /* Fused 3x3 (64 channels) + affine + ReLU, then 1x1 + affine (+ReLU): the 64-channel tile
  * never leaves the registers between the two layers (cf. dn_conv2d_post1x1).
  * out_f32 == 0: out_a is an SP tensor of c_out2 channels (p->split, ldo_* ignored);

@@ -207,3 +207,24 @@ def test_conv_random_shapes_fuzz():
         except AssertionError as e:
             fails.append((case, n, h, w, c0, c1, c_out, k, stride, up0, math, str(e)[:80]))
     assert not fails, fails
+
+
+@pytest.mark.parametrize("h,w,c0,c_out,k,stride", [(32, 32, 256, 256, 3, 1), (20, 28, 48, 36, 3, 1), (32, 32, 64, 128, 3, 2),
+                                                   (24, 40, 128, 128, 1, 1)])
+def test_sp_conv_dual_output(h, w, c0, c_out, k, stride):
+    """dn_spconv2d_dual: the fp32 NHWC copy written by the same epilogue is the unsplit value -- the SP output
+    is its hi + lo split, bit for bit -- and the SP output equals the plain launch's"""
+    from disconet_amd import ops
+    g = torch.Generator().manual_seed(h + c0)
+    wgt = (torch.randn(c_out, c0, k, k, generator=g) * (2.0 / (c0 * k * k)) ** 0.5).cuda()
+    x = ops.SpTensor.from_nhwc(torch.randn(3, h, w, c0, generator=g).cuda())
+    scale = (torch.rand(c_out, generator=g) + 0.5).cuda()
+    shift = (torch.randn(c_out, generator=g) * 0.1).cuda()
+    d = ops.conv_desc(3, h, w, c0, c_out, k, stride, True, math="sp")
+    packed, wmul = ops.sp_pack_conv_weights(d, wgt)
+    plain = ops.sp_conv2d(d, x, packed, scale / wmul, shift)
+    sp, flat = ops.sp_conv2d(d, x, packed, scale / wmul, shift, nhwc_copy=True)
+    torch.cuda.synchronize()
+    assert torch.equal(sp.data, plain.data)
+    assert torch.equal(ops.SpTensor.from_nhwc(flat).data, sp.data)
+    assert (flat - sp.nhwc()).abs().max().item() <= 2e-6 * max(1.0, flat.abs().max().item())
