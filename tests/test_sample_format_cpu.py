@@ -1,0 +1,40 @@
+"""The sparse-voxel sample reader (disconet_amd/sample_format.py; SURVEY.md §8(f) #4, second half): files written in the
+recalled on-disk form round-trip into the hot path's batch inputs, and the dense rebuild of those inputs (numpy here; the
+GPU scatter is covered by tests/test_gpu_voxel.py) equals the grid the files were made from."""
+import numpy as np
+import pytest
+import torch
+
+from disconet_amd import sample_format
+from disconet_amd.synthetic import make_bevs, make_trans_matrices
+
+
+def test_round_trip_through_npy_files(tmp_path):
+    A, B, hw = 3, 2, 32
+    bevs = make_bevs(B, A, hw)                       # [A*B, 1, hw, hw, 13]
+    trans = make_trans_matrices(B, A).numpy()
+    samples = [[None] * A for _ in range(B)]
+    for a in range(A):
+        for b in range(B):
+            grid = bevs[a * B + b, 0].numpy()
+            idx = np.argwhere(grid > 0).astype(np.int64)             # sorted unique, as voxelize_occupy leaves it
+            path = tmp_path / ("scene%d_agent%d.npy" % (b, a))
+            np.save(path, {"voxel_indices_0": idx, "trans_matrices": trans[b, a], "num_sensor": A,
+                           "reg_target_sparse": np.zeros((1, 6))}, allow_pickle=True)
+            samples[b][a] = sample_format.load_sample(str(path))
+            assert samples[b][a]["indices"].dtype == np.int32 and "reg_target_sparse" in samples[b][a]["rest"]
+    indices, offsets, tr, na = sample_format.batch_from_samples(samples, A, device="cpu")
+    assert offsets.dtype == torch.int32 and offsets.shape == (A * B + 1,) and int(offsets[-1]) == indices.shape[0]
+    assert torch.equal(tr, torch.from_numpy(trans)) and torch.equal(na, torch.full((B, A), A))
+    dense = torch.zeros(A * B, hw, hw, 13)
+    for g in range(A * B):
+        rows = indices[int(offsets[g]):int(offsets[g + 1])].long()
+        dense[g, rows[:, 0], rows[:, 1], rows[:, 2]] = 1.0
+    assert torch.equal(dense, bevs[:, 0])
+
+
+def test_missing_key_is_reported(tmp_path):
+    path = tmp_path / "bad.npy"
+    np.save(path, {"voxel_indices": np.zeros((0, 3))}, allow_pickle=True)
+    with pytest.raises(KeyError, match="voxel_indices_0"):
+        sample_format.load_sample(str(path))
