@@ -92,6 +92,8 @@ def parse():
     ap.add_argument("--agent-check", type=int, default=0,
                     help="--mode agent: replay this many extra steps and compare every step's output checksum with "
                          "the first (all-gather kernel between the two compute graphs)")
+    ap.add_argument("--agent-batch", type=int, default=BATCH,
+                    help="scenes per step of the agent-sharded leg (configs[4] does not fix it; 4 = the det batch)")
     ap.add_argument("--no-pg", action="store_true",
                     help="--mode agent on one GPU: no process group at all (the exchange is a local copy): isolates "
                          "the compute graphs from the collective in --agent-check")
@@ -192,7 +194,7 @@ def cpu_baseline_bounded(state_dict, threads, timeout_s):
 def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
     """BASELINE configs[4] (the north star's multi-GPU split): 8-agent scenes, the agents sharded across the
     ranks, ONE RCCL all-gather of the layer-3 maps per step as the V2X exchange, everything else rank-local.
-    Fixed work (batch 4 of 8-agent scenes) for every N -> strong scaling.  One step = dense rebuild of this
+    Fixed work (--agent-batch, default 4, 8-agent scenes) for every N -> strong scaling.  One step = dense rebuild of this
     rank's voxel lists + encoder (hipGraph A) -> all-gather (eager, in stream order) -> fusion of this rank's
     egos + decoder + heads (hipGraph B): disconet_amd.sharded.GraphedAgentStep.
 
@@ -205,27 +207,28 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
     from disconet_amd import Config, DiscoNet, ops, sharded
     from disconet_amd.synthetic import make_sparse_scene_batch, make_trans_matrices, randomize_bn_stats
     agents = 8
+    batch = args.agent_batch
     torch.manual_seed(0)
     model = DiscoNet(Config(map_hw=MAP_HW), kd_flag=0, num_agent=agents)
     randomize_bn_stats(model)
     model.conv_math = args.math
     model.eval().cuda()
     engine = sharded.HipEngine(model)
-    indices, offsets, _ = make_sparse_scene_batch(BATCH, agents, MAP_HW)
-    trans = make_trans_matrices(BATCH, agents).cuda()
-    na = torch.full((BATCH, agents), agents, dtype=torch.int64).cuda()
+    indices, offsets, _ = make_sparse_scene_batch(batch, agents, MAP_HW)
+    trans = make_trans_matrices(batch, agents).cuda()
+    na = torch.full((batch, agents), agents, dtype=torch.int64).cuda()
     dims = (MAP_HW, MAP_HW, 13)
 
     def rank_inputs(first, count):
         # this rank's agents: images [first*B, (first+count)*B) of the agent-major stack
-        lo, hi = int(offsets[first * BATCH]), int(offsets[(first + count) * BATCH])
+        lo, hi = int(offsets[first * batch]), int(offsets[(first + count) * batch])
         idx = indices[lo:hi].contiguous().cuda()
-        off = (offsets[first * BATCH:(first + count) * BATCH + 1] - lo).to(torch.int32).cuda()
+        off = (offsets[first * batch:(first + count) * batch + 1] - lo).to(torch.int32).cuda()
 
         def make_bevs():
             if model.conv_math == "sp":
-                return ops.scatter_dense_sp(idx, off, count * BATCH, dims, hi_only=True)
-            return ops.scatter_dense(idx, off, count * BATCH, dims)
+                return ops.scatter_dense_sp(idx, off, count * batch, dims, hi_only=True)
+            return ops.scatter_dense(idx, off, count * batch, dims)
         return make_bevs
 
     def checksum(out):
@@ -269,7 +272,7 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
         return round(1e3 * e0.elapsed_time(e1) / reps, 2)
 
     first, count = sharded.agent_range(agents, world, rank)
-    stepper = sharded.GraphedAgentStep(engine, rank_inputs(first, count), trans, na, BATCH, first, count)
+    stepper = sharded.GraphedAgentStep(engine, rank_inputs(first, count), trans, na, batch, first, count)
     elapsed = time_steps(stepper, args.steps, args.warmup)
     # per-phase times on EVERY rank (the exchange is a collective: all ranks must call it the same number of times)
     phases = {"graph_a_encode": phase_us(stepper.graph_a), "allgather": phase_us(stepper.exchange),
@@ -279,14 +282,14 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
     if rank == 0:
         res = {
             "metric": "scenes/sec (8-agent 256x256 BEV, agents sharded across GPUs)",
-            "value": round(BATCH * args.steps / elapsed, 3), "unit": "scenes/s", "n_gpus": world,
+            "value": round(batch * args.steps / elapsed, 3), "unit": "scenes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": DTYPE_NAME[args.math], "data": "synthetic",
-            "config": {"workload": "DiscoNet det eval forward (--com disco), 8-agent scenes, batch 4, 256x256x13 BEV, "
+            "config": {"workload": "DiscoNet det eval forward (--com disco), 8-agent scenes, batch %d, 256x256x13 BEV, "
                                    "%d agent(s) per GPU, one RCCL all-gather of the 256x32x32 layer-3 maps per "
-                                   "step (BASELINE configs[4])" % count,
-                       "agents": agents, "batch": BATCH, "conv_math": args.math,
+                                   "step (BASELINE configs[4])" % (batch, count),
+                       "agents": agents, "batch": batch, "conv_math": args.math,
                        "launch": "hipGraph A (rebuild + encoder) -> all-gather -> hipGraph B (fusion + decoder + heads)",
                        "parallelism": "agent-parallel x%d" % world},
             "phases_us": phases,
@@ -325,12 +328,12 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
         full_out = stepper()
         full = {"cls": full_out[0]["cls"].clone(), "loc": full_out[0]["loc"].clone()}
         cnt = agents // W
-        share = sharded.GraphedAgentStep(engine, rank_inputs(0, cnt), trans, na, BATCH, 0, cnt,
+        share = sharded.GraphedAgentStep(engine, rank_inputs(0, cnt), trans, na, batch, 0, cnt,
                                          emulate_feat_all=full_feat)
         t_share = time_steps(share, args.steps, args.warmup)
         got = share()
         torch.cuda.synchronize()
-        rows = cnt * BATCH
+        rows = cnt * batch
         same = bool(torch.equal(got[0]["cls"], full["cls"][:rows]) and torch.equal(got[0]["loc"], full["loc"][:rows]))
         res["emulated_share"] = {
             "world": W, "agents_per_rank": cnt, "ms_per_step": round(1e3 * t_share / args.steps, 4),
@@ -446,8 +449,15 @@ def seg_bench(args, world, rank, dist, use_pg):
             "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_PEAK_TFLOPS["sp"], "unit": "TFLOP/s",
             "frac": round(ach / MFMA_PEAK_TFLOPS["sp"], 4), "executed_flop_factor": 3,
             "frac_executed": round(3 * ach / MFMA_PEAK_TFLOPS["sp"], 4), "traffic": None,
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": None,
             "flop_per_step": flops / args.steps, "kernel_ms_per_step": round(ms / args.steps, 4),
             "note": "achieved = algorithmic FLOP (true channel counts) / HIP-event kernel time"}
+        try:   # HBM bytes per conv launch from the committed rocprofv3 --pmc passes over this command (eager)
+            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic_seg.json"))[-1]
+            result["roofline"]["traffic"] = json.load(open(os.path.join(ROOT, "profiles", prof)))["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = "profiles/" + prof
+        except (OSError, IndexError, KeyError, ValueError):
+            pass
         if args.layers:
             for k, v in summ.items():
                 print("[seg] %-12s %8.4f ms/step %9.2f TFLOP/s" % (

@@ -1040,19 +1040,36 @@ inline size_t packed_blocks(const dn_conv_desc& d) {   // 16-byte-piece blocks o
 }
 
 enum SpCfgId { S3_256x64, S3_256x32, S3_128x64, S3_64x64, S3S2_128x64, S3S2_64x64, S1_256x64, S1_64x64,
-               S3_256x64_T9, S3_512x64, S3_256x128, S1_256x64_C1, SP_CFG_COUNT };
+               S3_256x64_T9, S3_512x64, S3_256x128, S1_256x64_C1, S3_256x32_ST, S3_64x64_T9, S3_128x64_T9,
+               S3S2_64x64_T9, S3S2_128x64_T9, SP_CFG_COUNT };
 // chunks per A stage of the 1x1 tiles: the chunk count of the input must be a multiple
 inline int ca_of(SpCfgId id) { return id == S1_256x64 ? 2 : id == S1_64x64 ? 4 : 1; }
 struct SpCfg { SpCfgId id; int th, tw, bn; float bias; };
 // biases: measured time per unit of tile area relative to 256x64 (tools/sp_conv_check.hip sweep)
-float g_sp_bias[SP_CFG_COUNT] = {1.00f, 1.15f, 1.10f, 1.40f, 1.45f, 1.00f, 1.00f, 1.30f, 1.f, 1.f, 1.f, 1.2f};
+float g_sp_bias[SP_CFG_COUNT] = {1.00f, 1.15f, 1.10f, 1.40f, 1.45f, 1.00f, 1.00f, 1.30f, 1.f, 1.f, 1.f, 1.2f,
+                                 1.f, 1.f, 1.f, 1.f, 1.f};
 const SpCfg kSpCfgs[SP_CFG_COUNT] = {
     {S3_256x64, 8, 32, 64, 0},   {S3_256x32, 8, 32, 32, 0},   {S3_128x64, 8, 16, 64, 0},
     {S3_64x64, 8, 8, 64, 0},     {S3S2_128x64, 8, 16, 64, 0}, {S3S2_64x64, 8, 8, 64, 0},
     {S1_256x64, 8, 32, 64, 0},   {S1_64x64, 8, 8, 64, 0},
     {S3_256x64_T9, 8, 32, 64, 0}, {S3_512x64, 16, 32, 64, 0}, {S3_256x128, 8, 32, 128, 0},
-    {S1_256x64_C1, 8, 32, 64, 0},
+    {S1_256x64_C1, 8, 32, 64, 0}, {S3_256x32_ST, 8, 32, 32, 0},
+    {S3_64x64_T9, 8, 8, 64, 0},  {S3_128x64_T9, 8, 16, 64, 0}, {S3S2_64x64_T9, 8, 8, 64, 0},
+    {S3S2_128x64_T9, 8, 16, 64, 0},
 };
+// Launches that leave most CUs with one workgroup or none (the deep layers of a 4-image agent share) run at the
+// latency of one K step, not at MFMA throughput: the all-nine-taps-per-step variant of the same tile has a third
+// of the steps (one 36 KB weight stage per 16-channel chunk instead of three 12 KB ones)
+inline SpCfgId deep_variant(SpCfgId id) {
+  switch (id) {
+    case S3_256x64: return S3_256x64_T9;
+    case S3_128x64: return S3_128x64_T9;
+    case S3_64x64: return S3_64x64_T9;
+    case S3S2_64x64: return S3S2_64x64_T9;
+    case S3S2_128x64: return S3S2_128x64_T9;
+    default: return id;
+  }
+}
 int g_sp_force = -1;   // tools: force one configuration
 
 SpCfg select_cfg(const dn_conv_desc& d) {
@@ -1069,11 +1086,15 @@ SpCfg select_cfg(const dn_conv_desc& d) {
   if (g_sp_force >= 0) {
     for (int k = 0; k < ncand; ++k)
       if (cand[k] == g_sp_force && nchunks % ca_of(cand[k]) == 0) return kSpCfgs[cand[k]];
-    if (d.ksize == 3 && d.stride == 1 && g_sp_force >= S3_256x64_T9 && g_sp_force < SP_CFG_COUNT)
+    if (d.ksize == 3 && d.stride == 1 && !upm && g_sp_force >= S3_256x64_T9 && g_sp_force <= S3_128x64_T9 &&
+        g_sp_force != S1_256x64_C1)
+      return kSpCfgs[g_sp_force];
+    if (d.ksize == 3 && d.stride == 2 && (g_sp_force == S3S2_64x64_T9 || g_sp_force == S3S2_128x64_T9))
       return kSpCfgs[g_sp_force];
   }
   SpCfg best = kSpCfgs[cand[0]];
   double best_cost = 1e300;
+  long best_blocks = 0;
   for (int k = 0; k < ncand; ++k) {
     const SpCfg& c = kSpCfgs[cand[k]];
     if (nchunks % ca_of(c.id) != 0) continue;
@@ -1081,8 +1102,10 @@ SpCfg select_cfg(const dn_conv_desc& d) {
     const long blocks = tiles * ((d.c_out + c.bn - 1) / c.bn);
     const double rounds = (double)((blocks + kCUs - 1) / kCUs);
     const double cost = rounds * c.th * c.tw * c.bn * g_sp_bias[c.id];
-    if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
+    if (cost < best_cost * 0.999) { best_cost = cost; best = c; best_blocks = blocks; }
   }
+  static const int deep_env = [] { const char* e = getenv("DN_SP_DEEP"); return e ? atoi(e) : 1; }();
+  if (deep_env && g_sp_force < 0 && !upm && best_blocks <= kCUs) best = kSpCfgs[deep_variant(best.id)];
   return best;
 }
 
@@ -1314,7 +1337,7 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
   if (up_mode(*d) == 2) {   // the packed image is the quad-merged one: conv_spq.hip (tools: 20 / 21 force BN = 32 / 64)
     DN_REQUIRE(a.c1g == 0 || d->c0 % 16 == 0, "spconv: concat needs c0 %% 16 == 0");
     return dn::spq_conv(d, src0, src1, packed, (size_t)a.wpk_bytes, scale, shift, out, a.cout_pad,
-                        g_sp_force == 20 ? 32 : g_sp_force == 21 ? 64 : 0, s);
+                        g_sp_force == 20 ? 32 : g_sp_force == 21 ? 64 : g_sp_force == 22 ? 33 : 0, s);
   }
   if (d->math == 3) {   // hi-only source 0: the 8 x 32 x 32 tile, weight-stationary when the layer fits
     using T32 = SpTile<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 1, 0, 1>;
@@ -1344,6 +1367,11 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
       case 205: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 5>(a, *d, s);
       case 206: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 6>(a, *d, s);
       case 207: return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 7>(a, *d, s);
+      case 301: return launch<3, 1, 8, 8, 64, 9, 1, 2, 2, 1, 1, 0, 1>(a, *d, s);   // the deep-regime tile
+      case 302: return launch<3, 1, 8, 8, 64, 9, 1, 2, 2, 1, 1, 0, 2>(a, *d, s);
+      case 303: return launch<3, 1, 8, 8, 64, 9, 1, 2, 2, 1, 1, 0, 3>(a, *d, s);
+      case 304: return launch<3, 1, 8, 8, 64, 9, 1, 2, 2, 1, 1, 0, 4>(a, *d, s);
+      case 305: return launch<3, 1, 8, 8, 64, 9, 1, 2, 2, 1, 1, 0, 5>(a, *d, s);
       default: break;
     }
   }
@@ -1359,7 +1387,7 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
     if (fits_stationary(*d, 32, T32::A_STAGE, 0, 2))
       return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1>(a, *d, s);
   }
-  if (g_sp_force == 12) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1>(a, *d, s);
+  if (g_sp_force == S3_256x32_ST) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1>(a, *d, s);
   switch (c.id) {
     //                               KS S  TH TW  BN TG CA WM WN WTM WTN
     case S3_256x64:   return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2>(a, *d, s);
@@ -1374,6 +1402,10 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
     case S3_512x64:   return launch<3, 1, 16, 32, 64, 3, 1, 8, 1, 2, 2>(a, *d, s);
     case S3_256x128:  return launch<3, 1, 8, 32, 128, 3, 1, 4, 2, 2, 2>(a, *d, s);
     case S1_256x64_C1: return launch<1, 1, 8, 32, 64, 1, 1, 4, 1, 2, 2>(a, *d, s);
+    case S3_64x64_T9:  return launch<3, 1, 8, 8, 64, 9, 1, 2, 2, 1, 1>(a, *d, s);
+    case S3_128x64_T9: return launch<3, 1, 8, 16, 64, 9, 1, 2, 2, 2, 1>(a, *d, s);
+    case S3S2_64x64_T9: return launch<3, 2, 8, 8, 64, 9, 1, 2, 2, 1, 1>(a, *d, s);
+    case S3S2_128x64_T9: return launch<3, 2, 8, 16, 64, 9, 1, 2, 2, 2, 1>(a, *d, s);
     default: break;
   }
   return dn::fail(DN_ERR_UNSUPPORTED, "spconv: no tile configuration");

@@ -41,7 +41,6 @@ constexpr int QA_PIECES = 4 * QNPIX;                       // 4 quarters
 constexpr int QA_INSTR = (QA_PIECES + 63) / 64;            // 22 DMA instructions per patch stage
 constexpr int QA_IT = (QA_INSTR + QNW - 1) / QNW;          // rounds; the last one is ragged (waves 0, 1 only)
 constexpr int QA_STAGE = QA_INSTR * 1024;
-constexpr int QB_STAGE = 16 * 1024;                        // one weight stage: 16 blocks of BN = 32 or 4 of BN = 64
 static_assert(QA_INSTR == 22 && QA_IT == 6, "patch stage: 22 instructions, waves 0 / 1 issue 6, waves 2 / 3 issue 5");
 
 struct SpqArgs {
@@ -64,26 +63,33 @@ struct QTile {
   int img, oy0, ox0, n0;
 };
 
-template <int BN>
+// DEEP: one step per 16-channel chunk (all 4 merged taps x 4 classes of a source-0 chunk, all 9 taps of a source-1
+// chunk).  A launch of fewer items than CUs (one rank's 4-image share of the agent-sharded step) runs at the latency
+// of a step -- one workgroup per CU, nothing to switch to while its weight DMA is in flight -- so the step count is
+// what it pays for: 48 steps instead of 112 on conv5_1.  One workgroup per CU (111 KB of LDS).
+template <int BN, int DEEP = 0>
 struct SpqTile {
   static constexpr int WTN = BN / 32;
-  static constexpr int TGQ = BN == 64 ? 1 : 2;         // merged taps of source 0 per step
+  static constexpr int TGQ = DEEP ? 4 : (BN == 64 ? 1 : 2);   // merged taps of source 0 per step
   static constexpr int NS0 = 4 / TGQ;                  // steps per chunk of source 0
+  static constexpr int TG1 = DEEP ? 9 : 3;             // taps of source 1 per step
+  static constexpr int NS1 = 9 / TG1;
   static constexpr int BLK = 4 * BN * 16;              // bytes of one weight block [4 quarters][BN] in LDS
   static constexpr int B_PIECES0 = TGQ * 4 * 4 * BN;   // step of source 0: TGQ taps x 4 classes
-  static constexpr int B_PIECES1 = 3 * 4 * BN;         // step of source 1: 3 taps
+  static constexpr int B_PIECES1 = TG1 * 4 * BN;       // step of source 1: TG1 taps
   static constexpr int B_IT0 = (B_PIECES0 + QNT - 1) / QNT;
   static constexpr int B_IT1 = (B_PIECES1 + QNT - 1) / QNT;
-  static_assert(B_IT0 * QNT * 16 <= QB_STAGE && B_IT1 * QNT * 16 <= QB_STAGE, "weight stage");
+  static_assert(B_IT1 <= B_IT0, "the source-0 step is the larger one");
+  static constexpr int QB_STAGE = B_IT0 * QNT * 16;    // one weight stage: 16 KB (16 blocks of BN = 32 or 4 of BN = 64); DEEP 32 KB
   static constexpr int AFF_BYTES = QNW * 2 * 64 * 4;   // per-wave copy of the epilogue affine (scale, shift) of a channel block
   static constexpr int LDS_BYTES = 2 * QA_STAGE + 2 * QB_STAGE + AFF_BYTES;
-  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+  static_assert((DEEP ? 1 : 2) * LDS_BYTES <= 160 * 1024, "two workgroups per CU (DEEP: one)");
 };
 
-template <int BN>
+template <int BN, int DEEP>
 __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
-  using T = SpqTile<BN>;
-  constexpr int WTN = T::WTN, TGQ = T::TGQ, NS0 = T::NS0, BLK = T::BLK;
+  using T = SpqTile<BN, DEEP>;
+  constexpr int WTN = T::WTN, TGQ = T::TGQ, NS0 = T::NS0, NS1 = T::NS1, BLK = T::BLK, QB_STAGE = T::QB_STAGE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int OFF_B = 2 * QA_STAGE;
 
@@ -226,7 +232,7 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
   // [merged tap t = 2 a + b][class], the others 9 blocks [dy][dx]; a block = [4 quarters][cout_pad] pieces.
   auto issue_b = [&](int g, int st, int sb) {
     const bool from1 = g >= a.c0g;
-    const int blk = from1 ? a.c0g * 16 + (g - a.c0g) * 9 + st * 3 : g * 16 + st * (TGQ * 4);
+    const int blk = from1 ? a.c0g * 16 + (g - a.c0g) * 9 + st * T::TG1 : g * 16 + st * (TGQ * 4);
     const int soff = blk * 4 * a.cout_pad * 16;
     unsigned char* base = smem + OFF_B + sb * QB_STAGE + wave * 1024;
 #pragma unroll
@@ -305,7 +311,21 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
       }
     };
     load(std::integral_constant<int, 0>{});
-    if constexpr (TGQ == 2) {
+    if constexpr (TGQ == 4) {
+      load(std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      load(std::integral_constant<int, 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      load(std::integral_constant<int, 3>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f[1]);
+    } else if constexpr (TGQ == 2) {
       load(std::integral_constant<int, 1>{});
       __builtin_amdgcn_sched_barrier(0);
       mma(f[0]);
@@ -400,7 +420,7 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
       auto step = [&](auto st_c, auto kind_c) {
         constexpr int ST = decltype(st_c)::value;
         constexpr bool SRC1 = decltype(kind_c)::value;
-        constexpr int NSG = SRC1 ? 3 : NS0;
+        constexpr int NSG = SRC1 ? NS1 : NS0;
         // This step's weights (and, at ST == 0, this chunk's patch) have landed.  At ST == 1 the NEXT chunk's
         // patch may still be in flight behind them: it was issued after them, so waiting until only this
         // wave's patch instructions remain outstanding is enough.  Raw s_barrier: __syncthreads() would drain vmcnt.
@@ -432,7 +452,11 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
             a_pending = false;
           }
         }
-        if constexpr (SRC1)
+        if constexpr (SRC1 && NS1 == 1) {   // all nine taps in the stage: rows dy = 0..2 of 3 blocks each
+          compute1(std::integral_constant<int, 0>{}, smem + sa * QA_STAGE, smem + OFF_B + sb * QB_STAGE);
+          compute1(std::integral_constant<int, 1>{}, smem + sa * QA_STAGE, smem + OFF_B + sb * QB_STAGE + 3 * BLK);
+          compute1(std::integral_constant<int, 2>{}, smem + sa * QA_STAGE, smem + OFF_B + sb * QB_STAGE + 6 * BLK);
+        } else if constexpr (SRC1)
           compute1(st_c, smem + sa * QA_STAGE, smem + OFF_B + sb * QB_STAGE);
         else
           compute0(st_c, smem + sa * QA_STAGE, smem + OFF_B + sb * QB_STAGE);
@@ -440,15 +464,17 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
       };
       if (g < a.c0g) {
         step(std::integral_constant<int, 0>{}, std::false_type{});
-        step(std::integral_constant<int, 1>{}, std::false_type{});
+        if constexpr (NS0 >= 2) step(std::integral_constant<int, 1>{}, std::false_type{});
         if constexpr (NS0 == 4) {
           step(std::integral_constant<int, 2>{}, std::false_type{});
           step(std::integral_constant<int, 3>{}, std::false_type{});
         }
       } else {
         step(std::integral_constant<int, 0>{}, std::true_type{});
-        step(std::integral_constant<int, 1>{}, std::true_type{});
-        step(std::integral_constant<int, 2>{}, std::true_type{});
+        if constexpr (NS1 == 3) {
+          step(std::integral_constant<int, 1>{}, std::true_type{});
+          step(std::integral_constant<int, 2>{}, std::true_type{});
+        }
       }
       sa ^= 1;
     }
@@ -504,10 +530,10 @@ __global__ void spq_pack_weights_kernel(const float* __restrict__ w, unsigned ch
   }
 }
 
-template <int BN>
+template <int BN, int DEEP = 0>
 int launch_spq(SpqArgs& a, hipStream_t stream) {
-  using T = SpqTile<BN>;
-  auto kern = conv_spq_kernel<BN>;
+  using T = SpqTile<BN, DEEP>;
+  auto kern = conv_spq_kernel<BN, DEEP>;
   static dn::PerDeviceFlag attr_flag;
   bool& attr_set = attr_flag.here();
   if (!attr_set) {
@@ -525,7 +551,7 @@ int launch_spq(SpqArgs& a, hipStream_t stream) {
   a.total_items = (int)total;
   a.n_cb = (a.c_out + BN - 1) / BN;
   a.rcp_ncb = 1.0f / (float)a.n_cb; a.rcp_tx = 1.0f / (float)a.tiles_x; a.rcp_ty = 1.0f / (float)a.tiles_y;
-  const long resident = 2L * kCUs;
+  const long resident = (DEEP ? 1L : 2L) * kCUs;
   dim3 grid((unsigned)(total > resident ? resident : total));
   hipLaunchKernelGGL(kern, grid, dim3(QNT), T::LDS_BYTES, stream, a);
   return dn::check_launch("conv_spq_kernel");
@@ -546,7 +572,7 @@ int spq_pack_weights(const float* weight_oihw, void* packed, int c_out, int c_in
   return check_launch("spq_pack_weights_kernel");
 }
 
-// bn: 32 or 64 output channels per workgroup; 0 = choose
+// bn: 32 or 64 output channels per workgroup; 33 = 32 in the one-step-per-chunk (DEEP) form; 0 = choose
 int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed, size_t packed_bytes,
              const float* scale, const float* shift, void* out, int cout_pad, int bn, hipStream_t stream) {
   SpqArgs a;
@@ -562,8 +588,12 @@ int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const vo
     // BN = 64 halves the patch traffic per MAC but needs >= two full rounds of 64-wide items (measured: conv7_1
     // 1280 items: 129 vs 153 us; conv6_1 640 items: 146 vs 142 us; conv5_1 320 items: 174 vs 171 us)
     bn = (d->c_out > 32 && tiles * ((d->c_out + 63) / 64) >= 4L * kCUs) ? 64 : 32;
+    // fewer items than CUs: latency regime (SpqTile DEEP)
+    static const int deep_env = [] { const char* e = getenv("DN_SP_DEEP"); return e ? atoi(e) : 1; }();
+    if (deep_env && bn == 32 && tiles * ((d->c_out + 31) / 32) <= (long)kCUs) bn = 33;
   }
   if (bn == 64) return launch_spq<64>(a, stream);
+  if (bn == 33) return launch_spq<32, 1>(a, stream);
   return launch_spq<32>(a, stream);
 }
 

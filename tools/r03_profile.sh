@@ -24,4 +24,17 @@ done
 python3 $R/tools/pmc_table.py $OUT 30 > $OUT/pmc_table.txt 2>&1
 python3 $R/tools/pmc_traffic.py $OUT sp conv_sp_kernel,conv_spq_kernel > $OUT/pmc_traffic_sp.json 2> $OUT/pmc_traffic.err
 python3 $R/tools/rocprof_conv.py $OUT/kernel_trace.csv conv_sp_kernel,conv_spq_kernel 20 3 $V > $OUT/rocprof_conv_sp.json 2> $OUT/rocprof_conv.err
+# 3. segmentation task (configs[3]): FETCH_SIZE / WRITE_SIZE of its conv launches, same method
+S="python $R/bench.py --task seg --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-events --train-steps 0"
+mkdir -p $OUT/seg
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/r03_s2 -o p2 -- $S > $OUT/seg/p2.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/r03_s3 -o p3 -- $S > $OUT/seg/p3.log 2>&1
+for i in 2 3; do
+  f=$(find /tmp/r03_s$i -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/seg/pmc$i.csv
+done
+python3 $R/tools/pmc_traffic.py $OUT/seg seg conv_sp_kernel,conv_spq_kernel > $OUT/pmc_traffic_seg.json 2> $OUT/pmc_traffic_seg.err
+# 4. training step (eager launches): per-kernel totals of 6 steps (+ 3 forward-only bench steps, < 2 % of the time)
+T="python $R/bench.py --steps 2 --warmup 1 --no-alt-math --no-cpu-baseline --no-kernel-events --no-voxelize --no-agent-leg --train-steps 6"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r03_tr -o tr -- $T > $OUT/train.log 2>&1
+p=$(find /tmp/r03_tr -name "*kernel_stats.csv" | head -1); [ -n "$p" ] && cp "$p" $OUT/train_step_kernel_stats.csv
 ls -la $OUT

@@ -89,7 +89,8 @@ static void dump_mismatch(const float* d_a, const float* d_b, int n, int h, int 
 
 // names of conv_sp.hip's tile menu
 static const char* kCfgName[] = {"256x64", "256x32", "128x64", "64x64", "s2_128x64", "s2_64x64", "p256x64", "p64x64",
-                                 "256x64/T9", "512x64", "256x128", "p256x64/C1", "256x32/stat"};
+                                 "256x64/T9", "512x64", "256x128", "p256x64/C1", "256x32/stat", "64x64/T9",
+                                 "128x64/T9", "s2_64x64/T9", "s2_128x64/T9"};
 static const char* g_filter = nullptr;   // substring of the layer name
 static int g_mode = 0;                   // 0 = every tile, 1 = automatic selection only, 2 = + ablations
 
@@ -139,12 +140,12 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
   std::vector<int> cfgs = {-1};
   if (up0 && upmode == 2) {
     printf(" [quad]");
-    cfgs.insert(cfgs.end(), {20, 21});
+    cfgs.insert(cfgs.end(), {20, 21, 22});
   } else if (!quick) {
     if (ks == 1) cfgs.insert(cfgs.end(), {6, 7});
-    else if (stride == 2) cfgs.insert(cfgs.end(), {4, 5});
-    else cfgs.insert(cfgs.end(), {0, 1, 2, 3, 8, 9, 10, 12});
-    if (g_mode == 2 && ks == 3 && stride == 1) cfgs.insert(cfgs.end(), {101, 102, 103, 104, 105, 201, 202, 203, 204, 205, 206, 207});
+    else if (stride == 2) cfgs.insert(cfgs.end(), {4, 5, 15, 16});
+    else cfgs.insert(cfgs.end(), {0, 1, 2, 3, 8, 9, 10, 12, 13, 14});
+    if (g_mode == 2 && ks == 3 && stride == 1) cfgs.insert(cfgs.end(), {101, 102, 103, 104, 105, 201, 202, 203, 204, 205, 206, 207, 301, 302, 303, 304, 305});
   }
   for (int cfg : cfgs) {
     dn_spconv_force_config(cfg);
@@ -166,7 +167,7 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
     const float t = tm.us([&] { dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, spo, 0); });
     const bool ok = err < 2e-5;
     if (!ok) ++g_fail;
-    printf(" %s %6.1f us %6.1f TF err %.1e%s |", cfg < 0 ? "auto" : cfg == 20 ? "q32" : cfg == 21 ? "q64" : kCfgName[cfg], t,
+    printf(" %s %6.1f us %6.1f TF err %.1e%s |", cfg < 0 ? "auto" : cfg == 20 ? "q32" : cfg == 21 ? "q64" : cfg == 22 ? "q32/deep" : kCfgName[cfg], t,
            gf / t * 1e3, err, ok ? "" : " FAIL");
     if (!ok) dump_mismatch(out_new, out_ref, n, ho, wo, cout);
   }
@@ -339,6 +340,15 @@ int main(int argc, char** argv) {
   run_post("heads 256^2 32->64->48 f32", n, 256, 256, 32, 48, 12, true);
   run_post("heads 256^2 blockdiag f32", n, 256, 256, 32, 48, 12, true, true);
   run_post("conv1_2+3d 128^2 64->64->64", n, 128, 128, 64, 64, 64, false);
+  // one rank's share of the agent-sharded step (4 images): the deep layers under-fill the chip
+  run_layer("share conv3_1 64^2 128->256 s2", 4, 64, 64, 128, 0, 0, 256, 3, 2, quick);
+  run_layer("share conv3_2 32^2 256->256", 4, 32, 32, 256, 0, 0, 256, 3, 1, quick);
+  run_layer("share conv4_1 32^2 256->512 s2", 4, 32, 32, 256, 0, 0, 512, 3, 2, quick);
+  run_layer("share conv4_2 16^2 512->512", 4, 16, 16, 512, 0, 0, 512, 3, 1, quick);
+  run_layer("share conv5_1 32^2 768->256 up+cat", 4, 32, 32, 512, 256, 1, 256, 3, 1, quick);
+  run_layer("share conv5_2 32^2 256->256", 4, 32, 32, 256, 0, 0, 256, 3, 1, quick);
+  run_layer("share conv6_1 64^2 384->128 up+cat", 4, 64, 64, 256, 128, 1, 128, 3, 1, quick);
+  run_layer("share conv6_2 64^2 128->128", 4, 64, 64, 128, 0, 0, 128, 3, 1, quick);
   printf("%s (%d failures)\n", g_fail ? "SP CONV CHECK FAILED" : "SP CONV CHECK PASSED", g_fail);
   return g_fail ? 1 : 0;
 }
