@@ -90,6 +90,7 @@ SIGNATURES = {
                                    POINTER(MlpTailParams), c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dn_fuse_mlp_supported": (c_int, [c_int]),
+    "dn_fuse_mlp_set_waves": (c_int, [c_int]),
     "dn_fuse_mlp_packed_bytes": (c_size_t, [c_int]),
     "dn_fuse_mlp_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p,
                                  c_void_p]),

@@ -25,6 +25,7 @@
 // upstream:coperception/models/det/DiscoNet.py :: DiscoNet.forward (Appx A.5).
 #include "dn_internal.h"
 #include "sp_device.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -55,9 +56,18 @@ __device__ inline half8 frag_of(const unsigned char* base, int idx) {
 // once per group (they are the kernel's L2 traffic: 128 KB per pass at C = 256) and each slot adds
 // 12 MFMAs behind them, which is what hides the fragment loads' latency.  One wave per workgroup:
 // G accumulator sets of 64 registers need the whole 512-entry register file of a SIMD lane.
-template <int C, int G>
-__global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs a) {
+//
+// NW = 4 (launches of fewer than 512 tiles): FOUR waves share the 32 pixels.  One wave per 32 pixels is 640 waves for 1024 SIMDs at
+// the BASELINE size (128 for one rank's share of the agent-sharded step), each a serial chain of 6 layer-1 passes:
+// the kernel ran at the latency of that chain.  With four waves the ego term E is computed one 32-unit tile per
+// wave, the list slots go round-robin to the waves (slot k to wave k % 4, one slot per layer-1 pass), and
+// pass 2 splits the channels (KS / 4 k-steps per wave).  Every output is produced by the same instruction
+// sequence on the same operands as with NW = 1: the results are bit-identical (tests/test_gpu_fusion.py).
+template <int C, int G, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kernel(const FuseMlpArgs a) {
   constexpr int KS = C / 16;
+  constexpr int KSW = KS / NW;             // k-steps (16-channel chunks) of pass 2 / the pass-through per wave
+  static_assert(KS % NW == 0, "pass 2 splits the k-steps over the waves");
   __shared__ float ek_s[MAX_AGENTS][64];   // exp(s_k) of this wave's pixels, per list slot
   __shared__ float e_s[64][64];            // layer-1 ego term of this wave's pixels: [reg][lane]
   __shared__ int jl_s[MAX_AGENTS];         // agent of each list slot (slot 0 = the ego)
@@ -66,7 +76,8 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
   __shared__ __attribute__((aligned(16))) unsigned char w23_s[kW2Bytes + kW3Bytes];
   __shared__ __attribute__((aligned(16))) float aff_s[2 * 128 + 2 * 32 + 3 * 8];   // s1 t1 s2 t2 s3 t3 w4
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = NW > 1 ? threadIdx.x >> 6 : 0;
+  const int ks_first = wave * KSW;
   const int li = lane & 31, lh = lane >> 5;
   const int wid = blockIdx.x;
   const int tile = wid % a.tiles, il = (wid / a.tiles) % a.ego_count, b = wid / (a.tiles * a.ego_count);
@@ -105,11 +116,12 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
   };
 
   if (i < live) {
-    for (int q = lane; q < (int)((kW2Bytes + kW3Bytes) / 16); q += 64)   // w3 follows w2 in the packed block
+    const int t = threadIdx.x;
+    for (int q = t; q < (int)((kW2Bytes + kW3Bytes) / 16); q += 64 * NW)   // w3 follows w2 in the packed block
       *reinterpret_cast<u32x4*>(w23_s + q * 16) = *reinterpret_cast<const u32x4*>(a.w2 + (size_t)q * 16);
-    for (int q = lane; q < 128; q += 64) { aff_s[q] = a.s1[q]; aff_s[128 + q] = a.t1[q]; }
-    if (lane < 32) { aff_s[256 + lane] = a.s2[lane]; aff_s[288 + lane] = a.t2[lane]; }
-    if (lane < 8) { aff_s[320 + lane] = a.s3[lane]; aff_s[328 + lane] = a.t3[lane]; aff_s[336 + lane] = a.w4[lane]; }
+    for (int q = t; q < 128; q += 64 * NW) { aff_s[q] = a.s1[q]; aff_s[128 + q] = a.t1[q]; }
+    if (t < 32) { aff_s[256 + t] = a.s2[t]; aff_s[288 + t] = a.t2[t]; }
+    if (t < 8) { aff_s[320 + t] = a.s3[t]; aff_s[328 + t] = a.t3[t]; aff_s[336 + t] = a.w4[t]; }
   }
   const float b4v = a.b4[0];   // read once: a global load inside every tail() sat on its critical path
   const unsigned char* w2l = w23_s;
@@ -119,18 +131,21 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
 
   if (i >= live) {   // padded agent: its map passes through un-fused
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int u = 0; u < KSW; ++u) {
+      const int ks = ks_first + u;
       store_piece(ks, *reinterpret_cast<const f32x4*>(xrow + 16 * ks),
                   *reinterpret_cast<const f32x4*>(xrow + 16 * ks + 4));
+    }
     note_range(amax);
     return;
   }
 
   // neighbour list, in the reference's order: the ego, then j ascending
   int n = 1;
-  jl_s[0] = i;
+  jl_s[0] = i;   // NW > 1: every wave writes the same values
   for (int j = 0; j < live; ++j)
     if (j != i && (!a.only_v2i || i == 0 || j == 0)) jl_s[n++] = j;
+  if constexpr (NW > 1) __syncthreads();   // list, layer 2-4 weights and affines visible to every wave
   auto row_of = [&](int k) { return k == 0 ? xrow : yrow_of(jl_s[k]); };
 
   auto frag_from = [&](const f32x4 v0, const f32x4 v1, half8& fh, half8& fl) {
@@ -263,7 +278,7 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
   };
 
   // ---- pass 1a: E = W1_ego . x_ego, parked in LDS between the groups ([reg][lane])
-  {
+  if constexpr (NW == 1) {
     f32x16 acc[G][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -277,52 +292,106 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) e_s[nt * 16 + r][lane] = acc[0][nt][r];
-  }
-  // ---- pass 1b: scores of the list, G slots at a time
-  for (int g0 = 0; g0 < n; g0 += G) {
-    const int cnt = n - g0 < G ? n - g0 : G;
-    f32x16 acc[G][4];
-    const float* rows[G];
+  } else {
+    // unit tile nt = wave of E: per tile the same MFMA sequence as layer1 (wl.fh, wh.fl, wh.fh per k-step)
+    static_assert(NW == 1 || NW == 4, "one layer-1 unit tile per wave");
+    f32x16 acc;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      rows[g] = row_of(g0 + g < n ? g0 + g : 0);
-      if (g < cnt) {
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const unsigned char* wb = a.w1 + (size_t)(lh * 32 + li) * 16 + (size_t)(wave * KS) * 2 * 64 * 16;
+    half8 wh[2], wl[2];
+    f32x4 r0[4], r1[4];
+    auto wload = [&](int ks, int sl) {
+      wh[sl] = *reinterpret_cast<const half8*>(wb + (size_t)((ks * 2 + 0) * 64) * 16);
+      wl[sl] = *reinterpret_cast<const half8*>(wb + (size_t)((ks * 2 + 1) * 64) * 16);
+    };
+    auto rload = [&](int ks, int sl) {
+      r0[sl] = *reinterpret_cast<const f32x4*>(xrow + 16 * ks);
+      r1[sl] = *reinterpret_cast<const f32x4*>(xrow + 16 * ks + 4);
+    };
+    rload(0, 0);
+    rload(1, 1);
+    rload(2, 2);
+    wload(0, 0);
+#pragma unroll 1
+    for (int ks0 = 0; ks0 < KS; ks0 += 4) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[g][nt][r] = e_s[nt * 16 + r][lane];
+      for (int u = 0; u < 4; ++u) {
+        const int ks = ks0 + u;
+        if (ks + 3 < KS) rload(ks + 3, (u + 3) & 3);
+        if (ks + 1 < KS) wload(ks + 1, (u + 1) & 1);
+        half8 fh, fl;
+        frag_from(r0[u], r1[u], fh, fl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[u & 1], fh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u & 1], fl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u & 1], fh, acc, 0, 0, 0);
       }
     }
-    layer1(std::integral_constant<int, G>{}, rows, cnt, 1, acc);
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-      if (g < cnt) ek_s[g0 + g][lane] = tail(acc[g]);
+    for (int r = 0; r < 16; ++r) e_s[wave * 16 + r][lane] = acc[r];
+    __syncthreads();
+  }
+  // ---- pass 1b: scores of the list.  NW = 1: G slots at a time; NW = 4: this wave's slots wave, wave + 4, ...
+  if constexpr (NW == 1) {
+    for (int g0 = 0; g0 < n; g0 += G) {
+      const int cnt = n - g0 < G ? n - g0 : G;
+      f32x16 acc[G][4];
+      const float* rows[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        rows[g] = row_of(g0 + g < n ? g0 + g : 0);
+        if (g < cnt) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][nt][r] = e_s[nt * 16 + r][lane];
+        }
+      }
+      layer1(std::integral_constant<int, G>{}, rows, cnt, 1, acc);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (g < cnt) ek_s[g0 + g][lane] = tail(acc[g]);
+    }
+  } else {
+    for (int k = wave; k < n; k += NW) {   // one slot per pass: two accumulator sets would spill at 256 registers
+      f32x16 acc[G][4];
+      const float* rows[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) rows[g] = row_of(k);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nt][r] = e_s[nt * 16 + r][lane];
+      layer1(std::integral_constant<int, 1>{}, rows, 1, 1, acc);
+      ek_s[k][lane] = tail(acc[0]);
+    }
+    __syncthreads();
   }
   float den = 0.f;
   for (int k = 0; k < n; ++k) den += ek_s[k][lane];
 
   // ---- pass 2: weighted sum in list order; the next slot's row is in flight under the FMAs
-  f32x4 f0[KS], f1[KS], y0[2][KS], y1[2][KS];
+  f32x4 f0[KSW], f1[KSW], y0[2][KSW], y1[2][KSW];
   auto yload = [&](int k, int s) {
-    const float* row = row_of(k);
+    const float* row = row_of(k) + 16 * ks_first;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KSW; ++ks) {
       y0[s][ks] = *reinterpret_cast<const f32x4*>(row + 16 * ks);
       y1[s][ks] = *reinterpret_cast<const f32x4*>(row + 16 * ks + 4);
     }
   };
   auto yacc = [&](int k, int s) {
     const float w = ek_s[k][lane] / den;
-    if (a.weights_out && pvalid && lh == 0)
+    if (a.weights_out && pvalid && lh == 0 && wave == 0)
       a.weights_out[(((size_t)b * a.ego_count + il) * a.agents + k) * a.hw + p] = w;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KSW; ++ks) {
       f0[ks] += y0[s][ks] * w;
       f1[ks] += y1[s][ks] * w;
     }
   };
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) f0[ks] = f1[ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < KSW; ++ks) f0[ks] = f1[ks] = f32x4{0.f, 0.f, 0.f, 0.f};
   yload(0, 0);
   for (int k = 0; k < n; k += 2) {
     if (k + 1 < n) yload(k + 1, 1);
@@ -333,7 +402,7 @@ __global__ void __launch_bounds__(64, 1) disco_fuse_mlp_kernel(const FuseMlpArgs
     }
   }
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) store_piece(ks, f0[ks], f1[ks]);
+  for (int ks = 0; ks < KSW; ++ks) store_piece(ks_first + ks, f0[ks], f1[ks]);
   note_range(amax);
 }
 
@@ -362,6 +431,15 @@ inline size_t w1_bytes(int c) { return (size_t)2 * 4 * (c / 16) * 2 * 2 * 32 * 1
 }  // namespace
 
 namespace dn { unsigned range_flags_fuse_mlp(bool reset) { return sp_range_flags_here(reset); } }
+
+int g_fuse_waves = 0;   // 0 = DN_FUSE_MLP_WAVES, else chosen per launch
+
+// tools / tests: 1 or 4 waves per 32-pixel tile (0 = default)
+extern "C" int dn_fuse_mlp_set_waves(int waves) {
+  DN_REQUIRE(waves == 0 || waves == 1 || waves == 4, "fuse_mlp: waves per tile is 1 or 4 (0 = default), got %d", waves);
+  g_fuse_waves = waves;
+  return DN_OK;
+}
 
 extern "C" int dn_fuse_mlp_supported(int c) { return c == 64 || c == 128 || c == 256; }
 
@@ -413,10 +491,23 @@ extern "C" int dn_disco_fuse_mlp(const float* feat, const float* warped, const i
   a.batch = batch; a.agents = agents; a.hw = hw; a.only_v2i = only_v2i;
   a.ego_first = ego_first; a.ego_count = ego_count;
   a.tiles = (hw + 31) / 32;
-  dim3 grid(batch * ego_count * a.tiles);   // one wave per 32 pixels of one (sample, ego)
+  dim3 grid(batch * ego_count * a.tiles);   // one workgroup per 32 pixels of one (sample, ego)
   hipStream_t s = (hipStream_t)stream;
-  if (c == 256) hipLaunchKernelGGL((disco_fuse_mlp_kernel<256, FUSE_G>), grid, dim3(64), 0, s, a);
-  else if (c == 128) hipLaunchKernelGGL((disco_fuse_mlp_kernel<128, FUSE_G>), grid, dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((disco_fuse_mlp_kernel<64, FUSE_G>), grid, dim3(64), 0, s, a);
+  // Four waves per tile when the launch leaves SIMDs idle (fewer tiles than 2 per CU: 128 tiles for one rank's
+  // share of the agent-sharded step, 87 -> 45 us); at the BASELINE size (640 tiles) the two forms run within
+  // 3 % of each other (85.9 vs 88.6 us) and the one-wave chain stays.  DN_FUSE_MLP_WAVES / dn_fuse_mlp_set_waves
+  // force one form (tools, tests); the results are bit-identical either way.
+  static const int waves_env = [] { const char* e = getenv("DN_FUSE_MLP_WAVES"); return e ? atoi(e) : 0; }();
+  const int forced = g_fuse_waves > 0 ? g_fuse_waves : waves_env;
+  const int waves = forced > 0 ? forced : (grid.x < 2u * 256u ? 4 : 1);
+  if (waves == 1) {
+    if (c == 256) hipLaunchKernelGGL((disco_fuse_mlp_kernel<256, FUSE_G, 1>), grid, dim3(64), 0, s, a);
+    else if (c == 128) hipLaunchKernelGGL((disco_fuse_mlp_kernel<128, FUSE_G, 1>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((disco_fuse_mlp_kernel<64, FUSE_G, 1>), grid, dim3(64), 0, s, a);
+  } else {
+    if (c == 256) hipLaunchKernelGGL((disco_fuse_mlp_kernel<256, 1, 4>), grid, dim3(256), 0, s, a);
+    else if (c == 128) hipLaunchKernelGGL((disco_fuse_mlp_kernel<128, 1, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((disco_fuse_mlp_kernel<64, 1, 4>), grid, dim3(256), 0, s, a);
+  }
   return dn::check_launch("disco_fuse_mlp_kernel");
 }

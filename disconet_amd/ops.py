@@ -496,6 +496,12 @@ def fuse_mlp_supported(c):
     return bool(_lib.load().dn_fuse_mlp_supported(int(c)))
 
 
+def set_fuse_mlp_waves(waves):
+    """tools / tests: 4 or 1 wave(s) per 32-pixel tile of dn_disco_fuse_mlp; 0 = chosen per launch.
+    The two forms give bit-identical results."""
+    check(_lib.load().dn_fuse_mlp_set_waves(int(waves)), "dn_fuse_mlp_set_waves")
+
+
 def make_fuse_mlp_params(w1, b1, bn1, w2, b2, bn2, w3, b3, bn3, w4, b4, c):
     """Packs the attention MLP for dn_disco_fuse_mlp.  w1 [128, 2c], w2 [32, 128], w3 [8, 32],
     w4 [8]; bn* = (scale, shift) of the eval BatchNorm after each of the first three layers.

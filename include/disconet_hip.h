@@ -313,6 +313,11 @@ typedef struct dn_fuse_mlp_params {
   const float* w4; const float* b4;
 } dn_fuse_mlp_params;
 int dn_fuse_mlp_supported(int c);
+/* tools / tests only: waves per 32-pixel tile of dn_disco_fuse_mlp: 4 (the ego term, the list slots and
+ * the channels of the weighted sum are split over four waves) or 1 (one wave does the whole chain);
+ * 0 = chosen per launch (4 below 512 tiles) unless DN_FUSE_MLP_WAVES is set.  Both forms give
+ * bit-identical results.  Process-wide, not thread-safe. */
+int dn_fuse_mlp_set_waves(int waves);
 size_t dn_fuse_mlp_packed_bytes(int c);
 int dn_fuse_mlp_pack(const float* w1, const float* w2, const float* w3, int c, float wmul1,
                      float wmul2, float wmul3, void* packed, void* stream);

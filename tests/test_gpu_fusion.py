@@ -164,3 +164,46 @@ def test_warp_fused_into_the_attention_launch_matches_the_two_kernel_form(A, B, 
     scale = max(1.0, outs[False][0].abs().max().item())
     assert (outs[True][0] - outs[False][0]).abs().max().item() <= 1e-5 * scale
     assert (outs[True][1] - outs[False][1]).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("A,B,h,w,C,live,v2i", [
+    (5, 2, 32, 32, 256, None, False),       # the BASELINE fusion shape: waves get 2, 1, 1, 1 list slots
+    (8, 1, 32, 32, 256, None, False),       # the agent-sharded scenes: two slots per wave
+    (8, 2, 32, 32, 256, [5, 2], False),     # padded agents pass through; a sample with fewer slots than waves
+    (4, 2, 20, 28, 128, [4, 3], True),      # ragged last tile, only_v2i
+    (3, 1, 12, 16, 64, None, False),        # one k-step per wave in the weighted sum
+    (1, 2, 16, 16, 256, None, False),       # the ego alone
+])
+def test_four_wave_attention_launch_is_bit_identical_to_the_one_wave_form(A, B, h, w, C, live, v2i):
+    """dn_disco_fuse_mlp with the work of a 32-pixel tile split over four waves (small launches) against the
+    one-wave chain: fused maps (fp32 and split-planar), softmax weights and the ego sub-range form, bitwise"""
+    from disconet_amd import Config, DiscoNet, ops
+    from disconet_amd.synthetic import make_trans_matrices
+    torch.manual_seed(A * 10 + h)
+    layer = {256: 3, 128: 2, 64: 1}[C]
+    feat = torch.randn(A * B, h, w, C).clamp_(min=0).cuda()
+    trans = make_trans_matrices(B, A, jitter_seed=2).cuda()
+    na = torch.tensor(live or [A] * B, dtype=torch.int32).cuda()
+    torch.manual_seed(3)
+    m = DiscoNet(Config(), layer=layer, kd_flag=1, num_agent=A, only_v2i=v2i).eval()
+    for bn in (m.pixel_weighted_fusion.bn1_1, m.pixel_weighted_fusion.bn1_2, m.pixel_weighted_fusion.bn1_3):
+        bn.running_mean.normal_(0, 0.1)
+        bn.running_var.uniform_(0.5, 1.5)
+    m.cuda()
+    P = m._get_plan()
+    assert "_fuse_mlp" in P
+    outs = {}
+    try:
+        for waves in (1, 4):
+            ops.set_fuse_mlp_waves(waves)
+            fused, weights = m.fuse(feat, trans, na, B, P, want_weights=True)
+            sp = m.fuse(feat, trans, na, B, P, sp_out=True)
+            part = m.fuse(feat, trans, na, B, P, ego_first=A - 1, ego_count=1)
+            torch.cuda.synchronize()
+            outs[waves] = (fused, weights, sp.data.clone(), part)
+    finally:
+        ops.set_fuse_mlp_waves(0)
+    assert torch.isfinite(outs[4][0]).all()
+    for x, y in zip(outs[1], outs[4]):
+        assert torch.equal(x, y)
+    assert torch.equal(outs[4][3], outs[4][0][(A - 1) * B:])
