@@ -417,30 +417,31 @@ conv_sp_kernel(const SpArgs a) {
           sh_r[wn][g][e] = co < a.c_out ? a.shift[ci] : 0.f;
         }
   };
+  // One 32-pixel x 32-channel accumulator tile -> SP pieces.  Stores are buffer stores against a descriptor of the
+  // output IMAGE (32-bit lane offset computed once per tile + the quarter-plane offset; a lane outside the map
+  // carries an out-of-range offset and the bounds check drops its store): no 64-bit address
+  // arithmetic and no exec-mask juggling per store.  ReLU is a max against a uniform floor (0 or -inf).
   auto store_sp_tile = [&](const f32x16& c, const float* scale, const float* shift, int relu,
                            int ch0, int c_lim, unsigned char* out, int cog, int img, int oy, int ox,
                            int wn_r = -1) {
     const bool inside = oy < a.h_out && ox < a.w_out;
-    const size_t plane = (size_t)a.h_out * a.w_out * 16;
-    unsigned char* obase = out + (size_t)img * cog * 4 * plane + ((size_t)oy * a.w_out + ox) * 16;
-    u32x2 hi[4], lo[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    const int plane = a.h_out * a.w_out * 16;                       // bytes of one quarter plane (launch checks the image < 2 GiB)
+    const int img_bytes = cog * 4 * plane;
+    const auto rsrc_o = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)img * img_bytes, 0, img_bytes, 0x00020000);
+    const int voff = inside ? (oy * a.w_out + ox) * 16 + lh * plane : (int)0x80000000;
+    const float floor_v = relu ? 0.f : -__builtin_inff();
+    auto affine = [&](int g, f32x4& v) {
       const int co = ch0 + 8 * g + 4 * lh;
-      f32x4 v;
       if (wn_r >= 0) {            // register-resident affine (channels past c_out: scale = shift = 0 -> 0)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = c[4 * g + e] * sc_r[kRegAffine ? wn_r : 0][g][e] + sh_r[kRegAffine ? wn_r : 0][g][e];
-          if (relu) v[e] = fmaxf(v[e], 0.f);
-        }
+        for (int e = 0; e < 4; ++e)
+          v[e] = fmaxf(c[4 * g + e] * sc_r[kRegAffine ? wn_r : 0][g][e] + sh_r[kRegAffine ? wn_r : 0][g][e], floor_v);
       } else if (POST == 1 && wn_r == -2) {   // stage-2 affine of the fused 1x1 from LDS (zero past c_out2)
         const f32x4 sc = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 2 : 0][co & 63]);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 3 : 0][co & 63]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = c[4 * g + e] * sc[e] + sh[e];
-          if (relu) v[e] = fmaxf(v[e], 0.f);
+          v[e] = fmaxf(c[4 * g + e] * sc[e] + sh[e], floor_v);
           v[e] = co + e < c_lim ? v[e] : 0.f;
         }
       } else {
@@ -448,15 +449,30 @@ conv_sp_kernel(const SpArgs a) {
         for (int e = 0; e < 4; ++e) {
           // clamped index + select: no divergent branch per channel
           const int ci = min(co + e, c_lim - 1);
-          v[e] = c[4 * g + e] * scale[ci] + shift[ci];
-          if (relu) v[e] = fmaxf(v[e], 0.f);
+          v[e] = fmaxf(c[4 * g + e] * scale[ci] + shift[ci], floor_v);
           v[e] = co + e < c_lim ? v[e] : 0.f;
         }
       }
-      if constexpr (POST == 0) {   // optional second output: the same values as fp32 NHWC rows (the exchanged level)
-        if (a.out_b != nullptr && inside && co < c_lim)
-          *reinterpret_cast<f32x4*>(a.out_b + (((size_t)img * a.h_out + oy) * a.w_out + ox) * a.ldo_b + co) = v;
+    };
+    if constexpr (POST == 0) {   // optional second output: the same values as fp32 NHWC rows (the exchanged level).
+      // A block of its own behind ONE uniform branch: written inside the loop below, every launch without a second
+      // output paid a masked-off store sequence per register quad.
+      if (a.out_b != nullptr) {
+        float* orow = a.out_b + (((size_t)img * a.h_out + oy) * a.w_out + ox) * a.ldo_b;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = ch0 + 8 * g + 4 * lh;
+          f32x4 v;
+          affine(g, v);
+          if (inside && co < c_lim) *reinterpret_cast<f32x4*>(orow + co) = v;
+        }
       }
+    }
+    u32x2 hi[4], lo[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+      affine(g, v);
       split4(v, hi[g], lo[g], amax);
     }
 #pragma unroll
@@ -465,9 +481,14 @@ conv_sp_kernel(const SpArgs a) {
       const u32x4 ph = gather_octet(hi[2 * m], hi[2 * m + 1]);
       const u32x4 pl = gather_octet(lo[2 * m], lo[2 * m + 1]);
       const int cg = ch0 / 16 + m;
-      if (inside && cg < cog && (!kNoStore || ph[0] == 0x12345678u)) {
-        *reinterpret_cast<u32x4*>(obase + (size_t)(cg * 4 + lh) * plane) = ph;
-        *reinterpret_cast<u32x4*>(obase + (size_t)(cg * 4 + 2 + lh) * plane) = pl;
+      if (cg < cog && (!kNoStore || ph[0] == 0x12345678u)) {
+        // The plane offset rides in the VECTOR offset, the scalar offset operand stays 0.  With it in the scalar
+        // operand (one s_lshl / s_add per store, rewritten for the next store right behind the instruction) the
+        // WTN = 2 streaming tiles wrote ~1e-4 of their lo pieces wrong -- lanes 12-15 / 28-31 of both halves, second
+        // chunk of a channel tile, errors of lo magnitude (tools/sp_conv_check, 18 of 300 cases) -- while this form
+        // is clean on every tile.  Not root-caused; one v_add per store is the price.
+        __builtin_amdgcn_raw_buffer_store_b128(ph, rsrc_o, voff + cg * 4 * plane, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(pl, rsrc_o, voff + (cg * 4 + 2) * plane, 0, 0);
       }
     }
   };
@@ -1178,6 +1199,9 @@ int fill_args(const dn_conv_desc* d, const void* src0, const void* src1, const v
   a.up0 = d->up0; a.c_out = d->c_out; a.cog = chunks_of(d->c_out); a.relu = d->relu;
   a.cout_pad = cout_pad_of(d->c_out);
   a.wpk_bytes = (int)(packed_blocks(*d) * 4 * a.cout_pad * 16);
+  // the epilogue's buffer stores address one output image with 32-bit offsets (64 is the widest fused second stage)
+  DN_REQUIRE((long)a.h_out * a.w_out * 16 * 4 * (a.cog > 4 ? a.cog : 4) < (1L << 31),
+             "spconv: one output image of %d x %d x %d channels exceeds 2 GiB", a.h_out, a.w_out, d->c_out);
   a.w2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out_b = nullptr;
   a.c_out2 = 0; a.relu2 = 0; a.split2 = 0; a.ldo_a = 0; a.ldo_b = 0; a.post_f32 = 0;
   a.b_total = 0; a.stg_row = 0;

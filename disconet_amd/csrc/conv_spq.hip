@@ -353,13 +353,19 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
       aff_s[64 + lane] = co < a.c_out ? a.shift[ci] : 0.f;
     }
   };
+  // Stores: buffer stores against a descriptor of the output image (32-bit lane offset + quarter-plane offset in the
+  // vector operand, out-of-map lanes dropped by the bounds check), ReLU as a max against a uniform floor -- as in
+  // conv_sp_kernel's store_sp_tile (which also says why the plane offset is not in the scalar operand).
   auto epilogue = [&](const QTile& tc) {
-    const size_t plane = (size_t)a.h * a.w * 16;
+    const int plane = a.h * a.w * 16;
+    const int img_bytes = a.cog * 4 * plane;
+    const auto rsrc_o = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)tc.img * img_bytes, 0, img_bytes, 0x00020000);
+    const float floor_v = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int wm = 0; wm < 2; ++wm) {
       const int oy = tc.oy0 + prow[wm], ox = tc.ox0 + pcol;
       const bool inside = oy < a.h && ox < a.w;
-      unsigned char* obase = a.out + (size_t)tc.img * a.cog * 4 * plane + ((size_t)oy * a.w + ox) * 16;
+      const int voff = inside ? (oy * a.w + ox) * 16 + lh * plane : (int)0x80000000;
 #pragma unroll
       for (int wn = 0; wn < WTN; ++wn) {
         u32x2 hi[4], lo[4];
@@ -369,10 +375,7 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
           const f32x4 sh = *reinterpret_cast<const f32x4*>(aff_s + 64 + wn * 32 + 8 * g + 4 * lh);
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
-            if (a.relu) v[e] = fmaxf(v[e], 0.f);
-          }
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[wm][wn][4 * g + e] * sc[e] + sh[e], floor_v);
           split4(v, hi[g], lo[g], amax);
         }
 #pragma unroll
@@ -381,9 +384,9 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
           const u32x4 ph = gather_octet(hi[2 * m], hi[2 * m + 1]);
           const u32x4 pl = gather_octet(lo[2 * m], lo[2 * m + 1]);
           const int cg = (tc.n0 + 32 * wn) / 16 + m;
-          if (inside && cg < a.cog) {
-            *reinterpret_cast<u32x4*>(obase + (size_t)(cg * 4 + lh) * plane) = ph;
-            *reinterpret_cast<u32x4*>(obase + (size_t)(cg * 4 + 2 + lh) * plane) = pl;
+          if (cg < a.cog) {
+            __builtin_amdgcn_raw_buffer_store_b128(ph, rsrc_o, voff + cg * 4 * plane, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(pl, rsrc_o, voff + (cg * 4 + 2) * plane, 0, 0);
           }
         }
       }
@@ -548,6 +551,7 @@ int launch_spq(SpqArgs& a, hipStream_t stream) {
   a.tiles_y = (a.h + QTH - 1) / QTH;
   const long total = (long)a.n_images * a.tiles_y * a.tiles_x * ((a.c_out + BN - 1) / BN);
   DN_REQUIRE(total < (1L << 22), "spconv (quad-merged): too many tiles (%ld)", total);
+  DN_REQUIRE((long)a.h * a.w * 16 * 4 * a.cog < (1L << 31), "spconv (quad-merged): one output image exceeds 2 GiB");
   a.total_items = (int)total;
   a.n_cb = (a.c_out + BN - 1) / BN;
   a.rcp_ncb = 1.0f / (float)a.n_cb; a.rcp_tx = 1.0f / (float)a.tiles_x; a.rcp_ty = 1.0f / (float)a.tiles_y;
