@@ -30,7 +30,7 @@ hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
 }
 }  // namespace dn
 
-extern "C" int dn_version(void) { return 111; }  // 0.1.1 + round-3 kernels (profiles carry this number)
+extern "C" int dn_version(void) { return 112; }  // 0.1.1 + round-3 kernels (profiles carry this number)
 
 extern "C" unsigned dn_sp_range_flags(int reset) {
   return dn::range_flags_conv_sp(reset != 0) | dn::range_flags_conv_spq(reset != 0) | dn::range_flags_fuse_mlp(reset != 0) |
