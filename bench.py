@@ -357,7 +357,7 @@ def agent_sharded_bench(args, world, rank, dist):
                                 timeout=datetime.timedelta(seconds=120))
     res = agent_sharded_leg(args, world, rank, dist, emulate_world=args.emulate_world, check_steps=args.agent_check)
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit(res)
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -508,13 +508,37 @@ def seg_bench(args, world, rank, dist, use_pg):
                                             "eager launches, wall clock"}
         except Exception as e:
             result["train_step"] = {"error": repr(e)}
-    print(json.dumps(result), flush=True)
+    emit(result)
+
+
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """stdout carries the ONE JSON line and nothing else: RCCL prints a version banner on the process's stdout (at
+    process-group teardown, i.e. possibly AFTER our line), so file descriptor 1 is pointed at stderr for everything
+    that is not the result and the line goes out through a saved duplicate of the original stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(result):
+    line = (json.dumps(result) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
 
 
 def main():
     args = parse()
     if args.cpu_baseline_child:
         return cpu_baseline_child(*args.cpu_baseline_child)
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -941,7 +965,7 @@ def main():
                                                    "kd_loss": round(klast["kd_loss"], 4)}
             except Exception as e:
                 result.setdefault("train_step", {})["error"] = repr(e)
-        print(json.dumps(result), flush=True)
+        emit(result)
 
     if use_pg:
         dist.destroy_process_group()
