@@ -1361,7 +1361,8 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
   if (up_mode(*d) == 2) {   // the packed image is the quad-merged one: conv_spq.hip (tools: 20 / 21 force BN = 32 / 64)
     DN_REQUIRE(a.c1g == 0 || d->c0 % 16 == 0, "spconv: concat needs c0 %% 16 == 0");
     return dn::spq_conv(d, src0, src1, packed, (size_t)a.wpk_bytes, scale, shift, out, a.cout_pad,
-                        g_sp_force == 20 ? 32 : g_sp_force == 21 ? 64 : g_sp_force == 22 ? 33 : 0, s);
+                        g_sp_force == 20 ? 32 : g_sp_force == 21 ? 64 : g_sp_force == 22 ? 33 :
+                        (g_sp_force >= 23 && g_sp_force <= 25) ? 78 + g_sp_force : 0, s);
   }
   if (d->math == 3) {   // hi-only source 0: the 8 x 32 x 32 tile, weight-stationary when the layer fits
     using T32 = SpTile<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 1, 0, 1>;

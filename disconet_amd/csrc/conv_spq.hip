@@ -86,7 +86,8 @@ struct SpqTile {
   static_assert((DEEP ? 1 : 2) * LDS_BYTES <= 160 * 1024, "two workgroups per CU (DEEP: one)");
 };
 
-template <int BN, int DEEP>
+// ABL (tools/sp_conv_check only, results are garbage): 1 = no weight DMA, 2 = no patch DMA, 3 = neither
+template <int BN, int DEEP, int ABL = 0>
 __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
   using T = SpqTile<BN, DEEP>;
   constexpr int WTN = T::WTN, TGQ = T::TGQ, NS0 = T::NS0, NS1 = T::NS1, BLK = T::BLK, QB_STAGE = T::QB_STAGE;
@@ -216,6 +217,7 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
   };
   // patch of chunk g -> stage sa
   auto issue_a = [&](int g, int sa) {
+    if constexpr ((ABL & 2) != 0) return;
     const bool from1 = g >= a.c0g;
     const int soff = from1 ? (g - a.c0g) * 4 * (int)plane1 : g * 4 * (int)plane0;
     unsigned char* base = smem + sa * QA_STAGE + wave * 1024;
@@ -231,6 +233,7 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
   // weights of step st of chunk g -> stage sb.  Packed image: chunks of source 0 carry 16 blocks
   // [merged tap t = 2 a + b][class], the others 9 blocks [dy][dx]; a block = [4 quarters][cout_pad] pieces.
   auto issue_b = [&](int g, int st, int sb) {
+    if constexpr ((ABL & 1) != 0) return;
     const bool from1 = g >= a.c0g;
     const int blk = from1 ? a.c0g * 16 + (g - a.c0g) * 9 + st * T::TG1 : g * 16 + st * (TGQ * 4);
     const int soff = blk * 4 * a.cout_pad * 16;
@@ -533,10 +536,10 @@ __global__ void spq_pack_weights_kernel(const float* __restrict__ w, unsigned ch
   }
 }
 
-template <int BN, int DEEP = 0>
+template <int BN, int DEEP = 0, int ABL = 0>
 int launch_spq(SpqArgs& a, hipStream_t stream) {
   using T = SpqTile<BN, DEEP>;
-  auto kern = conv_spq_kernel<BN, DEEP>;
+  auto kern = conv_spq_kernel<BN, DEEP, ABL>;
   static dn::PerDeviceFlag attr_flag;
   bool& attr_set = attr_flag.here();
   if (!attr_set) {
@@ -598,6 +601,9 @@ int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const vo
   }
   if (bn == 64) return launch_spq<64>(a, stream);
   if (bn == 33) return launch_spq<32, 1>(a, stream);
+  if (bn == 101) return launch_spq<32, 0, 1>(a, stream);   // timing-only ablations of the BN = 32 form
+  if (bn == 102) return launch_spq<32, 0, 2>(a, stream);
+  if (bn == 103) return launch_spq<32, 0, 3>(a, stream);
   return launch_spq<32>(a, stream);
 }
 

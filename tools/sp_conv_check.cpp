@@ -141,6 +141,7 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
   if (up0 && upmode == 2) {
     printf(" [quad]");
     cfgs.insert(cfgs.end(), {20, 21, 22});
+    if (g_mode == 2) cfgs.insert(cfgs.end(), {23, 24, 25});   // timing only: no weight DMA / no patch DMA / neither
   } else if (!quick) {
     if (ks == 1) cfgs.insert(cfgs.end(), {6, 7});
     else if (stride == 2) cfgs.insert(cfgs.end(), {4, 5, 15, 16});
@@ -149,7 +150,7 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
   }
   for (int cfg : cfgs) {
     dn_spconv_force_config(cfg);
-    if (cfg >= 100) {   // ablation: timing only (results are garbage by construction)
+    if (cfg >= 100 || (cfg >= 23 && cfg <= 25)) {   // ablation: timing only (results are garbage by construction)
       if (cfg >= 200 && cout > 32 && 0) continue;
       CK(dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, spo, 0));
       const float t = tm.us([&] { dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, spo, 0); });
