@@ -175,3 +175,20 @@ def test_synthetic_generator_is_deterministic_and_agent_major():
     assert torch.allclose(prod, torch.eye(4, dtype=torch.float64), atol=1e-5)
     idx, off, bevs = make_sparse_scene_batch(1, 2, 64)
     assert off[-1] == idx.shape[0] == int(bevs.sum())
+
+
+def test_bench_stdout_carries_only_the_result_line(tmp_path):
+    """bench.py's contract with the driver: ONE JSON line on stdout.  Libraries (RCCL's version banner at
+    process-group teardown) write to the process's stdout behind Python's back, so bench.py points file
+    descriptor 1 at stderr and emits the result through a saved duplicate (claim_stdout / emit)."""
+    import json
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.claim_stdout(); "
+            "os.write(1, b'banner from a C library\\n'); print('python noise'); bench.emit({'metric': 'x', 'value': 1.5})"
+            % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == {"metric": "x", "value": 1.5}
+    assert r.stdout.count("\n") == 1
+    assert "banner from a C library" in r.stderr and "python noise" in r.stderr
