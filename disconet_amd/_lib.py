@@ -46,6 +46,7 @@ SIGNATURES = {
     "dn_version": (c_int, []),
     "dn_last_error": (c_char_p, []),
     "dn_sp_range_flags": (ctypes.c_uint, [c_int]),
+    "dn_sp_range_flags_async": (c_int, [c_void_p, c_int, c_void_p]),
     "dn_voxelize_occupy": (c_int, [c_void_p, c_int, c_int, POINTER(c_double), POINTER(c_double),
                                    POINTER(c_int), c_void_p, c_void_p]),
     "dn_voxel_compact_workspace": (c_size_t, [POINTER(c_int)]),
@@ -97,9 +98,6 @@ SIGNATURES = {
     "dn_disco_fuse_mlp": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(FuseMlpParams), c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
-    "dn_disco_fuse_warp": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(FuseMlpParams), c_int, c_int,
-                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                   c_void_p]),
     # ---- include/disconet_seg.h ----
     "dn_sp_maxpool2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dn_sp_upsample2_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -117,7 +115,7 @@ SIGNATURES = {
                               c_int, c_int, c_void_p]),
     "dn_conv_dgrad_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                       c_void_p]),
-    "dn_bn_train_stats": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p,
+    "dn_bn_train_stats": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                   c_void_p, c_void_p]),
     "dn_bn_train_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                   c_int, c_long, c_int, c_int, c_void_p, c_void_p]),
@@ -125,9 +123,9 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p]),
     "dn_bn_train_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int,
-                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                      c_int, c_void_p]),
-    "dn_channel_sum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "dn_channel_sum": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     "dn_upsample2_sum": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dn_add_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_void_p]),
     "dn_pair_add_ego": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["common.hip", "conv_mfma.hip", "conv_sp.hip", "conv_spq.hip", "voxel.hip", "warp.hip", "fuse_tail.hip", "fuse_mlp.hip", "fuse_warp.hip", "decode.hip",
+SOURCES = ["common.hip", "conv_mfma.hip", "conv_sp.hip", "conv_spq.hip", "voxel.hip", "warp.hip", "fuse_tail.hip", "fuse_mlp.hip", "decode.hip",
            "conv_wgrad.hip", "train_ops.hip", "seg_ops.hip"]
 LIB_PATH = os.path.join(os.path.dirname(HERE), "libdisconet_hip.so")
 

@@ -30,11 +30,29 @@ hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
 }
 }  // namespace dn
 
-extern "C" int dn_version(void) { return 112; }  // 0.1.1 + round-3 kernels (profiles carry this number)
+extern "C" int dn_version(void) { return 120; }  // 0.1.2: round-4 kernels (profiles carry this number)
 
+// Stream-ordered form: every split-f16 translation unit ORs its sticky word into *dst_device (which the caller
+// zeroed) behind whatever the stream holds; kernel launches only, so it is legal inside a capture.
+extern "C" int dn_sp_range_flags_async(unsigned* dst_device, int reset, void* stream) {
+  DN_REQUIRE(dst_device != nullptr, "sp_range_flags_async: null destination");
+  hipStream_t s = (hipStream_t)stream;
+  dn::range_collect_conv_sp(dst_device, reset != 0, s);
+  dn::range_collect_conv_spq(dst_device, reset != 0, s);
+  dn::range_collect_fuse_mlp(dst_device, reset != 0, s);
+  return dn::check_launch("sp_range_collect_kernel");
+}
+
+// Blocking form: waits for the device (every stream, blocking or not), then reads through the same collectors.
 extern "C" unsigned dn_sp_range_flags(int reset) {
-  return dn::range_flags_conv_sp(reset != 0) | dn::range_flags_conv_spq(reset != 0) | dn::range_flags_fuse_mlp(reset != 0) |
-         dn::range_flags_fuse_warp(reset != 0);
+  unsigned* d = nullptr;
+  unsigned v = 0;
+  if (hipDeviceSynchronize() != hipSuccess || hipMalloc((void**)&d, sizeof v) != hipSuccess) return 0x80000000u;
+  bool ok = hipMemcpy(d, &v, sizeof v, hipMemcpyHostToDevice) == hipSuccess &&
+            dn_sp_range_flags_async(d, reset, nullptr) == DN_OK &&
+            hipMemcpy(&v, d, sizeof v, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  return ok ? v : 0x80000000u;
 }
 
 extern "C" const char* dn_last_error(void) { return dn::err_buf(); }

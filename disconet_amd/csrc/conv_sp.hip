@@ -24,6 +24,9 @@
 // Replaces the conv2d + batch_norm + relu (+ interpolate x2 + cat) chains of
 // upstream:coperception/models/det/backbone/Backbone.py :: encode / decode and the heads of
 // upstream:coperception/models/det/base/* (SURVEY.md §8 a3, a8, a9).
+#ifndef DN_EPI_SOFF
+#define DN_EPI_SOFF 0
+#endif
 #include "dn_internal.h"
 #include "sp_layout.h"
 #include "sp_device.h"
@@ -210,6 +213,7 @@ conv_sp_kernel(const SpArgs a) {
 
   f32x16 acc[WTM][WTN];
   float amax = 0.f;   // max |value| this lane has split (range flags, sp_device.h)
+  bool nan_seen = false;   // a NaN reached an epilogue (ReLU / the clamp of the split would hide it)
 
   // ---- DMA state
   constexpr unsigned OOB = 0xFFFFFFFFu;
@@ -434,14 +438,19 @@ conv_sp_kernel(const SpArgs a) {
       const int co = ch0 + 8 * g + 4 * lh;
       if (wn_r >= 0) {            // register-resident affine (channels past c_out: scale = shift = 0 -> 0)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] = fmaxf(c[4 * g + e] * sc_r[kRegAffine ? wn_r : 0][g][e] + sh_r[kRegAffine ? wn_r : 0][g][e], floor_v);
+        for (int e = 0; e < 4; ++e) v[e] = c[4 * g + e] * sc_r[kRegAffine ? wn_r : 0][g][e] + sh_r[kRegAffine ? wn_r : 0][g][e];
+        note_nan4(nan_seen, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);
       } else if (POST == 1 && wn_r == -2) {   // stage-2 affine of the fused 1x1 from LDS (zero past c_out2)
         const f32x4 sc = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 2 : 0][co & 63]);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 3 : 0][co & 63]);
 #pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = c[4 * g + e] * sc[e] + sh[e];
+        note_nan4(nan_seen, v);
+#pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = fmaxf(c[4 * g + e] * sc[e] + sh[e], floor_v);
+          v[e] = fmaxf(v[e], floor_v);
           v[e] = co + e < c_lim ? v[e] : 0.f;
         }
       } else {
@@ -449,7 +458,12 @@ conv_sp_kernel(const SpArgs a) {
         for (int e = 0; e < 4; ++e) {
           // clamped index + select: no divergent branch per channel
           const int ci = min(co + e, c_lim - 1);
-          v[e] = fmaxf(c[4 * g + e] * scale[ci] + shift[ci], floor_v);
+          v[e] = c[4 * g + e] * scale[ci] + shift[ci];
+        }
+        note_nan4(nan_seen, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = fmaxf(v[e], floor_v);
           v[e] = co + e < c_lim ? v[e] : 0.f;
         }
       }
@@ -487,8 +501,28 @@ conv_sp_kernel(const SpArgs a) {
         // WTN = 2 streaming tiles wrote ~1e-4 of their lo pieces wrong -- lanes 12-15 / 28-31 of both halves, second
         // chunk of a channel tile, errors of lo magnitude (tools/sp_conv_check, 18 of 300 cases) -- while this form
         // is clean on every tile.  Not root-caused; one v_add per store is the price.
+#if DN_EPI_SOFF == 4   // both scalar offsets formed BEFORE the pair: no SALU write of a store's soffset register behind it
+        int so_h = __builtin_amdgcn_readfirstlane(cg * 4 * plane), so_l = __builtin_amdgcn_readfirstlane((cg * 4 + 2) * plane);
+        asm volatile("" : "+s"(so_h), "+s"(so_l));
+        __builtin_amdgcn_raw_buffer_store_b128(ph, rsrc_o, voff, so_h, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(pl, rsrc_o, voff, so_l, 0);
+#elif DN_EPI_SOFF >= 1   // tools/soff: the round-3 form with the plane offset in the SCALAR operand (1), + wait states behind each store (2, 3)
+        __builtin_amdgcn_raw_buffer_store_b128(ph, rsrc_o, voff, cg * 4 * plane, 0);
+#if DN_EPI_SOFF == 2
+        asm volatile("s_nop 1" ::: "memory");
+#elif DN_EPI_SOFF == 3
+        asm volatile("s_nop 7" ::: "memory");
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(pl, rsrc_o, voff, (cg * 4 + 2) * plane, 0);
+#if DN_EPI_SOFF == 2
+        asm volatile("s_nop 1" ::: "memory");
+#elif DN_EPI_SOFF == 3
+        asm volatile("s_nop 7" ::: "memory");
+#endif
+#else
         __builtin_amdgcn_raw_buffer_store_b128(ph, rsrc_o, voff + cg * 4 * plane, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(pl, rsrc_o, voff + (cg * 4 + 2) * plane, 0, 0);
+#endif
       }
     }
   };
@@ -527,9 +561,11 @@ conv_sp_kernel(const SpArgs a) {
           const f32x4 sh1 = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 1 : 0][POST == 2 ? co & 63 : 0]);
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = acc[wm][wn][4 * g + e] * sc1[e] + sh1[e];
-            if (a.relu) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = acc[wm][wn][4 * g + e] * sc1[e] + sh1[e];
+          note_nan4(nan_seen, v);
+          if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
           split4(v, hi[g], lo[g], amax);
         }
@@ -602,9 +638,11 @@ conv_sp_kernel(const SpArgs a) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(&aff1_s[0][POST == 1 ? co : 0]);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 1 : 0][POST == 1 ? co : 0]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
-              if (a.relu) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
+            note_nan4(nan_seen, v);
+            if (a.relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             split4(v, hi[g], lo[g], amax);
           }
@@ -765,7 +803,7 @@ conv_sp_kernel(const SpArgs a) {
         sa ^= 1;
       }
       epilogue(cur);
-      note_range(amax);
+      note_range(amax, nan_seen);
       if (!has_next) break;
       item += G;
       cur = nxt;
@@ -860,7 +898,7 @@ conv_sp_kernel(const SpArgs a) {
       sa ^= 1;
     }
     epilogue(cur);
-      note_range(amax);
+      note_range(amax, nan_seen);
     if (!has_next) break;
     item += G;
     cur = nxt;
@@ -876,6 +914,7 @@ __global__ void sp_from_nhwc_kernel(const float* __restrict__ src, unsigned char
                                     int c, int ld, int cg_total, long hw, long total) {
   // idx over (img, cg, oct, pixel): pixel fastest -> coalesced 16-byte stores per plane
   float amax = 0.f;
+  bool nan_in = false;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
     const long px = idx % hw;
@@ -889,6 +928,7 @@ __global__ void sp_from_nhwc_kernel(const float* __restrict__ src, unsigned char
     for (int e = 0; e < 8; ++e) {
       float x = (cg * 16 + oct * 8 + e < c) ? s[e] : 0.f;
       amax = fmaxf(amax, fabsf(x));
+      nan_in |= x != x;
       x = fminf(fmaxf(x, -65504.f), 65504.f);
       hi[e] = (_Float16)x;
       lo[e] = (_Float16)(x - (float)hi[e]);
@@ -897,7 +937,7 @@ __global__ void sp_from_nhwc_kernel(const float* __restrict__ src, unsigned char
     *reinterpret_cast<half8*>(d) = hi;
     *reinterpret_cast<half8*>(d + 2 * hw * 16) = lo;
   }
-  note_range(amax);
+  note_range(amax, nan_in);
 }
 
 __global__ void sp_to_nhwc_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst,
@@ -1213,7 +1253,7 @@ int fill_args(const dn_conv_desc* d, const void* src0, const void* src1, const v
 
 }  // namespace
 
-namespace dn { unsigned range_flags_conv_sp(bool reset) { return sp_range_flags_here(reset); } }
+namespace dn { void range_collect_conv_sp(unsigned* dst, bool reset, hipStream_t s) { sp_range_collect_here(dst, reset, s); } }
 
 extern "C" size_t dn_sp_tensor_bytes(int n_images, int h, int w, int channels) {
   return (size_t)n_images * chunks_of(channels) * 4 * h * w * 16;

@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
 
   f32x16 acc[2][WTN];
   float amax = 0.f;
+  bool nan_seen = false;
 
   // ---- DMA state
   constexpr unsigned OOB = 0xFFFFFFFFu;
@@ -378,7 +379,10 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
           const f32x4 sh = *reinterpret_cast<const f32x4*>(aff_s + 64 + wn * 32 + 8 * g + 4 * lh);
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[wm][wn][4 * g + e] * sc[e] + sh[e], floor_v);
+          for (int e = 0; e < 4; ++e) v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
+          note_nan4(nan_seen, v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);
           split4(v, hi[g], lo[g], amax);
         }
 #pragma unroll
@@ -485,7 +489,7 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
       sa ^= 1;
     }
     epilogue(cur);
-    note_range(amax);
+    note_range(amax, nan_seen);
     if (!has_next) break;
     item += G;
     cur = nxt;
@@ -568,7 +572,7 @@ int launch_spq(SpqArgs& a, hipStream_t stream) {
 
 namespace dn {
 
-unsigned range_flags_conv_spq(bool reset) { return sp_range_flags_here(reset); }
+void range_collect_conv_spq(unsigned* dst, bool reset, hipStream_t s) { sp_range_collect_here(dst, reset, s); }
 
 size_t spq_packed_blocks(int c0g, int nchunks) { return (size_t)c0g * 16 + (size_t)(nchunks - c0g) * 9; }
 

@@ -48,10 +48,9 @@ int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const vo
              const float* scale, const float* shift, void* out, int cout_pad, int bn, hipStream_t stream);
 
 // per-translation-unit words of the split-f16 range flags (sp_device.h); dn_sp_range_flags() ORs them
-unsigned range_flags_conv_sp(bool reset);
-unsigned range_flags_conv_spq(bool reset);
-unsigned range_flags_fuse_mlp(bool reset);
-unsigned range_flags_fuse_warp(bool reset);
+void range_collect_conv_sp(unsigned* dst, bool reset, hipStream_t stream);
+void range_collect_conv_spq(unsigned* dst, bool reset, hipStream_t stream);
+void range_collect_fuse_mlp(unsigned* dst, bool reset, hipStream_t stream);
 
 }  // namespace dn
 

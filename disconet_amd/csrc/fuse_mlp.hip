@@ -96,11 +96,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
   };
 
   float amax = 0.f;   // max |value| split into the SP output (range flags, sp_device.h)
+  bool nan_seen = false;
   // ---- store helpers: this lane's 8 channels of k-step ks
   auto store_piece = [&](int ks, const f32x4 v0, const f32x4 v1) {
     if (!pvalid) return;
     if (a.fused_sp) {
       u32x2 h0, l0, h1, l1;
+      note_nan4(nan_seen, v0);
+      note_nan4(nan_seen, v1);
       split4(v0, h0, l0, amax);
       split4(v1, h1, l1, amax);
       const size_t plane = (size_t)a.hw * 16;
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
       store_piece(ks, *reinterpret_cast<const f32x4*>(xrow + 16 * ks),
                   *reinterpret_cast<const f32x4*>(xrow + 16 * ks + 4));
     }
-    note_range(amax);
+    note_range(amax, nan_seen);
     return;
   }
 
@@ -403,7 +406,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
   }
 #pragma unroll
   for (int ks = 0; ks < KSW; ++ks) store_piece(ks_first + ks, f0[ks], f1[ks]);
-  note_range(amax);
+  note_range(amax, nan_seen);
 }
 
 // weights [rows][cols] * wmul -> A-operand fragments [nt][ks][part][h][32 rows] x 16 B (rows / cols
@@ -430,7 +433,7 @@ inline size_t w1_bytes(int c) { return (size_t)2 * 4 * (c / 16) * 2 * 2 * 32 * 1
 
 }  // namespace
 
-namespace dn { unsigned range_flags_fuse_mlp(bool reset) { return sp_range_flags_here(reset); } }
+namespace dn { void range_collect_fuse_mlp(unsigned* dst, bool reset, hipStream_t s) { sp_range_collect_here(dst, reset, s); } }
 
 int g_fuse_waves = 0;   // 0 = DN_FUSE_MLP_WAVES, else chosen per launch
 

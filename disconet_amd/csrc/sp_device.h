@@ -46,22 +46,32 @@ __device__ inline void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, un
 
 // Sticky range flags of the split-f16 engines (include/disconet_hip.h :: dn_sp_range_flags): bit 1 = a value
 // with |x| > 2^14 was split (within two binades of the f16 limit), bit 0 = a value was clamped to +-65504 (the
-// result no longer follows the fp32 reference).  One word per translation unit (no relocatable device code in this
+// result no longer follows the fp32 reference), bit 2 = a NaN reached an epilogue (ReLU / the clamp turn it into a
+// finite number: without the flag it would vanish).  One word per translation unit (no relocatable device code in this
 // build); dn_sp_range_flags() ORs them.  Written only by lanes that saw such a value: free in the normal case.
 __device__ unsigned g_sp_range_flags = 0;
 
-__device__ inline void note_range(float amax) {
+__device__ inline void note_range(float amax, bool nan_seen = false) {
   if (amax > 16384.f) atomicOr(&g_sp_range_flags, amax >= 65504.f ? 3u : 2u);
+  if (nan_seen) atomicOr(&g_sp_range_flags, 5u);
+}
+// NaN test of four values BEFORE a max / clamp can hide them: two unordered compares (true when either operand is a
+// NaN), the lane masks OR-ed on the scalar unit -- half a VALU instruction per value.
+__device__ inline void note_nan4(bool& seen, const f32x4 t) {
+  seen |= __builtin_isunordered(t[0], t[1]) | __builtin_isunordered(t[2], t[3]);
 }
 
-inline unsigned sp_range_flags_here(bool reset) {   // host: this translation unit's word, on the current device
-  unsigned v = 0;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sp_range_flags), sizeof v) != hipSuccess) return 0x80000000u;
-  if (reset && v) {
-    const unsigned z = 0;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sp_range_flags), &z, sizeof z);
+// Stream-ordered readers (no null-stream copy: a hipMemcpyFromSymbol would neither wait for kernels on non-blocking
+// streams nor be legal inside a capture).  One thread ORs this translation unit's word into *dst.
+__global__ void sp_range_collect_kernel(unsigned* dst, int reset) {
+  const unsigned v = g_sp_range_flags;
+  if (v) {
+    atomicOr(dst, v);
+    if (reset) g_sp_range_flags = 0;
   }
-  return v;
+}
+inline void sp_range_collect_here(unsigned* dst, bool reset, hipStream_t stream) {
+  hipLaunchKernelGGL(sp_range_collect_kernel, dim3(1), dim3(1), 0, stream, dst, reset ? 1 : 0);
 }
 
 // x -> (hi, lo) halves, 4 values -> two dword pairs.  amax: running max |x| of what this lane has split

@@ -627,10 +627,13 @@ extern "C" size_t dn_reduce_workspace_bytes(int n_groups, long rows_per_group, i
 }
 
 extern "C" int dn_bn_train_stats(const float* z, int n_groups, long rows_per_group, int c, int ldz,
-                                 double* sums, float* mean, float* var, void* stream) {
+                                 double* sums, size_t sums_bytes, float* mean, float* var, void* stream) {
   DN_REQUIRE(z && sums && mean && var, "bn stats: null pointer");
   DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0 && c <= kMaxC && ldz >= c,
              "bn stats: bad shape (groups %d rows %ld c %d ld %d)", n_groups, rows_per_group, c, ldz);
+  DN_REQUIRE(sums_bytes >= dn_reduce_workspace_bytes(n_groups, rows_per_group, c),
+             "bn stats: workspace of %zu bytes, dn_reduce_workspace_bytes() asks for %zu", sums_bytes,
+             dn_reduce_workspace_bytes(n_groups, rows_per_group, c));
   hipStream_t s = (hipStream_t)stream;
   // workspace: [n_groups][2 c] folded sums, then the workgroups' partials [n_groups][blocks][2 c]
   const int nblk = blocks_per_group(rows_per_group, n_groups);
@@ -678,7 +681,7 @@ extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const
                                     const float* y, const float* z, const float* mean,
                                     const float* var, const float* gamma, float eps, int relu,
                                     int n_groups, int h, int w, int images_per_group, int c,
-                                    double* sums, float* dz, float* dgamma, float* dbeta,
+                                    double* sums, size_t sums_bytes, float* dz, float* dgamma, float* dbeta,
                                     int accumulate, void* stream) {
   DN_REQUIRE(dy_a && z && mean && var && gamma && sums && dz && dgamma && dbeta,
              "bn backward: null pointer");
@@ -688,6 +691,9 @@ extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const
              "bn backward: bad shape");
   hipStream_t s = (hipStream_t)stream;
   const long rows_per_group = (long)images_per_group * h * w;
+  DN_REQUIRE(sums_bytes >= dn_reduce_workspace_bytes(n_groups, rows_per_group, c),
+             "bn backward: workspace of %zu bytes, dn_reduce_workspace_bytes() asks for %zu", sums_bytes,
+             dn_reduce_workspace_bytes(n_groups, rows_per_group, c));
   GradSrc src{dy_a, dy_b, y, ld_a, up_a, ld_b, relu, h, w, c};
   const long total = (long)n_groups * rows_per_group * c;
   const int nblk = blocks_per_group(rows_per_group, n_groups);
@@ -714,10 +720,13 @@ extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const
   return dn::check_launch("bn_backward kernels");
 }
 
-extern "C" int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, float* out,
+extern "C" int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, size_t sums_bytes, float* out,
                               int accumulate, void* stream) {
   DN_REQUIRE(x && sums && out, "channel sum: null pointer");
   DN_REQUIRE(rows > 0 && c > 0 && c <= kMaxC && ld >= c, "channel sum: bad shape");
+  DN_REQUIRE(sums_bytes >= dn_reduce_workspace_bytes(1, rows, c),
+             "channel sum: workspace of %zu bytes, dn_reduce_workspace_bytes() asks for %zu", sums_bytes,
+             dn_reduce_workspace_bytes(1, rows, c));
   hipStream_t s = (hipStream_t)stream;
   const int nblk = blocks_per_group(rows, 1);
   double* part = sums + c;                              // [c] folded sums, then the workgroups' partials [blocks][c]

@@ -1,5 +1,5 @@
 // Device helpers of the pose warp (upstream:coperception/models/det/base/* :: feature_transformation, SURVEY.md
-// Appx A.4) shared by warp.hip and fuse_warp.hip: grid_sample's bilinear tap set and a branch-free bilinear read
+// Appx A.4) of warp.hip: grid_sample's bilinear tap set and a branch-free bilinear read
 // of an NHWC fp32 image through a buffer resource.
 #pragma once
 #include <hip/hip_runtime.h>

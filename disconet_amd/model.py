@@ -294,12 +294,6 @@ class DiscoNet(nn.Module):
         # one-launch attention MLP + softmax + weighted sum (csrc/fuse_mlp.hip) instead of
         # two 1x1 conv launches + the tail kernel (split-f16 engines, C in {64, 128, 256})
         self.fuse_mlp = os.environ.get("DISCONET_FUSE_MLP", "1") != "0"
-        # ... and the pose warp inside that launch as well (csrc/fuse_warp.hip): the warped neighbour maps are
-        # re-derived tile by tile in LDS and never written.  Opt-in (DISCONET_FUSE_WARP=1): it removes the 84 MB
-        # `warped` tensor but measures 225 us against 137 us for warp + fuse_mlp at the BASELINE shape -- the
-        # block is bound by gather latency, not bytes, and the fused form derives every warped value twice
-        # (DESIGN.md 3.4).
-        self.fuse_warp = os.environ.get("DISCONET_FUSE_WARP", "0") == "1"
         # run the encoder levels above the exchanged one beside the fusion block on a second HIP stream:
         # REFUSED unless DISCONET_UNSAFE_OVERLAP=1 (the property below).  A kernel that shares a SIMD with
         # the split-f16 conv kernels has been observed to compute with corrupted VGPR lanes (DESIGN.md
@@ -320,6 +314,16 @@ class DiscoNet(nn.Module):
     # ------------------------------------------------------------------
     # checkpoint compatibility
     # ------------------------------------------------------------------
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel over ONE device never replicates (it calls self.module directly): the reference tools'
+        # wrapper works unchanged there.  Over several devices it would clone this module per call and per thread --
+        # replicas sharing one packed-weight plan and one stream: refused instead of undefined behaviour.
+        raise RuntimeError(
+            "disconet_amd: nn.DataParallel over more than one device is not supported (its per-call replicas would "
+            "share one packed-weight plan and one HIP stream).  Keep nn.DataParallel(model, device_ids=[k]) for one "
+            "device, or launch one process per GPU: python -m torch.distributed.run --nproc-per-node N ... "
+            "(bench.py --gpus N, disconet_amd.sharded)")
+
     def load_state_dict(self, state_dict, strict=True, **kw):
         """Accepts a reference model_state_dict: strips the DataParallel
         `module.` prefix and ignores the duplicate, unused parameters the
@@ -364,7 +368,7 @@ class DiscoNet(nn.Module):
     def _signature(self):
         if self.conv_math not in ops.MATH_MODES:
             raise ValueError("conv_math must be one of %s" % sorted(ops.MATH_MODES))
-        return (self.conv_math, self.fuse_1x1, self.fuse_mlp, self.fuse_warp) + tuple((t.data_ptr(), t._version) for t in
+        return (self.conv_math, self.fuse_1x1, self.fuse_mlp) + tuple((t.data_ptr(), t._version) for t in
                                          list(self.parameters()) + list(self.buffers()))
 
     def _build_plan(self):
@@ -522,12 +526,6 @@ class DiscoNet(nn.Module):
         B = batch_size
         map_bytes = 4.0 * h * w * c
         pairs = B * E * (A - 1)
-        if "_fuse_mlp" in P and self.fuse_warp and A <= 8:
-            # one launch, no `warped` tensor: every agent's map read (L2), the served egos' fused maps written
-            flops = 2.0 * B * E * h * w * (128.0 * c * (2 + (A - 1)) + A * (128 * 32 + 32 * 8 + 8))
-            with region("fuse_warp", "disco_fuse_warp_kernel", flops, map_bytes * (n + E * B)):
-                return ops.disco_fuse_warp(feat, trans_matrices, num_agent, P["_fuse_mlp"], B, A, self.only_v2i,
-                                           want_weights, ego_first, E, sp_out=sp_out)
         warped = torch.empty((B, E, max(A - 1, 0), h, w, c), dtype=torch.float32,
                              device=feat.device)
         with region("warp", "warp_neighbors_kernel", 0.0, map_bytes * (n + pairs)):
@@ -619,7 +617,7 @@ class DiscoNet(nn.Module):
         x8, x7, x6, x5 = self.decode(enc, P)
 
         result = self.heads(x8, P)
-        ops.check_sp_range("DiscoNet.forward")      # DN_SP_CHECK=1 only: one blocking flag read per forward
+        ops.check_sp_range("DiscoNet.forward")      # asynchronous range guard: a clamp / NaN of THIS forward raises at the next one
         if self.kd_flag == 1:
             # NCHW-shaped, channels-last-strided views of the NHWC buffers
             nchw = lambda t: ops.as_nhwc(t).permute(0, 3, 1, 2)

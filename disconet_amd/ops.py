@@ -247,16 +247,18 @@ class SpTensor:
 def sp_range_flags(reset=True):
     """Sticky range flags of the split-f16 engines on the current device (include/disconet_hip.h ::
     dn_sp_range_flags): bit 1 = a value above 2^14 was stored as an f16 hi/lo pair, bit 0 = a value was clamped
-    to +-65504 (results no longer follow the fp32 reference).  Blocking: validation time, not per step."""
+    to +-65504 (results no longer follow the fp32 reference), bit 2 = a NaN reached an epilogue.  Blocking:
+    validation time, not per step (check_sp_range is the asynchronous guard the model uses)."""
+    if reset:
+        _range_guard.pending.pop(torch.cuda.current_device(), None)
     return int(_lib.load().dn_sp_range_flags(1 if reset else 0))
 
 
-def check_sp_range(what="forward"):
-    """DN_SP_CHECK=1: turn a raised clamp flag into an error (and a near-limit flag into a warning)."""
-    import os
-    if os.environ.get("DN_SP_CHECK", "0") != "1":
-        return
-    flags = sp_range_flags(reset=True)
+def _raise_on_range_flags(flags, what):
+    if flags & 4:
+        raise _lib.DnError("%s: a NaN reached a conv / fusion epilogue of the split-f16 engines (ReLU and the clamp of the "
+                           "split turn it into a finite number, so the outputs hold plausible garbage).  Check the inputs "
+                           "and the weights." % what)
     if flags & 1:
         raise _lib.DnError("%s: a value was clamped to +-65504 by the split-f16 (hi + lo binary16) activation format; "
                            "the outputs do not follow the fp32 reference.  Rescale the layer (fold a power of two into "
@@ -264,6 +266,71 @@ def check_sp_range(what="forward"):
     if flags & 2:
         import warnings
         warnings.warn("%s: activations above 2^14 were stored as f16 hi/lo pairs (limit 65504)" % what)
+
+
+class _RangeGuard:
+    """The range guard without a synchronisation: behind a forward the sticky device flags are collected into a
+    device word on the forward's stream (dn_sp_range_flags_async) and copied to pinned host memory; the NEXT
+    call looks at the copy if its event has completed and raises.  A clamp is therefore reported one call late (or by
+    drain(), which waits) -- but it is reported by default, and the cost is four tiny launches per polled call."""
+
+    def __init__(self):
+        self.pending = {}       # device index -> (event, pinned host word, device word, what)
+
+    def poll(self, what):
+        dev = torch.cuda.current_device()
+        self._look(dev, wait=False)
+        if dev in self.pending or torch.cuda.is_current_stream_capturing():
+            return
+        word = torch.zeros(1, dtype=torch.int32, device="cuda")
+        check(_lib.load().dn_sp_range_flags_async(_ptr(word), 0, _stream()), "dn_sp_range_flags_async")
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(word, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending[dev] = (ev, host, word, what)
+
+    def _look(self, dev, wait):
+        ent = self.pending.get(dev)
+        if ent is None:
+            return
+        ev, host, _, what = ent
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        del self.pending[dev]
+        flags = int(host[0]) & 0xffffffff
+        if flags:
+            _lib.load().dn_sp_range_flags(1)       # the flags are sticky: cleared here, where they are reported
+        _raise_on_range_flags(flags, what)
+
+    def drain(self):
+        """wait for the outstanding read of the current device and raise if it carried a flag"""
+        self._look(torch.cuda.current_device(), wait=True)
+
+
+_range_guard = _RangeGuard()
+
+
+def check_sp_range(what="forward"):
+    """Range guard of the split-f16 engines, called behind a forward.  Default: asynchronous (see _RangeGuard) --
+    a clamped activation / a NaN raises at the next call, with no synchronisation.  DN_SP_CHECK=1: blocking read,
+    this very call raises; DN_SP_CHECK=0: off.  Never inside a stream capture."""
+    import os
+    mode = os.environ.get("DN_SP_CHECK", "")
+    if mode == "0" or torch.cuda.is_current_stream_capturing():
+        return
+    if mode == "1":
+        _range_guard.pending.pop(torch.cuda.current_device(), None)
+        _raise_on_range_flags(sp_range_flags(reset=True), what)
+        return
+    _range_guard.poll(what)
+
+
+def drain_sp_range():
+    """block until the outstanding asynchronous range-guard read (if any) has landed; raises like check_sp_range"""
+    _range_guard.drain()
 
 
 def as_sp(x):
@@ -543,28 +610,6 @@ def disco_fuse_mlp(feat, warped, num_agent, params, batch, agents, only_v2i=Fals
                                         batch, agents, h * w, c, int(only_v2i), ego_first, ego_count,
                                         _ptr(out_sp.data) if sp_out else None, _ptr(out), _ptr(weights),
                                         _stream()), "dn_disco_fuse_mlp")
-    res = out_sp if sp_out else out
-    return (res, weights) if want_weights else res
-
-
-def disco_fuse_warp(feat, trans, num_agent, params, batch, agents, only_v2i=False, want_weights=False,
-                    ego_first=0, ego_count=None, sp_out=False):
-    """Pose warp + attention MLP + agent softmax + weighted sum in ONE launch (no `warped` tensor).
-    feat [A*B, h, w, C] NHWC (all agents), trans [B, A, A, 4, 4]; -> SpTensor (sp_out) or float32 NHWC
-    [E*B, h, w, C] (+ weights [B, E, A, h*w] when want_weights)."""
-    _need_gpu(feat, num_agent, trans)
-    _f32c(feat, "feat")
-    _f32c(trans, "trans_matrices")
-    ego_count = agents if ego_count is None else ego_count
-    n, h, w, c = feat.shape
-    out_sp = SpTensor(ego_count * batch, h, w, c, device=feat.device) if sp_out else None
-    out = None if sp_out else torch.empty((ego_count * batch, h, w, c), dtype=torch.float32, device=feat.device)
-    weights = (torch.zeros((batch, ego_count, agents, h * w), dtype=torch.float32, device=feat.device)
-               if want_weights else None)
-    check(_lib.load().dn_disco_fuse_warp(_ptr(feat), _ptr(trans), _ptr(num_agent), ctypes.byref(params),
-                                         batch, agents, h, w, c, int(only_v2i), ego_first, ego_count,
-                                         _ptr(out_sp.data) if sp_out else None, _ptr(out), _ptr(weights),
-                                         _stream()), "dn_disco_fuse_warp")
     res = out_sp if sp_out else out
     return (res, weights) if want_weights else res
 

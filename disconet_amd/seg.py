@@ -76,6 +76,16 @@ class SegDiscoNet(nn.Module):
         self.pixel_weighted_fusion = _FusionParams(self.FUSE_CHANNELS)
         self._plan, self._plan_sig = None, None
 
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel over ONE device never replicates (it calls self.module directly): the reference tools'
+        # wrapper works unchanged there.  Over several devices it would clone this module per call and per thread --
+        # replicas sharing one packed-weight plan and one stream: refused instead of undefined behaviour.
+        raise RuntimeError(
+            "disconet_amd: nn.DataParallel over more than one device is not supported (its per-call replicas would "
+            "share one packed-weight plan and one HIP stream).  Keep nn.DataParallel(model, device_ids=[k]) for one "
+            "device, or launch one process per GPU: python -m torch.distributed.run --nproc-per-node N ... "
+            "(bench.py --gpus N, disconet_amd.sharded)")
+
     def load_state_dict(self, state_dict, strict=True, **kw):
         cleaned = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         self._plan = None

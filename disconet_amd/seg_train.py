@@ -5,6 +5,7 @@ Mirrors upstream:coperception/utils/SegModule.py :: SegModule.step (recollection
 /root/reference/coperception is an empty submodule directory -- README.md:15, :37, :49 are the mounted mentions):
 
     model.train();  pred = model(bev, trans_matrices, num_agent)
+    pred, labels = the images whose BEV is not empty (torch.sum(bev[i]) > 1e-4; padded agent slots are dropped)
     loss = nn.CrossEntropyLoss()(pred, labels);  optimizer.zero_grad();  loss.backward();  optimizer.step()
 
 Built on the detector's training engine (train.py): the same conv forward / BatchNorm-statistics / data-gradient /
@@ -143,6 +144,7 @@ class SegTrainStep:
 
     def __init__(self, model, optimizer=None, lr=1e-3):
         kw = {}
+        self.optimizer = optimizer      # its param_groups[0]["lr"] is re-read every step: an lr scheduler on it is honoured
         if optimizer is not None:
             grp = optimizer.param_groups[0]
             lr = grp["lr"]
@@ -166,10 +168,26 @@ class SegTrainStep:
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
         B = x.shape[0] // m.agent_num if batch_size is None else batch_size
+        if self.optimizer is not None:
+            eng.lr = float(self.optimizer.param_groups[0]["lr"])
         with torch.no_grad():
             logits = eng.forward(x, data["trans_matrices"], data["num_agent"], B)
-            loss, dlogits = ops.seg_ce_loss(logits, data["labels"], want_grad=True, check_labels=False)
+            # the reference drops the images whose BEV is empty (sum <= 1e-4: the padded slots of scenes with fewer
+            # live agents than num_agent) from pred and labels before the criterion.  Same loss, divisor and
+            # gradients with their labels set to the ignore index -- on the device, no host sync.
+            labels = data["labels"].to(device=x.device)
+            empty = x.reshape(x.shape[0], -1).sum(1) <= 1e-4
+            labels = torch.where(empty.view(-1, 1, 1), torch.full_like(labels, -100), labels)
+            loss, dlogits = ops.seg_ce_loss(logits, labels, want_grad=True, check_labels=False)
             eng.backward(dlogits)
             eng.allreduce_grads()
             eng.optimizer_step()
         return {"loss": float(loss)}
+
+    def scheduler_step(self, lr=None):
+        """lr for the following steps (the detector's CoDetModule.scheduler_step): an explicit value, or the passed
+        optimizer's current one (already re-read every step)."""
+        if lr is not None:
+            self.engine.lr = float(lr)
+        elif self.optimizer is not None:
+            self.engine.lr = float(self.optimizer.param_groups[0]["lr"])

@@ -194,8 +194,9 @@ class TrainEngine:
     def _math(self):
         return ops.nhwc_math(self.model.conv_math)      # the training kernels take fp32 NHWC
 
-    def _conv(self, w, bias, src0, src1=None, up0=0, stride=1, ksize=3, out=None, h_in=None, w_in=None):
-        """raw conv + bias through the forward engine (weights packed on the fly)"""
+    def _conv(self, w, bias, src0, src1=None, up0=0, stride=1, ksize=3, out=None, h_in=None, w_in=None, lift_of=None):
+        """raw conv + bias through the forward engine (weights packed on the fly).  lift_of: the Parameter whose
+        power-of-two lift applies when `w` is a temporary cut out of it (the attention MLP's W1 halves)"""
         n, h0, w0 = src0.shape[0], src0.shape[1], src0.shape[2]
         c0 = src0.shape[3]
         if h_in is None:
@@ -206,7 +207,7 @@ class TrainEngine:
                           ld0=src0.stride(2), ld1=src1.stride(2) if src1 is not None else None,
                           ldo=out.stride(2) if out is not None else None, math=self._math())
         dev = src0.device
-        wmul = self._wmul_of(w) if d.math == 1 else 1.0
+        wmul = self._wmul_of(w if lift_of is None else lift_of) if d.math == 1 else 1.0
         packed = ops.pack_conv_weights(d, w if wmul == 1.0 else w.detach() * wmul)
         one = self._const(dev, c_out, 1.0 / wmul)
         shift = bias if bias is not None else self._const(dev, c_out, 0.0)
@@ -219,11 +220,17 @@ class TrainEngine:
     def _wmul_of(self, w):
         """power-of-two lift of a layer's weights for the split-f16 forward (ops._pow2_lift: keeps the lo halves
         of small weights out of the f16 subnormal range; 1 / wmul rides in the conv's scale vector).  The max |w|
-        behind it is read back from the device: cached per weight tensor, refreshed every 64 optimizer steps."""
-        key = (w.data_ptr(), tuple(w.shape))
+        behind it is read back from the device (a host sync): cached per PARAMETER -- its offset in the flat buffer, a
+        key that survives allocator address reuse; temporaries cut out of a parameter pass the parent (`lift_of`) --
+        and refreshed when the step count has moved 64 either way (a resumed run may step backwards); load_state_dict
+        drops the cache."""
+        ent = self.grad_of.get(id(w))
+        key = ("p", ent[0]) if ent is not None else ("t", w.data_ptr(), tuple(w.shape), w._version)
         cache = self.__dict__.setdefault("_wmul_cache", {})
         hit = cache.get(key)
-        if hit is None or self.step_count - hit[1] >= 64:
+        if hit is None or abs(self.step_count - hit[1]) >= 64:
+            if ent is None and len(cache) > 256:      # temporaries without a parent: do not let the table grow
+                cache.clear()
             hit = (ops._pow2_lift(w), self.step_count)
             cache[key] = hit
         return hit[0]
@@ -425,8 +432,8 @@ class TrainEngine:
             T.warp_list(maps, F["poses"], F["src_image"], out=maps[NI:])
         w1 = f.conv1_1.weight.reshape(128, 2 * C)
         w_ego, w_nbr = w1[:, :C].contiguous(), w1[:, C:].contiguous()
-        E, d_e = self._conv(w_ego.view(128, C, 1, 1), None, maps[:NI], ksize=1)
-        z1, d_f = self._conv(w_nbr.view(128, C, 1, 1), f.conv1_1.bias, maps, ksize=1)
+        E, d_e = self._conv(w_ego.view(128, C, 1, 1), None, maps[:NI], ksize=1, lift_of=f.conv1_1.weight)
+        z1, d_f = self._conv(w_nbr.view(128, C, 1, 1), f.conv1_1.bias, maps, ksize=1, lift_of=f.conv1_1.weight)
         T.pair_add_ego(z1, E, F["ego_image"])
         mean1, var1 = T.bn_stats(z1, P)
         h1 = T.bn_apply(z1, mean1, var1, f.bn1_1.weight, f.bn1_1.bias, _EPS, relu=True)
@@ -572,6 +579,7 @@ class TrainEngine:
                 "exp_avg_sq": {names[id(p)]: view(self.flat_v, p).clone() for p in self.params}}
 
     def load_state_dict(self, sd):
+        self.__dict__.pop("_wmul_cache", None)      # weight lifts belong to the weights that were just replaced
         self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
         self.betas, self.eps, self.weight_decay = tuple(sd["betas"]), float(sd["eps"]), float(sd["weight_decay"])
         for n, p in self.model.named_parameters():

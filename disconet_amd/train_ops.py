@@ -67,7 +67,7 @@ def bn_stats(z, n_groups=1):
     mean = torch.empty((n_groups, c), dtype=torch.float32, device=z.device)
     var = torch.empty_like(mean)
     sums = _ws(z.device, _lib.load().dn_reduce_workspace_bytes(n_groups, rows // n_groups, c))
-    check(_lib.load().dn_bn_train_stats(_ptr(z), n_groups, rows // n_groups, c, c, _ptr(sums),
+    check(_lib.load().dn_bn_train_stats(_ptr(z), n_groups, rows // n_groups, c, c, _ptr(sums), sums.numel(),
                                         _ptr(mean), _ptr(var), _stream()), "dn_bn_train_stats")
     return mean, var
 
@@ -106,7 +106,7 @@ def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_
     check(_lib.load().dn_bn_train_backward(
         _ptr(dy_a), _ld(dy_a), int(bool(up_a)), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0,
         _ptr(y), _ptr(z), _ptr(mean), _ptr(var), _ptr(gamma), float(eps), int(relu), n_groups, h, w,
-        n // n_groups, c, _ptr(sums), _ptr(dz), _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)),
+        n // n_groups, c, _ptr(sums), sums.numel(), _ptr(dz), _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)),
         _stream()), "dn_bn_train_backward")
     return dz
 
@@ -117,7 +117,7 @@ def channel_sum(x, out, accumulate=False):
     c = x.shape[-1]
     rows = x.numel() // c
     sums = _ws(x.device, _lib.load().dn_reduce_workspace_bytes(1, rows, c))
-    check(_lib.load().dn_channel_sum(_ptr(x), rows, c, _ld(x), _ptr(sums), _ptr(out),
+    check(_lib.load().dn_channel_sum(_ptr(x), rows, c, _ld(x), _ptr(sums), sums.numel(), _ptr(out),
                                      int(bool(accumulate)), _stream()), "dn_channel_sum")
     return out
 

@@ -49,18 +49,28 @@ extern "C" {
 int dn_version(void);
 const char* dn_last_error(void);
 
-/* Range guard of the split-f16 engines (dn_spconv2d*, dn_sp_from_nhwc, dn_disco_fuse_mlp*).  A value is
- * stored as hi + lo f16 halves, so the format has the f16 EXPONENT range: a split clamps at +-65504
- * (the result then no longer follows the fp32 reference) and `lo` is a subnormal below |x| ~ 0.125 (an
- * absolute error floor of 2^-25 per operand instead of 2^-22 relative).  Every kernel that splits
- * values keeps a sticky word in device memory:
+/* Range guard of the split-f16 engines (dn_spconv2d*, dn_sp_from_nhwc, dn_disco_fuse_mlp).  A value is
+ * stored as hi + lo f16 halves, so the format has the f16 EXPONENT range:
+ *   - a split clamps at +-65504 (the result then no longer follows the fp32 reference);
+ *   - PRECISION FLOOR: `lo = half(x - hi)` is a subnormal once |x| < ~0.125, so below that magnitude an operand
+ *     carries an ABSOLUTE error floor of 2^-25 (~3e-8) instead of 2^-22 relative (18 significant bits at
+ *     |x| ~ 0.02, 14 at ~1e-3).  Weights are lifted out of that range at pack time by a power of two folded
+ *     into the layer's scale (exact); activations are not lifted -- post-ReLU maps of O(1) meet the 1e-4 parity
+ *     bar with three orders of margin, maps that are uniformly tiny (|x| << 1e-3) should be rescaled through
+ *     their BatchNorm.
+ * Every kernel that splits values keeps a sticky word in device memory:
  *   bit 1 (2): a value with |x| > 2^14 was split -- within two binades of the limit, rescale;
- *   bit 0 (1): a value was clamped to +-65504 -- results of this device since the last reset are wrong.
- * Returns the OR over the library's kernels on the current device and, with reset != 0, clears it.
- * Blocking (a device -> host copy behind everything enqueued): poll it at plan / validation time, not per
- * step.  The Python host raises on it when DN_SP_CHECK=1.  NaN inputs are not flagged (a split turns a
- * NaN into -65504). */
+ *   bit 0 (1): a value was clamped to +-65504 -- results of this device since the last reset are wrong;
+ *   bit 2 (4): a NaN reached an epilogue (always together with bit 0).  ReLU and the clamp turn a NaN into a
+ *              finite number, so without this bit it would vanish from the outputs.
+ * dn_sp_range_flags: the OR over the library's kernels on the current device; with reset != 0 it clears them.
+ *   BLOCKING (hipDeviceSynchronize + a device -> host copy): validation time.
+ * dn_sp_range_flags_async: the same OR enqueued on `stream` into *dst_device (a device word the caller zeroed):
+ *   no synchronisation, legal inside a stream capture.  The Python host enqueues it behind a forward, copies the
+ *   word to pinned memory and raises at the next call once the copy has landed: the guard is on by default and
+ *   costs nothing but four tiny launches (DN_SP_CHECK=0 switches it off, =1 makes every forward block and check). */
 unsigned dn_sp_range_flags(int reset);
+int dn_sp_range_flags_async(unsigned* dst_device, int reset, void* stream);
 
 /* ------------------------------------------------------------------------
  * K1 -- point cloud -> BEV occupancy.
@@ -325,21 +335,6 @@ int dn_disco_fuse_mlp(const float* feat, const float* warped, const int32_t* num
                       const dn_fuse_mlp_params* p, int batch, int agents, int hw, int c,
                       int only_v2i, int ego_first, int ego_count, void* fused_sp,
                       float* fused_nhwc, float* weights_out, void* stream);
-
-/* ------------------------------------------------------------------------
- * K4 + K5 + K6 in ONE launch (disconet_amd/csrc/fuse_warp.hip): dn_warp_neighbors and
- * dn_disco_fuse_mlp fused -- the warped neighbour maps are re-derived tile by tile in LDS (rotated
- * block of an 8 x 4 pixel tile, then the translation blend straight into the MFMA operands) and never
- * written: no `warped` tensor.  Same semantics, neighbour order, ego range, only_v2i and outputs as
- * dn_disco_fuse_mlp; feat [A*B][h][w][c] float32 NHWC (all agents), trans [B][A][A][4][4], p from
- * dn_fuse_mlp_pack.  c in {64, 128, 256}, agents <= 8.
- * Replaces feature_transformation + PixelWeightedFusionSoftmax.forward + the fusion loop body of
- * upstream:coperception/models/det/DiscoNet.py :: DiscoNet.forward.
- * ------------------------------------------------------------------------ */
-int dn_disco_fuse_warp(const float* feat, const float* trans, const int32_t* num_agent,
-                       const dn_fuse_mlp_params* p, int batch, int agents, int h, int w, int c,
-                       int only_v2i, int ego_first, int ego_count, void* fused_sp, float* fused_nhwc,
-                       float* weights_out, void* stream);
 
 /* ------------------------------------------------------------------------
  * Detection decode (first step after the hot path).

@@ -33,7 +33,10 @@ extern "C" {
  * weight (the attention MLP's [W_ego | W_nbr]) can be written in place.  Slices are summed
  * in a fixed order: deterministic.  accumulate != 0 adds to dw. */
 size_t dn_conv_wgrad_workspace(const dn_conv_desc* d);
-/* workspace of the per-channel reductions below (dn_bn_train_stats, dn_bn_train_backward, dn_channel_sum) */
+/* workspace of the per-channel reductions below (dn_bn_train_stats, dn_bn_train_backward, dn_channel_sum): the
+ * folded sums AND every workgroup's partial.  The size depends on the library version (it grew with the
+ * deterministic reductions of dn_version 112), so those entry points take the size of what was allocated
+ * (`sums_bytes`) and refuse a workspace that is too small instead of writing past it. */
 size_t dn_reduce_workspace_bytes(int n_groups, long rows_per_group, int c);
 int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz,
                   void* workspace, float* dw, int dw_cin_total, int accumulate, void* stream);
@@ -54,7 +57,7 @@ int dn_conv_dgrad_weights(const float* w_oihw, int c_out, int cin_total, int ci_
  * workgroup's partial: the per-channel sums are DETERMINISTIC -- fixed thread, workgroup and fold order, no
  * atomics).  var is the biased variance. */
 int dn_bn_train_stats(const float* z, int n_groups, long rows_per_group, int c, int ldz,
-                      double* sums, float* mean, float* var, void* stream);
+                      double* sums, size_t sums_bytes, float* mean, float* var, void* stream);
 
 /* y = act((z - mean) * rsqrt(var + eps) * gamma + beta), act = ReLU if relu */
 int dn_bn_train_apply(const float* z, const float* mean, const float* var, const float* gamma,
@@ -77,11 +80,11 @@ int dn_bn_update_running(const float* mean, const float* var, int n_groups, long
 int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
                          const float* y, const float* z, const float* mean, const float* var,
                          const float* gamma, float eps, int relu, int n_groups, int h, int w,
-                         int images_per_group, int c, double* sums, float* dz, float* dgamma,
-                         float* dbeta, int accumulate, void* stream);
+                         int images_per_group, int c, double* sums, size_t sums_bytes, float* dz,
+                         float* dgamma, float* dbeta, int accumulate, void* stream);
 
 /* out[c] (+)= sum over rows of x[row][c] (bias gradients); sums: dn_reduce_workspace_bytes(1, rows, c) bytes */
-int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, float* out,
+int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, size_t sums_bytes, float* out,
                    int accumulate, void* stream);
 
 /* Backward of the decoder's nearest x2 upsample as a pass of its own (only needed where no

@@ -151,6 +151,16 @@ def seg_loss(logits, labels):
     return F.cross_entropy(logits, labels.long())
 
 
+def seg_train_loss(logits, labels, bev):
+    """upstream SegModule.step with `com` on: pred / labels of the images whose BEV is empty (torch.sum(bev[i]) <= 1e-4:
+    padded agent slots) are dropped, image by image, before the criterion"""
+    keep = [i for i in range(bev.shape[0]) if float(torch.sum(bev[i])) > 1e-4]
+    if len(keep) != bev.shape[0]:
+        idx = torch.tensor(keep, dtype=torch.long)
+        logits, labels = logits[idx], labels[idx]
+    return seg_loss(logits, labels)
+
+
 def build_seg_ref(seed=0, init="kaiming", **kw):
     torch.manual_seed(seed)
     m = SegDiscoNetRef(**kw)

@@ -232,14 +232,14 @@ def oracle_seg_train_fp64(case, ref):
     """the seg oracle's training forward / backward in float64 (fp32 warp grids): -> (loss, grads)"""
     import copy
     import torch.nn.functional as F
-    from oracle.seg_ref import seg_loss
+    from oracle.seg_ref import seg_train_loss
     c = SEG_CASES[case]
     x, trans, na, labels = seg_inputs(case)
     ref64 = copy.deepcopy(ref).double().train()
     orig = F.grid_sample
     F.grid_sample = lambda inp, grid, **kw: orig(inp, grid.to(inp.dtype), **kw)
     try:
-        loss = seg_loss(ref64(x.double(), trans, na, c["batch"]), labels)
+        loss = seg_train_loss(ref64(x.double(), trans, na, c["batch"]), labels, x)
         loss.backward()
     finally:
         F.grid_sample = orig

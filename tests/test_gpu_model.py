@@ -244,8 +244,9 @@ def test_model_with_trained_like_statistics(math):
 
 
 def test_range_guard_reports_a_clamped_activation(monkeypatch):
-    """an activation beyond 65504 cannot be stored as an f16 hi/lo pair: the sticky flag is raised and, with
-    DN_SP_CHECK=1, the forward refuses to return numbers that no longer follow the reference"""
+    """an activation beyond 65504 cannot be stored as an f16 hi/lo pair: the sticky flag is raised and the guard --
+    on by default, asynchronous: no synchronisation in the forward -- refuses to go on at the next call; with
+    DN_SP_CHECK=1 the offending forward itself raises, with DN_SP_CHECK=0 nothing does"""
     from disconet_amd import ops
     from disconet_amd._lib import DnError
     c = cases.MODEL_CASES["cfg1_f1"]
@@ -254,10 +255,61 @@ def test_range_guard_reports_a_clamped_activation(monkeypatch):
         ref.u_encoder.conv_pre_2.weight.mul_(3.0e5)
     bevs, trans, na = cases.model_inputs("cfg1_f1")
     m = _product(ref, c["map_hw"], c["agents"], math="sp")
+    monkeypatch.delenv("DN_SP_CHECK", raising=False)
     ops.sp_range_flags(reset=True)
-    _gpu_outputs(m, bevs, trans, na, c["batch"])
-    assert ops.sp_range_flags(reset=False) & 1
+    _gpu_outputs(m, bevs, trans, na, c["batch"])            # clamps; the asynchronous read is in flight
+    assert ops.sp_range_flags(reset=False) & 1              # (blocking read: the flag is sticky)
+    with pytest.raises(DnError, match="clamped"):           # default mode: reported at the next call
+        torch.cuda.synchronize()
+        _gpu_outputs(m, bevs, trans, na, c["batch"])
+    assert ops.sp_range_flags(reset=True) == 0              # reporting clears the sticky flags
+    ops.drain_sp_range()                                    # nothing outstanding
     monkeypatch.setenv("DN_SP_CHECK", "1")
     with pytest.raises(DnError, match="clamped"):
         _gpu_outputs(m, bevs, trans, na, c["batch"])
     assert ops.sp_range_flags(reset=True) == 0
+    monkeypatch.setenv("DN_SP_CHECK", "0")
+    _gpu_outputs(m, bevs, trans, na, c["batch"])
+    _gpu_outputs(m, bevs, trans, na, c["batch"])
+    assert ops.sp_range_flags(reset=True) & 1
+
+
+def test_range_guard_reports_a_nan(monkeypatch):
+    """ReLU and the split's clamp turn a NaN into a finite number; the epilogues test for it before that happens"""
+    from disconet_amd import ops
+    from disconet_amd._lib import DnError
+    c = cases.MODEL_CASES["cfg1_f1"]
+    ref = cases.ref_model(c["map_hw"], c["agents"])
+    with torch.no_grad():
+        ref.u_encoder.conv1_1.bias[3] = float("nan")
+    bevs, trans, na = cases.model_inputs("cfg1_f1")
+    m = _product(ref, c["map_hw"], c["agents"], math="sp")
+    monkeypatch.setenv("DN_SP_CHECK", "1")
+    ops.sp_range_flags(reset=True)
+    with pytest.raises(DnError, match="NaN"):
+        _gpu_outputs(m, bevs, trans, na, c["batch"])
+    assert ops.sp_range_flags(reset=True) == 0
+
+
+def test_dataparallel_wrapper_on_one_device():
+    """the reference tools wrap the model in nn.DataParallel (/root/reference/README.md:54-75): on ONE
+    device the wrapper is a pass-through -- forward bitwise equal to the bare model, `module.`-prefixed checkpoints
+    load through the wrapper -- and over several devices replication is refused with the one-process-per-GPU message"""
+    import torch.nn as nn
+    c = cases.MODEL_CASES["cfg1_f1"]
+    ref = cases.ref_model(c["map_hw"], c["agents"])
+    bevs, trans, na = cases.model_inputs("cfg1_f1")
+    bare = _product(ref, c["map_hw"], c["agents"], math="sp")
+    want = _gpu_outputs(bare, bevs, trans, na, c["batch"])
+    from disconet_amd import Config, DiscoNet
+    inner = DiscoNet(Config(map_hw=c["map_hw"]), kd_flag=1, num_agent=c["agents"]).eval().cuda()
+    wrapped = nn.DataParallel(inner, device_ids=[0])
+    sd = {"module." + k: v for k, v in ref.state_dict().items()}          # a released DataParallel checkpoint
+    own = set(wrapped.state_dict().keys())
+    wrapped.load_state_dict({k: v for k, v in sd.items() if k in own})    # the wrapper's strict load, module. keys
+    got = _gpu_outputs(wrapped, bevs, trans, na, c["batch"])
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    assert all(k.startswith("module.") for k in wrapped.state_dict())
+    with pytest.raises(RuntimeError, match="one process per GPU"):
+        inner._replicate_for_data_parallel()

@@ -56,11 +56,11 @@ def _setup(case):
 
 
 def _fp64_grads(ref, x, trans, na, batch, labels, monkeypatch):
-    from oracle.seg_ref import seg_loss
+    from oracle.seg_ref import seg_train_loss
     orig = F.grid_sample
     monkeypatch.setattr(F, "grid_sample", lambda inp, grid, **kw: orig(inp, grid.to(inp.dtype), **kw))
     ref64 = copy.deepcopy(ref).double().train()
-    loss = seg_loss(ref64(x.double(), trans, na, batch), labels)
+    loss = seg_train_loss(ref64(x.double(), trans, na, batch), labels, x)    # padded agents' images dropped
     loss.backward()
     monkeypatch.undo()
     return {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
@@ -159,3 +159,34 @@ def test_seg_train_step_at_baseline_size_properties():
     losses2 = [mod2.step(data, B)["loss"] for _ in range(3)]
     assert torch.equal(mod2._trainer.engine.flat_g, eng.flat_g) and torch.equal(mod2._trainer.engine.flat_p, eng.flat_p)
     assert abs(losses2[2] - losses[2]) <= 1e-12 * abs(losses[2])
+
+
+def test_seg_step_drops_the_images_of_padded_agents():
+    """upstream SegModule.step drops pred / labels of every image whose BEV is empty (padded agent slots) before the
+    criterion: whatever the labels of those images are, loss and gradients are the same; an optimizer's lr schedule
+    reaches the engine"""
+    from disconet_amd import SegDiscoNet, SegModule
+    from disconet_amd.synthetic import make_scene_batch
+    A, B, hw = 3, 2, 64
+    bevs, trans, na = make_scene_batch(B, A, hw, live=[3, 1])
+    x = bevs[:, 0].permute(0, 3, 1, 2).contiguous()
+    g = torch.Generator().manual_seed(9)
+    labels = torch.randint(0, 8, (A * B, hw, hw), generator=g)
+    empty = [i for i in range(A * B) if float(x[i].sum()) <= 1e-4]
+    assert empty == [3, 5]                                   # agents 1, 2 of scene 1 (image = a * B + b)
+    outs = []
+    for variant in range(2):
+        torch.manual_seed(0)
+        model = SegDiscoNet(num_agent=A).cuda()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        mod = SegModule(model, optimizer=opt)
+        lab = labels.clone()
+        if variant:
+            lab[empty] = 7 - lab[empty]                      # other labels on the dropped images
+        data = {"bev_seq": x.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(), "labels": lab.cuda()}
+        loss = mod.step(data, B)["loss"]
+        outs.append((loss, mod._trainer.engine.flat_g.clone()))
+        opt.param_groups[0]["lr"] = 5e-4                     # what a MultiStepLR does
+        mod.step(data, B)
+        assert mod._trainer.engine.lr == 5e-4
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])

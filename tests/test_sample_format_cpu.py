@@ -21,7 +21,7 @@ def test_round_trip_through_npy_files(tmp_path):
             path = tmp_path / ("scene%d_agent%d.npy" % (b, a))
             np.save(path, {"voxel_indices_0": idx, "trans_matrices": trans[b, a], "num_sensor": A,
                            "reg_target_sparse": np.zeros((1, 6))}, allow_pickle=True)
-            samples[b][a] = sample_format.load_sample(str(path))
+            samples[b][a] = sample_format.load_sample(str(path), grid_x=hw)
             assert samples[b][a]["indices"].dtype == np.int32 and "reg_target_sparse" in samples[b][a]["rest"]
     indices, offsets, tr, na = sample_format.batch_from_samples(samples, A, device="cpu")
     assert offsets.dtype == torch.int32 and offsets.shape == (A * B + 1,) and int(offsets[-1]) == indices.shape[0]
@@ -30,7 +30,22 @@ def test_round_trip_through_npy_files(tmp_path):
     for g in range(A * B):
         rows = indices[int(offsets[g]):int(offsets[g + 1])].long()
         dense[g, rows[:, 0], rows[:, 1], rows[:, 2]] = 1.0
-    assert torch.equal(dense, bevs[:, 0])
+    # the model's frame is the stored grid after the loader's np.rot90(grid, 3) over (x, y)
+    want = torch.from_numpy(np.stack([np.rot90(bevs[g, 0].numpy(), 3).copy() for g in range(A * B)]))
+    assert torch.equal(dense, want)
+    # ... and with rotate=False the stored list is handed through
+    raw = sample_format.load_sample(str(tmp_path / "scene0_agent0.npy"), rotate=False)["indices"]
+    assert np.array_equal(raw, np.argwhere(bevs[0, 0].numpy() > 0).astype(np.int32))
+
+
+def test_rot90_index_map_equals_numpy_rot90_of_the_dense_rebuild():
+    rng = np.random.default_rng(5)
+    for (X, Y, Z) in ((8, 8, 3), (16, 12, 13), (5, 9, 2)):
+        dense = rng.random((X, Y, Z)) < 0.2
+        idx = np.argwhere(dense).astype(np.int32)
+        got = sample_format.rot90_indices(idx, X)
+        want = np.argwhere(np.rot90(dense, 3)).astype(np.int32)       # argwhere is row-major: the sorted-unique order
+        assert np.array_equal(got, want)
 
 
 def test_missing_key_is_reported(tmp_path):

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 #include "disconet_hip.h"
 
@@ -91,12 +92,24 @@ static void dump_mismatch(const float* d_a, const float* d_b, int n, int h, int 
 static const char* kCfgName[] = {"256x64", "256x32", "128x64", "64x64", "s2_128x64", "s2_64x64", "p256x64", "p64x64",
                                  "256x64/T9", "512x64", "256x128", "p256x64/C1", "256x32/stat", "64x64/T9",
                                  "128x64/T9", "s2_64x64/T9", "s2_128x64/T9"};
-static const char* g_filter = nullptr;   // substring of the layer name
+static const char* g_filter = nullptr;   // substring of the layer name; several separated by ','
+static bool name_selected(const char* name) {
+  if (!g_filter) return true;
+  const char* p = g_filter;
+  while (*p) {
+    const char* e = strchr(p, ',');
+    const size_t len = e ? (size_t)(e - p) : strlen(p);
+    if (len && std::string(name).find(std::string(p, len)) != std::string::npos) return true;
+    p += len + (e ? 1 : 0);
+  }
+  return false;
+}
+static std::vector<int> g_only_cfgs;     // SPCHECK_CFGS=0,8,9: only these forced tile configurations (and no "auto")
 static int g_mode = 0;                   // 0 = every tile, 1 = automatic selection only, 2 = + ablations
 
 static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int up0, int cout, int ks,
                       int stride, bool quick) {
-  if (g_filter && !strstr(name, g_filter)) return;
+  if (!name_selected(name)) return;
   Timer tm;
   dn_conv_desc d = {n, h, w, c0, c1, up0, cout, ks, stride, 1, c0, c1, cout, 1};
   const int ho = (h + 2 * (ks / 2) - ks) / stride + 1, wo = (w + 2 * (ks / 2) - ks) / stride + 1;
@@ -148,6 +161,11 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
     else cfgs.insert(cfgs.end(), {0, 1, 2, 3, 8, 9, 10, 12, 13, 14});
     if (g_mode == 2 && ks == 3 && stride == 1) cfgs.insert(cfgs.end(), {101, 102, 103, 104, 105, 201, 202, 203, 204, 205, 206, 207, 301, 302, 303, 304, 305});
   }
+  if (!g_only_cfgs.empty()) {
+    std::vector<int> keep;
+    for (int c : cfgs) for (int o : g_only_cfgs) if (c == o) keep.push_back(c);
+    cfgs = keep;
+  }
   for (int cfg : cfgs) {
     dn_spconv_force_config(cfg);
     if (cfg >= 100 || (cfg >= 23 && cfg <= 25)) {   // ablation: timing only (results are garbage by construction)
@@ -183,7 +201,7 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
 
 // fused 3x3 (cin -> 64) + 1x1 (64 -> c2): fp32 two-output form (heads) and SP form (conv1_2 + Conv3D)
 static void run_post(const char* name, int n, int h, int w, int cin, int c2, int split, bool f32, bool block = false) {
-  if (g_filter && !strstr(name, g_filter)) return;
+  if (!name_selected(name)) return;
   Timer tm;
   dn_conv_desc d = {n, h, w, cin, 0, 0, 64, 3, 1, 1, cin, 0, 64, 1};
   dn_post1x1_desc p = {c2, f32 ? 0 : 1, split, split, c2 - split, block ? 1 : 0};
@@ -251,7 +269,7 @@ static void run_post(const char* name, int n, int h, int w, int cin, int c2, int
 
 // conv_pre_1: 13 -> 32 over a 0/1 occupancy grid, full SP source vs the hi-only form (math = 3): bit-equal, timed
 static void run_hi_only(const char* name, int n, int h, int w, int cin, int cout) {
-  if (g_filter && !strstr(name, g_filter)) return;
+  if (!name_selected(name)) return;
   Timer tm;
   dn_conv_desc d = {n, h, w, cin, 0, 0, cout, 3, 1, 1, cin, 0, cout, 2};
   const size_t nx = (size_t)n * h * w * cin, no = (size_t)n * h * w * cout;
@@ -305,6 +323,7 @@ int main(int argc, char** argv) {
   if (argc > 2 && strcmp(argv[2], "all")) g_filter = argv[2];
   if (argc > 3) g_mode = !strcmp(argv[3], "auto") ? 1 : !strcmp(argv[3], "abl") ? 2 : 0;
   const bool quick = g_mode == 1;
+  if (const char* e = getenv("SPCHECK_CFGS")) for (const char* p = e; *p; ) { g_only_cfgs.push_back(atoi(p)); p = strchr(p, ','); if (!p) break; ++p; }
   printf("dn_version %d, %d images\n", dn_version(), n);
   roundtrip();
   // odd shapes first: ragged maps, channel counts that are not tile multiples
