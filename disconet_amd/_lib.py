@@ -74,6 +74,9 @@ SIGNATURES = {
     "dn_spconv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_float, c_void_p, c_void_p]),
     "dn_spconv2d": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p]),
+    "dn_spconv_workspace_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "dn_spconv2d_ks": (c_int, [POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "dn_spconv2d_dual": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_int, c_void_p]),
     "dn_sp_post1x1_packed_bytes": (c_size_t, []),
@@ -87,6 +90,8 @@ SIGNATURES = {
                                 c_void_p]),
     "dn_warp_neighbors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dn_warp_neighbors_fm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_void_p, c_void_p]),
     "dn_disco_fuse_tail": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    POINTER(MlpTailParams), c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -98,6 +103,10 @@ SIGNATURES = {
     "dn_disco_fuse_mlp": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(FuseMlpParams), c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    "dn_disco_fuse_mlp_fm": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(FuseMlpParams), c_int, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
+    "dn_warp_fm_supported": (c_int, [c_int, c_int, c_int]),
     # ---- include/disconet_seg.h ----
     "dn_sp_maxpool2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dn_sp_upsample2_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -60,6 +60,9 @@ struct SpArgs {
   int c_out2, relu2, split2, ldo_a, ldo_b, post_f32;
   int b_total;   // stationary form: bytes of the resident weight block (ngroups * NS * B_STEP)
   int stg_row;   // floats per staged fp32 output row (POST, fp32 out)
+  // K slices (KSL kernels; sp_device.h :: KSlices)
+  KSlices ks;
+  size_t ks_ws_bytes;   // host side: bytes behind ks.partial
 };
 
 struct TileCoord {
@@ -79,7 +82,7 @@ struct TileCoord {
 // AHI: source 0 is a HI-ONLY SP tensor ([image][chunk][2 octets][H][W] x 16 B: values that are exact in binary16,
 // e.g. the 0/1 occupancy grid): half the patch bytes, no lo fragments, two MFMAs per product instead of three.
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST, int BSTAT = 0, int UPM = 0, int AHI = 0>
+          int WTM, int WTN, int POST, int BSTAT = 0, int UPM = 0, int AHI = 0, int KSL = 0>
 struct SpTile {
   using P = sp::Patch<KS, STRIDE, TH, TW>;
   static constexpr int NW = WAVES_M * WAVES_N;
@@ -119,7 +122,10 @@ struct SpTile {
   }
   static constexpr int OCC_LDS = BSTAT ? (POST == 1 ? 1 : 2) : 160 * 1024 / LDS_BYTES;
   // four accumulator tiles per wave + two fragment sets want > 168 VGPRs: at most 2 workgroups
-  static constexpr int OCC_MAX = WTM * WTN >= 4 ? 2 : 3;
+  // K-sliced form: a second accumulator set (the running sum of the slices) -- two workgroups at two tiles per wave
+  static constexpr int OCC_MAX = (WTM * WTN >= 4 || (KSL && WTM * WTN >= 2)) ? 2 : 3;
+  static_assert(!KSL || (KS == 3 && CA == 1 && POST == 0 && BSTAT == 0 && UPM == 0 && AHI == 0 && WTM * WTN <= 2),
+                "K slices: plain streaming 3x3 tiles with at most two accumulator tiles per wave");
   static constexpr int OCC_W = OCC_LDS < 1 ? 1 : (OCC_LDS > OCC_MAX ? OCC_MAX : OCC_LDS);
   // waves per SIMD the launch bounds promise: NW / 4 per workgroup
   static constexpr int WPS = (OCC_W * NW + 3) / 4;
@@ -143,12 +149,12 @@ struct SpTile {
 // 1 = no weight DMA after the first step, 2 = no patch DMA after the first group, 3 = neither,
 // 4 = no epilogue stores, 5 = 3 + operands from registers (pure MFMA stream).
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST, int ABL = 0, int BSTAT = 0, int UPM = 0, int AHI = 0>
+          int WTM, int WTN, int POST, int ABL = 0, int BSTAT = 0, int UPM = 0, int AHI = 0, int KSL = 0>
 __global__ void __launch_bounds__(
     (WAVES_M * WAVES_N * 64),
-    (SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI>::WPS))
+    (SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI, KSL>::WPS))
 conv_sp_kernel(const SpArgs a) {
-  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI>;
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI, KSL>;
   using P = typename T::P;
   constexpr bool kNoB = ABL == 1 || ABL == 3 || ABL >= 5, kNoA = ABL == 2 || ABL == 3 || ABL >= 5;
   constexpr bool kNoStore = ABL == 4 || ABL == 6 || ABL == 7, kNoLds = ABL >= 5;
@@ -197,6 +203,29 @@ conv_sp_kernel(const SpArgs a) {
     return tc;
   };
 
+  // K-sliced launches (KSL): work item v < n_whole is a whole tile (all K slices, folded in registers); the others
+  // are single slices of the tiles behind them, `kslices` consecutive work items per tile (sp_device.h :: KSlices)
+  // sl0 .. sl1: the slices the item computes (all of them: a whole tile, folded in registers; one: a split tile's
+  // slice `sl0`, partial index j = v - n_whole = tile * kslices + slice)
+  struct Work {
+    TileCoord tc;
+    int sl0, sl1, j;
+  };
+  auto decode_work = [&](int v) {
+    Work w;
+    if (KSL == 0 || v < a.ks.n_whole) {
+      w.tc = decode(v);
+      w.sl0 = 0; w.sl1 = KSL ? a.ks.count : 1; w.j = -1;
+    } else {
+      w.j = v - a.ks.n_whole;
+      w.sl0 = w.j & ((1 << a.ks.log2) - 1);
+      w.sl1 = w.sl0 + 1;
+      w.tc = decode(a.ks.n_whole + (w.j >> a.ks.log2));
+    }
+    return w;
+  };
+  auto first_group = [&](const Work& w) { return KSL ? a.ks.bound(w.sl0) : 0; };
+
   // ---- LDS read offsets (bytes) of this lane's MFMA fragments
   int a_off[WTM], b_off[WTN], prow[WTM], pcol;
   pcol = sp::tile_col<TW>(li);
@@ -212,6 +241,7 @@ conv_sp_kernel(const SpArgs a) {
   for (int wn = 0; wn < WTN; ++wn) b_off[wn] = (lh * BN + (wave_n * WTN + wn) * 32 + li) * 16;
 
   f32x16 acc[WTM][WTN];
+  f32x16 tot[KSL ? WTM : 1][KSL ? WTN : 1];   // K slices: the sum, in slice order, of the slices' accumulation chains
   float amax = 0.f;   // max |value| this lane has split (range flags, sp_device.h)
   bool nan_seen = false;   // a NaN reached an epilogue (ReLU / the clamp of the split would hide it)
 
@@ -748,7 +778,7 @@ conv_sp_kernel(const SpArgs a) {
     }
     __syncthreads();
   }
-  TileCoord cur = decode(item);
+  TileCoord cur = decode(KSL != 0 ? 0 : item);   // (K-sliced launches decode their first WORK item below)
   setup_rsrc(cur);
   auto zero_acc = [&]() {
 #pragma unroll
@@ -817,10 +847,78 @@ conv_sp_kernel(const SpArgs a) {
     return;
   }
 
+  // K slices: partial sums of a split tile <-> global memory, one f32x4 per lane and register quad (1 KB runs)
+  auto partial_of = [&](int j) {     // j = tile * kslices + slice
+    return a.ks.partial + ((size_t)j * NW + wave) * (WTM * WTN * 16 * 64) + lane * 4;
+  };
+  auto fold_acc = [&]() {       // tot += acc (fp32 adds, the order the fix-up pass uses), acc = 0
+    if constexpr (KSL != 0) {
+#pragma unroll
+      for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            tot[wm][wn][r] += acc[wm][wn][r];
+            acc[wm][wn][r] = 0.f;
+          }
+    }
+  };
+  auto zero_tot = [&]() {
+    if constexpr (KSL != 0) {
+#pragma unroll
+      for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tot[wm][wn][r] = 0.f;
+    }
+  };
+  auto tot_to_acc = [&]() {
+    if constexpr (KSL != 0) {
+#pragma unroll
+      for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn) acc[wm][wn] = tot[wm][wn];
+    }
+  };
+  if constexpr (KSL != 0) {
+    if (a.ks.fixup) {
+      // ---- fix-up pass: the split tiles' slices, added in slice order from zero -- the arithmetic of fold_acc --
+      // then the ordinary epilogue.  No operand DMA, no LDS.
+      for (int p = blockIdx.x; p < a.ks.n_split; p += G) {
+        const TileCoord tc = decode(a.ks.n_whole + p);
+        load_affine(tc.n0);
+        zero_tot();
+        for (int sl = 0; sl < a.ks.count; ++sl) {
+          const float* pb = partial_of((p << a.ks.log2) + sl);
+#pragma unroll
+          for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+            for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(pb + ((wm * WTN + wn) * 4 + q) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[wm][wn][4 * q + e] = v[e];
+              }
+          fold_acc();
+        }
+        tot_to_acc();
+        epilogue(tc);
+        note_range(amax, nan_seen);
+      }
+      return;
+    }
+  }
+
+  Work cw = decode_work(item);
+  cur = cw.tc;
+  setup_rsrc(cur);
   setup_voff_b(cur);
-  setup_voff_a(cur, a.c0g == 0);
-  issue_b(0, 0, 0, false);
-  issue_a(0, 0, false);
+  setup_voff_a(cur, first_group(cw) * CA >= a.c0g);
+  issue_b(first_group(cw), 0, 0, false);
+  issue_a(first_group(cw), 0, false);
   int sb = 0;
   bool a_pending = true;   // A DMAs issued after the B DMAs the next step waits for
 
@@ -829,10 +927,20 @@ conv_sp_kernel(const SpArgs a) {
     load_affine(cur.n0);
     const bool has_next = item + G < a.total_items;
     TileCoord nxt = cur;
-    if (has_next) nxt = decode(item + G);
+    int ng0 = 0;                            // first K group of the next work item
+    if (has_next) {
+      const Work nw = decode_work(item + G);
+      nxt = nw.tc;
+      ng0 = first_group(nw);
+    }
+    if constexpr (KSL != 0) zero_tot();
+    const int g_end = KSL ? a.ks.bound(cw.sl1) : a.ngroups;      // last group of the item + 1
 
-    for (int g = 0; g < a.ngroups; ++g) {
-      const bool last_g = g + 1 == a.ngroups;
+    // K slices: one pass of the group loop per slice (KSL == 0: one pass over all groups), the loop body is the same
+    for (int sl = cw.sl0; sl < cw.sl1; ++sl) {
+    const int g_lo = KSL ? a.ks.bound(sl) : 0, g_hi = KSL ? a.ks.bound(sl + 1) : a.ngroups;
+    for (int g = g_lo; g < g_hi; ++g) {
+      const bool last_g = g + 1 == g_end;
       auto step = [&](auto st_c, auto merged_c) {
         constexpr int ST = decltype(st_c)::value;
         constexpr bool MERGED = decltype(merged_c)::value;      // UPM: a row-merged step of the upsampled source
@@ -851,7 +959,7 @@ conv_sp_kernel(const SpArgs a) {
           issue_b(g + 1, 0, sb ^ 1);
         } else if (has_next) {
           setup_voff_b(nxt);
-          issue_b(0, 0, sb ^ 1);
+          issue_b(ng0, 0, sb ^ 1);
         }
         if (ST == 0) {
           a_pending = true;
@@ -860,8 +968,8 @@ conv_sp_kernel(const SpArgs a) {
             issue_a(g + 1, sa ^ 1);
           } else if (has_next) {
             setup_rsrc(nxt);
-            setup_voff_a(nxt, a.c0g == 0);
-            issue_a(0, sa ^ 1);
+            setup_voff_a(nxt, ng0 * CA >= a.c0g);
+            issue_a(ng0, sa ^ 1);
           } else {
             a_pending = false;
           }
@@ -897,10 +1005,28 @@ conv_sp_kernel(const SpArgs a) {
       }
       sa ^= 1;
     }
-    epilogue(cur);
+    if (KSL != 0 && cw.j < 0) fold_acc();      // a slice of a whole tile is complete: add it, restart the chain from zero
+    }
+    if (KSL != 0 && cw.j >= 0) {
+      if constexpr (KSL != 0) {                  // one slice of a split tile: raw accumulators to the partial buffer
+        float* pb = partial_of(cw.j);
+#pragma unroll
+        for (int wm = 0; wm < WTM; ++wm)
+#pragma unroll
+          for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<f32x4*>(pb + ((wm * WTN + wn) * 4 + q) * 256) =
+                  f32x4{acc[wm][wn][4 * q], acc[wm][wn][4 * q + 1], acc[wm][wn][4 * q + 2], acc[wm][wn][4 * q + 3]};
+      }
+    } else {
+      tot_to_acc();
+      epilogue(cur);
       note_range(amax, nan_seen);
+    }
     if (!has_next) break;
     item += G;
+    if constexpr (KSL != 0) cw = decode_work(item);   // (decoded again rather than carried through the tile: fewer live scalars)
     cur = nxt;
   }
 }
@@ -1133,7 +1259,7 @@ inline SpCfgId deep_variant(SpCfgId id) {
 }
 int g_sp_force = -1;   // tools: force one configuration
 
-SpCfg select_cfg(const dn_conv_desc& d) {
+SpCfg select_cfg(const dn_conv_desc& d, int kslices = 1, bool can_split = false) {
   const int ho = out_dim(d.h_in, d.ksize, d.stride), wo = out_dim(d.w_in, d.ksize, d.stride);
   static const SpCfgId c3[] = {S3_256x64, S3_256x32, S3_128x64, S3_64x64};   // merged layers: the first three
   static const SpCfgId c3s2[] = {S3S2_128x64, S3S2_64x64};
@@ -1141,8 +1267,11 @@ SpCfg select_cfg(const dn_conv_desc& d) {
   // row-merged layers: the 256x64 tile's doubled weight stage leaves one workgroup per CU (201 vs 180 us on conv7_1)
   static const SpCfgId c3up[] = {S3_256x32, S3_128x64};
   const bool upm = up_merged(d);
-  const SpCfgId* cand = d.ksize == 1 ? c1 : (d.stride == 2 ? c3s2 : (upm ? c3up : c3));
-  const int ncand = d.ksize == 1 ? 3 : (d.stride == 2 ? 2 : (upm ? 2 : 4));
+  // K-sliced layers: tiles with at most two accumulator tiles per wave (the slices' running sum is a second set)
+  static const SpCfgId c3ks[] = {S3_256x32, S3_128x64, S3_64x64};
+  const bool ksl = kslices > 1 && d.ksize == 3 && !upm;
+  const SpCfgId* cand = d.ksize == 1 ? c1 : (d.stride == 2 ? c3s2 : (upm ? c3up : (ksl ? c3ks : c3)));
+  const int ncand = d.ksize == 1 ? 3 : (d.stride == 2 ? 2 : (upm ? 2 : (ksl ? 3 : 4)));
   const int nchunks = chunks_of(d.c0) + chunks_of(d.c1);
   if (g_sp_force >= 0) {
     for (int k = 0; k < ncand; ++k)
@@ -1161,20 +1290,36 @@ SpCfg select_cfg(const dn_conv_desc& d) {
     if (nchunks % ca_of(c.id) != 0) continue;
     const long tiles = (long)d.n_images * ((ho + c.th - 1) / c.th) * ((wo + c.tw - 1) / c.tw);
     const long blocks = tiles * ((d.c_out + c.bn - 1) / c.bn);
-    const double rounds = (double)((blocks + kCUs - 1) / kCUs);
+    // a K-sliced launch fills its last round with slices: rounds in units of 1 / kslices
+    const double rounds = ksl && can_split ? (double)((blocks * kslices + kCUs - 1) / kCUs) / kslices
+                              : (double)((blocks + kCUs - 1) / kCUs);
     const double cost = rounds * c.th * c.tw * c.bn * g_sp_bias[c.id];
     if (cost < best_cost * 0.999) { best_cost = cost; best = c; best_blocks = blocks; }
   }
   static const int deep_env = [] { const char* e = getenv("DN_SP_DEEP"); return e ? atoi(e) : 1; }();
-  if (deep_env && g_sp_force < 0 && !upm && best_blocks <= kCUs) best = kSpCfgs[deep_variant(best.id)];
+  if (deep_env && g_sp_force < 0 && !upm && best_blocks * (ksl && can_split ? kslices : 1) <= kCUs) best = kSpCfgs[deep_variant(best.id)];
   return best;
 }
 
+// Which tiles of a K-sliced launch are split (sp_device.h :: KSlices).  T whole-tile items on R resident workgroups run
+// floor(T / R) full rounds and a last one that leaves CUs idle (or, T < R, never fills the chip): the tiles of that
+// round are handed out slice by slice when that shortens the launch by a fifth of a round or more, as far as the
+// workspace reaches.  -> number of whole tiles.
+inline long ks_plan(long T, long R, int S, size_t ws_bytes, size_t bytes_per_tile) {
+  if (S <= 1 || ws_bytes < bytes_per_tile) return T;
+  const long full = T / R, tail = T - full * R;
+  if (tail == 0) return T;
+  const double cost_split = (double)full + (double)((tail * S + R - 1) / R) / S;
+  if (cost_split > (double)(full + 1) - 0.2) return T;
+  const long max_split = (long)(ws_bytes / bytes_per_tile);
+  return tail > max_split ? T - max_split : full * R;
+}
+
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST = 0, int ABL = 0, int BSTAT = 0, int UPM = 0, int AHI = 0>
+          int WTM, int WTN, int POST = 0, int ABL = 0, int BSTAT = 0, int UPM = 0, int AHI = 0, int KSL = 0>
 int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
-  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI>;
-  auto kern = conv_sp_kernel<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, ABL, BSTAT, UPM, AHI>;
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI, KSL>;
+  auto kern = conv_sp_kernel<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, ABL, BSTAT, UPM, AHI, KSL>;
   const int nchunks = a.c0g + a.c1g;
   DN_REQUIRE(nchunks % CA == 0, "spconv: chunk count %d not a multiple of %d", nchunks, CA);
   a.ngroups = nchunks / CA;
@@ -1214,6 +1359,28 @@ int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
   a.n_cb = (d.c_out + BN - 1) / BN;
   a.rcp_ncb = 1.0f / (float)a.n_cb; a.rcp_tx = 1.0f / (float)a.tiles_x; a.rcp_ty = 1.0f / (float)a.tiles_y;
   const long resident = (long)occupancy * kCUs;
+  if constexpr (KSL != 0) {
+    const int S = a.ks.count;
+    DN_REQUIRE(S == 2 || S == 4, "spconv: %d K slices (1, 2 or 4)", S);
+    DN_REQUIRE(a.ngroups >= S, "spconv: %d K slices of a %d-chunk layer", S, a.ngroups);
+    KSlices& k = a.ks;
+    k.count = S; k.log2 = S == 4 ? 2 : 1; k.ngroups = a.ngroups;
+    k.b1 = a.ngroups / S; k.b2 = 2 * a.ngroups / S; k.b3 = 3 * a.ngroups / S;   // equal shares of the chunks
+    if (S == 2) { k.b2 = k.b3 = a.ngroups; }
+    const size_t per_tile = (size_t)S * T::NW * WTM * WTN * 16 * 64 * sizeof(float);
+    k.n_whole = (int)ks_plan(total, resident, S, k.partial ? a.ks_ws_bytes : 0, per_tile);
+    k.n_split = (int)(total - k.n_whole);
+    k.fixup = 0;
+    const long work = k.n_whole + (long)k.n_split * S;
+    a.total_items = (int)work;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(work > resident ? resident : work)), dim3(T::NT), lds_bytes, stream, a);
+    if (k.n_split) {     // the split tiles' slices added in slice order + their epilogue: same kernel, no operands
+      k.fixup = 1;
+      a.total_items = k.n_split;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(k.n_split > 4 * kCUs ? 4 * kCUs : k.n_split)), dim3(T::NT), 0, stream, a);
+    }
+    return dn::check_launch("conv_sp_kernel (K slices)");
+  }
   dim3 grid((unsigned)(total > resident ? resident : total));
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), lds_bytes, stream, a);
   return dn::check_launch("conv_sp_kernel");
@@ -1245,6 +1412,8 @@ int fill_args(const dn_conv_desc* d, const void* src0, const void* src1, const v
   a.w2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out_b = nullptr;
   a.c_out2 = 0; a.relu2 = 0; a.split2 = 0; a.ldo_a = 0; a.ldo_b = 0; a.post_f32 = 0;
   a.b_total = 0; a.stg_row = 0;
+  a.ks = KSlices{nullptr, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+  a.ks_ws_bytes = 0;
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   DN_REQUIRE(aligned16(src0) && aligned16(src1) && aligned16(packed) && aligned16(out),
              "spconv: tensors must be 16-byte aligned");
@@ -1368,7 +1537,8 @@ extern "C" int dn_spconv_set_upmode(int mode) {
 
 namespace {
 int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed, const float* scale,
-                  const float* shift, void* out, float* out_nhwc, int ld_nhwc, void* stream);
+                  const float* shift, void* out, float* out_nhwc, int ld_nhwc, void* stream, int kslices = 1,
+                  void* workspace = nullptr, size_t workspace_bytes = 0);
 }
 
 extern "C" int dn_spconv2d(const dn_conv_desc* d, const void* src0, const void* src1,
@@ -1386,9 +1556,31 @@ extern "C" int dn_spconv2d_dual(const dn_conv_desc* d, const void* src0, const v
   return spconv2d_impl(d, src0, src1, packed, scale, shift, out_sp, out_nhwc, ld_nhwc, stream);
 }
 
+// K-sliced form: does the layer qualify?  (3x3, no row-merged image, no hi-only source)
+inline bool ks_layer(const dn_conv_desc& d) { return d.ksize == 3 && d.math != 3 && up_mode(d) != 1; }
+
+extern "C" size_t dn_spconv_workspace_bytes(const dn_conv_desc* d, int kslices) {
+  if (validate(d) != DN_OK || kslices <= 1 || !ks_layer(*d)) return 0;
+  const size_t ho = out_dim(d->h_in, d->ksize, d->stride), wo = out_dim(d->w_in, d->ksize, d->stride);
+  // every tile of the launch split, at the padding of the smallest tiles (8 rows, 32 columns, 64 channels)
+  return (size_t)kslices * d->n_images * ((ho + 7) / 8 * 8) * ((wo + 31) / 32 * 32) * ((d->c_out + 63) / 64 * 64) * sizeof(float);
+}
+
+extern "C" int dn_spconv2d_ks(const dn_conv_desc* d, int kslices, const void* src0, const void* src1, const void* packed,
+                              const float* scale, const float* shift, void* out, float* out_nhwc, int ld_nhwc,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  DN_REQUIRE(kslices == 1 || kslices == 2 || kslices == 4, "spconv: kslices must be 1, 2 or 4 (got %d)", kslices);
+  DN_REQUIRE(workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "spconv: workspace must be 16-byte aligned");
+  DN_REQUIRE(!out_nhwc || (d && ld_nhwc >= d->c_out && ld_nhwc % 4 == 0 && d->c_out % 4 == 0 &&
+                           (reinterpret_cast<uintptr_t>(out_nhwc) & 15) == 0),
+             "spconv: the fp32 NHWC output needs c_out %% 4 == 0, ld >= c_out, ld %% 4 == 0, 16-byte alignment");
+  return spconv2d_impl(d, src0, src1, packed, scale, shift, out, out_nhwc, ld_nhwc, stream, kslices, workspace, workspace_bytes);
+}
+
 namespace {
 int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed, const float* scale,
-                  const float* shift, void* out, float* out_nhwc, int ld_nhwc, void* stream) {
+                  const float* shift, void* out, float* out_nhwc, int ld_nhwc, void* stream, int kslices,
+                  void* workspace, size_t workspace_bytes) {
   if (int rc = validate(d)) return rc;
   DN_REQUIRE(src0 && packed && scale && shift && out, "spconv: null pointer");
   DN_REQUIRE(d->c1 == 0 || src1, "spconv: c1 > 0 but src1 is null");
@@ -1398,11 +1590,36 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
   DN_REQUIRE(!out_nhwc || (up_mode(*d) != 2 && g_sp_force < 100),
              "spconv dual: not available on the tap-merged up-conv kernel");
   hipStream_t s = (hipStream_t)stream;
+  // K slices: a property of the LAYER (the caller passes the same count whatever the batch): results do not depend
+  // on how a launch distributes the slices.  Layers with fewer chunks than slices, 1x1 layers, the row-merged image
+  // and hi-only sources are refused rather than silently computed in another order.
+  DN_REQUIRE(kslices == 1 || (ks_layer(*d) && a.c0g + a.c1g >= kslices),
+             "spconv: %d K slices need a 3x3 layer of at least that many 16-channel chunks", kslices);
   if (up_mode(*d) == 2) {   // the packed image is the quad-merged one: conv_spq.hip (tools: 20 / 21 force BN = 32 / 64)
     DN_REQUIRE(a.c1g == 0 || d->c0 % 16 == 0, "spconv: concat needs c0 %% 16 == 0");
     return dn::spq_conv(d, src0, src1, packed, (size_t)a.wpk_bytes, scale, shift, out, a.cout_pad,
                         g_sp_force == 20 ? 32 : g_sp_force == 21 ? 64 : g_sp_force == 22 ? 33 :
-                        (g_sp_force >= 23 && g_sp_force <= 25) ? 78 + g_sp_force : 0, s);
+                        (g_sp_force >= 23 && g_sp_force <= 25) ? 78 + g_sp_force : 0, s, kslices, (float*)workspace,
+                        workspace_bytes);
+  }
+  if (kslices > 1) {
+    a.ks.count = kslices;
+    a.ks.partial = (float*)workspace;
+    a.ks_ws_bytes = workspace_bytes;
+    const SpCfg c = select_cfg(*d, kslices, workspace != nullptr && workspace_bytes > 0);
+    switch (c.id) {
+      //                                   KS S  TH TW  BN TG CA WM WN WTM WTN          KSL
+      case S3_256x32:      return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 0, 0, 0, 1>(a, *d, s);
+      case S3_128x64:      return launch<3, 1, 8, 16, 64, 3, 1, 2, 2, 2, 1, 0, 0, 0, 0, 0, 1>(a, *d, s);
+      case S3_64x64:       return launch<3, 1, 8, 8, 64, 3, 1, 2, 2, 1, 1, 0, 0, 0, 0, 0, 1>(a, *d, s);
+      case S3S2_128x64:    return launch<3, 2, 8, 16, 64, 3, 1, 2, 2, 2, 1, 0, 0, 0, 0, 0, 1>(a, *d, s);
+      case S3S2_64x64:     return launch<3, 2, 8, 8, 64, 3, 1, 2, 2, 1, 1, 0, 0, 0, 0, 0, 1>(a, *d, s);
+      case S3_64x64_T9:    return launch<3, 1, 8, 8, 64, 9, 1, 2, 2, 1, 1, 0, 0, 0, 0, 0, 1>(a, *d, s);
+      case S3_128x64_T9:   return launch<3, 1, 8, 16, 64, 9, 1, 2, 2, 2, 1, 0, 0, 0, 0, 0, 1>(a, *d, s);
+      case S3S2_64x64_T9:  return launch<3, 2, 8, 8, 64, 9, 1, 2, 2, 1, 1, 0, 0, 0, 0, 0, 1>(a, *d, s);
+      case S3S2_128x64_T9: return launch<3, 2, 8, 16, 64, 9, 1, 2, 2, 2, 1, 0, 0, 0, 0, 0, 1>(a, *d, s);
+      default: return dn::fail(DN_ERR_UNSUPPORTED, "spconv: tile configuration %d has no K-sliced form", (int)c.id);
+    }
   }
   if (d->math == 3) {   // hi-only source 0: the 8 x 32 x 32 tile, weight-stationary when the layer fits
     using T32 = SpTile<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 1, 0, 1>;

@@ -57,6 +57,7 @@ struct SpqArgs {
   int cout_pad, wpk_bytes;
   int n_cb;                    // channel blocks; reciprocals of the work-item decode's divisors (sp_device.h :: fdivmod)
   float rcp_ncb, rcp_tx, rcp_ty;
+  KSlices ks;                  // K slices (KSL kernels; sp_device.h :: KSlices)
 };
 
 struct QTile {
@@ -87,8 +88,11 @@ struct SpqTile {
 };
 
 // ABL (tools/sp_conv_check only, results are garbage): 1 = no weight DMA, 2 = no patch DMA, 3 = neither
-template <int BN, int DEEP, int ABL = 0>
+// KSL: K-sliced launch (sp_device.h :: KSlices): whole tiles fold their slices in a second accumulator set, split
+// tiles hand theirs through `ks.partial` to the fix-up pass.  BN = 32 only (at BN = 64 the second set does not fit).
+template <int BN, int DEEP, int ABL = 0, int KSL = 0>
 __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
+  static_assert(!KSL || BN == 32, "K slices: the 32-channel tile");
   using T = SpqTile<BN, DEEP>;
   constexpr int WTN = T::WTN, TGQ = T::TGQ, NS0 = T::NS0, NS1 = T::NS1, BLK = T::BLK, QB_STAGE = T::QB_STAGE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -126,6 +130,28 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
     return tc;
   };
 
+  // sl0 .. sl1: the slices the item computes (all of them: a whole tile, folded in registers; one: a split tile's
+  // slice `sl0`, partial index j = v - n_whole = tile * kslices + slice)
+  struct Work {
+    QTile tc;
+    int sl0, sl1, j;
+  };
+  const int nchunks = a.c0g + a.c1g;
+  auto decode_work = [&](int v) {
+    Work w;
+    if (KSL == 0 || v < a.ks.n_whole) {
+      w.tc = decode(v);
+      w.sl0 = 0; w.sl1 = KSL ? a.ks.count : 1; w.j = -1;
+    } else {
+      w.j = v - a.ks.n_whole;
+      w.sl0 = w.j & ((1 << a.ks.log2) - 1);
+      w.sl1 = w.sl0 + 1;
+      w.tc = decode(a.ks.n_whole + (w.j >> a.ks.log2));
+    }
+    return w;
+  };
+  auto first_group = [&](const Work& w) { return KSL ? a.ks.bound(w.sl0) : 0; };
+
   // ---- this lane's pixels and LDS read bases (bytes).  MFMA tile wm of the class: tile rows
   // r = py + 4 wm + 2 rsel, columns c = px + 2 k; one 16-lane ds_read_b128 group = one row, k = 0..15.
   const int rsel = sp::in_g2(li) ? 1 : 0, kcol = sp::rank16(li);
@@ -153,6 +179,7 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
   }
 
   f32x16 acc[2][WTN];
+  f32x16 tot[KSL ? 2 : 1][KSL ? WTN : 1];   // K slices: the sum, in slice order, of the slices' accumulation chains
   float amax = 0.f;
   bool nan_seen = false;
 
@@ -403,15 +430,76 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
   // ---- main loop
   int item = blockIdx.x;
   if (item >= a.total_items) return;
-  QTile cur = decode(item);
+  auto partial_of = [&](int j) {     // j = tile * kslices + slice
+    return a.ks.partial + ((size_t)j * QNW + wave) * (2 * WTN * 16 * 64) + lane * 4;
+  };
+  auto fold_acc = [&]() {       // tot += acc (fp32 adds, the order the fix-up pass uses), acc = 0
+    if constexpr (KSL != 0) {
+#pragma unroll
+      for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            tot[wm][wn][r] += acc[wm][wn][r];
+            acc[wm][wn][r] = 0.f;
+          }
+    }
+  };
+  auto zero_tot = [&]() {
+    if constexpr (KSL != 0) {
+#pragma unroll
+      for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tot[wm][wn][r] = 0.f;
+    }
+  };
+  auto tot_to_acc = [&]() {
+    if constexpr (KSL != 0) {
+#pragma unroll
+      for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn) acc[wm][wn] = tot[wm][wn];
+    }
+  };
+  if constexpr (KSL != 0) {
+    if (a.ks.fixup) {   // fix-up pass: the split tiles' slices added in slice order from zero, then the epilogue
+      for (int p = blockIdx.x; p < a.ks.n_split; p += G) {
+        const QTile tc = decode(a.ks.n_whole + p);
+        load_affine(tc.n0);
+        zero_tot();
+        for (int sl = 0; sl < a.ks.count; ++sl) {
+          const float* pb = partial_of((p << a.ks.log2) + sl);
+#pragma unroll
+          for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+            for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(pb + ((wm * WTN + wn) * 4 + q) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[wm][wn][4 * q + e] = v[e];
+              }
+          fold_acc();
+        }
+        tot_to_acc();
+        epilogue(tc);
+        note_range(amax, nan_seen);
+      }
+      return;
+    }
+  }
+  Work cw = decode_work(item);
+  QTile cur = cw.tc;
   setup_rsrc(cur);
   setup_voff_b(cur);
-  setup_voff_a(cur, false);
-  issue_b(0, 0, 0);
-  issue_a(0, 0);
+  setup_voff_a(cur, first_group(cw) >= a.c0g);
+  issue_b(first_group(cw), 0, 0);
+  issue_a(first_group(cw), 0);
   int sa = 0, sb = 0;
   bool a_pending = true;   // patch DMAs issued AFTER the weight DMAs the next step waits for
-  const int nchunks = a.c0g + a.c1g;
 
   while (true) {
 #pragma unroll
@@ -423,10 +511,20 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
     load_affine(cur.n0);
     const bool has_next = item + G < a.total_items;
     QTile nxt = cur;
-    if (has_next) nxt = decode(item + G);
+    int ng0 = 0;                            // first chunk of the next work item
+    if (has_next) {
+      const Work nw = decode_work(item + G);
+      nxt = nw.tc;
+      ng0 = first_group(nw);
+    }
+    if constexpr (KSL != 0) zero_tot();
+    const int g_end = KSL ? a.ks.bound(cw.sl1) : nchunks;      // last chunk of the item + 1
 
-    for (int g = 0; g < nchunks; ++g) {
-      const bool last_g = g + 1 == nchunks;
+    // K slices: one pass of the chunk loop per slice (KSL == 0: one pass over all chunks), the loop body is the same
+    for (int sl = cw.sl0; sl < cw.sl1; ++sl) {
+    const int g_lo = KSL ? a.ks.bound(sl) : 0, g_hi = KSL ? a.ks.bound(sl + 1) : nchunks;
+    for (int g = g_lo; g < g_hi; ++g) {
+      const bool last_g = g + 1 == g_end;
       auto step = [&](auto st_c, auto kind_c) {
         constexpr int ST = decltype(st_c)::value;
         constexpr bool SRC1 = decltype(kind_c)::value;
@@ -447,7 +545,7 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
           issue_b(g + 1, 0, sb ^ 1);
         } else if (has_next) {
           setup_voff_b(nxt);
-          issue_b(0, 0, sb ^ 1);
+          issue_b(ng0, 0, sb ^ 1);
         }
         if (ST == 0) {
           a_pending = true;
@@ -456,8 +554,8 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
             issue_a(g + 1, sa ^ 1);
           } else if (has_next) {
             setup_rsrc(nxt);
-            setup_voff_a(nxt, false);
-            issue_a(0, sa ^ 1);
+            setup_voff_a(nxt, ng0 >= a.c0g);
+            issue_a(ng0, sa ^ 1);
           } else {
             a_pending = false;
           }
@@ -488,10 +586,28 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
       }
       sa ^= 1;
     }
-    epilogue(cur);
-    note_range(amax, nan_seen);
+    if (KSL != 0 && cw.j < 0) fold_acc();      // a slice of a whole tile is complete: add it, restart the chain from zero
+    }
+    if (KSL != 0 && cw.j >= 0) {
+      if constexpr (KSL != 0) {                  // one slice of a split tile: raw accumulators to the partial buffer
+        float* pb = partial_of(cw.j);
+#pragma unroll
+        for (int wm = 0; wm < 2; ++wm)
+#pragma unroll
+          for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<f32x4*>(pb + ((wm * WTN + wn) * 4 + q) * 256) =
+                  f32x4{acc[wm][wn][4 * q], acc[wm][wn][4 * q + 1], acc[wm][wn][4 * q + 2], acc[wm][wn][4 * q + 3]};
+      }
+    } else {
+      tot_to_acc();
+      epilogue(cur);
+      note_range(amax, nan_seen);
+    }
     if (!has_next) break;
     item += G;
+    if constexpr (KSL != 0) cw = decode_work(item);   // (decoded again rather than carried through the tile: fewer live scalars)
     cur = nxt;
   }
 }
@@ -540,10 +656,21 @@ __global__ void spq_pack_weights_kernel(const float* __restrict__ w, unsigned ch
   }
 }
 
-template <int BN, int DEEP = 0, int ABL = 0>
-int launch_spq(SpqArgs& a, hipStream_t stream) {
+// whole tiles of a K-sliced launch (as conv_sp.hip :: ks_plan): split the tiles of the last, under-filled round
+inline long spq_ks_plan(long T, long R, int S, size_t ws_bytes, size_t bytes_per_tile) {
+  if (S <= 1 || ws_bytes < bytes_per_tile) return T;
+  const long full = T / R, tail = T - full * R;
+  if (tail == 0) return T;
+  const double cost_split = (double)full + (double)((tail * S + R - 1) / R) / S;
+  if (cost_split > (double)(full + 1) - 0.2) return T;
+  const long max_split = (long)(ws_bytes / bytes_per_tile);
+  return tail > max_split ? T - max_split : full * R;
+}
+
+template <int BN, int DEEP = 0, int ABL = 0, int KSL = 0>
+int launch_spq(SpqArgs& a, hipStream_t stream, size_t ws_bytes = 0) {
   using T = SpqTile<BN, DEEP>;
-  auto kern = conv_spq_kernel<BN, DEEP, ABL>;
+  auto kern = conv_spq_kernel<BN, DEEP, ABL, KSL>;
   static dn::PerDeviceFlag attr_flag;
   bool& attr_set = attr_flag.here();
   if (!attr_set) {
@@ -563,6 +690,37 @@ int launch_spq(SpqArgs& a, hipStream_t stream) {
   a.n_cb = (a.c_out + BN - 1) / BN;
   a.rcp_ncb = 1.0f / (float)a.n_cb; a.rcp_tx = 1.0f / (float)a.tiles_x; a.rcp_ty = 1.0f / (float)a.tiles_y;
   const long resident = (DEEP ? 1L : 2L) * kCUs;
+  if constexpr (KSL != 0) {
+    KSlices& k = a.ks;
+    const int S = k.count, ng = a.c0g + a.c1g;
+    DN_REQUIRE((S == 2 || S == 4) && ng >= S, "spconv (quad-merged): %d K slices of a %d-chunk layer", S, ng);
+    // canonical boundaries: equal shares of the K loop's WORK -- a chunk of the upsampled source runs 4 merged taps, a
+    // chunk of the second source 9 -- slice s begins at the first chunk whose preceding work reaches s / S of the total
+    const long wtot = 4L * a.c0g + 9L * a.c1g;
+    int b[5] = {0, 0, 0, 0, ng};
+    for (int sl = 1; sl < S; ++sl) {
+      int g = b[sl - 1] + 1;       // at least one chunk per slice
+      auto before = [&](int gg) { return gg <= a.c0g ? 4L * gg : 4L * a.c0g + 9L * (gg - a.c0g); };
+      while (g < ng - (S - 1 - sl) - 1 && before(g) * S < wtot * sl) ++g;
+      b[sl] = g;
+    }
+    k.log2 = S == 4 ? 2 : 1; k.ngroups = ng;
+    k.b1 = b[1]; k.b2 = S == 2 ? ng : b[2]; k.b3 = S == 2 ? ng : b[3];
+    const size_t per_tile = (size_t)S * QNW * 2 * (BN / 32) * 16 * 64 * sizeof(float);
+    k.n_whole = (int)spq_ks_plan(total, resident, S, k.partial ? ws_bytes : 0, per_tile);
+    k.n_split = (int)(total - k.n_whole);
+    k.fixup = 0;
+    const long work = k.n_whole + (long)k.n_split * S;
+    a.total_items = (int)work;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(work > resident ? resident : work)), dim3(QNT), T::LDS_BYTES, stream, a);
+    if (k.n_split) {
+      k.fixup = 1;
+      a.total_items = k.n_split;
+      // the fix-up pass reads the epilogue affine through the wave-private LDS block: same dynamic LDS
+      hipLaunchKernelGGL(kern, dim3((unsigned)(k.n_split > 2 * kCUs ? 2 * kCUs : k.n_split)), dim3(QNT), T::LDS_BYTES, stream, a);
+    }
+    return dn::check_launch("conv_spq_kernel (K slices)");
+  }
   dim3 grid((unsigned)(total > resident ? resident : total));
   hipLaunchKernelGGL(kern, grid, dim3(QNT), T::LDS_BYTES, stream, a);
   return dn::check_launch("conv_spq_kernel");
@@ -585,7 +743,8 @@ int spq_pack_weights(const float* weight_oihw, void* packed, int c_out, int c_in
 
 // bn: 32 or 64 output channels per workgroup; 33 = 32 in the one-step-per-chunk (DEEP) form; 0 = choose
 int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed, size_t packed_bytes,
-             const float* scale, const float* shift, void* out, int cout_pad, int bn, hipStream_t stream) {
+             const float* scale, const float* shift, void* out, int cout_pad, int bn, hipStream_t stream,
+             int kslices, float* workspace, size_t workspace_bytes) {
   SpqArgs a;
   a.src0 = (const unsigned char*)src0; a.src1 = (const unsigned char*)src1; a.wpk = (const unsigned char*)packed;
   a.scale = scale; a.shift = shift; a.out = (unsigned char*)out;
@@ -594,6 +753,16 @@ int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const vo
   a.c_out = d->c_out; a.cog = (d->c_out + 15) / 16; a.relu = d->relu;
   a.cout_pad = cout_pad; a.wpk_bytes = (int)packed_bytes;
   a.tiles_x = a.tiles_y = a.total_items = 0;
+  a.ks = KSlices{workspace, kslices, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (kslices > 1) {
+    // K-sliced layer: the 32-channel tile whatever the launch size (the result must not depend on it); the
+    // one-step-per-chunk form when even the slices leave CUs without a workgroup
+    const long tiles = (long)d->n_images * ((d->h_in + QTH - 1) / QTH) * ((d->w_in + QTW - 1) / QTW);
+    static const int deep_env = [] { const char* e = getenv("DN_SP_DEEP"); return e ? atoi(e) : 1; }();
+    const bool deep = deep_env && tiles * ((d->c_out + 31) / 32) * kslices <= (long)kCUs;
+    if (bn == 33 || (bn == 0 && deep)) return launch_spq<32, 1, 0, 1>(a, stream, workspace_bytes);
+    return launch_spq<32, 0, 0, 1>(a, stream, workspace_bytes);
+  }
   if (bn == 0) {
     const long tiles = (long)d->n_images * ((d->h_in + QTH - 1) / QTH) * ((d->w_in + QTW - 1) / QTW);
     // BN = 64 halves the patch traffic per MAC but needs >= two full rounds of 64-wide items (measured: conv7_1

@@ -46,6 +46,7 @@ struct FuseMlpArgs {
   float* fused_nhwc;
   float* weights_out;
   int batch, agents, hw, only_v2i, ego_first, ego_count, tiles;
+  int warped_fm;   // `warped` is fragment-major (dn_warp_neighbors_fm): a k-step of a tile is two contiguous 1 KB runs
 };
 
 __device__ inline half8 frag_of(const unsigned char* base, int idx) {
@@ -89,10 +90,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
   live = live < 0 ? 0 : (live < a.agents ? live : a.agents);   // never index past the agents that exist
   const size_t oimg = (size_t)il * a.batch + b;
 
-  const float* xrow = a.feat + (((size_t)i * a.batch + b) * a.hw + pc) * C + 8 * lh;
+  // A row = this lane's view of one map: piece (ks, r) = 4 floats at p + ks * kss + r * r1.  NHWC rows (the ego map,
+  // `warped` in pixel-major form): kss = 16, r1 = 4; fragment-major `warped`: this lane's slot of the tile's k-step
+  // block, kss = 512, r1 = 256 -- every load instruction of the wave is then one contiguous 1 KB run.
+  struct Row {
+    const float* p;
+    int kss, r1;
+  };
+  const Row xrow_r = {a.feat + (((size_t)i * a.batch + b) * a.hw + pc) * C + 8 * lh, 16, 4};
+  const float* xrow = xrow_r.p;
   auto yrow_of = [&](int j) {
     const int jj = j - (j > i ? 1 : 0);
-    return a.warped + ((((size_t)b * a.ego_count + il) * (a.agents - 1) + jj) * a.hw + pc) * C + 8 * lh;
+    const float* pair = a.warped + (((size_t)b * a.ego_count + il) * (a.agents - 1) + jj) * a.hw * C;
+    return a.warped_fm ? Row{pair + ((size_t)tile * KS * 2 * 64 + lane) * 4, 512, 256} : Row{pair + (size_t)pc * C + 8 * lh, 16, 4};
   };
 
   float amax = 0.f;   // max |value| split into the SP output (range flags, sp_device.h)
@@ -149,7 +159,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
   for (int j = 0; j < live; ++j)
     if (j != i && (!a.only_v2i || i == 0 || j == 0)) jl_s[n++] = j;
   if constexpr (NW > 1) __syncthreads();   // list, layer 2-4 weights and affines visible to every wave
-  auto row_of = [&](int k) { return k == 0 ? xrow : yrow_of(jl_s[k]); };
+  auto row_of = [&](int k) { return k == 0 ? xrow_r : yrow_of(jl_s[k]); };
 
   auto frag_from = [&](const f32x4 v0, const f32x4 v1, half8& fh, half8& fl) {
     u32x2 h0, l0, h1, l1;
@@ -162,7 +172,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
   // ---- layer 1 for NG rows at once: acc[g][nt] += W[mat][nt] . row_g.  The k loop runs two k-steps
   // per trip (never unrolled as a whole: hipcc would hoist every fragment load and spill) with the
   // next step's weight fragments and row pieces in flight under the current step's MFMAs.
-  auto layer1 = [&](auto ng_c, const float* const (&rows)[G], int cnt, int mat, f32x16 (&acc)[G][4]) {
+  auto layer1 = [&](auto ng_c, const Row (&rows)[G], int cnt, int mat, f32x16 (&acc)[G][4]) {
     constexpr int NG = decltype(ng_c)::value;
     const unsigned char* wbase = a.w1 + (size_t)mat * 4 * KS * 2 * 2 * 32 * 16 + (size_t)(lh * 32 + li) * 16;
     // fragment (nt, ks, part) at wbase + (((nt * KS + ks) * 2 + part) * 64) * 16
@@ -179,8 +189,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
 #pragma unroll
       for (int g = 0; g < NG; ++g)
         if (g < cnt) {
-          r0[s][g] = *reinterpret_cast<const f32x4*>(rows[g] + 16 * ks);
-          r1[s][g] = *reinterpret_cast<const f32x4*>(rows[g] + 16 * ks + 4);
+          r0[s][g] = *reinterpret_cast<const f32x4*>(rows[g].p + ks * rows[g].kss);
+          r1[s][g] = *reinterpret_cast<const f32x4*>(rows[g].p + ks * rows[g].kss + rows[g].r1);
         }
     };
     auto mma = [&](int sw, int sr) {
@@ -287,9 +297,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][nt][r] = 0.f;
-    const float* rows[G];
+    Row rows[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) rows[g] = xrow;
+    for (int g = 0; g < G; ++g) rows[g] = xrow_r;
     layer1(std::integral_constant<int, 1>{}, rows, 1, 0, acc);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -339,7 +349,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
     for (int g0 = 0; g0 < n; g0 += G) {
       const int cnt = n - g0 < G ? n - g0 : G;
       f32x16 acc[G][4];
-      const float* rows[G];
+      Row rows[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         rows[g] = row_of(g0 + g < n ? g0 + g : 0);
@@ -358,7 +368,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
   } else {
     for (int k = wave; k < n; k += NW) {   // one slot per pass: two accumulator sets would spill at 256 registers
       f32x16 acc[G][4];
-      const float* rows[G];
+      Row rows[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) rows[g] = row_of(k);
 #pragma unroll
@@ -376,11 +386,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
   // ---- pass 2: weighted sum in list order; the next slot's row is in flight under the FMAs
   f32x4 f0[KSW], f1[KSW], y0[2][KSW], y1[2][KSW];
   auto yload = [&](int k, int s) {
-    const float* row = row_of(k) + 16 * ks_first;
+    const Row row = row_of(k);
 #pragma unroll
     for (int ks = 0; ks < KSW; ++ks) {
-      y0[s][ks] = *reinterpret_cast<const f32x4*>(row + 16 * ks);
-      y1[s][ks] = *reinterpret_cast<const f32x4*>(row + 16 * ks + 4);
+      y0[s][ks] = *reinterpret_cast<const f32x4*>(row.p + (ks_first + ks) * row.kss);
+      y1[s][ks] = *reinterpret_cast<const f32x4*>(row.p + (ks_first + ks) * row.kss + row.r1);
     }
   };
   auto yacc = [&](int k, int s) {
@@ -466,10 +476,35 @@ extern "C" int dn_fuse_mlp_pack(const float* w1, const float* w2, const float* w
   return dn::check_launch("pack_frags_kernel");
 }
 
+namespace {
+int fuse_mlp_impl(const float* feat, const float* warped, int warped_fm, const int32_t* num_agent, const dn_fuse_mlp_params* p,
+                  int batch, int agents, int hw, int c, int only_v2i, int ego_first, int ego_count, void* fused_sp,
+                  float* fused_nhwc, float* weights_out, void* stream);
+}
+
 extern "C" int dn_disco_fuse_mlp(const float* feat, const float* warped, const int32_t* num_agent,
                                  const dn_fuse_mlp_params* p, int batch, int agents, int hw, int c,
                                  int only_v2i, int ego_first, int ego_count, void* fused_sp,
                                  float* fused_nhwc, float* weights_out, void* stream) {
+  return fuse_mlp_impl(feat, warped, 0, num_agent, p, batch, agents, hw, c, only_v2i, ego_first, ego_count, fused_sp,
+                       fused_nhwc, weights_out, stream);
+}
+
+// `warped` in the fragment-major form dn_warp_neighbors_fm writes (hw % 32 == 0): identical results, the neighbour
+// rows arrive as contiguous 1 KB runs per load instruction instead of 32 half cache lines.
+extern "C" int dn_disco_fuse_mlp_fm(const float* feat, const float* warped_fm, const int32_t* num_agent,
+                                    const dn_fuse_mlp_params* p, int batch, int agents, int hw, int c,
+                                    int only_v2i, int ego_first, int ego_count, void* fused_sp,
+                                    float* fused_nhwc, float* weights_out, void* stream) {
+  DN_REQUIRE(hw % 32 == 0, "fuse_mlp (fragment-major): hw %d must be a multiple of 32", hw);
+  return fuse_mlp_impl(feat, warped_fm, 1, num_agent, p, batch, agents, hw, c, only_v2i, ego_first, ego_count, fused_sp,
+                       fused_nhwc, weights_out, stream);
+}
+
+namespace {
+int fuse_mlp_impl(const float* feat, const float* warped, int warped_fm, const int32_t* num_agent, const dn_fuse_mlp_params* p,
+                  int batch, int agents, int hw, int c, int only_v2i, int ego_first, int ego_count, void* fused_sp,
+                  float* fused_nhwc, float* weights_out, void* stream) {
   DN_REQUIRE(feat && num_agent && p && (fused_sp || fused_nhwc), "fuse_mlp: null pointer");
   DN_REQUIRE(agents < 2 || warped, "fuse_mlp: neighbours present but warped is null");
   DN_REQUIRE(batch > 0 && agents > 0 && hw > 0, "fuse_mlp: empty problem");
@@ -494,6 +529,7 @@ extern "C" int dn_disco_fuse_mlp(const float* feat, const float* warped, const i
   a.batch = batch; a.agents = agents; a.hw = hw; a.only_v2i = only_v2i;
   a.ego_first = ego_first; a.ego_count = ego_count;
   a.tiles = (hw + 31) / 32;
+  a.warped_fm = warped_fm;
   dim3 grid(batch * ego_count * a.tiles);   // one workgroup per 32 pixels of one (sample, ego)
   hipStream_t s = (hipStream_t)stream;
   // Four waves per tile when the launch leaves SIMDs idle (fewer tiles than 2 per CU: 128 tiles for one rank's
@@ -514,3 +550,4 @@ extern "C" int dn_disco_fuse_mlp(const float* feat, const float* warped, const i
   }
   return dn::check_launch("disco_fuse_mlp_kernel");
 }
+}  // namespace

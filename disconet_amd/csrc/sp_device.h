@@ -53,7 +53,7 @@ __device__ unsigned g_sp_range_flags = 0;
 
 __device__ inline void note_range(float amax, bool nan_seen = false) {
   if (amax > 16384.f) atomicOr(&g_sp_range_flags, amax >= 65504.f ? 3u : 2u);
-  if (nan_seen) atomicOr(&g_sp_range_flags, 5u);
+  if (nan_seen) atomicOr(&g_sp_range_flags, 4u);
 }
 // NaN test of four values BEFORE a max / clamp can hide them: two unordered compares (true when either operand is a
 // NaN), the lane masks OR-ed on the scalar unit -- half a VALU instruction per value.
@@ -94,6 +94,24 @@ __device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
   float unused = 0.f;
   split4(v, hi, lo, unused);
 }
+
+// K slices of a conv launch (conv_sp.hip / conv_spq.hip, `KSL` kernels; include/disconet_hip.h :: dn_spconv2d_ks).
+// A layer with `count` > 1 canonical K slices defines every output as the fp32 sum, in slice order and starting from
+// zero, of the slices' accumulation chains (slice s = K groups [bound(s), bound(s + 1)), each chain from a zeroed
+// accumulator).  HOW the slices are distributed does not change a bit of the result: a workgroup that owns a whole
+// tile folds them in registers; a tile that is split hands its slices to `count` work items whose raw accumulators
+// go to `partial` and a fix-up pass of the same kernel (`fixup`) adds them in the same order.  The launcher splits the
+// tiles of the last, under-filled round of a launch (and every tile of a launch smaller than the chip).
+struct KSlices {
+  float* partial;      // [n_split][count][waves][acc tiles][4 quads][64 lanes] x f32x4
+  int count, log2;     // 1, 2 or 4 slices
+  int b1, b2, b3;      // group index where slice 1, 2, 3 begins (slice 0 begins at 0, the last ends at ngroups)
+  int ngroups;
+  int n_whole;         // work items [0, n_whole) are whole tiles
+  int n_split;         // tiles behind them, each split into `count` work items
+  int fixup;           // this launch only adds the partials of the split tiles and runs their epilogue
+  __host__ __device__ int bound(int s) const { return s <= 0 ? 0 : s == 1 ? b1 : s == 2 ? b2 : s == 3 ? b3 : ngroups; }
+};
 
 // Lanes (j, 0) and (j, 1) hold channels 4h..4h+3 of octet X (x) and of octet Y (y).  After the
 // swaps lane (j, 0) holds octet X complete and lane (j, 1) octet Y complete, as 16 bytes.

@@ -293,7 +293,7 @@ constexpr int WT = 8, WQ = WT + 2, WCS = 64;
 __global__ void __launch_bounds__(256)
 warp_neighbors_tiled_kernel(const float* __restrict__ feat, const float* __restrict__ trans,
                             const int32_t* __restrict__ num_agent, int batch, int agents, int h, int w,
-                            int c, int only_v2i, int ego_first, int ego_count, int tiles_x,
+                            int c, int only_v2i, int ego_first, int ego_count, int tiles_x, int fm,
                             float* __restrict__ warped) {
   __shared__ f32x4 rot[WQ * WQ][WCS / 4];
   const int n_slices = c / WCS;
@@ -306,12 +306,20 @@ warp_neighbors_tiled_kernel(const float* __restrict__ feat, const float* __restr
   n_live = n_live < 0 ? 0 : (n_live > agents ? agents : n_live);
   const int tid = threadIdx.x, l = tid & 15;
   const int hw = h * w;
-  float* dst = warped + ((size_t)bi * (agents - 1) + jj) * hw * c + slice * WCS + 4 * l;
+  float* dst = warped + ((size_t)bi * (agents - 1) + jj) * hw * c + (fm ? 0 : slice * WCS + 4 * l);
+  // fm: FRAGMENT-MAJOR pair block (include/disconet_hip.h :: dn_warp_neighbors_fm) -- the order in which the attention
+  // launch reads it: [tile of 32 pixels][k-step of 16 channels][half r][lane = 32 h + j] x 4 floats, channel
+  // 16 ks + 8 h + 4 r + e of pixel 32 t + j.  This thread's four channels 64 slice + 4 l .. + 3 are one such piece.
+  const int fm_ks = slice * 4 + (l >> 2), fm_h = (l >> 1) & 1, fm_r = l & 1, fm_kss = c >> 4;
+  auto out_of = [&](int p) {
+    return fm ? dst + (((((size_t)(p >> 5) * fm_kss + fm_ks) * 2 + fm_r) * 64) + fm_h * 32 + (p & 31)) * 4
+              : dst + (size_t)p * c;
+  };
   const bool live = i < n_live && j < n_live && !(only_v2i && i != 0 && j != 0);
   if (!live) {
     for (int pl = tid >> 4; pl < WT * WT; pl += 16) {
       const int px = tile_x0 + pl % WT, py = tile_y0 + pl / WT;
-      if (px < w && py < h) *reinterpret_cast<f32x4*>(dst + (size_t)(py * w + px) * c) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (px < w && py < h) *reinterpret_cast<f32x4*>(out_of(py * w + px)) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     return;
   }
@@ -355,7 +363,7 @@ warp_neighbors_tiled_kernel(const float* __restrict__ feat, const float* __restr
       const int lx = min(max(qx - qx_base, 0), WQ - 1), ly = min(max(qy - qy_base, 0), WQ - 1);
       acc += rot[ly * WQ + lx][l] * (qok ? qw[k] : 0.f);
     }
-    *reinterpret_cast<f32x4*>(dst + (size_t)(py * w + px) * c) = acc;
+    *reinterpret_cast<f32x4*>(out_of(py * w + px)) = acc;
   }
 }
 
@@ -396,9 +404,29 @@ extern "C" int dn_warp_backward(const float* d_warped, const float* poses, const
   return dn::check_launch("warp_scatter_kernel");
 }
 
+namespace {
+int warp_neighbors_impl(const float* feat, const float* trans, const int32_t* num_agent, int batch, int agents, int h, int w,
+                        int c, int only_v2i, int ego_first, int ego_count, float* warped, int fm, void* stream);
+}
+
 extern "C" int dn_warp_neighbors(const float* feat, const float* trans, const int32_t* num_agent,
                                  int batch, int agents, int h, int w, int c, int only_v2i,
                                  int ego_first, int ego_count, float* warped, void* stream) {
+  return warp_neighbors_impl(feat, trans, num_agent, batch, agents, h, w, c, only_v2i, ego_first, ego_count, warped, 0, stream);
+}
+
+extern "C" int dn_warp_fm_supported(int h, int w, int c) { return c % WCS == 0 && (h * w) % 32 == 0; }
+
+extern "C" int dn_warp_neighbors_fm(const float* feat, const float* trans, const int32_t* num_agent,
+                                    int batch, int agents, int h, int w, int c, int only_v2i,
+                                    int ego_first, int ego_count, float* warped, void* stream) {
+  DN_REQUIRE(dn_warp_fm_supported(h, w, c), "warp (fragment-major): needs c %% 64 == 0 and h * w %% 32 == 0 (got %d x %d x %d)", h, w, c);
+  return warp_neighbors_impl(feat, trans, num_agent, batch, agents, h, w, c, only_v2i, ego_first, ego_count, warped, 1, stream);
+}
+
+namespace {
+int warp_neighbors_impl(const float* feat, const float* trans, const int32_t* num_agent, int batch, int agents, int h, int w,
+                        int c, int only_v2i, int ego_first, int ego_count, float* warped, int fm, void* stream) {
   DN_REQUIRE(batch > 0 && agents > 0 && h > 0 && w > 0, "warp: empty problem");
   DN_REQUIRE(feat && trans && num_agent && (warped || agents < 2), "warp: null pointer");
   DN_REQUIRE(c > 0 && c % 4 == 0, "warp: channel count %d must be a multiple of 4", c);
@@ -407,11 +435,11 @@ extern "C" int dn_warp_neighbors(const float* feat, const float* trans, const in
   if (agents < 2) return DN_OK;   // no neighbours to warp
   const int hw = h * w;
   static const int tiled_env = [] { const char* e = getenv("DN_WARP_TILED"); return e ? atoi(e) : 1; }();
-  if (tiled_env && c % WCS == 0) {
+  if ((tiled_env || fm) && c % WCS == 0) {
     const int tiles_x = (w + WT - 1) / WT, tiles_y = (h + WT - 1) / WT;
     dim3 tgrid(tiles_x * tiles_y * (c / WCS), agents - 1, batch * ego_count);
     hipLaunchKernelGGL(warp_neighbors_tiled_kernel, tgrid, dim3(256), 0, (hipStream_t)stream, feat, trans,
-                       num_agent, batch, agents, h, w, c, only_v2i, ego_first, ego_count, tiles_x, warped);
+                       num_agent, batch, agents, h, w, c, only_v2i, ego_first, ego_count, tiles_x, fm, warped);
     return dn::check_launch("warp_neighbors_tiled_kernel");
   }
   dim3 grid((hw + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, agents - 1, batch * ego_count);
@@ -419,3 +447,4 @@ extern "C" int dn_warp_neighbors(const float* feat, const float* trans, const in
                      num_agent, batch, agents, h, w, c, only_v2i, ego_first, ego_count, warped);
   return dn::check_launch("warp_neighbors_kernel");
 }
+}  // namespace

@@ -124,11 +124,21 @@ _DUPLICATE_BACKBONE_KEY = re.compile(
     r"|com_compresser|bn_compress|com_decompresser|bn_decompress)\." + _TENSORS + r")$")
 
 
+# K-sliced layers of the detector (SURVEY.md 8 a3 / a8 names).  DN_SP_KSLICES=all slices every deep layer (A/B runs);
+# the default is the one layer where it pays in both regimes: conv5_1, 48 chunks of K on 640 tiles
+_KSLICES_ALL = {"conv3_2": 4, "conv4_1": 4, "conv4_2": 4, "conv5_1": 4, "conv5_2": 4, "conv6_1": 4}
+_KSLICES = {"conv5_1": 4}
+
+
+def _ks_enabled():
+    return os.environ.get("DN_SP_KSLICES", "1") != "0"
+
+
 class _ConvLayer:
     """One packed conv of the plan: weights in tile-major layout + folded affine."""
 
     __slots__ = ("name", "packed", "scale", "shift", "c_in", "c_out", "ksize", "stride", "relu",
-                 "math", "affine", "weight", "packed_sig")
+                 "math", "affine", "weight", "packed_sig", "kslices")
 
     def __init__(self, name, weight, bias, bn, ksize, stride=1, relu=True, scale_shift=None,
                  math=0, up_split=None):
@@ -136,6 +146,11 @@ class _ConvLayer:
         (the decoder's *_1 convs) -- its SP weight image is the tap-merged one and is packed here, once."""
         self.name = name
         self.math = math
+        # K slices of the layer (SP engine; include/disconet_hip.h :: dn_spconv2d_ks): a property of the LAYER, never of
+        # the batch -- the deep layers, whose launches are a round and a quarter on the chip at the BASELINE batch and
+        # fewer tiles than CUs on an agent-sharded rank
+        table = _KSLICES_ALL if os.environ.get("DN_SP_KSLICES", "1") == "all" else _KSLICES
+        self.kslices = table.get(name, 1) if (math == 2 and _ks_enabled()) else 1
         c_out = weight.shape[0]
         c_in = weight.shape[1]
         if up_split is not None and math == 2:
@@ -188,8 +203,9 @@ class _ConvLayer:
             # split-planar engine: NHWC inputs (the voxel grid, the fused map) are split once here
             src0, src1 = ops.as_sp(src0), (ops.as_sp(src1) if src1 is not None else None)
             with region(self.name, "conv_sp_kernel", flops, nbytes):
-                return ops.sp_conv2d(d, src0, self.packed, self.scale, self.shift, src1=src1,
-                                     nhwc_copy=nhwc_copy and not up0 and self.c_out % 4 == 0)
+                dual = nhwc_copy and not up0 and self.c_out % 4 == 0
+                return ops.sp_conv2d(d, src0, self.packed, self.scale, self.shift, src1=src1, nhwc_copy=dual,
+                                     kslices=self.kslices)
         src0, src1 = ops.as_nhwc(src0), (ops.as_nhwc(src1) if src1 is not None else None)
         out = torch.empty((n, ho, wo, self.c_out), dtype=torch.float32, device=src0.device)
         with region(self.name, "conv_mfma_kernel", flops, nbytes):
@@ -528,14 +544,17 @@ class DiscoNet(nn.Module):
         pairs = B * E * (A - 1)
         warped = torch.empty((B, E, max(A - 1, 0), h, w, c), dtype=torch.float32,
                              device=feat.device)
+        # the one-launch attention kernel takes the warped maps in its own (fragment-major) read order when the shape
+        # allows: an opaque intermediate between the two launches (include/disconet_hip.h :: dn_warp_neighbors_fm)
+        fm = ("_fuse_mlp" in P and os.environ.get("DN_FUSE_FM", "1") != "0" and A > 1 and ops.warp_fm_supported(h, w, c))
         with region("warp", "warp_neighbors_kernel", 0.0, map_bytes * (n + pairs)):
             ops.warp_neighbors(feat, trans_matrices, num_agent, B, A, self.only_v2i,
-                               ego_first, E, out=warped)
+                               ego_first, E, out=warped, fm=fm)
         if "_fuse_mlp" in P:
             flops = 2.0 * B * E * h * w * (128.0 * c * (2 + (A - 1)) + A * (128 * 32 + 32 * 8 + 8))
             with region("fuse_mlp", "disco_fuse_mlp_kernel", flops, map_bytes * (3 * E * B + 2 * pairs)):
                 return ops.disco_fuse_mlp(feat, warped, num_agent, P["_fuse_mlp"], B, A, self.only_v2i,
-                                          want_weights, ego_first, E, sp_out=sp_out)
+                                          want_weights, ego_first, E, sp_out=sp_out, fm=fm)
         g = P["mlp_g"].run(feat[ego_first * B:(ego_first + E) * B])
         fw = None
         if A > 1:

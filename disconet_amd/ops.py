@@ -255,14 +255,15 @@ def sp_range_flags(reset=True):
 
 
 def _raise_on_range_flags(flags, what):
+    if flags & 1:
+        raise _lib.DnError("%s: a value was clamped to +-65504 by the split-f16 (hi + lo binary16) activation format; "
+                           "the outputs do not follow the fp32 reference%s.  Rescale the layer (fold a power of two into "
+                           "its BatchNorm) or run conv_math = 'f32'."
+                           % (what, " (and a NaN reached a later epilogue)" if flags & 4 else ""))
     if flags & 4:
         raise _lib.DnError("%s: a NaN reached a conv / fusion epilogue of the split-f16 engines (ReLU and the clamp of the "
                            "split turn it into a finite number, so the outputs hold plausible garbage).  Check the inputs "
                            "and the weights." % what)
-    if flags & 1:
-        raise _lib.DnError("%s: a value was clamped to +-65504 by the split-f16 (hi + lo binary16) activation format; "
-                           "the outputs do not follow the fp32 reference.  Rescale the layer (fold a power of two into "
-                           "its BatchNorm) or run conv_math = 'f32'." % what)
     if flags & 2:
         import warnings
         warnings.warn("%s: activations above 2^14 were stored as f16 hi/lo pairs (limit 65504)" % what)
@@ -366,28 +367,37 @@ def sp_pack_conv_weights(d, weight):
     return packed, wmul
 
 
-def sp_conv2d(d, src0, packed, scale, shift, src1=None, out=None, nhwc_copy=False):
+_KS_WORKSPACE_CAP = 32 << 20      # bytes of partial sums per K-sliced launch (the launcher splits fewer tiles beyond)
+
+
+def sp_conv2d(d, src0, packed, scale, shift, src1=None, out=None, nhwc_copy=False, kslices=1):
     """SP conv: src0 / src1 SpTensors -> SpTensor [n_images, h_out, w_out, c_out].
     nhwc_copy: also return the output as a float32 NHWC tensor written by the same launch (dn_spconv2d_dual)
-    -> (SpTensor, tensor)."""
+    -> (SpTensor, tensor).
+    kslices > 1: the layer's K-sliced form (dn_spconv2d_ks): results independent of the batch, the launch's last
+    round / small launches handed out slice by slice through a scratch buffer."""
     _need_gpu(src0, packed, scale, shift, src1)
     ho, wo = conv_out_hw(d)
     if out is None:
         out = SpTensor(d.n_images, ho, wo, d.c_out, device=src0.device)
-    if nhwc_copy:
-        if src1 is not None and src1.hi_only:
-            raise _lib.DnError("sp_conv2d: only source 0 may be a hi-only SP tensor")
-        if src0.hi_only:
-            d.math = 3
-        flat = torch.empty((d.n_images, ho, wo, d.c_out), dtype=torch.float32, device=src0.device)
-        check(_lib.load().dn_spconv2d_dual(ctypes.byref(d), _ptr(src0.data), _ptr(src1.data) if src1 is not None else None,
-                                           _ptr(packed), _ptr(scale), _ptr(shift), _ptr(out.data), _ptr(flat), d.c_out,
-                                           _stream()), "dn_spconv2d_dual")
-        return out, flat
     if src1 is not None and src1.hi_only:
         raise _lib.DnError("sp_conv2d: only source 0 may be a hi-only SP tensor")
     if src0.hi_only:
         d.math = 3            # include/disconet_hip.h: source 0 is a hi-only SP tensor
+    lib = _lib.load()
+    flat = torch.empty((d.n_images, ho, wo, d.c_out), dtype=torch.float32, device=src0.device) if nhwc_copy else None
+    p1 = _ptr(src1.data) if src1 is not None else None
+    if kslices > 1 and d.math != 3:
+        nbytes = min(int(lib.dn_spconv_workspace_bytes(ctypes.byref(d), kslices)), _KS_WORKSPACE_CAP)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=src0.device)
+        check(lib.dn_spconv2d_ks(ctypes.byref(d), kslices, _ptr(src0.data), p1, _ptr(packed), _ptr(scale), _ptr(shift),
+                                 _ptr(out.data), _ptr(flat), d.c_out if nhwc_copy else 0, _ptr(ws), nbytes, _stream()),
+              "dn_spconv2d_ks")
+        return (out, flat) if nhwc_copy else out
+    if nhwc_copy:
+        check(lib.dn_spconv2d_dual(ctypes.byref(d), _ptr(src0.data), p1, _ptr(packed), _ptr(scale), _ptr(shift),
+                                   _ptr(out.data), _ptr(flat), d.c_out, _stream()), "dn_spconv2d_dual")
+        return out, flat
     check(_lib.load().dn_spconv2d(ctypes.byref(d), _ptr(src0.data), _ptr(src1.data) if src1 is not None else None,
                                   _ptr(packed), _ptr(scale), _ptr(shift), _ptr(out.data), _stream()),
           "dn_spconv2d")
@@ -525,10 +535,16 @@ def conv2d_post1x1(d, src0, packed, scale, shift, packed2, scale2, shift2, c_out
 # ---------------------------------------------------------------------------
 # K4-K6
 # ---------------------------------------------------------------------------
+def warp_fm_supported(h, w, c):
+    """can the warped maps take the fragment-major form (dn_warp_neighbors_fm / dn_disco_fuse_mlp_fm)?"""
+    return bool(_lib.load().dn_warp_fm_supported(h, w, c))
+
+
 def warp_neighbors(feat, trans, num_agent, batch, agents, only_v2i=False, ego_first=0,
-                   ego_count=None, out=None):
+                   ego_count=None, out=None, fm=False):
     """feat [A*B, h, w, C] agent-major NHWC (all agents) -> warped
-    [B, ego_count, A-1, h, w, C] for the egos [ego_first, ego_first + ego_count)."""
+    [B, ego_count, A-1, h, w, C] for the egos [ego_first, ego_first + ego_count).
+    fm: every [h, w, C] block in the fragment-major order dn_disco_fuse_mlp_fm reads (an opaque intermediate)."""
     _need_gpu(feat, trans, num_agent)
     _f32c(feat, "feat")
     _f32c(trans, "trans_matrices")
@@ -536,9 +552,10 @@ def warp_neighbors(feat, trans, num_agent, batch, agents, only_v2i=False, ego_fi
     n, h, w, c = feat.shape
     warped = out if out is not None else torch.empty(
         (batch, ego_count, max(agents - 1, 0), h, w, c), dtype=torch.float32, device=feat.device)
-    check(_lib.load().dn_warp_neighbors(_ptr(feat), _ptr(trans), _ptr(num_agent), batch, agents, h,
-                                        w, c, int(only_v2i), ego_first, ego_count, _ptr(warped),
-                                        _stream()), "dn_warp_neighbors")
+    lib = _lib.load()
+    fn = lib.dn_warp_neighbors_fm if fm else lib.dn_warp_neighbors
+    check(fn(_ptr(feat), _ptr(trans), _ptr(num_agent), batch, agents, h, w, c, int(only_v2i), ego_first, ego_count,
+             _ptr(warped), _stream()), "dn_warp_neighbors_fm" if fm else "dn_warp_neighbors")
     return warped
 
 
@@ -594,10 +611,10 @@ def make_fuse_mlp_params(w1, b1, bn1, w2, b2, bn2, w3, b3, bn3, w4, b4, c):
 
 
 def disco_fuse_mlp(feat, warped, num_agent, params, batch, agents, only_v2i=False, want_weights=False,
-                   ego_first=0, ego_count=None, sp_out=False):
+                   ego_first=0, ego_count=None, sp_out=False, fm=False):
     """Attention MLP + agent softmax + weighted sum in one launch.  feat [A*B, h, w, C] NHWC (all
-    agents), warped [B, E, A-1, h, w, C]; -> SpTensor (sp_out) or float32 NHWC [E*B, h, w, C]
-    (+ weights [B, E, A, h*w] when want_weights)."""
+    agents), warped [B, E, A-1, h, w, C] (fm: in the fragment-major form of warp_neighbors(fm=True));
+    -> SpTensor (sp_out) or float32 NHWC [E*B, h, w, C] (+ weights [B, E, A, h*w] when want_weights)."""
     _need_gpu(feat, num_agent, warped)
     _f32c(feat, "feat")
     ego_count = agents if ego_count is None else ego_count
@@ -606,10 +623,11 @@ def disco_fuse_mlp(feat, warped, num_agent, params, batch, agents, only_v2i=Fals
     out = None if sp_out else torch.empty((ego_count * batch, h, w, c), dtype=torch.float32, device=feat.device)
     weights = (torch.zeros((batch, ego_count, agents, h * w), dtype=torch.float32, device=feat.device)
                if want_weights else None)
-    check(_lib.load().dn_disco_fuse_mlp(_ptr(feat), _ptr(warped), _ptr(num_agent), ctypes.byref(params),
-                                        batch, agents, h * w, c, int(only_v2i), ego_first, ego_count,
-                                        _ptr(out_sp.data) if sp_out else None, _ptr(out), _ptr(weights),
-                                        _stream()), "dn_disco_fuse_mlp")
+    lib = _lib.load()
+    fn = lib.dn_disco_fuse_mlp_fm if fm else lib.dn_disco_fuse_mlp
+    check(fn(_ptr(feat), _ptr(warped), _ptr(num_agent), ctypes.byref(params), batch, agents, h * w, c, int(only_v2i),
+             ego_first, ego_count, _ptr(out_sp.data) if sp_out else None, _ptr(out), _ptr(weights), _stream()),
+          "dn_disco_fuse_mlp_fm" if fm else "dn_disco_fuse_mlp")
     res = out_sp if sp_out else out
     return (res, weights) if want_weights else res
 

@@ -61,8 +61,8 @@ const char* dn_last_error(void);
  * Every kernel that splits values keeps a sticky word in device memory:
  *   bit 1 (2): a value with |x| > 2^14 was split -- within two binades of the limit, rescale;
  *   bit 0 (1): a value was clamped to +-65504 -- results of this device since the last reset are wrong;
- *   bit 2 (4): a NaN reached an epilogue (always together with bit 0).  ReLU and the clamp turn a NaN into a
- *              finite number, so without this bit it would vanish from the outputs.
+ *   bit 2 (4): a NaN reached an epilogue.  ReLU and the clamp turn a NaN into a finite number, so without this
+ *              bit it would vanish from the outputs.
  * dn_sp_range_flags: the OR over the library's kernels on the current device; with reset != 0 it clears them.
  *   BLOCKING (hipDeviceSynchronize + a device -> host copy): validation time.
  * dn_sp_range_flags_async: the same OR enqueued on `stream` into *dst_device (a device word the caller zeroed):
@@ -218,6 +218,24 @@ int dn_spconv_pack_weights(const dn_conv_desc* d, const float* weight_oihw, floa
 int dn_spconv2d(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp,
                 const void* packed, const float* scale, const float* shift, void* out_sp,
                 void* stream);
+/* K-SLICED form of dn_spconv2d (3x3 layers; conv_sp.hip / conv_spq.hip `KSL` kernels).  `kslices` (1, 2 or 4) is a
+ * property of the LAYER: every output is defined as the fp32 sum, in slice order and starting from zero, of
+ * `kslices` accumulation chains over equal shares of the K loop (16-channel chunks; on the tap-merged up-conv equal
+ * shares of its work).  How a launch distributes the slices does not change a bit of the result: a workgroup that
+ * owns a whole tile folds them in registers, the tiles of the launch's last, under-filled round (every tile of a
+ * launch smaller than the chip) are handed out slice by slice through `workspace` and added by a second, tiny launch
+ * of the same kernel in the same order.  So the outputs of an image are bit-identical whatever the batch it is part
+ * of (tests/test_gpu_conv.py), a 640-tile layer no longer runs two rounds on 512 resident workgroups, and the
+ * 4-image launches of an agent-sharded rank fill the chip.  kslices = 1 is dn_spconv2d.  workspace may be NULL
+ * (nothing is split) or smaller than dn_spconv_workspace_bytes() (fewer tiles are split).  Same packed weights as
+ * dn_spconv2d.  Refused (DN_ERR_ARG): 1x1 layers, hi-only sources (math = 3), the row-merged image
+ * (dn_spconv_set_upmode(1)), layers with fewer chunks than slices. */
+size_t dn_spconv_workspace_bytes(const dn_conv_desc* d, int kslices);
+int dn_spconv2d_ks(const dn_conv_desc* d, int kslices, const void* src0, const void* src1, const void* packed,
+                   const float* scale, const float* shift, void* out, float* out_nhwc /* may be NULL: the second,
+                   fp32 NHWC output of dn_spconv2d_dual (not on the tap-merged up-conv) */, int ld_nhwc,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same conv with a SECOND copy of its output as float32 NHWC rows [n][h_out][w_out][ld_nhwc] (first c_out
  * columns; c_out % 4 == 0), written from the same epilogue registers before the f16 split: the level a
  * consumer outside the conv engine reads (the fusion kernels' maps, the agent all-gather) needs no
@@ -335,6 +353,23 @@ int dn_disco_fuse_mlp(const float* feat, const float* warped, const int32_t* num
                       const dn_fuse_mlp_params* p, int batch, int agents, int hw, int c,
                       int only_v2i, int ego_first, int ego_count, void* fused_sp,
                       float* fused_nhwc, float* weights_out, void* stream);
+/* FRAGMENT-MAJOR form of the warped neighbour maps (the default of the Python host when h * w % 32 == 0 and
+ * c % 64 == 0).  dn_warp_neighbors_fm writes each (sample, ego, neighbour) block of hw * c floats as
+ *   [tile t of 32 pixels][k-step ks of 16 channels][half r][lane = 32 h + j] x 4 floats
+ *   = channels 16 ks + 8 h + 4 r + 0..3 of pixel 32 t + j
+ * -- the order dn_disco_fuse_mlp_fm's wavefronts read it (lane (j, h) of the wave that owns tile t holds exactly these
+ * pieces as its MFMA operand), so that every load instruction of a wave is one contiguous 1 KB run instead of 32 half
+ * cache lines.  Same values, same arithmetic and same results as dn_warp_neighbors + dn_disco_fuse_mlp; the block is an
+ * intermediate between the two calls, nothing else reads it. */
+int dn_warp_fm_supported(int h, int w, int c);
+int dn_warp_neighbors_fm(const float* feat, const float* trans, const int32_t* num_agent,
+                         int batch, int agents, int h, int w, int c, int only_v2i,
+                         int ego_first, int ego_count, float* warped_fm, void* stream);
+int dn_disco_fuse_mlp_fm(const float* feat, const float* warped_fm, const int32_t* num_agent,
+                         const dn_fuse_mlp_params* p, int batch, int agents, int hw, int c,
+                         int only_v2i, int ego_first, int ego_count, void* fused_sp,
+                         float* fused_nhwc, float* weights_out, void* stream);
+
 
 /* ------------------------------------------------------------------------
  * Detection decode (first step after the hot path).

@@ -228,3 +228,72 @@ def test_sp_conv_dual_output(h, w, c0, c_out, k, stride):
     assert torch.equal(sp.data, plain.data)
     assert torch.equal(ops.SpTensor.from_nhwc(flat).data, sp.data)
     assert (flat - sp.nhwc()).abs().max().item() <= 2e-6 * max(1.0, flat.abs().max().item())
+
+
+@pytest.mark.parametrize("n,h,w,c0,c1,c_out,stride,up0,ks", [
+    (20, 32, 32, 512, 256, 256, 1, True, 4),     # conv5_1 (the tap-merged kernel): 640 tiles, the last 128 split
+    (12, 32, 32, 256, 0, 256, 1, False, 4),      # conv3_2 / conv5_2 shape
+    (9, 16, 16, 512, 0, 512, 1, False, 4),       # conv4_2
+    (10, 32, 32, 256, 0, 512, 2, False, 2),      # conv4_1 (stride 2), two slices
+    (5, 20, 44, 64, 32, 48, 1, True, 2),         # ragged up + concat, c_out not a tile multiple
+    (6, 24, 40, 128, 0, 80, 1, False, 4),
+])
+def test_k_sliced_conv_is_batch_invariant(n, h, w, c0, c1, c_out, stride, up0, ks):
+    """dn_spconv2d_ks: a layer's K slices define its result -- the sum, in slice order, of the slices' accumulation
+    chains -- however a launch distributes them: all tiles whole (no workspace), the under-filled round split
+    through the workspace, or the first images as a launch of their own give the SAME BITS; the values follow the
+    torch-CPU conv within the engine's tolerance; a second fp32 NHWC output rides along"""
+    from disconet_amd import ops, _lib
+    import ctypes
+    g = torch.Generator().manual_seed(n * 100 + c_out)
+    cin = c0 + c1
+    wgt = torch.randn(c_out, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    h0, w0 = (h // 2, w // 2) if up0 else (h, w)
+    x0 = torch.randn(n, h0, w0, c0, generator=g).clamp_(min=0)
+    x1 = torch.randn(n, h, w, c1, generator=g).clamp_(min=0) if c1 else None
+    scale = torch.rand(c_out, generator=g) + 0.5
+    shift = torch.randn(c_out, generator=g) * 0.1
+    xin = x0.permute(0, 3, 1, 2)
+    if up0:
+        xin = F.interpolate(xin, scale_factor=(2, 2))
+    if c1:
+        xin = torch.cat((xin, x1.permute(0, 3, 1, 2)), 1)
+    want = F.relu(F.conv2d(xin, wgt, None, stride=stride, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    want = want.permute(0, 2, 3, 1)
+
+    s0 = ops.SpTensor.from_nhwc(x0.cuda())
+    s1 = ops.SpTensor.from_nhwc(x1.cuda()) if c1 else None
+    lib = _lib.load()
+
+    def run(n_img, workspace):
+        d = ops.conv_desc(n_img, h, w, c0, c_out, 3, stride, True, c1=c1, up0=up0, math="sp")
+        packed, wmul = ops.sp_pack_conv_weights(d, wgt.cuda())
+        ho, wo = ops.conv_out_hw(d)
+        out = ops.SpTensor(n_img, ho, wo, c_out, device="cuda")
+        out.data.fill_(255)
+        nb = int(lib.dn_spconv_workspace_bytes(ctypes.byref(d), ks)) if workspace else 0
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+        sc, sh = (scale / wmul).cuda(), shift.cuda()         # (named: a temporary would be freed before the launch reads it)
+        ops.check(lib.dn_spconv2d_ks(ctypes.byref(d), ks, ops._ptr(s0.data), ops._ptr(s1.data) if s1 is not None else None,
+                                     ops._ptr(packed), ops._ptr(sc), ops._ptr(sh),
+                                     ops._ptr(out.data), None, 0, ops._ptr(ws) if workspace else None, nb,
+                                     ops._stream()), "dn_spconv2d_ks")
+        torch.cuda.synchronize()
+        return out
+
+    split = run(n, True)
+    whole = run(n, False)
+    few = run(min(n, 3), True)
+    assert torch.equal(split.data, whole.data)
+    per_img = split.data.numel() // n
+    assert torch.equal(few.data.reshape(-1), split.data.reshape(-1)[:per_img * min(n, 3)])
+    got = split.nhwc().cpu()
+    assert (got - want).abs().max().item() <= TOL * max(1.0, want.abs().max().item() / 4)
+    # through ops.sp_conv2d (what the plan calls), with the second output of the exchanged level
+    if not up0:
+        d = ops.conv_desc(n, h, w, c0, c_out, 3, stride, True, c1=c1, up0=up0, math="sp")
+        packed, wmul = ops.sp_pack_conv_weights(d, wgt.cuda())
+        sp, flat = ops.sp_conv2d(d, s0, packed, (scale / wmul).cuda(), shift.cuda(), src1=s1, nhwc_copy=True, kslices=ks)
+        torch.cuda.synchronize()
+        assert torch.equal(sp.data, split.data)
+        assert torch.equal(ops.SpTensor.from_nhwc(flat).data, sp.data)

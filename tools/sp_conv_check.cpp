@@ -305,6 +305,72 @@ static void run_hi_only(const char* name, int n, int h, int w, int cin, int cout
   hipFree(f1); hipFree(f2);
 }
 
+// K-sliced form (dn_spconv2d_ks): value against the reference engine, and the property it is built for -- the outputs
+// of an image do not depend on the launch: n images with the tail split through the workspace == the same launch with
+// nothing split (workspace NULL) == the first 4 images as a launch of their own, BIT FOR BIT.  Timed beside dn_spconv2d.
+static void run_ks(const char* name, int n, int h, int w, int c0, int c1, int up0, int cout, int stride, int S) {
+  if (!name_selected(name)) return;
+  Timer tm;
+  const int ks = 3;
+  dn_conv_desc d = {n, h, w, c0, c1, up0, cout, ks, stride, 1, c0, c1, cout, 1};
+  const int ho = (h + 2 - ks) / stride + 1, wo = (w + 2 - ks) / stride + 1;
+  const int h0 = up0 ? h / 2 : h, w0 = up0 ? w / 2 : w;
+  const size_t n0 = (size_t)n * h0 * w0 * c0, n1 = (size_t)n * h * w * c1, no = (size_t)n * ho * wo * cout;
+  float* s0 = dev_random(n0, 1.5f, true);
+  float* s1 = c1 ? dev_random(n1, 1.5f, true) : nullptr;
+  const int cin = c0 + c1;
+  float* wt = dev_random((size_t)cout * cin * 9, sqrtf(6.f / (cin * 9)));
+  float* sc = dev_random(cout, 0.5f, true); float* sh = dev_random(cout, 0.3f);
+  const float wmul = 256.f;
+  { std::vector<float> hsc(cout); for (auto& x : hsc) x = (1.f + 0.25f * frand()); hipMemcpy(sc, hsc.data(), cout * 4, hipMemcpyHostToDevice); }
+  float *out_ref, *out_new; HCK(hipMalloc(&out_ref, no * 4)); HCK(hipMalloc(&out_new, no * 4));
+  float* pk_ref; HCK(hipMalloc(&pk_ref, dn_conv_packed_weight_floats(&d) * 4));
+  CK(dn_conv_pack_weights(&d, wt, pk_ref, 0));
+  CK(dn_conv2d(&d, s0, s1, pk_ref, sc, sh, out_ref, 0));
+  float* sc2; HCK(hipMalloc(&sc2, cout * 4));
+  { std::vector<float> hsc(cout); hipMemcpy(hsc.data(), sc, cout * 4, hipMemcpyDeviceToHost); for (auto& x : hsc) x /= wmul; hipMemcpy(sc2, hsc.data(), cout * 4, hipMemcpyHostToDevice); }
+  void *sp0, *sp1 = nullptr, *o_full, *o_nows, *o_small, *pk, *ws;
+  const size_t ob = dn_sp_tensor_bytes(n, ho, wo, cout), ob4 = dn_sp_tensor_bytes(4, ho, wo, cout);
+  HCK(hipMalloc(&sp0, dn_sp_tensor_bytes(n, h0, w0, c0)));
+  if (c1) HCK(hipMalloc(&sp1, dn_sp_tensor_bytes(n, h, w, c1)));
+  HCK(hipMalloc(&o_full, ob)); HCK(hipMalloc(&o_nows, ob)); HCK(hipMalloc(&o_small, ob4));
+  HCK(hipMemset(o_full, 0xFF, ob)); HCK(hipMemset(o_nows, 0xFF, ob)); HCK(hipMemset(o_small, 0xFF, ob4));
+  CK(dn_sp_from_nhwc(s0, n, h0, w0, c0, c0, sp0, 0));
+  if (c1) CK(dn_sp_from_nhwc(s1, n, h, w, c1, c1, sp1, 0));
+  HCK(hipMalloc(&pk, dn_spconv_packed_weight_bytes(&d)));
+  CK(dn_spconv_pack_weights(&d, wt, wmul, pk, 0));
+  const size_t wsb = dn_spconv_workspace_bytes(&d, S);
+  HCK(hipMalloc(&ws, wsb ? wsb : 16));
+  HCK(hipMemset(ws, 0xFF, wsb ? wsb : 16));
+  dn_conv_desc d4 = d; d4.n_images = n < 4 ? n : 4;
+  CK(dn_spconv2d_ks(&d, S, sp0, sp1, pk, sc2, sh, o_full, nullptr, 0, ws, wsb, 0));
+  CK(dn_spconv2d_ks(&d, S, sp0, sp1, pk, sc2, sh, o_nows, nullptr, 0, nullptr, 0, 0));
+  CK(dn_spconv2d_ks(&d4, S, sp0, sp1, pk, sc2, sh, o_small, nullptr, 0, ws, wsb, 0));      // SP tensors are image-major: a prefix
+  CK(dn_sp_to_nhwc(o_full, n, ho, wo, cout, cout, out_new, 0));
+  HCK(hipDeviceSynchronize());
+  const double err = compare(out_new, out_ref, no, name);
+  std::vector<unsigned char> a(ob), b(ob), c(ob4);
+  HCK(hipMemcpy(a.data(), o_full, ob, hipMemcpyDeviceToHost)); HCK(hipMemcpy(b.data(), o_nows, ob, hipMemcpyDeviceToHost));
+  HCK(hipMemcpy(c.data(), o_small, ob4, hipMemcpyDeviceToHost));
+  const size_t per_img = ob / n;
+  const bool same_nows = memcmp(a.data(), b.data(), ob) == 0;
+  const bool same_small = memcmp(a.data(), c.data(), per_img * d4.n_images) == 0;
+  const float t_ks = tm.us([&] { dn_spconv2d_ks(&d, S, sp0, sp1, pk, sc2, sh, o_full, nullptr, 0, ws, wsb, 0); });
+  const float t_nows = tm.us([&] { dn_spconv2d_ks(&d, S, sp0, sp1, pk, sc2, sh, o_full, nullptr, 0, nullptr, 0, 0); });
+  const float t_plain = tm.us([&] { dn_spconv2d(&d, sp0, sp1, pk, sc2, sh, o_full, 0); });
+  const float t_ks4 = tm.us([&] { dn_spconv2d_ks(&d4, S, sp0, sp1, pk, sc2, sh, o_small, nullptr, 0, ws, wsb, 0); });
+  const float t_plain4 = tm.us([&] { dn_spconv2d(&d4, sp0, sp1, pk, sc2, sh, o_small, 0); });
+  const bool ok = err < 2e-5 && same_nows && same_small;
+  if (!ok) ++g_fail;
+  printf("[ks%d] %-30s err %.1e | split == unsplit %s | 4-image launch == rows of the %d-image one %s | %d img: plain %6.1f  sliced/unsplit %6.1f  sliced %6.1f us | 4 img: plain %6.1f  sliced %6.1f us%s\n",
+         S, name, err, same_nows ? "bitwise" : "DIFFERS", n, same_small ? "bitwise" : "DIFFERS", n, t_plain, t_nows, t_ks, t_plain4, t_ks4,
+         ok ? "" : " FAIL");
+  if (err >= 2e-5) dump_mismatch(out_new, out_ref, n, ho, wo, cout);
+  fflush(stdout);
+  hipFree(s0); hipFree(s1); hipFree(wt); hipFree(sc); hipFree(sh); hipFree(out_ref); hipFree(out_new); hipFree(pk_ref);
+  hipFree(sp0); hipFree(sp1); hipFree(o_full); hipFree(o_nows); hipFree(o_small); hipFree(pk); hipFree(ws); hipFree(sc2);
+}
+
 static void roundtrip() {
   const int n = 2, h = 20, w = 24, c = 45;
   float* s = dev_random((size_t)n * h * w * c, 3.f);
@@ -369,6 +435,22 @@ int main(int argc, char** argv) {
   run_layer("share conv5_2 32^2 256->256", 4, 32, 32, 256, 0, 0, 256, 3, 1, quick);
   run_layer("share conv6_1 64^2 384->128 up+cat", 4, 64, 64, 256, 128, 1, 128, 3, 1, quick);
   run_layer("share conv6_2 64^2 128->128", 4, 64, 64, 128, 0, 0, 128, 3, 1, quick);
+  // K-sliced form of the deep layers (model.py :: _KSLICES), odd shapes first
+  if (g_mode != 2) {
+    run_ks("ks ragged 3x3 40x72 64->80", 6, 40, 72, 64, 0, 0, 80, 1, 4);
+    run_ks("ks ragged 3x3 s2 40x72 64->96", 6, 40, 72, 64, 0, 0, 96, 2, 2);
+    run_ks("ks ragged up+cat 24x40", 6, 24, 40, 48, 32, 1, 48, 1, 4);
+    run_ks("ks ragged up only 16x32", 5, 16, 32, 64, 0, 1, 96, 1, 2);
+    run_ks("ks conv3_2 32^2 256->256", n, 32, 32, 256, 0, 0, 256, 1, 4);
+    run_ks("ks conv4_1 32^2 256->512 s2", n, 32, 32, 256, 0, 0, 512, 2, 4);
+    run_ks("ks conv4_2 16^2 512->512", n, 16, 16, 512, 0, 0, 512, 1, 4);
+    run_ks("ks conv5_1 32^2 768->256 up+cat", n, 32, 32, 512, 256, 1, 256, 1, 4);
+    run_ks("ks conv5_2 32^2 256->256", n, 32, 32, 256, 0, 0, 256, 1, 4);
+    run_ks("ks conv6_1 64^2 384->128 up+cat", n, 64, 64, 256, 128, 1, 128, 1, 4);
+    run_ks("ks conv6_2 64^2 128->128", n, 64, 64, 128, 0, 0, 128, 1, 2);
+    run_ks("ks conv2_2 64^2 128->128 (4)", n, 64, 64, 128, 0, 0, 128, 1, 4);
+    run_ks("ks conv3_1 64^2 128->256 s2", n, 64, 64, 128, 0, 0, 256, 2, 2);
+  }
   printf("%s (%d failures)\n", g_fail ? "SP CONV CHECK FAILED" : "SP CONV CHECK PASSED", g_fail);
   return g_fail ? 1 : 0;
 }
