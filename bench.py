@@ -335,9 +335,27 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
         full_out = stepper()
         full = {"cls": full_out[0]["cls"].clone(), "loc": full_out[0]["loc"].clone()}
         cnt = agents // W
-        share = sharded.GraphedAgentStep(engine, rank_inputs(0, cnt), trans, na, batch, 0, cnt,
-                                         emulate_feat_all=full_feat)
-        t_share = time_steps(share, args.steps, args.warmup)
+        # the collective's launch + kernel latency belongs in the share: a one-rank RCCL group runs the real
+        # all_gather_into_tensor between the two graphs (what it cannot show is link time and rank skew)
+        have_pg = dist.is_initialized()
+        if not have_pg and not args.no_pg:
+            try:
+                import datetime
+                dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29530 + os.getpid() % 400), rank=0,
+                                        world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()),
+                                        timeout=datetime.timedelta(seconds=60))
+                have_pg = True
+            except Exception as e:      # noqa: BLE001 -- the projection then carries no collective (said in the note)
+                print("bench: no one-rank process group for the emulated share (%r)" % (e,), file=sys.stderr)
+        share_plain = sharded.GraphedAgentStep(engine, rank_inputs(0, cnt), trans, na, batch, 0, cnt,
+                                               emulate_feat_all=full_feat)
+        t_plain = time_steps(share_plain, args.steps, args.warmup)
+        share = share_plain
+        t_share = t_plain
+        if have_pg:
+            share = sharded.GraphedAgentStep(engine, rank_inputs(0, cnt), trans, na, batch, 0, cnt,
+                                             emulate_feat_all=full_feat, emulate_collective=True)
+            t_share = time_steps(share, args.steps, args.warmup)
         got = share()
         torch.cuda.synchronize()
         rows = cnt * batch
@@ -347,10 +365,15 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
             "phases_us": {"graph_a_encode": phase_us(share.graph_a), "exchange_copy": phase_us(share.exchange),
                           "graph_b_fuse_decode_heads": phase_us(share.graph_b)},
             "projected_speedup": round(elapsed / t_share, 3),
+            "collective_in_share": ("RCCL all_gather_into_tensor of this rank's maps on a one-rank group (launch + kernel "
+                                    "latency; no link time)") if have_pg else "none (no process group)",
+            "ms_per_step_without_collective": round(1e3 * t_plain / args.steps, 4),
+            "projected_speedup_without_collective": round(elapsed / t_plain, 3),
             "outputs_equal_unsharded_rows": same,
-            "note": "rank 0's share of a %d-rank run timed on one GPU (peers' maps arrive by a device copy: no "
-                    "link latency, no rank skew); projected_speedup = T(8 agents, 1 GPU) / T(share) bounds the "
-                    "measured curve from above" % W}
+            "note": "rank 0's share of a %d-rank run timed on one GPU: the peers' maps arrive by a device copy and, when a "
+                    "process group exists, the real RCCL all-gather kernel runs between the two graphs (its launch + "
+                    "kernel latency; no link time, no rank skew); projected_speedup = T(8 agents, 1 GPU) / T(share) "
+                    "bounds the measured curve from above" % W}
     return res
 
 

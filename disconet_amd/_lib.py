@@ -64,6 +64,8 @@ SIGNATURES = {
                            c_void_p, c_void_p, c_void_p]),
     "dn_conv2d": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p]),
+    "dn_conv2d_taps": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                               c_long, c_int, c_int, c_void_p]),
     "dn_post1x1_packed_floats": (c_size_t, []),
     "dn_post1x1_pack_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dn_conv2d_post1x1": (c_int, [POINTER(ConvDesc), POINTER(Post1x1Desc)] + [c_void_p] * 11),
@@ -124,6 +126,8 @@ SIGNATURES = {
                               c_int, c_int, c_void_p]),
     "dn_conv_dgrad_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                       c_void_p]),
+    "dn_conv_dgrad_class_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                            POINTER(c_int), c_void_p]),
     "dn_bn_train_stats": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                   c_void_p, c_void_p]),
     "dn_bn_train_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,

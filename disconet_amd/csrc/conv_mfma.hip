@@ -92,6 +92,11 @@ struct ConvArgs {
   const float* shift2;
   float* out_b;         // columns [split2, c_out2) of the fused stage (may be null)
   int c_out2, relu2, split2, ldo_b;
+  // dn_conv2d_taps: only the taps of `tap_mask` are multiplied (bit ky * 3 + kx), and the output pixel (oy, ox) of
+  // image n lands at out + n * out_img + oy * out_row + ox * out_px floats (POST == 0 epilogue)
+  int tap_mask;
+  long out_img;
+  int out_row, out_px;
 };
 
 constexpr int kcp_of(int ksize) { return ksize == 3 ? 16 : 32; }
@@ -388,6 +393,7 @@ conv_mfma_kernel(const ConvArgs a) {
   auto mfma_chunk = [&]() {
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
+      if (TAPS > 1 && !((a.tap_mask >> tap) & 1)) continue;      // uniform: a masked tap costs one scalar test
       const int toff = ((tap / KS) * PW + (tap % KS)) * PS;
       if constexpr (!kSplit) {
 #pragma unroll
@@ -584,7 +590,7 @@ conv_mfma_kernel(const ConvArgs a) {
     }
     __syncthreads();
     const int ncol = min(BN, a.c_out - tc.n0);             // valid channels of this tile
-    float* obase = a.out + (size_t)tc.img * a.h_out * a.w_out * a.ldo + tc.n0;
+    float* obase = a.out + (size_t)tc.img * a.out_img + tc.n0;
     if (a.vec_out && (ncol & 3) == 0) {
       const int nc4 = ncol >> 2;
       for (int idx = t; idx < T::BM * nc4; idx += NT) {
@@ -593,7 +599,7 @@ conv_mfma_kernel(const ConvArgs a) {
         if (oy < a.h_out && ox < a.w_out) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[m * CS + 4 * c4]);
           if (!kNoStore || v[0] == 12345.678f)
-            *reinterpret_cast<f32x4*>(obase + ((size_t)oy * a.w_out + ox) * a.ldo + 4 * c4) = v;
+            *reinterpret_cast<f32x4*>(obase + (size_t)oy * a.out_row + (size_t)ox * a.out_px + 4 * c4) = v;
         }
       }
     } else {
@@ -602,7 +608,7 @@ conv_mfma_kernel(const ConvArgs a) {
         const int oy = tc.oy0 + m / TW, ox = tc.ox0 + m % TW;
         if (oy < a.h_out && ox < a.w_out) {
           const float v = Cs[m * CS + c];
-          if (!kNoStore || v == 12345.678f) obase[((size_t)oy * a.w_out + ox) * a.ldo + c] = v;
+          if (!kNoStore || v == 12345.678f) obase[(size_t)oy * a.out_row + (size_t)ox * a.out_px + c] = v;
         }
       }
     }
@@ -984,6 +990,8 @@ int fill_args(const dn_conv_desc* d, const float* src0, const float* src1, const
   a.wpk_bytes = (int)(dn_conv_packed_weight_floats(d) * sizeof(float));
   a.w2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out_b = nullptr;
   a.c_out2 = 0; a.relu2 = 0; a.split2 = 0; a.ldo_b = 0;
+  a.tap_mask = 0x1ff;
+  a.out_px = d->ldo; a.out_row = a.w_out * d->ldo; a.out_img = (long)a.h_out * a.w_out * d->ldo;
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec0 = (d->c0 % 4 == 0 && d->ld0 % 4 == 0 && aligned16(src0)) ? 1 : 0;
   a.vec1 = (d->c1 > 0 && d->c1 % 4 == 0 && d->ld1 % 4 == 0 && aligned16(src1)) ? 1 : 0;
@@ -999,15 +1007,40 @@ int fill_args(const dn_conv_desc* d, const float* src0, const float* src1, const
 
 }  // namespace
 
+namespace {
+int conv2d_impl(const dn_conv_desc* d, const float* src0, const float* src1, const float* packed, const float* scale,
+                const float* shift, float* out, int tap_mask, long out_img, int out_row, int out_px, void* stream);
+}
+
 extern "C" int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* src1,
                          const float* packed, const float* scale, const float* shift,
                          float* out, void* stream) {
+  return conv2d_impl(d, src0, src1, packed, scale, shift, out, 0x1ff, 0, 0, 0, stream);
+}
+
+extern "C" int dn_conv2d_taps(const dn_conv_desc* d, const float* src0, const float* src1, const float* packed,
+                              const float* scale, const float* shift, float* out, int tap_mask, long out_img_stride,
+                              int out_row_stride, int out_px_stride, void* stream) {
+  DN_REQUIRE(d && d->ksize == 3 && tap_mask > 0 && tap_mask <= 0x1ff, "conv (taps): a 3x3 layer and a non-empty 9-bit mask");
+  DN_REQUIRE(out_px_stride >= d->c_out && out_row_stride > 0 && out_img_stride > 0,
+             "conv (taps): output strides (floats) must be positive, pixel stride >= c_out");
+  return conv2d_impl(d, src0, src1, packed, scale, shift, out, tap_mask, out_img_stride, out_row_stride, out_px_stride, stream);
+}
+
+namespace {
+int conv2d_impl(const dn_conv_desc* d, const float* src0, const float* src1, const float* packed, const float* scale,
+                const float* shift, float* out, int tap_mask, long out_img, int out_row, int out_px, void* stream) {
   if (int rc = validate(d)) return rc;
   DN_REQUIRE(src0 && packed && scale && shift && out, "conv: null pointer");
   DN_REQUIRE(d->c1 == 0 || src1, "conv: c1 > 0 but src1 is null");
   const Cfg c = select_cfg(*d);
   ConvArgs a;
   if (int rc = fill_args(d, src0, src1, packed, scale, shift, out, a)) return rc;
+  a.tap_mask = tap_mask;
+  if (out_img > 0) {
+    a.out_img = out_img; a.out_row = out_row; a.out_px = out_px;
+    a.vec_out = a.vec_out && out_px % 4 == 0 && out_row % 4 == 0 && out_img % 4 == 0;
+  }
   hipStream_t s = (hipStream_t)stream;
 #define DN_CONV_CASE(ID, ...)                                                         \
   case ID:                                                                            \
@@ -1030,3 +1063,4 @@ extern "C" int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* 
 #undef DN_CONV_CASE
   return dn::fail(DN_ERR_UNSUPPORTED, "conv: no tile configuration");
 }
+}  // namespace

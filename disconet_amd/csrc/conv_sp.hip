@@ -591,12 +591,13 @@ conv_sp_kernel(const SpArgs a) {
           const f32x4 sh1 = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 1 : 0][POST == 2 ? co & 63 : 0]);
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[wm][wn][4 * g + e] * sc1[e] + sh1[e];
-          note_nan4(nan_seen, v);
-          if (a.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[wm][wn][4 * g + e] * sc1[e] + sh1[e];
+            if (a.relu) v[e] = fmaxf(v[e], 0.f);
           }
+          // (no NaN test here: this launch sits at its register budget -- the test cost 30 us of spills -- and its
+          // outputs are fp32, where a NaN of the hidden layer that survives the ReLU shows; NaNs of the input were
+          // flagged by the epilogue that produced it)
           split4(v, hi[g], lo[g], amax);
         }
         half8 xh[2], xl[2];

@@ -500,6 +500,47 @@ __global__ void dgrad_weights_kernel(const float* __restrict__ w, int c_out, int
 }
 }  // namespace
 
+namespace {
+// Weights of ONE parity class of the data gradient of a STRIDE-2 3x3 layer (the "parity-phase" form).  Input pixel
+// i = 2 m + p of the forward layer receives  dx[i] = sum over taps t with (i - t + 1) even of  W[t]^T dz[(i - t + 1) / 2]:
+//   p = 0:  t = 1             -> dz[m]
+//   p = 1:  t = 0 -> dz[m + 1],  t = 2 -> dz[m]
+// per axis.  As a 3x3 stride-1 conv over dz (taps v reading dz[m + v - 1]) that is v[1] = W[1] (p = 0) and v[1] = W[2],
+// v[2] = W[0] (p = 1); every other tap is zero and is masked out of the launch (dn_conv2d_taps).  One class touches 1, 2,
+// 2 or 4 of the 9 taps: a quarter of the MFMAs of the zero-stuffed form (which runs all 9 taps on every input pixel).
+// v[ci][co][vy][vx] <- w[co][ci_first + ci][ty][tx], zero elsewhere
+__global__ void dgrad_class_weights_kernel(const float* __restrict__ w, int c_out, int cin_total, int ci_first, int c_in,
+                                           int py, int px, float* __restrict__ v) {
+  const long total = (long)c_in * c_out * 9;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(idx % 9), vy = t / 3, vx = t % 3;
+    const long r = idx / 9;
+    const int co = (int)(r % c_out), ci = (int)(r / c_out);
+    auto src_tap = [](int p, int vv) { return p == 0 ? (vv == 1 ? 1 : -1) : (vv == 1 ? 2 : vv == 2 ? 0 : -1); };
+    const int ty = src_tap(py, vy), tx = src_tap(px, vx);
+    v[idx] = (ty < 0 || tx < 0) ? 0.f : w[((size_t)co * cin_total + ci_first + ci) * 9 + ty * 3 + tx];
+  }
+}
+}  // namespace
+
+extern "C" int dn_conv_dgrad_class_weights(const float* w_oihw, int c_out, int cin_total, int ci_first, int c_in, int py,
+                                           int px, float* v_oihw, int* tap_mask, void* stream) {
+  DN_REQUIRE(w_oihw && v_oihw && tap_mask, "dgrad class weights: null pointer");
+  DN_REQUIRE(c_out > 0 && c_in > 0 && ci_first >= 0 && ci_first + c_in <= cin_total && (py | px) >= 0 && py <= 1 && px <= 1,
+             "dgrad class weights: bad shape / parity");
+  const long total = (long)c_in * c_out * 9;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(dgrad_class_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, c_out, cin_total,
+                     ci_first, c_in, py, px, v_oihw);
+  const int rows = py == 0 ? 0b010 : 0b110, cols = px == 0 ? 0b010 : 0b110;     // bit v set: tap row / column v is used
+  int m = 0;
+  for (int vy = 0; vy < 3; ++vy)
+    for (int vx = 0; vx < 3; ++vx)
+      if (((rows >> vy) & 1) && ((cols >> vx) & 1)) m |= 1 << (vy * 3 + vx);
+  *tap_mask = m;
+  return dn::check_launch("dgrad_class_weights_kernel");
+}
+
 extern "C" int dn_conv_dgrad_weights(const float* w_oihw, int c_out, int cin_total, int ci_first,
                                      int c_in, int ksize, float* wt_oihw, void* stream) {
   DN_REQUIRE(w_oihw && wt_oihw, "dgrad weights: null pointer");

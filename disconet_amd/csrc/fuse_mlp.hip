@@ -47,6 +47,8 @@ struct FuseMlpArgs {
   float* weights_out;
   int batch, agents, hw, only_v2i, ego_first, ego_count, tiles;
   int warped_fm;   // `warped` is fragment-major (dn_warp_neighbors_fm): a k-step of a tile is two contiguous 1 KB runs
+  int abl;         // DN_FUSE_ABL (tools/fuse_ab.py, timing only -- results are garbage): 1 = pass 2 reads no rows, 2 = layer 1
+                   // reads each row's first k-step only, 4 = no layers 2-4, 8 = layer 1 splits no operands
 };
 
 __device__ inline half8 frag_of(const unsigned char* base, int idx) {
@@ -189,8 +191,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
 #pragma unroll
       for (int g = 0; g < NG; ++g)
         if (g < cnt) {
-          r0[s][g] = *reinterpret_cast<const f32x4*>(rows[g].p + ks * rows[g].kss);
-          r1[s][g] = *reinterpret_cast<const f32x4*>(rows[g].p + ks * rows[g].kss + rows[g].r1);
+          const int kk = (a.abl & 2) ? 0 : ks;
+          r0[s][g] = *reinterpret_cast<const f32x4*>(rows[g].p + kk * rows[g].kss);
+          r1[s][g] = *reinterpret_cast<const f32x4*>(rows[g].p + kk * rows[g].kss + rows[g].r1);
         }
     };
     auto mma = [&](int sw, int sr) {
@@ -198,7 +201,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
       for (int g = 0; g < NG; ++g)
         if (g < cnt) {
           half8 fh, fl;
-          frag_from(r0[sr][g], r1[sr][g], fh, fl);
+          if (a.abl & 8) {
+            fh = __builtin_bit_cast(half8, r0[sr][g]);
+            fl = __builtin_bit_cast(half8, r1[sr][g]);
+          } else {
+            frag_from(r0[sr][g], r1[sr][g], fh, fl);
+          }
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[sw][nt], fh, acc[g][nt], 0, 0, 0);
 #pragma unroll
@@ -228,6 +236,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
 
   // ---- layers 2-4 on acc (= E + F_k) -> exp(s)
   auto tail = [&](f32x16 (&acc)[4]) -> float {
+    if (a.abl & 4) return acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
@@ -387,6 +396,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
   f32x4 f0[KSW], f1[KSW], y0[2][KSW], y1[2][KSW];
   auto yload = [&](int k, int s) {
     const Row row = row_of(k);
+    if (a.abl & 1) {
+#pragma unroll
+      for (int ks = 0; ks < KSW; ++ks) y0[s][ks] = y1[s][ks] = f32x4{1.f, 2.f, 3.f, (float)k};
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < KSW; ++ks) {
       y0[s][ks] = *reinterpret_cast<const f32x4*>(row.p + (ks_first + ks) * row.kss);
@@ -530,6 +544,8 @@ int fuse_mlp_impl(const float* feat, const float* warped, int warped_fm, const i
   a.ego_first = ego_first; a.ego_count = ego_count;
   a.tiles = (hw + 31) / 32;
   a.warped_fm = warped_fm;
+  static const int abl_env = [] { const char* e = getenv("DN_FUSE_ABL"); return e ? atoi(e) : 0; }();
+  a.abl = abl_env;
   dim3 grid(batch * ego_count * a.tiles);   // one workgroup per 32 pixels of one (sample, ego)
   hipStream_t s = (hipStream_t)stream;
   // Four waves per tile when the launch leaves SIMDs idle (fewer tiles than 2 per CU: 128 tiles for one rank's

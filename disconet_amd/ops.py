@@ -5,6 +5,7 @@ Every function requires float32 CUDA(HIP) tensors and launches on torch's
 current stream.  No CPU fallback: a CPU tensor raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -180,6 +181,20 @@ def conv2d(d, src0, packed, scale, shift, src1=None, out=None):
     check(_lib.load().dn_conv2d(ctypes.byref(d), _ptr(src0), _ptr(src1), _ptr(packed), _ptr(scale),
                                 _ptr(shift), _ptr(out), _stream()), "dn_conv2d")
     return out
+
+
+def conv2d_taps(d, src0, packed, scale, shift, out_view, tap_mask):
+    """3x3 NHWC conv restricted to the taps of `tap_mask`, written into `out_view` -- a strided [n, h_out, w_out, c_out]
+    view (channels contiguous), e.g. dx[:, py::2, px::2, :] -- through dn_conv2d_taps."""
+    _need_gpu(src0, packed, scale, shift, out_view)
+    ho, wo = conv_out_hw(d)
+    if tuple(out_view.shape) != (d.n_images, ho, wo, d.c_out) or out_view.stride(3) != 1:
+        raise _lib.DnError("conv2d_taps: output view %s / strides %s does not match [%d, %d, %d, %d] with contiguous channels"
+                           % (tuple(out_view.shape), out_view.stride(), d.n_images, ho, wo, d.c_out))
+    check(_lib.load().dn_conv2d_taps(ctypes.byref(d), _ptr(src0), None, _ptr(packed), _ptr(scale), _ptr(shift),
+                                     _ptr(out_view), int(tap_mask), out_view.stride(0), out_view.stride(1),
+                                     out_view.stride(2), _stream()), "dn_conv2d_taps")
+    return out_view
 
 
 # ---------------------------------------------------------------------------
@@ -389,9 +404,12 @@ def sp_conv2d(d, src0, packed, scale, shift, src1=None, out=None, nhwc_copy=Fals
     p1 = _ptr(src1.data) if src1 is not None else None
     if kslices > 1 and d.math != 3:
         nbytes = min(int(lib.dn_spconv_workspace_bytes(ctypes.byref(d), kslices)), _KS_WORKSPACE_CAP)
+        if os.environ.get("DN_SP_KS_NOSPLIT", "0") == "1":      # A/B runs: every tile whole (the slices folded in registers)
+            nbytes = 0
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=src0.device)
         check(lib.dn_spconv2d_ks(ctypes.byref(d), kslices, _ptr(src0.data), p1, _ptr(packed), _ptr(scale), _ptr(shift),
-                                 _ptr(out.data), _ptr(flat), d.c_out if nhwc_copy else 0, _ptr(ws), nbytes, _stream()),
+                                 _ptr(out.data), _ptr(flat), d.c_out if nhwc_copy else 0, _ptr(ws) if nbytes else None, nbytes,
+                                 _stream()),
               "dn_spconv2d_ks")
         return (out, flat) if nhwc_copy else out
     if nhwc_copy:

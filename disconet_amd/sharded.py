@@ -113,10 +113,15 @@ class GraphedAgentStep:
     """
 
     def __init__(self, engine, make_bevs, trans_matrices, num_agent_tensor, batch_size, first, count,
-                 group=None, emulate_feat_all=None):
+                 group=None, emulate_feat_all=None, emulate_collective=False):
+        """emulate_collective (with emulate_feat_all, needs an initialised process group -- one rank is enough): the
+        emulated exchange ALSO runs the real RCCL all_gather_into_tensor of this rank's maps, so that the collective's
+        launch + kernel latency sits between the two graphs as it will on 8 ranks (link time does not)."""
         from .graph import GraphedStep
         self.engine, self.group, self.first, self.count, self.batch = engine, group, first, count, batch_size
         self.emulated = emulate_feat_all is not None
+        self.emulate_collective = bool(emulate_collective and self.emulated and dist.is_available() and dist.is_initialized())
+        self._own_gather = None
         layer = engine.layer
         with torch.no_grad():
             self.graph_a = GraphedStep(lambda: engine.encode(make_bevs()))
@@ -145,6 +150,11 @@ class GraphedAgentStep:
     def exchange(self):
         x_local = self.enc[self.engine.layer]
         if self.emulated:
+            if self.emulate_collective:                          # the collective's own launch + kernel, on one rank
+                if self._own_gather is None:
+                    self._own_gather = x_local.new_empty((x_local.shape[0] * dist.get_world_size(self.group),)
+                                                         + tuple(x_local.shape[1:]))
+                all_gather_agent_major(x_local, self.group, out=self._own_gather)
             self.feat_all.copy_(self.peers)                      # the peers' maps arriving
             lo = self.first * self.batch
             self.feat_all[lo:lo + x_local.shape[0]].copy_(x_local)

@@ -21,6 +21,8 @@ Two ways in:
     DiscoNet.forward returns tensors attached to one autograd node whose backward is the
     explicit reverse pass (torch only routes d(loss)/d(cls, loc) in and parameter grads out).
 """
+import os
+
 import torch
 
 from . import ops, train_ops as T
@@ -285,7 +287,24 @@ class TrainEngine:
         this backward amplifies relative error by ~1e5 (BatchNorm's mean subtraction, see
         tests/test_gpu_train_step.py) -- measured 3.6 % error on conv5_1.weight's gradient with
         split-f16 dgrad against 1 % with fp32 (= ATen's own fp32 autograd)."""
-        wt = T.dgrad_weights(w.reshape(w.shape[0], w.shape[1], d.ksize, d.ksize), ci_first, c_in)
+        w4 = w.reshape(w.shape[0], w.shape[1], d.ksize, d.ksize)
+        if (d.stride == 2 and d.ksize == 3 and d.h_in % 2 == 0 and d.w_in % 2 == 0
+                and os.environ.get("DN_DGRAD_PARITY", "1") != "0"):
+            # parity-phase form: four stride-1 convs over dz of 1 / 2 / 2 / 4 taps, each writing one parity class of dx
+            # (include/disconet_train.h :: dn_conv_dgrad_class_weights) -- a quarter of the zero-stuffed form's MFMAs
+            n_in = (w4.shape[1] - ci_first) if c_in is None else c_in
+            dev = dz.device
+            if dx_out is None:
+                dx_out = torch.empty((d.n_images, d.h_in, d.w_in, n_in), dtype=torch.float32, device=dev)
+            ho, wo = d.h_in // 2, d.w_in // 2
+            dd = ops.conv_desc(d.n_images, ho, wo, d.c_out, n_in, 3, 1, False, ld0=dz.stride(2), math=0)
+            one, zero = self._const(dev, n_in, 1.0), self._const(dev, n_in, 0.0)
+            for py in (0, 1):
+                for px in (0, 1):
+                    v, mask = T.dgrad_class_weights(w4, py, px, ci_first, n_in)
+                    ops.conv2d_taps(dd, dz, ops.pack_conv_weights(dd, v), one, zero, dx_out[:, py::2, px::2, :], mask)
+            return dx_out
+        wt = T.dgrad_weights(w4, ci_first, c_in)
         c_in = wt.shape[0]
         dd = ops.conv_desc(d.n_images, d.h_in, d.w_in, d.c_out, c_in, d.ksize, 1, False,
                            up0=2 if d.stride == 2 else 0, ld0=dz.stride(2),

@@ -57,6 +57,18 @@ def dgrad_weights(w, ci_first=0, c_in=None):
     return wt
 
 
+def dgrad_class_weights(w, py, px, ci_first=0, c_in=None):
+    """parity class (py, px) of a stride-2 3x3 layer's data gradient: -> (v [c_in, c_out, 3, 3], tap mask)"""
+    _need_gpu(w)
+    c_out, cin_total = w.shape[0], w.shape[1]
+    c_in = cin_total - ci_first if c_in is None else c_in
+    v = torch.empty((c_in, c_out, 3, 3), dtype=torch.float32, device=w.device)
+    mask = ctypes.c_int(0)
+    check(_lib.load().dn_conv_dgrad_class_weights(_ptr(w), c_out, cin_total, ci_first, c_in, py, px, _ptr(v),
+                                                  ctypes.byref(mask), _stream()), "dn_conv_dgrad_class_weights")
+    return v, mask.value
+
+
 # ---- batch norm, training mode ------------------------------------------------------------
 def bn_stats(z, n_groups=1):
     """z [..., c] dense NHWC rows -> (mean, biased var) each [n_groups, c]"""

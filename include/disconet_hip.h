@@ -152,6 +152,13 @@ int dn_fold_bn(const float* bias, const float* gamma, const float* beta,
 int dn_conv2d(const dn_conv_desc* d, const float* src0, const float* src1,
               const float* packed, const float* scale, const float* shift,
               float* out, void* stream);
+/* dn_conv2d of a 3x3 layer restricted to the taps of `tap_mask` (bit ky * 3 + kx; the others are skipped, not
+ * multiplied by zero) with an explicitly strided output: pixel (oy, ox) of image n is written at
+ * out + n * out_img_stride + oy * out_row_stride + ox * out_px_stride floats (+ channel).  The training step's
+ * parity-phase stride-2 data gradient (disconet_train.h :: dn_conv_dgrad_class_weights) is four of these. */
+int dn_conv2d_taps(const dn_conv_desc* d, const float* src0, const float* src1, const float* packed,
+                   const float* scale, const float* shift, float* out, int tap_mask, long out_img_stride,
+                   int out_row_stride, int out_px_stride, void* stream);
 
 /* Fused "3x3 conv + affine + ReLU, then 1x1 conv + affine (+ReLU)" in one launch:
  * the activated 64-channel tile stays in LDS between the two layers.  Used for

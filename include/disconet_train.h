@@ -48,6 +48,15 @@ int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const float* src1, c
 int dn_conv_dgrad_weights(const float* w_oihw, int c_out, int cin_total, int ci_first, int c_in,
                           int ksize, float* wt_oihw, void* stream);
 
+/* Parity-phase data gradient of a STRIDE-2 3x3 layer (even h_in, w_in): input pixel (2 m + py, 2 n + px) receives
+ * gradient only through the taps whose offset has its parity, so dx splits into four stride-1 convs over dz, one per
+ * class (py, px), of 1, 2, 2 and 4 taps -- a quarter of the MFMAs of the zero-stuffed form (dn_conv_desc.up0 = 2, kept for
+ * odd map sizes).  dn_conv_dgrad_class_weights writes class (py, px)'s 3x3 kernel v[ci][co][3][3] (unused taps zero) and
+ * the mask of the taps it uses; dn_conv2d_taps (disconet_hip.h) runs it over dz [n][h_out][w_out][c_out] with only those
+ * taps multiplied, writing output pixel (m, n) to dx[2 m + py][2 n + px] through the output strides. */
+int dn_conv_dgrad_class_weights(const float* w_oihw, int c_out, int cin_total, int ci_first, int c_in, int py, int px,
+                                float* v_oihw, int* tap_mask, void* stream);
+
 /* ---- batch norm in training mode (+ ReLU) ---------------------------------------------- */
 
 /* Statistics over `rows_per_group` pixels for each of `n_groups` consecutive groups of rows

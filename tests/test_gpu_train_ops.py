@@ -117,6 +117,43 @@ def test_conv_dgrad_through_the_forward_engine(case, math):
     assert rel_err(dx, nhwc(x.grad)) < (2e-5 if math == "f32" else 1e-4)
 
 
+@pytest.mark.parametrize("n,h,w,c_in,c_out,ci_first,take", [(2, 32, 32, 32, 64, 0, None), (3, 20, 24, 128, 256, 0, None),
+                                                            (2, 64, 64, 64, 128, 0, None), (2, 16, 24, 96, 48, 32, 64)])
+def test_parity_phase_stride2_dgrad(n, h, w, c_in, c_out, ci_first, take):
+    """data gradient of a stride-2 3x3 layer as four tap-masked stride-1 convs over dz, one per input-pixel parity
+    class (dn_conv_dgrad_class_weights + dn_conv2d_taps): against float64 autograd, and against the zero-stuffed form
+    (same exact-fp32 products, another summation order); a column block of a wider weight; a strided dx destination"""
+    from disconet_amd import ops, train_ops
+    g = torch.Generator().manual_seed(5 + h)
+    x = torch.randn(n, c_in, h, w, generator=g).double().requires_grad_(True)
+    wgt = torch.randn(c_out, c_in, 3, 3, generator=g) * 0.1
+    z = F.conv2d(x, wgt.double(), None, 2, 1)
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz.double())
+    cnt = c_in - ci_first if take is None else take
+    want = nhwc(x.grad)[..., ci_first:ci_first + cnt]
+
+    dev = _dev()
+    dzd, wd = nhwc(dz).to(dev), wgt.to(dev)
+    wide = torch.full((n, h, w, cnt + 8), 7.0, device=dev)              # dx lands in a channel slice of a wider tensor
+    dx = wide[..., 4:4 + cnt]
+    dd = ops.conv_desc(n, h // 2, w // 2, c_out, cnt, 3, 1, False, math="f32")
+    one, zero = torch.ones(cnt, device=dev), torch.zeros(cnt, device=dev)
+    masks = []
+    for py in (0, 1):
+        for px in (0, 1):
+            v, mask = train_ops.dgrad_class_weights(wd, py, px, ci_first, cnt)
+            masks.append(bin(mask).count("1"))
+            ops.conv2d_taps(dd, dzd, ops.pack_conv_weights(dd, v), one, zero, dx[:, py::2, px::2, :], mask)
+    assert masks == [1, 2, 2, 4]
+    assert rel_err(dx, want) < 2e-5
+    assert float(wide[..., :4].min()) == 7.0 and float(wide[..., 4 + cnt:].max()) == 7.0      # nothing outside the slice
+    wt = train_ops.dgrad_weights(wd, ci_first, cnt)
+    ds = ops.conv_desc(n, h, w, c_out, cnt, 3, 1, False, up0=2, math="f32")
+    stuffed = ops.conv2d(ds, dzd, ops.pack_conv_weights(ds, wt), one, zero)
+    assert rel_err(dx, stuffed.cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("shape,groups", [((4, 32, 32, 64), 1), ((6, 16, 16, 128), 6),
                                           ((2, 64, 64, 13), 1), ((5, 32, 32, 8), 5),
                                           ((3, 32, 32, 1), 3), ((2, 16, 16, 512), 1)])

@@ -24,7 +24,23 @@ def is_conv(r):
     return "conv_sp_kernel" in r["Kernel_Name"] or "conv_spq_kernel" in r["Kernel_Name"]
 
 
-conv = [r for r in sel if is_conv(r)]
+def is_ksl(r):      # K-sliced launch (template flag KSL = 1): may be followed by its fix-up pass, the same kernel again
+    kn = r["Kernel_Name"]
+    args = kn.split("<")[1].split(">")[0].replace(" ", "").split(",") if "<" in kn else []
+    return ("conv_spq_kernel" in kn and len(args) >= 4 and args[3] == "1") or ("conv_sp_kernel" in kn and len(args) >= 17 and args[16] == "1")
+
+
+conv = []
+for r in sel:
+    if not is_conv(r):
+        continue
+    if conv and is_ksl(r) and conv[-1]["Kernel_Name"] == r["Kernel_Name"] and not conv[-1].get("_fixup"):
+        m = dict(conv[-1])          # main launch + fix-up pass of one layer: one row, durations added
+        m["End_Timestamp"] = str(int(m["End_Timestamp"]) + int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        m["_fixup"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        conv[-1] = m
+    else:
+        conv.append(dict(r))
 assert len(conv) == len(LAYERS), (len(conv), len(LAYERS))
 print("%-30s %9s %10s %9s   %s" % ("layer", "us", "GFLOP", "TFLOP/s", "kernel configuration <KS,S,TH,TW,BN,TG,CA,WM,WN,WTM,WTN,POST,ABL,BSTAT,UPM,AHI>"))
 tot_us = tot_gf = 0.0
@@ -34,6 +50,8 @@ for i, (r, (name, px, cin, cout, k)) in enumerate(zip(conv, LAYERS)):
     kn = r["Kernel_Name"]
     cfg = ("quad-merged BN=" + kn.split("conv_spq_kernel<")[1].split(">")[0]) if "conv_spq_kernel" in kn else \
         "<" + kn.split("conv_sp_kernel<")[1].split(">")[0].replace(" ", "") + ">"
+    if r.get("_fixup"):
+        cfg += "  K-sliced: %.1f us of it the fix-up pass" % r["_fixup"]
     print("%-30s %9.1f %10.2f %9.1f   %s" % (name, us, gf, gf / (us * 1e-6) / 1e3, cfg))
     tot_us += us
     tot_gf += gf
