@@ -469,7 +469,7 @@ conv_sp_kernel(const SpArgs a) {
       if (wn_r >= 0) {            // register-resident affine (channels past c_out: scale = shift = 0 -> 0)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = c[4 * g + e] * sc_r[kRegAffine ? wn_r : 0][g][e] + sh_r[kRegAffine ? wn_r : 0][g][e];
-        note_nan4(nan_seen, v);
+        note_nan4_tile(nan_seen, v, g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);
       } else if (POST == 1 && wn_r == -2) {   // stage-2 affine of the fused 1x1 from LDS (zero past c_out2)
@@ -477,7 +477,7 @@ conv_sp_kernel(const SpArgs a) {
         const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 3 : 0][co & 63]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = c[4 * g + e] * sc[e] + sh[e];
-        note_nan4(nan_seen, v);
+        note_nan4_tile(nan_seen, v, g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = fmaxf(v[e], floor_v);
@@ -490,7 +490,7 @@ conv_sp_kernel(const SpArgs a) {
           const int ci = min(co + e, c_lim - 1);
           v[e] = c[4 * g + e] * scale[ci] + shift[ci];
         }
-        note_nan4(nan_seen, v);
+        note_nan4_tile(nan_seen, v, g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = fmaxf(v[e], floor_v);
@@ -670,7 +670,7 @@ conv_sp_kernel(const SpArgs a) {
             const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 1 : 0][POST == 1 ? co : 0]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
-            note_nan4(nan_seen, v);
+            note_nan4_tile(nan_seen, v, g);
             if (a.relu) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);

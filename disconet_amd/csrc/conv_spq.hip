@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
-          note_nan4(nan_seen, v);
+          note_nan4_tile(nan_seen, v, g);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);
           split4(v, hi[g], lo[g], amax);

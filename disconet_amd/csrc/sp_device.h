@@ -57,8 +57,20 @@ __device__ inline void note_range(float amax, bool nan_seen = false) {
 }
 // NaN test of four values BEFORE a max / clamp can hide them: two unordered compares (true when either operand is a
 // NaN), the lane masks OR-ed on the scalar unit -- half a VALU instruction per value.
+#ifndef DN_NANCHECK
+#define DN_NANCHECK 0      // conv epilogues: 0 = no test (shipped), 1 = every register quad, 2 = quad 0 of every accumulator tile
+#endif
 __device__ inline void note_nan4(bool& seen, const f32x4 t) {
   seen |= __builtin_isunordered(t[0], t[1]) | __builtin_isunordered(t[2], t[3]);
+}
+// NaN test of a conv epilogue's pre-activation values.  Measured in one lease (profiles/r04_nancheck_ab.txt): every quad
+// costs 1.3 % of the step (3-8 us on each short-K layer), quad 0 of every tile 0.5-1 % -- so the shipped conv epilogues
+// carry NONE.  A NaN cannot appear inside the conv stack out of finite operands (overflow is clamped and flagged):
+// its sources are the parameters (refused when the plan is packed, model.py :: _check_finite_parameters), the inputs
+// (dn_sp_from_nhwc flags them; an occupancy grid cannot hold one) and inf / inf in the attention softmax, which
+// dn_disco_fuse_mlp's output test reports (bit 2).
+__device__ inline void note_nan4_tile(bool& seen, const f32x4 t, int g) {
+  if (DN_NANCHECK == 1 || (DN_NANCHECK == 2 && g == 0)) note_nan4(seen, t);
 }
 
 // Stream-ordered readers (no null-stream copy: a hipMemcpyFromSymbol would neither wait for kernels on non-blocking

@@ -479,9 +479,22 @@ class DiscoNet(nn.Module):
     def _get_plan(self):
         sig = self._signature()
         if self._plan is None or sig != self._plan_sig:
+            self._check_finite_parameters()
             self._plan = self._build_plan()
             self._plan_sig = sig
         return self._plan
+
+    def _check_finite_parameters(self):
+        """NaN / Inf in a weight, bias or BatchNorm statistic is refused HERE, once per plan (one reduction + one host
+        read): inside the step a ReLU or the clamp of the hi/lo split would turn the resulting NaN into a finite number
+        and nothing downstream could tell.  (Testing for NaN in the conv epilogues cost ~1 % of the step:
+        profiles/r04_nancheck_ab.txt; overflow at run time is the range guard's clamp bit, a NaN out of the attention
+        softmax its NaN bit.)"""
+        bad = [n for n, t in list(self.named_parameters()) + list(self.named_buffers())
+               if t.is_floating_point() and t.numel() and not bool(torch.isfinite(t).all())]
+        if bad:
+            raise ops._lib.DnError("DiscoNet: non-finite values in %s%s: refusing to pack a plan whose outputs would hold "
+                                   "plausible garbage" % (", ".join(bad[:4]), " ..." if len(bad) > 4 else ""))
 
     # ------------------------------------------------------------------
     # forward

@@ -61,8 +61,11 @@ const char* dn_last_error(void);
  * Every kernel that splits values keeps a sticky word in device memory:
  *   bit 1 (2): a value with |x| > 2^14 was split -- within two binades of the limit, rescale;
  *   bit 0 (1): a value was clamped to +-65504 -- results of this device since the last reset are wrong;
- *   bit 2 (4): a NaN reached an epilogue.  ReLU and the clamp turn a NaN into a finite number, so without this
- *              bit it would vanish from the outputs.
+ *   bit 2 (4): a NaN was split by dn_sp_from_nhwc (input) or came out of dn_disco_fuse_mlp (inf / inf in the softmax).
+ *              ReLU and the clamp turn a NaN into a finite number, so without this bit it would vanish.  The conv
+ *              epilogues do NOT test (it cost ~1 % of the step): out of finite operands they cannot produce a NaN
+ *              (overflow is clamped and flagged by bit 0) -- the caller must not pack non-finite weights / scale /
+ *              shift (the Python host refuses them when it packs a plan).
  * dn_sp_range_flags: the OR over the library's kernels on the current device; with reset != 0 it clears them.
  *   BLOCKING (hipDeviceSynchronize + a device -> host copy): validation time.
  * dn_sp_range_flags_async: the same OR enqueued on `stream` into *dst_device (a device word the caller zeroed):

@@ -274,8 +274,9 @@ def test_range_guard_reports_a_clamped_activation(monkeypatch):
     assert ops.sp_range_flags(reset=True) & 1
 
 
-def test_range_guard_reports_a_nan(monkeypatch):
-    """ReLU and the split's clamp turn a NaN into a finite number; the epilogues test for it before that happens"""
+def test_non_finite_parameters_and_inputs_are_refused():
+    """ReLU and the split's clamp turn a NaN into a finite number, so it has to be caught where it enters: a
+    non-finite parameter when the plan is packed, a NaN input when it is split (range flag bit 2)"""
     from disconet_amd import ops
     from disconet_amd._lib import DnError
     c = cases.MODEL_CASES["cfg1_f1"]
@@ -284,11 +285,13 @@ def test_range_guard_reports_a_nan(monkeypatch):
         ref.u_encoder.conv1_1.bias[3] = float("nan")
     bevs, trans, na = cases.model_inputs("cfg1_f1")
     m = _product(ref, c["map_hw"], c["agents"], math="sp")
-    monkeypatch.setenv("DN_SP_CHECK", "1")
-    ops.sp_range_flags(reset=True)
-    with pytest.raises(DnError, match="NaN"):
+    with pytest.raises(DnError, match="non-finite values in u_encoder.conv1_1.bias"):
         _gpu_outputs(m, bevs, trans, na, c["batch"])
-    assert ops.sp_range_flags(reset=True) == 0
+    ops.sp_range_flags(reset=True)
+    x = torch.rand(2, 8, 8, 16)
+    x[1, 3, 4, 5] = float("nan")
+    ops.SpTensor.from_nhwc(x.cuda())
+    assert ops.sp_range_flags(reset=True) & 4
 
 
 def test_dataparallel_wrapper_on_one_device():

@@ -1,0 +1,17 @@
+#!/bin/bash
+# A/B builds of libdisconet_hip.so that differ in one macro:  tools/ab/build.sh MACRO v0 v1 ...  ->  tools/ab/<MACRO>_<v>/libdisconet_hip.so
+# (conv_sp / conv_spq / fuse_mlp are recompiled with -D<MACRO>=<v>, the other objects come from disconet_amd/csrc/build).
+# tools/ab/run.sh swaps a variant in on the GPU box's scratch copy and runs a command.
+set -e
+R=$(cd "$(dirname "$0")/../.." && pwd); C=$R/disconet_amd/csrc
+M=$1; shift
+for v in "$@"; do
+  d=$R/tools/ab/${M}_$v; mkdir -p $d
+  for f in conv_sp conv_spq fuse_mlp; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment -I $R/include -I $C -D$M=$v -c $C/$f.hip -o $d/$f.o &
+  done
+  wait
+  objs=$(ls $C/build/*.o | grep -v -E "/(conv_sp|conv_spq|fuse_mlp)\.o")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $d/libdisconet_hip.so $objs $d/conv_sp.o $d/conv_spq.o $d/fuse_mlp.o
+  rm -f $d/*.o
+done
