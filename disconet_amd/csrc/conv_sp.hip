@@ -527,10 +527,9 @@ conv_sp_kernel(const SpArgs a) {
       const int cg = ch0 / 16 + m;
       if (cg < cog && (!kNoStore || ph[0] == 0x12345678u)) {
         // The plane offset rides in the VECTOR offset, the scalar offset operand stays 0.  With it in the scalar
-        // operand (one s_lshl / s_add per store, rewritten for the next store right behind the instruction) the
-        // WTN = 2 streaming tiles wrote ~1e-4 of their lo pieces wrong -- lanes 12-15 / 28-31 of both halves, second
-        // chunk of a channel tile, errors of lo magnitude (tools/sp_conv_check, 18 of 300 cases) -- while this form
-        // is clean on every tile.  Not root-caused; one v_add per store is the price.
+        // operand hipcc leaves out the wait states between a dwordx4 store and a VALU write of its data registers
+        // (its hazard recognizer exempts SGPR offsets; gfx950 needs them): the round-3 form wrote ~1e-4 of the lo
+        // pieces wrong, lanes 12-15 / 28-31 of both halves.  DESIGN.md 3.6 (C); tools/soff; tests/test_isa_hazard_cpu.py.
 #if DN_EPI_SOFF == 4   // both scalar offsets formed BEFORE the pair: no SALU write of a store's soffset register behind it
         int so_h = __builtin_amdgcn_readfirstlane(cg * 4 * plane), so_l = __builtin_amdgcn_readfirstlane((cg * 4 + 2) * plane);
         asm volatile("" : "+s"(so_h), "+s"(so_l));

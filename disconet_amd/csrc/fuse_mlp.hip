@@ -47,9 +47,14 @@ struct FuseMlpArgs {
   float* weights_out;
   int batch, agents, hw, only_v2i, ego_first, ego_count, tiles;
   int warped_fm;   // `warped` is fragment-major (dn_warp_neighbors_fm): a k-step of a tile is two contiguous 1 KB runs
-  int abl;         // DN_FUSE_ABL (tools/fuse_ab.py, timing only -- results are garbage): 1 = pass 2 reads no rows, 2 = layer 1
-                   // reads each row's first k-step only, 4 = no layers 2-4, 8 = layer 1 splits no operands
 };
+// Timing-only ablations (results are garbage), COMPILE-time so that the shipped kernel carries none of it: build a variant
+// with tools/ab/build.sh DN_FUSE_ABL <mask>: 1 = pass 2 reads no rows, 2 = layer 1 reads each row's first k-step only,
+// 4 = no layers 2-4, 8 = layer 1 splits no operands.  (As a run-time argument the four tests cost 4 us of the launch.)
+#ifndef DN_FUSE_ABL
+#define DN_FUSE_ABL 0
+#endif
+constexpr int kAbl = DN_FUSE_ABL;
 
 __device__ inline half8 frag_of(const unsigned char* base, int idx) {
   return *reinterpret_cast<const half8*>(base + (size_t)idx * 16);
@@ -191,7 +196,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
 #pragma unroll
       for (int g = 0; g < NG; ++g)
         if (g < cnt) {
-          const int kk = (a.abl & 2) ? 0 : ks;
+          const int kk = (kAbl & 2) ? 0 : ks;
           r0[s][g] = *reinterpret_cast<const f32x4*>(rows[g].p + kk * rows[g].kss);
           r1[s][g] = *reinterpret_cast<const f32x4*>(rows[g].p + kk * rows[g].kss + rows[g].r1);
         }
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
       for (int g = 0; g < NG; ++g)
         if (g < cnt) {
           half8 fh, fl;
-          if (a.abl & 8) {
+          if constexpr ((kAbl & 8) != 0) {
             fh = __builtin_bit_cast(half8, r0[sr][g]);
             fl = __builtin_bit_cast(half8, r1[sr][g]);
           } else {
@@ -236,7 +241,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
 
   // ---- layers 2-4 on acc (= E + F_k) -> exp(s)
   auto tail = [&](f32x16 (&acc)[4]) -> float {
-    if (a.abl & 4) return acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    if constexpr ((kAbl & 4) != 0) return acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
@@ -396,7 +401,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
   f32x4 f0[KSW], f1[KSW], y0[2][KSW], y1[2][KSW];
   auto yload = [&](int k, int s) {
     const Row row = row_of(k);
-    if (a.abl & 1) {
+    if constexpr ((kAbl & 1) != 0) {
 #pragma unroll
       for (int ks = 0; ks < KSW; ++ks) y0[s][ks] = y1[s][ks] = f32x4{1.f, 2.f, 3.f, (float)k};
       return;
@@ -544,8 +549,6 @@ int fuse_mlp_impl(const float* feat, const float* warped, int warped_fm, const i
   a.ego_first = ego_first; a.ego_count = ego_count;
   a.tiles = (hw + 31) / 32;
   a.warped_fm = warped_fm;
-  static const int abl_env = [] { const char* e = getenv("DN_FUSE_ABL"); return e ? atoi(e) : 0; }();
-  a.abl = abl_env;
   dim3 grid(batch * ego_count * a.tiles);   // one workgroup per 32 pixels of one (sample, ego)
   hipStream_t s = (hipStream_t)stream;
   // Four waves per tile when the launch leaves SIMDs idle (fewer tiles than 2 per CU: 128 tiles for one rank's

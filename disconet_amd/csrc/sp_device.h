@@ -91,9 +91,14 @@ inline void sp_range_collect_here(unsigned* dst, bool reset, hipStream_t stream)
 // Vector form on purpose: gfx950 has v_cvt_pk_f16_f32 (two fp32 -> packed halves, round to nearest even, the scalar
 // conversion's result) and v_med3_f32 / v_max3_f32 -- 18 VALU instructions per 4 values against ~30 for the
 // element-wise form; every epilogue of the short-K layers runs this for each of its outputs.
+#ifndef DN_RANGECHECK
+#define DN_RANGECHECK 1     // tools/ab: 0 = the splits track no magnitudes (what the range guard costs)
+#endif
 __device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo, float& amax) {
+#if DN_RANGECHECK
   amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
   amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
+#endif
   f32x4 x;
 #pragma unroll
   for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);

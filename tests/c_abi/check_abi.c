@@ -86,6 +86,29 @@ static int gpu_conv(int math) {
   for (size_t i = 0; i < ny; ++i) { const double e = fabs((double)y[i] - ref[i]); if (e > err) err = e; }
   printf("C ABI conv3x3 math=%d: max abs err %.3e\n", math, err);
   CHECK(err <= 1e-4, "conv error too large");
+  /* dn_conv2d_taps: every tap enabled and the dense output strides == dn_conv2d, bit for bit; the centre tap alone
+   * (mask 1 << 4) into every other pixel column of a twice-as-wide buffer == the 1x1 conv of the centre weights */
+  {
+    float *dy2, *y2 = malloc(ny * 4 * 2);
+    HIP(hipMalloc((void**)&dy2, ny * 4 * 2)); HIP(hipMemset(dy2, 0, ny * 4 * 2));
+    CHECK(dn_conv2d_taps(&d, dx_, NULL, dp, dsc, dsh, dy2, 0x1ff, (long)h * w * cout, w * cout, cout, NULL) == DN_OK, "taps: %s", dn_last_error());
+    HIP(hipDeviceSynchronize());
+    HIP(hipMemcpy(y2, dy2, ny * 4, hipMemcpyDeviceToHost));
+    CHECK(memcmp(y, y2, ny * 4) == 0, "dn_conv2d_taps with every tap differs from dn_conv2d");
+    CHECK(dn_conv2d_taps(&d, dx_, NULL, dp, dsc, dsh, dy2, 1 << 4, (long)h * w * cout * 2, w * cout * 2, cout * 2, NULL) == DN_OK, "taps: %s", dn_last_error());
+    HIP(hipDeviceSynchronize());
+    HIP(hipMemcpy(y2, dy2, ny * 4 * 2, hipMemcpyDeviceToHost));
+    double e2 = 0;
+    for (int im = 0; im < n; ++im) for (int oy = 0; oy < h; ++oy) for (int ox = 0; ox < w; ++ox) for (int co = 0; co < cout; ++co) {
+      double acc = bias[co];
+      for (int ci = 0; ci < cin; ++ci) acc += (double)x[((size_t)(im * h + oy) * w + ox) * cin + ci] * wt[((size_t)co * cin + ci) * 9 + 4];
+      const double want = acc > 0 ? acc : 0, got = y2[(((size_t)(im * h + oy) * w + ox) * 2) * cout + co];
+      if (fabs(got - want) > e2) e2 = fabs(got - want);
+    }
+    printf("C ABI conv3x3 math=%d, centre tap only, strided output: max abs err %.3e\n", math, e2);
+    CHECK(e2 <= 1e-4, "tap-masked conv error too large");
+    CHECK(dn_conv2d_taps(&d, dx_, NULL, dp, dsc, dsh, dy2, 0, 1, 1, cout, NULL) == DN_ERR_ARG, "empty tap mask accepted");
+  }
   return 0;
 }
 
@@ -178,6 +201,27 @@ static int gpu_spconv(int up) {
          dn_sp_range_flags(0));
   CHECK(err <= 1e-4, "spconv error too large");
   CHECK(dn_sp_range_flags(1) == 0, "range flags set on O(1) data");
+  /* K-sliced form (2 slices: cin is 24 or 48 channels = 2 or 3 chunks): split through the workspace == every tile whole,
+   * bit for bit; values within the engine's tolerance of the C loops */
+  {
+    const size_t ob = dn_sp_tensor_bytes(n, h, w, cout), wsb = dn_spconv_workspace_bytes(&d, 2);
+    void *o1, *o2, *ws;
+    CHECK(wsb > 0, "ks workspace size");
+    HIP(hipMalloc(&o1, ob)); HIP(hipMalloc(&o2, ob)); HIP(hipMalloc(&ws, wsb));
+    CHECK(dn_spconv2d_ks(&d, 2, sp0, sp1, pk, dsc, dsh, o1, NULL, 0, ws, wsb, NULL) == DN_OK, "spconv ks: %s", dn_last_error());
+    CHECK(dn_spconv2d_ks(&d, 2, sp0, sp1, pk, dsc, dsh, o2, NULL, 0, NULL, 0, NULL) == DN_OK, "spconv ks (no workspace): %s", dn_last_error());
+    CHECK(dn_sp_to_nhwc(o1, n, h, w, cout, cout, dy_, NULL) == DN_OK, "to_nhwc: %s", dn_last_error());
+    HIP(hipDeviceSynchronize());
+    unsigned char *b1 = malloc(ob), *b2 = malloc(ob);
+    HIP(hipMemcpy(b1, o1, ob, hipMemcpyDeviceToHost)); HIP(hipMemcpy(b2, o2, ob, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(y, dy_, ny * 4, hipMemcpyDeviceToHost));
+    double e2 = 0;
+    for (size_t i = 0; i < ny; ++i) { const double e = fabs((double)y[i] - ref[i]); if (e > e2) e2 = e; }
+    CHECK(memcmp(b1, b2, ob) == 0, "K-sliced conv: split and whole tiles differ");
+    CHECK(e2 <= 1e-4, "K-sliced conv error too large");
+    CHECK(dn_spconv2d_ks(&d, 3, sp0, sp1, pk, dsc, dsh, o1, NULL, 0, ws, wsb, NULL) == DN_ERR_ARG, "kslices = 3 accepted");
+    printf("C ABI spconv K-sliced (2 slices): max abs err %.3e, split == whole bitwise\n", e2);
+  }
   return 0;
 }
 
@@ -348,6 +392,21 @@ static int gpu_fusion(void) {
   }
   printf("C ABI fusion: warp max abs err %.3e, warp + fuse_mlp %.3e\n", ew, e1);
   CHECK(ew <= 1e-5 && e1 <= 1e-4, "fusion error too large");
+  /* fragment-major intermediate: dn_warp_neighbors_fm + dn_disco_fuse_mlp_fm == the pixel-major pair, bit for bit */
+  CHECK(dn_warp_fm_supported(H, W, C), "fm form not offered for %d x %d x %d", H, W, C);
+  CHECK(dn_warp_neighbors_fm(dfeat, dtrans, dna, B, A, H, W, C, 0, 0, A, dwarp, NULL) == DN_OK, "warp fm: %s", dn_last_error());
+  CHECK(dn_disco_fuse_mlp_fm(dfeat, dwarp, dna, &prm, B, A, HW, C, 0, 0, A, NULL, dout2, NULL, NULL) == DN_OK, "fuse_mlp fm: %s", dn_last_error());
+  {
+    unsigned *dflag, hflag = 0;
+    HIP(hipMalloc((void**)&dflag, 4)); HIP(hipMemcpy(dflag, &hflag, 4, hipMemcpyHostToDevice));
+    CHECK(dn_sp_range_flags_async(dflag, 0, NULL) == DN_OK, "flags async: %s", dn_last_error());
+    HIP(hipDeviceSynchronize());
+    float* o2 = malloc((size_t)A * HW * C * 4);
+    HIP(hipMemcpy(o2, dout2, (size_t)A * HW * C * 4, hipMemcpyDeviceToHost)); HIP(hipMemcpy(&hflag, dflag, 4, hipMemcpyDeviceToHost));
+    CHECK(memcmp(o1, o2, (size_t)A * HW * C * 4) == 0, "fragment-major fusion differs from the pixel-major one");
+    CHECK(hflag == 0, "stream-ordered range flags: %u on O(1) data", hflag);
+    printf("C ABI fusion: fragment-major form == pixel-major form bitwise; stream-ordered range flags 0\n");
+  }
   return 0;
 }
 

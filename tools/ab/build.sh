@@ -4,11 +4,14 @@
 # tools/ab/run.sh swaps a variant in on the GPU box's scratch copy and runs a command.
 set -e
 R=$(cd "$(dirname "$0")/../.." && pwd); C=$R/disconet_amd/csrc
+# tools/ab/build.sh FLAGS name "<extra hipcc flags>"  builds tools/ab/FLAGS_name with those flags instead of a macro
 M=$1; shift
+if [ "$M" = FLAGS ]; then set -- "$1:$2"; fi
 for v in "$@"; do
-  d=$R/tools/ab/${M}_$v; mkdir -p $d
+  if [ "$M" = FLAGS ]; then d=$R/tools/ab/FLAGS_${v%%:*}; X="${v#*:}"; else d=$R/tools/ab/${M}_$v; X="-D$M=$v"; fi
+  mkdir -p $d
   for f in conv_sp conv_spq fuse_mlp; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment -I $R/include -I $C -D$M=$v -c $C/$f.hip -o $d/$f.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment -I $R/include -I $C $X -c $C/$f.hip -o $d/$f.o &
   done
   wait
   objs=$(ls $C/build/*.o | grep -v -E "/(conv_sp|conv_spq|fuse_mlp)\.o")
