@@ -27,6 +27,9 @@
 #ifndef DN_EPI_SOFF
 #define DN_EPI_SOFF 0
 #endif
+#ifndef DN_MFMA_PRIO
+#define DN_MFMA_PRIO 0
+#endif
 #include "dn_internal.h"
 #include "sp_layout.h"
 #include "sp_device.h"
@@ -382,6 +385,9 @@ conv_sp_kernel(const SpArgs a) {
     };
     auto mma = [&](auto u_c) {
       constexpr int s = decltype(u_c)::value & 1;
+#if DN_MFMA_PRIO
+      __builtin_amdgcn_s_setprio(DN_MFMA_PRIO);     // tools/ab: the wave that has its fragments issues MFMAs ahead of a neighbour's epilogue VALU
+#endif
       // D[i = channel][j = pixel]; small terms first; independent accumulators interleaved
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm)
@@ -400,6 +406,9 @@ conv_sp_kernel(const SpArgs a) {
 #pragma unroll
         for (int wn = 0; wn < WTN; ++wn)
           acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s][wn], ah[s][wm], acc[wm][wn], 0, 0, 0);
+#if DN_MFMA_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     };
     load(std::integral_constant<int, 0>{});
     auto body = [&](auto u_c) {

@@ -24,6 +24,9 @@
 // Pipeline (double-buffered patch per chunk, double-buffered weights per step, raw s_barrier + counted
 // vmcnt waits, next tile's first operands under the current tile's last step), persistent workgroups, XCD-aware
 // item order and the register epilogue are those of conv_sp_kernel.
+#ifndef DN_MFMA_PRIO
+#define DN_MFMA_PRIO 0
+#endif
 #include "dn_internal.h"
 #include "sp_layout.h"
 #include "sp_device.h"
@@ -276,6 +279,9 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
     half8 ah[2], al[2], bh[WTN], bl[WTN];
   };
   auto mma = [&](const Frags& f) {
+#if DN_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(DN_MFMA_PRIO);
+#endif
 #pragma unroll
     for (int wm = 0; wm < 2; ++wm)
 #pragma unroll
@@ -291,6 +297,9 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
 #pragma unroll
       for (int wn = 0; wn < WTN; ++wn)
         acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[wn], f.ah[wm], acc[wm][wn], 0, 0, 0);
+#if DN_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   // step ST of a source-1 chunk: taps (dy = ST, dx = 0..2), weights shared by the four waves
   auto compute1 = [&](auto st_c, const unsigned char* As, const unsigned char* Bs) {

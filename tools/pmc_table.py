@@ -29,19 +29,29 @@ def short(n):
     return n.split('(')[0].split('<')[0][-34:]
 
 
+def product_only(d):
+    """the step's own kernels in launch order: the asynchronous range guard (sp_range_collect + a copy) polls at moments
+    that depend on event timing, so Dispatch_Ids differ between the counter passes -- rows are matched by their position
+    among the step's kernels, counted from the end"""
+    skip = ("sp_range_collect", "__amd_rocclr", "at::native", "elementwise_kernel")
+    return [e for e in d.values() if not any(k in e['name'] for k in skip)]
+
+
 def main(d, last):
-    p1, p2, p3 = (load('%s/pmc%d.csv' % (d, i)) for i in (1, 2, 3))
+    p1, p2, p3 = (product_only(load('%s/pmc%d.csv' % (d, i))) for i in (1, 2, 3))
+    p1, p2, p3 = p1[-last:], p2[-last:], p3[-last:]
+    for a_, b_, c_ in zip(p1, p2, p3):
+        assert a_['name'] == b_['name'] == c_['name'], (a_['name'][:60], b_['name'][:60], c_['name'][:60])
     print("%-34s %7s %8s %6s %6s %6s %6s %6s %9s %9s" % (
         "kernel", "blocks", "us", "GHz", "mfma%", "wInst%", "wAny%", "act%", "fetchMB*2", "writeMB"))
-    for k in list(p1.keys())[-last:]:
-        e = p1[k]
+    for k, e in enumerate(p1):
         c = e['c']
         gui = c.get('GRBM_GUI_ACTIVE', 0) / 8.0          # per-XCD cycles
         ghz = gui / (e['t'] * 1e3) if e['t'] else 0
         mfu = 100 * c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (1024 * gui) if gui else 0
         wc = c.get('SQ_WAVE_CYCLES', 1) or 1
-        f = 2 * p2.get(k, {'c': {}})['c'].get('FETCH_SIZE', 0) / 1024   # gfx950: x2 (MI355X guide)
-        w = p3.get(k, {'c': {}})['c'].get('WRITE_SIZE', 0) / 1024
+        f = 2 * p2[k]['c'].get('FETCH_SIZE', 0) / 1024   # gfx950: x2 (MI355X guide)
+        w = p3[k]['c'].get('WRITE_SIZE', 0) / 1024
         print("%-34s %7d %8.1f %6.2f %6.1f %6.1f %6.1f %6.1f %9.1f %9.1f" % (
             short(e['name']), e['grid'] // e['wg'], e['t'], ghz, mfu,
             100 * c.get('SQ_WAIT_INST_ANY', 0) / wc, 100 * c.get('SQ_WAIT_ANY', 0) / wc,
