@@ -50,6 +50,15 @@ MATH_LABEL = {"f32": "exact-fp32", "f16x3": "split-f16x3 (fp32 NHWC activations)
               "sp": "split-f16x3, split-planar activations staged by LDS-DMA"}
 
 
+def _sp_bevs(ops, indices, offsets, n_img, dims):
+    """the voxel batch in the form the split-planar engine's first layer reads: one occupancy word per pixel
+    (DN_BEV_FORM=hi: round 3's hi-only planes, for A/B runs -- the results are bit-identical)"""
+    if os.environ.get("DN_BEV_FORM", "bits") == "hi":
+        return ops.scatter_dense_sp(indices, offsets, n_img, dims, hi_only=True)
+    return ops.scatter_dense_bits(indices, offsets, n_img, dims)
+
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,7 +245,7 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
 
         def make_bevs():
             if model.conv_math == "sp":
-                return ops.scatter_dense_sp(idx, off, count * batch, dims, hi_only=True)
+                return _sp_bevs(ops, idx, off, count * batch, dims)
             return ops.scatter_dense(idx, off, count * batch, dims)
         return make_bevs
 
@@ -624,8 +633,8 @@ def main():
 
     def step():
         # dense rebuild of the batch (K1/a2) in the layout the conv engine of the chosen mode reads
-        if model.conv_math == "sp":      # hi-only planes: a 0/1 grid is exact in binary16 (half the bytes)
-            bevs = ops.scatter_dense_sp(indices, offsets, n_img, dims, hi_only=True)
+        if model.conv_math == "sp":      # occupancy words (1/32 of the float32 grid), expanded inside conv_pre_1
+            bevs = _sp_bevs(ops, indices, offsets, n_img, dims)
         else:
             bevs = ops.scatter_dense(indices, offsets, n_img, dims)
         with torch.no_grad():

@@ -58,6 +58,8 @@ SIGNATURES = {
                                     c_void_p]),
     "dn_scatter_dense_sp_hi": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_int), c_void_p,
                                        c_void_p]),
+    "dn_scatter_dense_bits": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_int), c_void_p,
+                                      c_void_p]),
     "dn_conv_packed_weight_floats": (c_size_t, [POINTER(ConvDesc)]),
     "dn_conv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
     "dn_fold_bn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,

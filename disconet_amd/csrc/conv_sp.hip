@@ -30,6 +30,12 @@
 #ifndef DN_MFMA_PRIO
 #define DN_MFMA_PRIO 0
 #endif
+#ifndef DN_UNIFORM_TILE
+#define DN_UNIFORM_TILE 0   // tools/ab: 1 = every kernel's tile coordinates through v_readfirstlane (scalar registers)
+#endif
+#ifndef DN_HEADS_W2_REGS
+#define DN_HEADS_W2_REGS 1   // 1: the heads' 1x1 weight fragments held in registers across tiles (shipped); 0: read per tile -- 54 VGPRs fewer, measured 0.5 % slower (round 4, same lease)
+#endif
 #include "dn_internal.h"
 #include "sp_layout.h"
 #include "sp_device.h"
@@ -84,6 +90,10 @@ struct TileCoord {
 // weight stage carries both parities' blocks.
 // AHI: source 0 is a HI-ONLY SP tensor ([image][chunk][2 octets][H][W] x 16 B: values that are exact in binary16,
 // e.g. the 0/1 occupancy grid): half the patch bytes, no lo fragments, two MFMAs per product instead of three.
+// AHI = 2: the same arithmetic from an occupancy BIT grid ([image][H][W] uint32, bit c = channel c, <= 32 channels --
+// dn_scatter_dense_bits): the patch's words are loaded to registers and expanded to the hi-only stage's 0x3C00 / 0 halves
+// with VALU + ds_write, so the MFMA loop, its operands and every result are those of AHI = 1 on the expanded grid;
+// the source is 1/8 of the hi-only bytes (1/32 of the float32 grid).  Weight-stationary form only.
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
           int WTM, int WTN, int POST, int BSTAT = 0, int UPM = 0, int AHI = 0, int KSL = 0>
 struct SpTile {
@@ -97,6 +107,7 @@ struct SpTile {
   static constexpr int AQ = AHI ? 2 : 4;                    // quarter planes of a source-0 chunk
   static constexpr int A_PIECES = CA * AQ * NPIX;
   static_assert(!AHI || (KS == 3 && CA == 1 && UPM == 0), "hi-only source: 3x3 layers");
+  static_assert(AHI != 2 || (BSTAT != 0 && STRIDE == 1), "bit-grid source: weight-stationary stride-1 form");
   // streaming form: every wave issues the same number of DMA instructions per stage (counted
   // vmcnt waits), so a stage is padded to whole rounds of NW instructions; stationary form:
   // only patch DMAs are ever in flight (vmcnt(0) waits), a stage is padded to whole instructions
@@ -203,6 +214,12 @@ conv_sp_kernel(const SpArgs a) {
     tc.img = fdivmod(spi, a.tiles_y, a.rcp_ty, ty);
     tc.ox0 = tx * TW;
     tc.oy0 = ty * TH;
+    if constexpr (AHI == 2 || DN_UNIFORM_TILE) {   // plain buffer loads in the K loop: without this the compiler treats the tile as divergent
+      tc.n0 = __builtin_amdgcn_readfirstlane(tc.n0);      // and wraps every buffer store of the epilogue in a waterfall loop
+      tc.img = __builtin_amdgcn_readfirstlane(tc.img);
+      tc.ox0 = __builtin_amdgcn_readfirstlane(tc.ox0);
+      tc.oy0 = __builtin_amdgcn_readfirstlane(tc.oy0);
+    }
     return tc;
   };
 
@@ -252,7 +269,8 @@ conv_sp_kernel(const SpArgs a) {
   constexpr unsigned OOB = 0xFFFFFFFFu;
   const int hs0 = a.up0 ? (a.h_in >> 1) : a.h_in, ws0 = a.up0 ? (a.w_in >> 1) : a.w_in;
   const unsigned plane0 = (unsigned)(hs0 * ws0) * 16u, plane1 = (unsigned)(a.h_in * a.w_in) * 16u;
-  const size_t img0_bytes = (size_t)a.c0g * T::AQ * plane0, img1_bytes = (size_t)a.c1g * 4 * plane1;
+  const size_t img0_bytes = AHI == 2 ? (size_t)(hs0 * ws0) * 4 : (size_t)a.c0g * T::AQ * plane0;
+  const size_t img1_bytes = (size_t)a.c1g * 4 * plane1;
   auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.src0), 0, 0, 0x00020000);
   auto rsrc1 = rsrc0;
   const auto rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wpk), 0,
@@ -289,6 +307,9 @@ conv_sp_kernel(const SpArgs a) {
       const int iy = iy0 + r, ix = ix0 + cc;
       const bool ok = (int)pm < 0 && iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
       const int sy = (!from1 && a.up0) ? (iy >> 1) : iy, sx = (!from1 && a.up0) ? (ix >> 1) : ix;
+      if constexpr (AHI == 2)
+        voff_a[it] = ok ? (unsigned)(sy * ws + sx) * 4u : OOB;       // the pixel's occupancy word
+      else
       voff_a[it] = ok ? (unsigned)cq * plane + (unsigned)(sy * ws + sx) * 16u : OOB;
     }
   };
@@ -317,9 +338,19 @@ conv_sp_kernel(const SpArgs a) {
         const_cast<unsigned char*>(a.c1g ? a.src1 + tc.img * img1_bytes : a.src0), 0,
         a.c1g ? (int)img1_bytes : 0, 0x00020000);
   };
+  // bit-grid source: the occupancy words of this lane's pieces, between issue_a (loads) and commit_a (expand -> LDS)
+  unsigned abits[AHI == 2 ? A_IT : 1];
+  int abits_g = 0;
   // A group g of the current source set -> stage sa
   auto issue_a = [&](int g, int sa, bool steady = true) {
     if (kNoA && steady) return;
+    if constexpr (AHI == 2) {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)      // (pieces past the stage carry the out-of-range offset: no branch around a load)
+        abits[it] = __builtin_amdgcn_raw_buffer_load_b32(rsrc0, voff_a[it], 0, 0);   // out of the image: 0
+      abits_g = g;
+      return;
+    }
     const int cg = g * CA;
     const bool from1 = cg >= a.c0g;
     const int soff = from1 ? (cg - a.c0g) * 4 * (int)plane1 : cg * T::AQ * (int)plane0;
@@ -331,6 +362,25 @@ conv_sp_kernel(const SpArgs a) {
         dma16(rsrc1, base + it * NW * 1024, voff_a[it], soff);
       else
         dma16(rsrc0, base + it * NW * 1024, voff_a[it], soff);
+    }
+  };
+  // bit-grid source: piece (octet cq of chunk abits_g, one pixel) = 8 halves, 0x3C00 where the channel's bit is set --
+  // the 16 bytes the hi-only DMA would have delivered, written where it would have written them
+  auto commit_a = [&](int sa) {
+    if constexpr (AHI == 2) {
+      unsigned char* base = smem + sa * T::A_STAGE + (wave * 64 + lane) * 16;
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) {
+        const unsigned oct = (piece_map[it] >> 16) & 1u;
+        const unsigned m = (abits[it] >> (16 * abits_g + 8 * oct)) & 0xffu;
+        u32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v[k] = ((m >> (2 * k)) & 1u ? 0x3C00u : 0u) | ((m >> (2 * k + 1)) & 1u ? 0x3C000000u : 0u);
+        if ((it + 1) * NW <= T::A_INSTR || it * NW + wave < T::A_INSTR)       // ragged last round: stay inside the stage
+          *reinterpret_cast<u32x4*>(base + it * NW * 1024) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // in LDS before this wave reaches the next barrier
     }
   };
   auto issue_b = [&](int g, int st, int sb, bool steady = true) {
@@ -441,10 +491,12 @@ conv_sp_kernel(const SpArgs a) {
   constexpr bool kRegAffine = POST == 0;
   f32x4 sc_r[kRegAffine ? WTN : 1][4], sh_r[kRegAffine ? WTN : 1][4];
   int aff_n0 = -1;
+#if DN_HEADS_W2_REGS
   half8 w2h[POST == 2 ? WTN : 1][2][2], w2l[POST == 2 ? WTN : 1][2][2];   // POST 2: the heads' 1x1 weights
   int w2_cb[POST == 2 ? WTN : 1];
 #pragma unroll
   for (int wn = 0; wn < (POST == 2 ? WTN : 1); ++wn) w2_cb[wn] = -1;
+#endif
   auto load_affine = [&](int n0) {
     if (!kRegAffine || n0 == aff_n0) return;
     aff_n0 = n0;
@@ -577,18 +629,39 @@ conv_sp_kernel(const SpArgs a) {
       const int c2 = cb ? a.c_out2 - a.split2 : a.split2, c2_0 = cb ? a.split2 : 0;
       float* obase = cb ? a.out_b : reinterpret_cast<float*>(a.out);
       const int ldo = cb ? a.ldo_b : a.ldo_a;
-      if (cb != w2_cb[wn]) {                  // stage-2 weight fragments of this head: registers, once per head
+      // stage-2 weight fragments of this head (W2 image: [cb][nt][ks][part][h][32] x 16 B, 4 KB per head, L2-resident):
+      // held in registers across tiles (245 VGPRs, no spills, two workgroups per CU either way).  The per-tile read
+      // (DN_HEADS_W2_REGS=0: 191 VGPRs) measured 10 us slower per launch in the same lease -- the L2 round trip sits in
+      // front of every tile's second stage.
+#if DN_HEADS_W2_REGS
+      if (cb != w2_cb[wn]) {
         w2_cb[wn] = cb;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            // W2 image: [cb][nt][ks][part][h][32] x 16 B
             const unsigned char* wp = a.w2 + (size_t)((((((cb * 2 + nt) * 2 + ks) * 2 + 0) * 2 + lh) * 32 + li)) * 16;
             w2h[wn][nt][ks] = *reinterpret_cast<const half8*>(wp);
             w2l[wn][nt][ks] = *reinterpret_cast<const half8*>(wp + 2 * 32 * 16);
           }
       }
+      auto w2_hi = [&](int nt, int ks) { return w2h[wn][nt][ks]; };
+      auto w2_lo = [&](int nt, int ks) { return w2l[wn][nt][ks]; };
+#else
+      half8 w2h_t[2][2], w2l_t[2][2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        if (nt * 32 >= c2) break;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const unsigned char* wp = a.w2 + (size_t)((((((cb * 2 + nt) * 2 + ks) * 2 + 0) * 2 + lh) * 32 + li)) * 16;
+          w2h_t[nt][ks] = *reinterpret_cast<const half8*>(wp);
+          w2l_t[nt][ks] = *reinterpret_cast<const half8*>(wp + 2 * 32 * 16);
+        }
+      }
+      auto w2_hi = [&](int nt, int ks) { return w2h_t[nt][ks]; };
+      auto w2_lo = [&](int nt, int ks) { return w2l_t[nt][ks]; };
+#endif
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm) {
         u32x2 hi[4], lo[4];
@@ -625,7 +698,7 @@ conv_sp_kernel(const SpArgs a) {
           for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            const half8 wh = w2h[wn][nt][ks], wl = w2l[wn][nt][ks];
+            const half8 wh = w2_hi(nt, ks), wl = w2_lo(nt, ks);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], acc2, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[ks], acc2, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], acc2, 0, 0, 0);
@@ -817,6 +890,7 @@ conv_sp_kernel(const SpArgs a) {
     load_weights(b_n0);
     setup_voff_a(cur, false);
     issue_a(0, 0, false);
+    commit_a(0);
     while (true) {
       zero_acc();
       load_affine(cur.n0);
@@ -839,6 +913,7 @@ conv_sp_kernel(const SpArgs a) {
         // all taps of the chunk back to back: nothing in LDS changes under them
         compute(std::integral_constant<int, 0>{}, std::integral_constant<int, NS * SUB>{},
                 smem + sa * T::A_STAGE, smem + T::OFF_B + g * (NS * T::B_STEP));
+        if (!last_g || has_next) commit_a(sa ^ 1);   // bit-grid source: the words loaded under the MFMAs -> the other stage
         sa ^= 1;
       }
       epilogue(cur);
@@ -1219,6 +1294,8 @@ int validate(const dn_conv_desc* d) {
   DN_REQUIRE(d->up0 == 0 || d->up0 == 1, "spconv: up0 must be 0 or 1");
   DN_REQUIRE(d->math != 3 || (d->ksize == 3 && d->stride == 1 && d->c1 == 0 && d->up0 == 0),
              "spconv: a hi-only source 0 (math = 3) needs a 3x3 stride-1 single-source layer");
+  DN_REQUIRE(d->math != 4 || (d->ksize == 3 && d->stride == 1 && d->c1 == 0 && d->up0 == 0 && d->c0 <= 32),
+             "spconv: a bit-grid source 0 (math = 4) needs a 3x3 stride-1 single-source layer of <= 32 channels");
   DN_REQUIRE(!d->up0 || (d->h_in % 2 == 0 && d->w_in % 2 == 0), "spconv: x2-upsampled source needs even h_in/w_in");
   DN_REQUIRE(d->c1 == 0 || (d->c0 % 16 == 0 && d->ksize == 3), "spconv: concat needs 3x3 and c0 %% 16 == 0 (c0 = %d)", d->c0);
   const size_t hs0 = d->up0 ? d->h_in / 2 : d->h_in, ws0 = d->up0 ? d->w_in / 2 : d->w_in;
@@ -1566,7 +1643,7 @@ extern "C" int dn_spconv2d_dual(const dn_conv_desc* d, const void* src0, const v
 }
 
 // K-sliced form: does the layer qualify?  (3x3, no row-merged image, no hi-only source)
-inline bool ks_layer(const dn_conv_desc& d) { return d.ksize == 3 && d.math != 3 && up_mode(d) != 1; }
+inline bool ks_layer(const dn_conv_desc& d) { return d.ksize == 3 && d.math != 3 && d.math != 4 && up_mode(d) != 1; }
 
 extern "C" size_t dn_spconv_workspace_bytes(const dn_conv_desc* d, int kslices) {
   if (validate(d) != DN_OK || kslices <= 1 || !ks_layer(*d)) return 0;
@@ -1634,6 +1711,11 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
     using T32 = SpTile<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 1, 0, 1>;
     if (fits_stationary(*d, 32, T32::A_STAGE, 0, 2)) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1, 0, 1>(a, *d, s);
     return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 0, 0, 1>(a, *d, s);
+  }
+  if (d->math == 4) {   // bit-grid source 0: the same tile, staged by expansion; weight-stationary only
+    using T32 = SpTile<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 1, 0, 2>;
+    if (fits_stationary(*d, 32, T32::A_STAGE, 0, 2)) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1, 0, 2>(a, *d, s);
+    return dn::fail(DN_ERR_UNSUPPORTED, "spconv: a bit-grid source needs a layer whose weights fit the LDS (c_out <= 32)");
   }
   const SpCfg c = select_cfg(*d);
   if (up_merged(*d)) {   // the packed image is the row-merged one: only the tiles that implement it

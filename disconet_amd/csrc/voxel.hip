@@ -156,6 +156,25 @@ __global__ void scatter_dense_sp_kernel(const int32_t* __restrict__ indices,
   }
 }
 
+// the same rebuild as ONE occupancy word per pixel (bit z = bin z holds a point; dz <= 32): 1/32 of the float32 grid.
+// Bins of one pixel share a word, so the store is an atomic OR (still idempotent: duplicates and the order of the
+// rows cannot change the result).  conv_sp.hip expands the words into f16 0/1 fragments in LDS (math = 4).
+__global__ void scatter_dense_bits_kernel(const int32_t* __restrict__ indices,
+                                          const int32_t* __restrict__ offsets, int n_images, int total,
+                                          int dx, int dy, int dz, unsigned* __restrict__ bits) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_images;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int ix = indices[3 * (size_t)i], iy = indices[3 * (size_t)i + 1],
+              iz = indices[3 * (size_t)i + 2];
+    if ((unsigned)ix < (unsigned)dx && (unsigned)iy < (unsigned)dy && (unsigned)iz < (unsigned)dz)
+      atomicOr(&bits[((size_t)lo * dx + ix) * dy + iy], 1u << iz);
+  }
+}
+
 inline int ntiles_of(const int* dims) {
   const long ncell = (long)dims[0] * dims[1] * dims[2];
   return (int)((ncell + COMPACT_TILE - 1) / COMPACT_TILE);
@@ -252,4 +271,20 @@ extern "C" int dn_scatter_dense_sp(const int32_t* indices, const int32_t* offset
 extern "C" int dn_scatter_dense_sp_hi(const int32_t* indices, const int32_t* offsets, int n_images,
                                       int total, const int* dims, void* dense_sp_hi, void* stream) {
   return scatter_dense_sp_impl(indices, offsets, n_images, total, dims, dense_sp_hi, 2, (hipStream_t)stream);
+}
+
+extern "C" int dn_scatter_dense_bits(const int32_t* indices, const int32_t* offsets, int n_images,
+                                     int total, const int* dims, uint32_t* bits, void* stream) {
+  DN_REQUIRE(dims && bits && offsets, "scatter_dense_bits: null pointer");
+  DN_REQUIRE(n_images > 0 && total >= 0 && (total == 0 || indices), "scatter_dense_bits: bad sizes");
+  DN_REQUIRE(dims[2] >= 1 && dims[2] <= 32, "scatter_dense_bits: %d height bins do not fit one word per pixel", dims[2]);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t bytes = (size_t)n_images * dims[0] * dims[1] * sizeof(uint32_t);
+  hipError_t e = dn::zero_fill(bits, bytes, s);
+  if (e != hipSuccess) return dn::fail(DN_ERR_LAUNCH, "scatter_dense_bits: memset: %s", hipGetErrorString(e));
+  if (total == 0) return DN_OK;
+  const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+  hipLaunchKernelGGL(scatter_dense_bits_kernel, dim3(blocks), dim3(256), 0, s, indices, offsets, n_images,
+                     total, dims[0], dims[1], dims[2], bits);
+  return dn::check_launch("scatter_dense_bits_kernel");
 }

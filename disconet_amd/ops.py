@@ -205,16 +205,23 @@ class SpTensor:
     data [n, ceil(c/16), 4, h, w, 8] float16 (quarter = 2*part + oct; part 0 = half(x),
     part 1 = half(x - half(x))).  `shape` is the logical NHWC shape."""
 
-    __slots__ = ("data", "n", "h", "w", "c", "hi_only")
+    __slots__ = ("data", "n", "h", "w", "c", "hi_only", "bits")
 
-    def __init__(self, n, h, w, c, device=None, data=None, hi_only=False):
+    def __init__(self, n, h, w, c, device=None, data=None, hi_only=False, bits=False):
         """hi_only: the HI-ONLY form [n, ceil(c/16), 2, h, w, 8] of values that are exact in binary16 (the 0/1
-        occupancy grid of scatter_dense_sp): accepted as source 0 of a 3x3 stride-1 SP conv."""
+        occupancy grid of scatter_dense_sp): accepted as source 0 of a 3x3 stride-1 SP conv.
+        bits: an occupancy BIT grid, data int32 [n, h, w] with bit k = channel k (c <= 32; scatter_dense_bits):
+        accepted as source 0 of a 3x3 stride-1 SP conv of <= 32 output channels."""
         self.n, self.h, self.w, self.c = int(n), int(h), int(w), int(c)
-        self.hi_only = bool(hi_only)
+        self.hi_only, self.bits = bool(hi_only), bool(bits)
+        if self.bits and (self.hi_only or self.c > 32):
+            raise _lib.DnError("SpTensor: a bit grid holds <= 32 channels and has no hi-only form")
         if data is None:
-            data = torch.empty((self.n, (self.c + 15) // 16, 2 if hi_only else 4, self.h, self.w, 8),
-                               dtype=torch.float16, device=device)
+            if self.bits:
+                data = torch.empty((self.n, self.h, self.w), dtype=torch.int32, device=device)
+            else:
+                data = torch.empty((self.n, (self.c + 15) // 16, 2 if hi_only else 4, self.h, self.w, 8),
+                                   dtype=torch.float16, device=device)
         self.data = data
 
     shape = property(lambda self: (self.n, self.h, self.w, self.c))
@@ -232,6 +239,12 @@ class SpTensor:
 
     def nhwc(self, out=None):
         """-> float32 [n, h, w, c] (x = hi + lo)"""
+        if self.bits:         # not a hot path either
+            x = ((self.data.unsqueeze(-1) >> torch.arange(self.c, device=self.data.device, dtype=torch.int32)) & 1).float()
+            if out is None:
+                return x.contiguous()
+            out.copy_(x)
+            return out
         if self.hi_only:      # not a hot path (training entry, tests): torch reshapes the two octet planes
             x = self.data.permute(0, 3, 4, 1, 2, 5).reshape(self.n, self.h, self.w, -1)[..., :self.c].float()
             if out is None:
@@ -395,14 +408,16 @@ def sp_conv2d(d, src0, packed, scale, shift, src1=None, out=None, nhwc_copy=Fals
     ho, wo = conv_out_hw(d)
     if out is None:
         out = SpTensor(d.n_images, ho, wo, d.c_out, device=src0.device)
-    if src1 is not None and src1.hi_only:
-        raise _lib.DnError("sp_conv2d: only source 0 may be a hi-only SP tensor")
+    if src1 is not None and (src1.hi_only or src1.bits):
+        raise _lib.DnError("sp_conv2d: only source 0 may be a hi-only SP tensor or a bit grid")
     if src0.hi_only:
         d.math = 3            # include/disconet_hip.h: source 0 is a hi-only SP tensor
+    elif src0.bits:
+        d.math = 4            # ... an occupancy bit grid
     lib = _lib.load()
     flat = torch.empty((d.n_images, ho, wo, d.c_out), dtype=torch.float32, device=src0.device) if nhwc_copy else None
     p1 = _ptr(src1.data) if src1 is not None else None
-    if kslices > 1 and d.math != 3:
+    if kslices > 1 and d.math not in (3, 4):
         nbytes = min(int(lib.dn_spconv_workspace_bytes(ctypes.byref(d), kslices)), _KS_WORKSPACE_CAP)
         if os.environ.get("DN_SP_KS_NOSPLIT", "0") == "1":      # A/B runs: every tile whole (the slices folded in registers)
             nbytes = 0
@@ -478,6 +493,20 @@ def scatter_dense_sp(indices, offsets, n_images, dims, hi_only=False):
     fn = _lib.load().dn_scatter_dense_sp_hi if hi_only else _lib.load().dn_scatter_dense_sp
     check(fn(_ptr(indices), _ptr(offsets), n_images, indices.shape[0], d, _ptr(out.data), _stream()),
           "dn_scatter_dense_sp")
+    return out
+
+
+def scatter_dense_bits(indices, offsets, n_images, dims):
+    """Batched dense rebuild as one occupancy word per pixel: -> SpTensor(bits=True) [n_images, X, Y, Z <= 32] --
+    1/32 of the float32 bevs tensor, 1/8 of the hi-only SP form.  DiscoNet.forward accepts it in place of bevs
+    (conv_pre_1 expands the words on their way into LDS; results bit-identical to the dense input's)."""
+    _need_gpu(indices, offsets)
+    if indices.dtype != torch.int32 or offsets.dtype != torch.int32:
+        raise _lib.DnError("scatter_dense_bits needs int32 indices/offsets")
+    d = (ctypes.c_int * 3)(*[int(v) for v in dims])
+    out = SpTensor(n_images, int(dims[0]), int(dims[1]), int(dims[2]), device=indices.device, bits=True)
+    check(_lib.load().dn_scatter_dense_bits(_ptr(indices), _ptr(offsets), n_images, indices.shape[0], d, _ptr(out.data),
+                                            _stream()), "dn_scatter_dense_bits")
     return out
 
 

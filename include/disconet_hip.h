@@ -112,6 +112,12 @@ int dn_scatter_dense_sp(const int32_t* indices, const int32_t* offsets, int n_im
  * product instead of three; the results are bit-identical to the full form). */
 int dn_scatter_dense_sp_hi(const int32_t* indices, const int32_t* offsets, int n_images,
                            int n_indices_total, const int* dims_host, void* dense_sp_hi, void* stream);
+/* ... and as an occupancy BIT grid bits[n_images][X][Y] (uint32; bit z = height bin z holds a point; Z <= 32):
+ * 1/32 of the float32 grid ("520 KB/scene as bits").  dn_spconv2d reads it as source 0 of a 3x3
+ * stride-1 layer with c_out <= 32 when dn_conv_desc.math == 4: the words are expanded to the hi-only form's halves on
+ * their way into LDS, the arithmetic and every result are those of math == 3 on the expanded grid. */
+int dn_scatter_dense_bits(const int32_t* indices, const int32_t* offsets, int n_images,
+                          int n_indices_total, const int* dims_host, uint32_t* bits, void* stream);
 
 /* ------------------------------------------------------------------------
  * K2/K3/K7 -- implicit-GEMM convolution on fp32 MFMA with fused
@@ -202,6 +208,8 @@ int dn_conv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc* p, const flo
  *   part 0 = half(x), part 1 = half(x - half(x)).  Channels past C are zero.
  * dn_conv_desc is reused: ld0/ld1/ldo are ignored; up0 is 0 or 1; math is ignored except
  * math == 3: source 0 is a HI-ONLY SP tensor (dn_scatter_dense_sp_hi; 3x3, stride 1, c1 == 0).
+ * math == 4: source 0 is an occupancy BIT grid (dn_scatter_dense_bits; 3x3, stride 1, c1 == 0, c0 <= 32, c_out <= 32;
+ * DN_ERR_UNSUPPORTED when the layer's weights do not fit the LDS); weights packed as for any other source.
  * Packed weights are specific to this engine (dn_spconv_pack_weights); `wmul`
  * is multiplied into the weights before the split -- pass a power of two that
  * lifts the layer's weights out of the f16 subnormal range and fold 1/wmul into
@@ -238,7 +246,7 @@ int dn_spconv2d(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp,
  * of (tests/test_gpu_conv.py), a 640-tile layer no longer runs two rounds on 512 resident workgroups, and the
  * 4-image launches of an agent-sharded rank fill the chip.  kslices = 1 is dn_spconv2d.  workspace may be NULL
  * (nothing is split) or smaller than dn_spconv_workspace_bytes() (fewer tiles are split).  Same packed weights as
- * dn_spconv2d.  Refused (DN_ERR_ARG): 1x1 layers, hi-only sources (math = 3), the row-merged image
+ * dn_spconv2d.  Refused (DN_ERR_ARG): 1x1 layers, hi-only and bit-grid sources (math = 3, 4), the row-merged image
  * (dn_spconv_set_upmode(1)), layers with fewer chunks than slices. */
 size_t dn_spconv_workspace_bytes(const dn_conv_desc* d, int kslices);
 int dn_spconv2d_ks(const dn_conv_desc* d, int kslices, const void* src0, const void* src1, const void* packed,

@@ -263,6 +263,29 @@ static int gpu_hi_only_and_flags(void) {
   HIP(hipMemcpy(h1, o1, ob, hipMemcpyDeviceToHost)); HIP(hipMemcpy(h2, o2, ob, hipMemcpyDeviceToHost));
   CHECK(memcmp(h1, h2, ob) == 0, "hi-only conv differs from the full form");
   printf("C ABI hi-only occupancy planes: conv output bit-equal to the full form\n");
+  /* occupancy words: dn_scatter_dense_bits against a host loop, dn_spconv2d(math = 4) against the same bytes */
+  {
+    uint32_t *dbits, *hb = malloc((size_t)n * X * Y * 4), *want = calloc((size_t)n * X * Y, 4);
+    HIP(hipMalloc((void**)&dbits, (size_t)n * X * Y * 4));
+    CHECK(dn_scatter_dense_bits(didx, doff, n, nidx, dims, dbits, NULL) == DN_OK, "scatter bits: %s", dn_last_error());
+    HIP(hipMemset(o2, 0xff, ob));
+    d.math = 4;
+    CHECK(dn_spconv2d(&d, dbits, NULL, pk, dsc, dsh, o2, NULL) == DN_OK, "spconv bit grid: %s", dn_last_error());
+    HIP(hipDeviceSynchronize());
+    HIP(hipMemcpy(hb, dbits, (size_t)n * X * Y * 4, hipMemcpyDeviceToHost));
+    for (int g = 0; g < n; ++g)
+      for (int i = off[g]; i < off[g + 1]; ++i)
+        want[((size_t)g * X + idx[3 * i]) * Y + idx[3 * i + 1]] |= 1u << idx[3 * i + 2];
+    CHECK(memcmp(hb, want, (size_t)n * X * Y * 4) == 0, "occupancy words differ from the host loop");
+    HIP(hipMemcpy(h2, o2, ob, hipMemcpyDeviceToHost));
+    CHECK(memcmp(h1, h2, ob) == 0, "bit-grid conv differs from the full form");
+    const int dims33[3] = {X, Y, 33};
+    CHECK(dn_scatter_dense_bits(didx, doff, n, nidx, dims33, dbits, NULL) == DN_ERR_ARG, "33 bins accepted");
+    d.c_out = 64;
+    CHECK(dn_spconv2d(&d, dbits, NULL, pk, dsc, dsh, o2, NULL) != DN_OK, "bit grid with 64 output channels accepted");
+    d.c_out = cout; d.math = 3;
+    printf("C ABI occupancy words: scatter == host loop, conv output bit-equal to the full form\n");
+  }
   /* range guard */
   CHECK(dn_sp_range_flags(1) == 0, "flags not clean before the probe");
   float big[16] = {0}; big[3] = 70000.f; big[9] = 20000.f;

@@ -297,3 +297,66 @@ def test_k_sliced_conv_is_batch_invariant(n, h, w, c0, c1, c_out, stride, up0, k
         torch.cuda.synchronize()
         assert torch.equal(sp.data, split.data)
         assert torch.equal(ops.SpTensor.from_nhwc(flat).data, sp.data)
+
+
+@pytest.mark.parametrize("n,h,w,c,c_out", [
+    (4, 64, 64, 13, 32),        # conv_pre_1's shape at a small map
+    (3, 20, 44, 13, 32),        # ragged: partial tiles right and bottom
+    (2, 40, 72, 29, 24),        # two 16-channel chunks of bits, c_out below the tile
+    (5, 8, 32, 5, 32),          # exactly one tile per image
+    (1, 3, 5, 16, 8),           # smaller than a tile
+])
+def test_bit_grid_source_equals_hi_only_source(n, h, w, c, c_out):
+    """dn_spconv2d with math = 4 (source 0 an occupancy bit grid, expanded into the patch stage by VALU + ds_write)
+    gives the bits of math = 3 on the hi-only SP tensor of the same grid and of the full SP form, and follows the
+    torch-CPU conv; many tiles per workgroup (persistent loop: first / steady / last tile) are covered by n x tiles"""
+    from disconet_amd import ops
+    g = torch.Generator().manual_seed(c * 7 + h)
+    occ = (torch.rand(n, h, w, c, generator=g) < 0.15).float()
+    occ[0, 0, 0, :] = 1.0                     # corners: halo rows / columns of the patch are zero padding
+    occ[-1, -1, -1, :] = 1.0
+    wgt = torch.randn(c_out, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5
+    scale = torch.rand(c_out, generator=g) + 0.5
+    shift = torch.randn(c_out, generator=g) * 0.1
+    want = F.relu(F.conv2d(occ.permute(0, 3, 1, 2), wgt, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    want = want.permute(0, 2, 3, 1)
+
+    full = ops.SpTensor.from_nhwc(occ.cuda())
+    hi = ops.SpTensor(n, h, w, c, device="cuda", hi_only=True, data=full.data[:, :, :2].contiguous())
+    words = (occ.to(torch.int64) << torch.arange(c, dtype=torch.int64)).sum(-1)
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)      # bit 31 set: the int32 pattern
+    bits = ops.SpTensor(n, h, w, c, device="cuda", bits=True, data=words.cuda())
+    assert torch.equal(bits.nhwc(), occ.cuda())
+
+    outs = []
+    for src in (full, hi, bits):
+        d = ops.conv_desc(n, h, w, c, c_out, 3, 1, True, math="sp")
+        packed, wmul = ops.sp_pack_conv_weights(d, wgt.cuda())
+        sc, sh = (scale / wmul).cuda(), shift.cuda()
+        out = ops.SpTensor(n, h, w, c_out, device="cuda")
+        out.data.fill_(255)
+        outs.append(ops.sp_conv2d(d, src, packed, sc, sh, out=out))
+        torch.cuda.synchronize()
+    assert torch.equal(outs[1].data, outs[0].data)
+    assert torch.equal(outs[2].data, outs[0].data)
+    assert (outs[2].nhwc().cpu() - want).abs().max().item() <= TOL * max(1.0, want.abs().max().item() / 4)
+
+
+def test_bit_grid_source_refusals():
+    """a bit grid is source 0 of a 3x3 stride-1 single-source layer whose weights stay in LDS; anything else is refused"""
+    from disconet_amd import ops, _lib
+    bits = ops.SpTensor(1, 16, 16, 13, device="cuda", bits=True, data=torch.zeros(1, 16, 16, dtype=torch.int32, device="cuda"))
+    g = torch.Generator().manual_seed(0)
+
+    def attempt(c_out, k, stride):
+        d = ops.conv_desc(1, 16, 16, 13, c_out, k, stride, True, math="sp")
+        packed, wmul = ops.sp_pack_conv_weights(d, torch.randn(c_out, 13, k, k, generator=g).cuda())
+        sc, sh = torch.ones(c_out, device="cuda"), torch.zeros(c_out, device="cuda")
+        return ops.sp_conv2d(d, bits, packed, sc, sh)
+
+    attempt(32, 3, 1)
+    for c_out, k, stride in ((64, 3, 1), (32, 3, 2), (32, 1, 1)):
+        with pytest.raises(_lib.DnError):
+            attempt(c_out, k, stride)
+    with pytest.raises(_lib.DnError):
+        ops.SpTensor(1, 16, 16, 33, device="cuda", bits=True)

@@ -201,6 +201,10 @@ def test_split_planar_bevs_input_equals_dense_input():
     assert torch.equal(dense["cls"], sp["cls"]) and torch.equal(dense["loc"], sp["loc"])
     # hi-only occupancy planes (half the bytes, 2 MFMAs per product in conv_pre_1): the dropped terms are exact zeros
     assert torch.equal(hi["cls"], sp["cls"]) and torch.equal(hi["loc"], sp["loc"])
+    # occupancy bit grid (1/32 of the float32 bytes, expanded on its way into LDS): the same operands, the same MFMAs
+    with torch.no_grad():
+        bits = m(ops.scatter_dense_bits(indices, offsets, A * B, dims), trans, na, B)
+    assert torch.equal(bits["cls"], sp["cls"]) and torch.equal(bits["loc"], sp["loc"])
 
 
 def _trained_like(ref):

@@ -99,3 +99,29 @@ def test_scatter_dense_sp_matches_dense():
     # empty batch entry / no voxels at all
     empty = ops.scatter_dense_sp(indices[:0], torch.zeros(3, dtype=torch.int32, device="cuda"), 2, dims)
     assert float(empty.data.float().abs().sum()) == 0.0
+
+
+def test_scatter_dense_bits_matches_dense():
+    """one occupancy word per pixel (bit z = bin z): the same cells as the dense rebuild, duplicates, out-of-range rows
+    and empty images included; more than 32 bins refused"""
+    from disconet_amd.synthetic import make_sparse_scene_batch
+    ops = _ops()
+    indices, offsets, _ = make_sparse_scene_batch(2, 3, 128)
+    dims = (128, 128, 13)
+    # image 2 sees its rows twice (duplicates), two rows fall outside the grid, image 5's list is emptied
+    o = offsets.tolist()
+    dup = indices[o[2]:o[3]]
+    bad = torch.tensor([[128, 0, 0], [5, 7, 13]], dtype=torch.int32)
+    rows = torch.cat([indices[:o[3]], dup, bad, indices[o[3]:o[5]]])
+    extra = dup.shape[0] + 2
+    offs = torch.tensor(o[:3] + [o[3] + extra, o[4] + extra, o[5] + extra, o[5] + extra], dtype=torch.int32)
+    rows, offs = rows.cuda(), offs.cuda()
+    dense = ops.scatter_dense(rows, offs, 6, dims)
+    bits = ops.scatter_dense_bits(rows, offs, 6, dims)
+    assert bits.bits and bits.data.shape == (6, 128, 128) and bits.data.dtype == torch.int32
+    want = (dense.view(6, 128, 128, 13).to(torch.int32) << torch.arange(13, device="cuda", dtype=torch.int32)).sum(-1)
+    assert torch.equal(bits.data, want.to(torch.int32))
+    assert torch.equal(bits.nhwc(), dense.view(6, 128, 128, 13))
+    assert int(bits.data[5].abs().sum()) == 0
+    with pytest.raises(ops._lib.DnError):
+        ops.scatter_dense_bits(rows, offs, 6, (128, 128, 33))
