@@ -15,7 +15,7 @@ R3 = {"conv_pre_1": 38, "conv_pre_2": 78, "conv1_1 (s2)": 76, "conv1_2 + Conv3D 
       "conv3d_2 (1x1)": 21, "conv3_1 (s2)": 44, "conv3_2": 66, "conv4_1 (s2)": 54, "conv4_2": 70, "conv5_1 (up+cat)": 163, "conv5_2": 65,
       "conv6_1 (up+cat)": 134, "conv6_2": 58, "conv7_1 (up+cat)": 131, "conv7_2": 60, "conv8_1 (up+cat)": 164, "conv8_2": 82,
       "heads (3x3 + block-diag 1x1)": 164}
-SHAPE = {"conv_pre_1": "13→32 @256² (hi-only source)", "conv_pre_2": "32→32 @256²", "conv1_1 (s2)": "32→64 s2 → 128²",
+SHAPE = {"conv_pre_1": "13→32 @256² (occupancy-word source)", "conv_pre_2": "32→32 @256²", "conv1_1 (s2)": "32→64 s2 → 128²",
          "conv1_2 + Conv3D 1x1": "64→64 (+1×1) @128²", "conv2_1 (s2)": "64→128 s2 → 64²", "conv2_2": "128→128 @64²", "conv3d_2 (1x1)": "128→128 1×1 @64²",
          "conv3_1 (s2)": "128→256 s2 → 32²", "conv3_2": "256→256 @32² (+ fp32 NHWC copy)", "conv4_1 (s2)": "256→512 s2 → 16²", "conv4_2": "512→512 @16²",
          "conv5_1 (up+cat)": "768→256 @32² (tap-merged BN 32, 4 K slices)", "conv5_2": "256→256 @32²", "conv6_1 (up+cat)": "384→128 @64² (tap-merged BN 32)",
