@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TRACE = os.path.join(ROOT, "profiles", "r03_bench_kernel_trace.csv")
+TRACE = os.path.join(ROOT, "profiles", "r04_bench_kernel_trace.csv")
 
 
 def _run(*args):
@@ -20,12 +20,12 @@ def test_layer_table_from_the_committed_trace():
     total = [l for l in out.splitlines() if l.startswith("all conv launches")][0].split()
     us, gflop = float(total[3]), float(total[4])
     assert 600 < gflop < 650 and 1000 < us < 3000
-    committed = open(os.path.join(ROOT, "profiles", "r03_bench_layers.txt")).read()
+    committed = open(os.path.join(ROOT, "profiles", "r04_bench_layers.txt")).read()
     assert committed.strip() == out.strip()
 
 
 def test_rocprof_conv_time_matches_the_committed_summary():
     got = json.loads(_run("tools/rocprof_conv.py", TRACE, "conv_sp_kernel,conv_spq_kernel", "20"))
-    want = json.load(open(os.path.join(ROOT, "profiles", "r03_rocprof_conv_sp.json")))
+    want = json.load(open(os.path.join(ROOT, "profiles", "r04_rocprof_conv_sp.json")))
     assert got["launches_per_step"] == 20.0
     assert abs(got["conv_ms_per_step"] - want["conv_ms_per_step"]) < 1e-9
