@@ -24,7 +24,7 @@ na = ops.live_agent_counts(torch.full((BATCH, AGENTS), AGENTS, dtype=torch.int64
 
 def step():
     with torch.no_grad():
-        return model(ops.scatter_dense_sp(indices, offsets, AGENTS * BATCH, (HW, HW, 13), hi_only=True), trans, na, BATCH)
+        return model(ops.scatter_dense_bits(indices, offsets, AGENTS * BATCH, (HW, HW, 13)), trans, na, BATCH)
 
 
 g = GraphedStep(step)
