@@ -55,6 +55,14 @@ struct FuseMlpArgs {
 #define DN_FUSE_ABL 0
 #endif
 constexpr int kAbl = DN_FUSE_ABL;
+// layer-1 weight fragments (L2): how many k-steps ahead of their MFMAs they are requested (1: two register sets, shipped).  2 and 3
+// (ring of four sets, no spills, counted vmcnt waits in the ISA) measured 83.7 us against 84.5 in the same lease: the launch is not
+// waiting on the L2 latency of these loads.
+#ifndef DN_FUSE_WAHEAD
+#define DN_FUSE_WAHEAD 1
+#endif
+constexpr int kWAhead = DN_FUSE_WAHEAD, kWRing = kWAhead == 1 ? 2 : 4;
+static_assert(kWAhead >= 1 && kWAhead <= 3, "weight prefetch distance");
 
 __device__ inline half8 frag_of(const unsigned char* base, int idx) {
   return *reinterpret_cast<const half8*>(base + (size_t)idx * 16);
@@ -183,7 +191,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
     constexpr int NG = decltype(ng_c)::value;
     const unsigned char* wbase = a.w1 + (size_t)mat * 4 * KS * 2 * 2 * 32 * 16 + (size_t)(lh * 32 + li) * 16;
     // fragment (nt, ks, part) at wbase + (((nt * KS + ks) * 2 + part) * 64) * 16
-    half8 wh[2][4], wl[2][4];
+    half8 wh[kWRing][4], wl[kWRing][4];   // weight fragments: ring of kWRing k-steps, loaded kWAhead k-steps before their MFMAs
     f32x4 r0[4][NG], r1[4][NG];   // row pieces: ring of 4 k-steps (the maps come from HBM / far L2)
     auto wload = [&](int ks, int s) {
 #pragma unroll
@@ -224,16 +232,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
     rload(0, 0);
     rload(1, 1);
     rload(2, 2);
-    wload(0, 0);
+#pragma unroll
+    for (int q = 0; q < kWAhead; ++q) wload(q, q);
 #pragma unroll 1
     for (int ks0 = 0; ks0 < KS; ks0 += 4) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int ks = ks0 + u;
         if (ks + 3 < KS) rload(ks + 3, (u + 3) & 3);
-        if (ks + 1 < KS) wload(ks + 1, (u + 1) & 1);
+        if (ks + kWAhead < KS) wload(ks + kWAhead, (u + kWAhead) & (kWRing - 1));
         __builtin_amdgcn_sched_barrier(0);
-        mma(u & 1, u);
+        mma(u & (kWRing - 1), u);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
