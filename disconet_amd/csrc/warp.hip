@@ -289,6 +289,11 @@ warp_gather1_kernel(const float* __restrict__ d_out1, const float* __restrict__ 
 // (the one-pixel kernel re-derives every R(q) four times and is bound by L2 -> L1 bandwidth, ~1.3 GB per
 // step).  A workgroup covers one 64-channel slice of the tile: 100 x 256 B = 25.6 KB of LDS.
 constexpr int WT = 8, WQ = WT + 2, WCS = 64;
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+typedef int i32x4w __attribute__((ext_vector_type(4)));
+#ifndef DN_WARP_SHARED_TAPS
+#define DN_WARP_SHARED_TAPS 1   // 0: round 3's form (every lane derives its pixel's tap sets), for A/B builds
+#endif
 
 __global__ void __launch_bounds__(256)
 warp_neighbors_tiled_kernel(const float* __restrict__ feat, const float* __restrict__ trans,
@@ -328,6 +333,92 @@ warp_neighbors_tiled_kernel(const float* __restrict__ feat, const float* __restr
   const float r00 = m[0], r01 = m[1], r10 = m[4], r11 = m[5];
   const float x_trans = (4.f * m[3]) / 128.f;
   const float y_trans = -(4.f * m[7]) / 128.f;
+#if DN_WARP_SHARED_TAPS
+  // The tap sets depend on the pixel only, and sixteen lanes share a pixel: computed ONCE per pixel into LDS (clamped byte
+  // offsets / LDS rows and validity-masked weights, the expressions of sample_src and of the blend below), then every lane
+  // does loads and FMAs only.  Round 3's form re-derived them in every lane: 1290 VALU instructions per wave, half of the
+  // launch's wave cycles stalled on VALU issue (profiles/r04_fuse_pmc.txt).  Same values, same order of operations.
+  __shared__ __attribute__((aligned(16))) unsigned tap1_off[WQ * WQ][4];
+  __shared__ __attribute__((aligned(16))) float tap1_w[WQ * WQ][4];
+  __shared__ __attribute__((aligned(16))) int tap2_row[WT * WT][4];
+  __shared__ __attribute__((aligned(16))) float tap2_w[WT * WT][4];
+  // north-west q of the tile: the smallest x0(p) - (p - tile origin) over the tile's columns / rows; column / row k on lane
+  // k mod 8, minimum over each group of eight lanes (every group holds all eight)
+  int qx_base, qy_base;
+  {
+    const int k = tid & 7;
+    const Bilinear t = bilinear_taps((2.f * (tile_x0 + k) + 1.f) / w - 1.f + x_trans,
+                                     (2.f * (tile_y0 + k) + 1.f) / h - 1.f + y_trans, w, h);
+    qx_base = t.x0 - k;
+    qy_base = t.y0 - k;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+      qx_base = min(qx_base, __shfl_xor(qx_base, d, 64));
+      qy_base = min(qy_base, __shfl_xor(qy_base, d, 64));
+    }
+  }
+  if (tid < WQ * WQ) {              // pass-1 tap set of rotated pixel q = tid
+    const int q = tid;
+    const int qx = qx_base + q % WQ, qy = qy_base + q / WQ;
+    const float qbx = (2.f * qx + 1.f) / w - 1.f;
+    const float qby = (2.f * qy + 1.f) / h - 1.f;
+    const Bilinear t1 = bilinear_taps(r00 * qbx + r01 * qby, r10 * qbx + r11 * qby, w, h);
+    const bool x0ok = t1.x0 >= 0 && t1.x0 < w, x1ok = t1.x0 + 1 >= 0 && t1.x0 + 1 < w;
+    const bool y0ok = t1.y0 >= 0 && t1.y0 < h, y1ok = t1.y0 + 1 >= 0 && t1.y0 + 1 < h;
+    const int x0 = min(max(t1.x0, 0), w - 1), x1 = min(max(t1.x0 + 1, 0), w - 1);
+    const int y0 = min(max(t1.y0, 0), h - 1), y1 = min(max(t1.y0 + 1, 0), h - 1);
+    *reinterpret_cast<u32x4w*>(tap1_off[q]) = u32x4w{(unsigned)((y0 * w + x0) * c) * 4u, (unsigned)((y0 * w + x1) * c) * 4u,
+                                                      (unsigned)((y1 * w + x0) * c) * 4u, (unsigned)((y1 * w + x1) * c) * 4u};
+    *reinterpret_cast<f32x4*>(tap1_w[q]) = f32x4{(y0ok && x0ok) ? t1.w_nw : 0.f, (y0ok && x1ok) ? t1.w_ne : 0.f,
+                                                 (y1ok && x0ok) ? t1.w_sw : 0.f, (y1ok && x1ok) ? t1.w_se : 0.f};
+  } else if (tid >= 128 && tid < 128 + WT * WT) {     // pass-2 tap set of output pixel pl (a wave of its own)
+    const int pl = tid - 128;
+    const int px = tile_x0 + pl % WT, py = tile_y0 + pl / WT;
+    const float bx = (2.f * px + 1.f) / w - 1.f;
+    const float by = (2.f * py + 1.f) / h - 1.f;
+    const Bilinear t2 = bilinear_taps(bx + x_trans, by + y_trans, w, h);
+    const float qw[4] = {t2.w_nw, t2.w_ne, t2.w_sw, t2.w_se};
+    int row[4];
+    float wk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int qx = t2.x0 + (k & 1), qy = t2.y0 + (k >> 1);
+      const bool qok = qx >= 0 && qx < w && qy >= 0 && qy < h;
+      const int lx = min(max(qx - qx_base, 0), WQ - 1), ly = min(max(qy - qy_base, 0), WQ - 1);
+      row[k] = ly * WQ + lx;
+      wk[k] = qok ? qw[k] : 0.f;
+    }
+    *reinterpret_cast<i32x4w*>(tap2_row[pl]) = i32x4w{row[0], row[1], row[2], row[3]};
+    *reinterpret_cast<f32x4*>(tap2_w[pl]) = f32x4{wk[0], wk[1], wk[2], wk[3]};
+  }
+  __syncthreads();
+  // pass 1 (rotation) of the tile's q block: nw, ne, sw, se as torch's CPU kernel (sample_src)
+  const unsigned lane_off = 16u * (slice * (WCS / 4) + l);
+  for (int idx = tid; idx < WQ * WQ * 16; idx += 256) {
+    const int q = idx >> 4;
+    const u32x4w off = *reinterpret_cast<const u32x4w*>(tap1_off[q]);
+    const f32x4 wt = *reinterpret_cast<const f32x4*>(tap1_w[q]);
+    const f32x4 v_nw = ldb4(src, off[0] + lane_off), v_ne = ldb4(src, off[1] + lane_off);
+    const f32x4 v_sw = ldb4(src, off[2] + lane_off), v_se = ldb4(src, off[3] + lane_off);
+    f32x4 acc = v_nw * wt[0];
+    acc += v_ne * wt[1];
+    acc += v_sw * wt[2];
+    acc += v_se * wt[3];
+    rot[q][l] = acc;
+  }
+  __syncthreads();
+  // pass 2 (translation): blend the four q of every output pixel
+  for (int pl = tid >> 4; pl < WT * WT; pl += 16) {
+    const int px = tile_x0 + pl % WT, py = tile_y0 + pl / WT;
+    if (px >= w || py >= h) continue;
+    const i32x4w row = *reinterpret_cast<const i32x4w*>(tap2_row[pl]);
+    const f32x4 wt = *reinterpret_cast<const f32x4*>(tap2_w[pl]);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += rot[row[k]][l] * wt[k];
+    *reinterpret_cast<f32x4*>(out_of(py * w + px)) = acc;
+  }
+#else
   // north-west q of the tile: the smallest x0(p) - (p - tile origin) over the tile's columns / rows
   int qx_base = 1 << 30, qy_base = 1 << 30;
 #pragma unroll
@@ -365,6 +456,7 @@ warp_neighbors_tiled_kernel(const float* __restrict__ feat, const float* __restr
     }
     *reinterpret_cast<f32x4*>(out_of(py * w + px)) = acc;
   }
+#endif
 }
 
 }  // namespace

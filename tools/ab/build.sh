@@ -5,16 +5,17 @@
 set -e
 R=$(cd "$(dirname "$0")/../.." && pwd); C=$R/disconet_amd/csrc
 # tools/ab/build.sh FLAGS name "<extra hipcc flags>"  builds tools/ab/FLAGS_name with those flags instead of a macro
+FILES=${AB_FILES:-"conv_sp conv_spq fuse_mlp"}     # AB_FILES="warp" tools/ab/build.sh DN_WARP_SHARED_TAPS 0 1
 M=$1; shift
 if [ "$M" = FLAGS ]; then set -- "$1:$2"; fi
 for v in "$@"; do
   if [ "$M" = FLAGS ]; then d=$R/tools/ab/FLAGS_${v%%:*}; X="${v#*:}"; else d=$R/tools/ab/${M}_$v; X="-D$M=$v"; fi
   mkdir -p $d
-  for f in conv_sp conv_spq fuse_mlp; do
+  for f in $FILES; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment -I $R/include -I $C $X -c $C/$f.hip -o $d/$f.o &
   done
   wait
-  objs=$(ls $C/build/*.o | grep -v -E "/(conv_sp|conv_spq|fuse_mlp)\.o")
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $d/libdisconet_hip.so $objs $d/conv_sp.o $d/conv_spq.o $d/fuse_mlp.o
+  objs=$(ls $C/build/*.o | grep -v -E "/($(echo $FILES | tr ' ' '|'))\.o")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $d/libdisconet_hip.so $objs $(for f in $FILES; do echo $d/$f.o; done)
   rm -f $d/*.o
 done
