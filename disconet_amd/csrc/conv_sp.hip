@@ -524,24 +524,27 @@ conv_sp_kernel(const SpArgs a) {
     const int img_bytes = cog * 4 * plane;
     const auto rsrc_o = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)img * img_bytes, 0, img_bytes, 0x00020000);
     const int voff = inside ? (oy * a.w_out + ox) * 16 + lh * plane : (int)0x80000000;
-    const float floor_v = relu ? 0.f : -__builtin_inff();
-    auto affine = [&](int g, f32x4& v) {
+    // ReLU: in the fp32 copy a max against a uniform floor (0 or -inf); in the split it is the lower clamp bound
+    // (sp_device.h :: split4), so the affine for the split applies none (`relu_here` false)
+    const float floor_v = relu ? 0.f : -__builtin_inff(), lo_clamp = relu ? 0.f : -65504.f;
+    auto affine = [&](int g, f32x4& v, bool relu_here) {
       const int co = ch0 + 8 * g + 4 * lh;
+      const float fl = relu_here ? floor_v : -__builtin_inff();
       if (wn_r >= 0) {            // register-resident affine (channels past c_out: scale = shift = 0 -> 0)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = c[4 * g + e] * sc_r[kRegAffine ? wn_r : 0][g][e] + sh_r[kRegAffine ? wn_r : 0][g][e];
+        v = affine4(quad_of(c, g), sc_r[kRegAffine ? wn_r : 0][g], sh_r[kRegAffine ? wn_r : 0][g]);
         note_nan4_tile(nan_seen, v, g);
+        if (relu_here) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], fl);
+        }
       } else if (POST == 1 && wn_r == -2) {   // stage-2 affine of the fused 1x1 from LDS (zero past c_out2)
         const f32x4 sc = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 2 : 0][co & 63]);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 3 : 0][co & 63]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = c[4 * g + e] * sc[e] + sh[e];
+        v = affine4(quad_of(c, g), sc, sh);
         note_nan4_tile(nan_seen, v, g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = fmaxf(v[e], floor_v);
+          if (relu_here) v[e] = fmaxf(v[e], fl);
           v[e] = co + e < c_lim ? v[e] : 0.f;
         }
       } else {
@@ -554,7 +557,7 @@ conv_sp_kernel(const SpArgs a) {
         note_nan4_tile(nan_seen, v, g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = fmaxf(v[e], floor_v);
+          if (relu_here) v[e] = fmaxf(v[e], fl);
           v[e] = co + e < c_lim ? v[e] : 0.f;
         }
       }
@@ -568,7 +571,7 @@ conv_sp_kernel(const SpArgs a) {
         for (int g = 0; g < 4; ++g) {
           const int co = ch0 + 8 * g + 4 * lh;
           f32x4 v;
-          affine(g, v);
+          affine(g, v, true);
           if (inside && co < c_lim) *reinterpret_cast<f32x4*>(orow + co) = v;
         }
       }
@@ -577,8 +580,8 @@ conv_sp_kernel(const SpArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 v;
-      affine(g, v);
-      split4(v, hi[g], lo[g], amax);
+      affine(g, v, false);
+      split4(v, hi[g], lo[g], amax, lo_clamp);
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -670,16 +673,11 @@ conv_sp_kernel(const SpArgs a) {
           const int co = tc.n0 + 32 * wn + 8 * g + 4 * lh;
           const f32x4 sc1 = *reinterpret_cast<const f32x4*>(&aff1_s[0][POST == 2 ? co & 63 : 0]);
           const f32x4 sh1 = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 1 : 0][POST == 2 ? co & 63 : 0]);
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = acc[wm][wn][4 * g + e] * sc1[e] + sh1[e];
-            if (a.relu) v[e] = fmaxf(v[e], 0.f);
-          }
+          const f32x4 v = affine4(quad_of(acc[wm][wn], g), sc1, sh1);   // the ReLU rides in the split's clamp
           // (no NaN test here: this launch sits at its register budget -- the test cost 30 us of spills -- and its
           // outputs are fp32, where a NaN of the hidden layer that survives the ReLU shows; NaNs of the input were
           // flagged by the epilogue that produced it)
-          split4(v, hi[g], lo[g], amax);
+          split4(v, hi[g], lo[g], amax, a.relu ? 0.f : -65504.f);
         }
         half8 xh[2], xl[2];
 #pragma unroll
@@ -749,14 +747,9 @@ conv_sp_kernel(const SpArgs a) {
             f32x4 v;
             const f32x4 sc = *reinterpret_cast<const f32x4*>(&aff1_s[0][POST == 1 ? co : 0]);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 1 : 0][POST == 1 ? co : 0]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
+            v = affine4(quad_of(acc[wm][wn], g), sc, sh);
             note_nan4_tile(nan_seen, v, g);
-            if (a.relu) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            split4(v, hi[g], lo[g], amax);
+            split4(v, hi[g], lo[g], amax, a.relu ? 0.f : -65504.f);   // the ReLU rides in the split's clamp
           }
 #pragma unroll
           for (int m = 0; m < 2; ++m) {

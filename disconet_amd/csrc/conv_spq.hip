@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
     const int plane = a.h * a.w * 16;
     const int img_bytes = a.cog * 4 * plane;
     const auto rsrc_o = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)tc.img * img_bytes, 0, img_bytes, 0x00020000);
-    const float floor_v = a.relu ? 0.f : -__builtin_inff();
+    const float lo_clamp = a.relu ? 0.f : -65504.f;
 #pragma unroll
     for (int wm = 0; wm < 2; ++wm) {
       const int oy = tc.oy0 + prow[wm], ox = tc.ox0 + pcol;
@@ -413,13 +413,9 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
         for (int g = 0; g < 4; ++g) {
           const f32x4 sc = *reinterpret_cast<const f32x4*>(aff_s + wn * 32 + 8 * g + 4 * lh);
           const f32x4 sh = *reinterpret_cast<const f32x4*>(aff_s + 64 + wn * 32 + 8 * g + 4 * lh);
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[wm][wn][4 * g + e] * sc[e] + sh[e];
+          const f32x4 v = affine4(quad_of(acc[wm][wn], g), sc, sh);
           note_nan4_tile(nan_seen, v, g);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);
-          split4(v, hi[g], lo[g], amax);
+          split4(v, hi[g], lo[g], amax, lo_clamp);      // the ReLU rides in the split's clamp (sp_device.h)
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {

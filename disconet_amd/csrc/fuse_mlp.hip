@@ -261,10 +261,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
       for (int g = 0; g < 4; ++g) {
         const int u = nt * 32 + 8 * g + 4 * lh;
         const f32x4 sc = *reinterpret_cast<const f32x4*>(s1l + u), sh = *reinterpret_cast<const f32x4*>(t1l + u);
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[nt][4 * g + e] * sc[e] + sh[e], 0.f);
-        split4(v, hi[g], lo[g]);
+        float unused = 0.f;
+        split4(affine4(quad_of(acc[nt], g), sc, sh), hi[g], lo[g], unused, 0.f);   // ReLU = the split's lower clamp
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
@@ -286,10 +284,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
       for (int g = 0; g < 4; ++g) {
         const int u = 8 * g + 4 * lh;
         const f32x4 sc = *reinterpret_cast<const f32x4*>(s2l + u), sh = *reinterpret_cast<const f32x4*>(t2l + u);
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc2[4 * g + e] * sc[e] + sh[e], 0.f);
-        split4(v, hi[g], lo[g]);
+        float unused = 0.f;
+        split4(affine4(quad_of(acc2, g), sc, sh), hi[g], lo[g], unused, 0.f);
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {

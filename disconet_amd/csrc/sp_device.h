@@ -94,23 +94,59 @@ inline void sp_range_collect_here(unsigned* dst, bool reset, hipStream_t stream)
 #ifndef DN_RANGECHECK
 #define DN_RANGECHECK 1     // tools/ab: 0 = the splits track no magnitudes (what the range guard costs)
 #endif
-__device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo, float& amax) {
-#if DN_RANGECHECK
-  amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
-  amax = fmaxf(fmaxf(amax, fabsf(v[2])), fabsf(v[3]));
+// lo_clamp: the lower clamp bound -- -65504 (a plain split) or 0 (the ReLU of an epilogue rides in the clamp: max(v, 0) then
+// clamp to +-65504 is med3(v, 0, 65504)).  amax is taken from the CLAMPED values: a clamped value is exactly +-65504, which is
+// what note_range() reports as "clamped", and anything a ReLU zeroes must not count.
+// The lo half: v - float(hi) is exact in fp32; v_fma_mix_f32 reads the f16 half of the packed hi pair directly
+// (fma(float(hi), -1, v): the same exact difference) -- one instruction instead of v_cvt_f32_f16 + v_sub_f32.
+// DN_SPLIT_V2 = 0 builds round 3's instruction sequence (tools/ab); the values are identical.
+#ifndef DN_SPLIT_V2
+#define DN_SPLIT_V2 1
 #endif
+template <int HIGH>
+__device__ inline float lo_of_pair(unsigned hpair, float x) {
+  float r;
+  if constexpr (HIGH) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+  return r;
+}
+__device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo, float& amax, float lo_clamp = -65504.f) {
   f32x4 x;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+  for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(v[e], lo_clamp, 65504.f);
+#if DN_RANGECHECK
+  amax = fmaxf(fmaxf(amax, fabsf(x[0])), fabsf(x[1]));
+  amax = fmaxf(fmaxf(amax, fabsf(x[2])), fabsf(x[3]));
+#endif
   const half4 h = __builtin_convertvector(x, half4);
-  const half4 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), half4);
   hi = __builtin_bit_cast(u32x2, h);
+#if DN_SPLIT_V2
+  const f32x4 d = {lo_of_pair<0>(hi[0], x[0]), lo_of_pair<1>(hi[0], x[1]), lo_of_pair<0>(hi[1], x[2]), lo_of_pair<1>(hi[1], x[3])};
+  const half4 l = __builtin_convertvector(d, half4);
+#else
+  const half4 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), half4);
+#endif
   lo = __builtin_bit_cast(u32x2, l);
 }
 __device__ inline void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
   float unused = 0.f;
   split4(v, hi, lo, unused);
 }
+// c * scale + shift of four values as two packed fp32 FMAs (v_pk_fma_f32: the IEEE fma of v_fma_f32, two per instruction)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ inline f32x4 affine4(const f32x4 c, const f32x4 sc, const f32x4 sh) {
+#if DN_SPLIT_V2
+  const f32x2 a = __builtin_elementwise_fma(f32x2{c[0], c[1]}, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]});
+  const f32x2 b = __builtin_elementwise_fma(f32x2{c[2], c[3]}, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+#else
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = c[e] * sc[e] + sh[e];
+  return v;
+#endif
+}
+__device__ inline f32x4 quad_of(const f32x16& c, int g) { return f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]}; }
 
 // K slices of a conv launch (conv_sp.hip / conv_spq.hip, `KSL` kernels; include/disconet_hip.h :: dn_spconv2d_ks).
 // A layer with `count` > 1 canonical K slices defines every output as the fp32 sum, in slice order and starting from
