@@ -30,6 +30,12 @@
 #ifndef DN_MFMA_PRIO
 #define DN_MFMA_PRIO 0
 #endif
+// tools/ab: 1 = the weight-stationary kernels time their phases with s_memtime (wave 0 of every workgroup, summed into
+// g_phase_cycles: [0] wait for the patch + barrier, [1] issue of the next patch, [2] MFMA loop, [3] epilogue, [4] tile decode + rest,
+// [5] tiles, [6] total) -- read with dn_sp_phase_cycles().  Never in the shipped build.
+#ifndef DN_PHASE_TIMING
+#define DN_PHASE_TIMING 0
+#endif
 #ifndef DN_UNIFORM_TILE
 #define DN_UNIFORM_TILE 0   // tools/ab: 1 = every kernel's tile coordinates through v_readfirstlane (scalar registers)
 #endif
@@ -41,6 +47,16 @@
 #include "sp_device.h"
 #include <cstdlib>
 #include <type_traits>
+
+#if DN_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[8];
+extern "C" int dn_sp_phase_cycles(unsigned long long* host8, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (host8 && hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 namespace {
 
@@ -511,6 +527,13 @@ conv_sp_kernel(const SpArgs a) {
           sc_r[wn][g][e] = co < a.c_out ? a.scale[ci] : 0.f;
           sh_r[wn][g][e] = co < a.c_out ? a.shift[ci] : 0.f;
         }
+    // Wait for these loads HERE, with the builtin the compiler's wait-count pass understands.  Left to the pass, their
+    // first use -- the epilogue, inside the persistent loop -- gets an s_waitcnt vmcnt(0), which in steady state (no loads
+    // pending, the registers long valid) waits for the NEXT tile's patch DMA instead: every epilogue started only after
+    // the prefetch it was meant to hide had landed (round 4, phase timing: tools/phase_probe.py).
+#if DN_EPI_NO_DMA_WAIT
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+#endif
   };
   // One 32-pixel x 32-channel accumulator tile -> SP pieces.  Stores are buffer stores against a descriptor of the
   // output IMAGE (32-bit lane offset computed once per tile + the quarter-plane offset; a lane outside the map
@@ -538,8 +561,8 @@ conv_sp_kernel(const SpArgs a) {
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], fl);
         }
       } else if (POST == 1 && wn_r == -2) {   // stage-2 affine of the fused 1x1 from LDS (zero past c_out2)
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 2 : 0][co & 63]);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 3 : 0][co & 63]);
+        const f32x4 sc = lds_table4(reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 2 : 0][co & 63]), smem);
+        const f32x4 sh = lds_table4(reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 3 : 0][co & 63]), smem);
         v = affine4(quad_of(c, g), sc, sh);
         note_nan4_tile(nan_seen, v, g);
 #pragma unroll
@@ -647,6 +670,9 @@ conv_sp_kernel(const SpArgs a) {
             w2h[wn][nt][ks] = *reinterpret_cast<const half8*>(wp);
             w2l[wn][nt][ks] = *reinterpret_cast<const half8*>(wp + 2 * 32 * 16);
           }
+#if DN_EPI_NO_DMA_WAIT
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // as in load_affine: no vmcnt(0) at the fragments' first use in later tiles
+#endif
       }
       auto w2_hi = [&](int nt, int ks) { return w2h[wn][nt][ks]; };
       auto w2_lo = [&](int nt, int ks) { return w2l[wn][nt][ks]; };
@@ -671,8 +697,8 @@ conv_sp_kernel(const SpArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int co = tc.n0 + 32 * wn + 8 * g + 4 * lh;
-          const f32x4 sc1 = *reinterpret_cast<const f32x4*>(&aff1_s[0][POST == 2 ? co & 63 : 0]);
-          const f32x4 sh1 = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 1 : 0][POST == 2 ? co & 63 : 0]);
+          const f32x4 sc1 = lds_table4(reinterpret_cast<const f32x4*>(&aff1_s[0][POST == 2 ? co & 63 : 0]), smem);
+          const f32x4 sh1 = lds_table4(reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 1 : 0][POST == 2 ? co & 63 : 0]), smem);
           const f32x4 v = affine4(quad_of(acc[wm][wn], g), sc1, sh1);   // the ReLU rides in the split's clamp
           // (no NaN test here: this launch sits at its register budget -- the test cost 30 us of spills -- and its
           // outputs are fp32, where a NaN of the hidden layer that survives the ReLU shows; NaNs of the input were
@@ -705,8 +731,8 @@ conv_sp_kernel(const SpArgs a) {
           for (int g = 0; g < 4; ++g) {
             const int ch = nt * 32 + 8 * g + 4 * lh;        // c2 is a multiple of 4: whole pieces
             if (ch < c2) {
-              const f32x4 sc = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 2 : 0][POST == 2 ? (c2_0 + ch) & 63 : 0]);
-              const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 3 : 0][POST == 2 ? (c2_0 + ch) & 63 : 0]);
+              const f32x4 sc = lds_table4(reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 2 : 0][POST == 2 ? (c2_0 + ch) & 63 : 0]), smem);
+              const f32x4 sh = lds_table4(reinterpret_cast<const f32x4*>(&aff1_s[POST == 2 ? 3 : 0][POST == 2 ? (c2_0 + ch) & 63 : 0]), smem);
               f32x4 v;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -745,8 +771,8 @@ conv_sp_kernel(const SpArgs a) {
           for (int g = 0; g < 4; ++g) {
             const int co = wn * 32 + 8 * g + 4 * lh;
             f32x4 v;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(&aff1_s[0][POST == 1 ? co : 0]);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 1 : 0][POST == 1 ? co : 0]);
+            const f32x4 sc = lds_table4(reinterpret_cast<const f32x4*>(&aff1_s[0][POST == 1 ? co : 0]), smem);
+            const f32x4 sh = lds_table4(reinterpret_cast<const f32x4*>(&aff1_s[POST == 1 ? 1 : 0][POST == 1 ? co : 0]), smem);
             v = affine4(quad_of(acc[wm][wn], g), sc, sh);
             note_nan4_tile(nan_seen, v, g);
             split4(v, hi[g], lo[g], amax, a.relu ? 0.f : -65504.f);   // the ReLU rides in the split's clamp
@@ -880,6 +906,14 @@ conv_sp_kernel(const SpArgs a) {
       }
     };
     int b_n0 = cur.n0;
+#if DN_PHASE_TIMING
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = __builtin_readcyclecounter();
+    const unsigned long long t_begin = t_prev;
+    auto mark = [&](int k) { const unsigned long long t = __builtin_readcyclecounter(); ph[k] += t - t_prev; t_prev = t; };
+#else
+    auto mark = [&](int) {};
+#endif
     load_weights(b_n0);
     setup_voff_a(cur, false);
     issue_a(0, 0, false);
@@ -890,11 +924,13 @@ conv_sp_kernel(const SpArgs a) {
       const bool has_next = item + G < a.total_items;
       TileCoord nxt = cur;
       if (has_next) nxt = decode(item + G);
+      mark(4);
       for (int g = 0; g < a.ngroups; ++g) {
         const bool last_g = g + 1 == a.ngroups;
         wait_vm0();                      // this group's patch (first time: and the weights) has landed ...
         __builtin_amdgcn_s_barrier();    // ... for every wave, and every wave is done with the other stage
         asm volatile("" ::: "memory");
+        mark(0);
         if (!last_g) {
           if ((g + 1) * CA == a.c0g && a.c1g) setup_voff_a(cur, true);
           issue_a(g + 1, sa ^ 1);
@@ -903,14 +939,27 @@ conv_sp_kernel(const SpArgs a) {
           setup_voff_a(nxt, false);
           issue_a(0, sa ^ 1);
         }
+        mark(1);
         // all taps of the chunk back to back: nothing in LDS changes under them
         compute(std::integral_constant<int, 0>{}, std::integral_constant<int, NS * SUB>{},
                 smem + sa * T::A_STAGE, smem + T::OFF_B + g * (NS * T::B_STEP));
         if (!last_g || has_next) commit_a(sa ^ 1);   // bit-grid source: the words loaded under the MFMAs -> the other stage
         sa ^= 1;
+#if DN_PHASE_TIMING
+        asm volatile("s_nop 0" ::: "memory");
+        {   // the MFMAs are asynchronous: read one accumulator register before the clock (forces the last MFMA to retire)
+          float probe = acc[0][0][0];
+          asm volatile("v_mov_b32 %0, %0" : "+v"(probe));
+        }
+#endif
+        mark(2);
       }
       epilogue(cur);
+      mark(3);
       note_range(amax, nan_seen);
+#if DN_PHASE_TIMING
+      ph[5] += 1;
+#endif
       if (!has_next) break;
       item += G;
       cur = nxt;
@@ -921,6 +970,11 @@ conv_sp_kernel(const SpArgs a) {
         load_weights(b_n0);
       }
     }
+#if DN_PHASE_TIMING
+    ph[6] = __builtin_readcyclecounter() - t_begin;
+    if (tid == 0)
+      for (int k = 0; k < 7; ++k) atomicAdd(&g_phase_cycles[k], ph[k]);
+#endif
     return;
   }
 

@@ -86,6 +86,23 @@ inline void sp_range_collect_here(unsigned* dst, bool reset, hipStream_t stream)
   hipLaunchKernelGGL(sp_range_collect_kernel, dim3(1), dim3(1), 0, stream, dst, reset ? 1 : 0);
 }
 
+// An LDS read the compiler's wait-count pass does not put behind the LDS-DMA loads in flight.  After a `buffer_load ... lds`
+// the pass makes every LDS access it cannot tell apart from the DMA's destination wait for vmcnt(0) -- in a persistent
+// kernel that is the NEXT tile's patch, i.e. the epilogue would start only once the prefetch it should hide has landed.
+// A load through a __restrict__ parameter carries alias-scope metadata after inlining, and the pass skips scoped loads when
+// no DMA store carries a scope (ours do not).  The tables read this way are written once, before the first DMA, behind a
+// barrier.  tools: count `s_waitcnt vmcnt(0)` outside ASMSTART blocks in the kernel's ISA.
+__device__ __attribute__((always_inline)) inline f32x4 lds_table4(const f32x4* __restrict__ p, const unsigned char* __restrict__ not_p) {
+  (void)not_p;
+  return *p;
+}
+#ifndef DN_EPI_NO_DMA_WAIT
+#define DN_EPI_NO_DMA_WAIT 1   // tools/ab: 0 = round 3's epilogues (their first affine use waits for the next tile's patch DMA)
+#endif
+#if !DN_EPI_NO_DMA_WAIT
+#define lds_table4(p, q) (*(p))
+#endif
+
 // x -> (hi, lo) halves, 4 values -> two dword pairs.  amax: running max |x| of what this lane has split
 // (note_range() reports it once per epilogue).
 // Vector form on purpose: gfx950 has v_cvt_pk_f16_f32 (two fp32 -> packed halves, round to nearest even, the scalar
