@@ -81,6 +81,9 @@ SIGNATURES = {
     "dn_spconv_workspace_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
     "dn_spconv2d_ks": (c_int, [POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "dn_spconv2d_pre_pair_supported": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc)]),
+    "dn_spconv2d_pre_pair": (c_int, [POINTER(ConvDesc), POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "dn_spconv2d_dual": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_int, c_void_p]),
     "dn_sp_post1x1_packed_bytes": (c_size_t, []),

@@ -1891,3 +1891,5 @@ extern "C" int dn_spconv2d_post1x1(const dn_conv_desc* d, const dn_post1x1_desc*
   }
   return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2, 1>(a, *d, (hipStream_t)stream);
 }
+
+#include "conv_pre_pair.inl"

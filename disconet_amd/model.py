@@ -511,6 +511,23 @@ class DiscoNet(nn.Module):
             x = x.float().contiguous()
         return x
 
+    def _stem_pair(self, x, P):
+        """conv_pre_1 -> conv_pre_2 as ONE launch (dn_spconv2d_pre_pair: the intermediate map stays in LDS) when the input is
+        an occupancy bit grid and the two layers have the stem's shape; else None.  DN_STEM_PAIR=0: the two launches (A/B)."""
+        l1, l2 = P["conv_pre_1"], P["conv_pre_2"]
+        if not (isinstance(x, ops.SpTensor) and x.bits and l1.math == 2 and l2.math == 2
+                and os.environ.get("DN_STEM_PAIR", "1") != "0"):
+            return None
+        n, h, w, c = x.shape
+        d1 = ops.conv_desc(n, h, w, c, l1.c_out, l1.ksize, l1.stride, l1.relu, math="sp")
+        d2 = ops.conv_desc(n, h, w, l2.c_in, l2.c_out, l2.ksize, l2.stride, l2.relu, math="sp")
+        if c != l1.c_in or not ops.sp_conv2d_pre_pair_supported(d1, d2):
+            return None
+        flops = 2.0 * n * h * w * 9 * (l1.c_out * l1.c_in + l2.c_out * l2.c_in)
+        nbytes = 4.0 * (n * h * w + n * h * w * l2.c_out)
+        with region("conv_pre_1+2", "conv_sp_kernel", flops, nbytes):      # (the SP engine's family name: bench.py sums it with the conv launches)
+            return ops.sp_conv2d_pre_pair(d1, d2, x, l1.packed, l1.scale, l1.shift, l2.packed, l2.scale, l2.shift)
+
     def _enc_group(self, k, x, P, nhwc_copy=False):
         """encoder group k: its last layer's output is the pyramid level e[k].  nhwc_copy (SP engine): the last
         layer also writes the level as fp32 NHWC from its epilogue (the exchanged level: no dn_sp_to_nhwc pass);
@@ -518,6 +535,9 @@ class DiscoNet(nn.Module):
         dual = nhwc_copy and self.conv_math == "sp"
         unpack = lambda r: r if isinstance(r, tuple) else (r, None)
         if k == 0:
+            pair = self._stem_pair(x, P) if not dual else None
+            if pair is not None:
+                return pair, None
             return unpack(P["conv_pre_2"].run(P["conv_pre_1"].run(x), nhwc_copy=dual))
         if k == 1:
             if "conv1_2_3d" in P:

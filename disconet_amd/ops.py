@@ -437,6 +437,24 @@ def sp_conv2d(d, src0, packed, scale, shift, src1=None, out=None, nhwc_copy=Fals
     return out
 
 
+def sp_conv2d_pre_pair_supported(d1, d2):
+    return bool(_lib.load().dn_spconv2d_pre_pair_supported(ctypes.byref(d1), ctypes.byref(d2)))
+
+
+def sp_conv2d_pre_pair(d1, d2, bits, packed1, scale1, shift1, packed2, scale2, shift2, out=None):
+    """The encoder stem's first two 3x3 layers in one launch (dn_spconv2d_pre_pair): `bits` an SpTensor(bits=True), the
+    layers' packed weights and folded affines -> SpTensor [n, h, w, d2.c_out]; bit-identical to the two launches."""
+    _need_gpu(bits, packed1, packed2, scale1, shift1, scale2, shift2)
+    if not getattr(bits, "bits", False):
+        raise _lib.DnError("sp_conv2d_pre_pair: the source must be an occupancy bit grid (ops.scatter_dense_bits)")
+    if out is None:
+        out = SpTensor(d2.n_images, d2.h_in, d2.w_in, d2.c_out, device=bits.device)
+    check(_lib.load().dn_spconv2d_pre_pair(ctypes.byref(d1), ctypes.byref(d2), _ptr(bits.data), _ptr(packed1), _ptr(scale1),
+                                           _ptr(shift1), _ptr(packed2), _ptr(scale2), _ptr(shift2), _ptr(out.data), _stream()),
+          "dn_spconv2d_pre_pair")
+    return out
+
+
 def sp_pack_post1x1_weights(weight):
     """weight [c_out2, c_in2(, 1, 1)] -> (packed A-operand fragments, wmul)"""
     _need_gpu(weight)

@@ -254,6 +254,16 @@ int dn_spconv2d_ks(const dn_conv_desc* d, int kslices, const void* src0, const v
                    fp32 NHWC output of dn_spconv2d_dual (not on the tap-merged up-conv) */, int ld_nhwc,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* The encoder stem's first two layers in one launch (conv_pre_1 -> conv_pre_2, both 3x3 + BN + ReLU at the
+ * full map): d1 / d2 describe the two layers (3x3, stride 1, one source each; c0 <= 16 -> 32 -> c_out <= 32, same images and
+ * map), `bits` is the occupancy bit grid of dn_scatter_dense_bits, packed1 / packed2 the layers' dn_spconv_pack_weights
+ * images, out the SP tensor of layer 2.  The intermediate map stays in LDS (it is never written); the result is
+ * bit-identical to dn_spconv2d(d1 with math = 4) followed by dn_spconv2d(d2).  dn_spconv2d_pre_pair_supported: 1 if the pair
+ * of descriptors fits this form (else DN_ERR_ARG from the launch). */
+int dn_spconv2d_pre_pair_supported(const dn_conv_desc* d1, const dn_conv_desc* d2);
+int dn_spconv2d_pre_pair(const dn_conv_desc* d1, const dn_conv_desc* d2, const uint32_t* bits, const void* packed1,
+                         const float* scale1, const float* shift1, const void* packed2, const float* scale2,
+                         const float* shift2, void* out_sp, void* stream);
 /* The same conv with a SECOND copy of its output as float32 NHWC rows [n][h_out][w_out][ld_nhwc] (first c_out
  * columns; c_out % 4 == 0), written from the same epilogue registers before the f16 split: the level a
  * consumer outside the conv engine reads (the fusion kernels' maps, the agent all-gather) needs no

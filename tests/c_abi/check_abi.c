@@ -283,7 +283,33 @@ static int gpu_hi_only_and_flags(void) {
     CHECK(dn_scatter_dense_bits(didx, doff, n, nidx, dims33, dbits, NULL) == DN_ERR_ARG, "33 bins accepted");
     d.c_out = 64;
     CHECK(dn_spconv2d(&d, dbits, NULL, pk, dsc, dsh, o2, NULL) != DN_OK, "bit grid with 64 output channels accepted");
-    d.c_out = cout; d.math = 3;
+    d.c_out = cout; d.math = 4;
+    /* the stem pair in one launch: dn_spconv2d_pre_pair == dn_spconv2d(math 4) then dn_spconv2d, bit for bit */
+    {
+      dn_conv_desc d2 = d;
+      d2.c0 = cout; d2.c_out = 24; d2.math = 2;
+      const size_t nw2 = (size_t)24 * cout * 9, ob2 = dn_sp_tensor_bytes(n, X, Y, 24);
+      float* wt2 = malloc(nw2 * 4);
+      for (size_t i = 0; i < nw2; ++i) wt2[i] = frand(&s) * 0.1f;
+      float* dw2; void *pk2, *mid, *o3, *o4;
+      HIP(hipMalloc((void**)&dw2, nw2 * 4)); HIP(hipMalloc(&pk2, dn_spconv_packed_weight_bytes(&d2)));
+      HIP(hipMalloc(&mid, ob)); HIP(hipMalloc(&o3, ob2)); HIP(hipMalloc(&o4, ob2));
+      HIP(hipMemcpy(dw2, wt2, nw2 * 4, hipMemcpyHostToDevice));
+      CHECK(dn_spconv_pack_weights(&d2, dw2, 1024.f, pk2, NULL) == DN_OK, "pack 2: %s", dn_last_error());
+      CHECK(dn_spconv2d_pre_pair_supported(&d, &d2) == 1, "stem pair not supported");
+      CHECK(dn_spconv2d(&d, dbits, NULL, pk, dsc, dsh, mid, NULL) == DN_OK, "layer 1: %s", dn_last_error());
+      CHECK(dn_spconv2d(&d2, mid, NULL, pk2, dsc, dsh, o3, NULL) == DN_OK, "layer 2: %s", dn_last_error());
+      HIP(hipMemset(o4, 0xff, ob2));
+      CHECK(dn_spconv2d_pre_pair(&d, &d2, dbits, pk, dsc, dsh, pk2, dsc, dsh, o4, NULL) == DN_OK, "pre pair: %s", dn_last_error());
+      HIP(hipDeviceSynchronize());
+      unsigned char *h3 = malloc(ob2), *h4 = malloc(ob2);
+      HIP(hipMemcpy(h3, o3, ob2, hipMemcpyDeviceToHost)); HIP(hipMemcpy(h4, o4, ob2, hipMemcpyDeviceToHost));
+      CHECK(memcmp(h3, h4, ob2) == 0, "one-launch stem pair differs from the two launches");
+      d2.stride = 2;
+      CHECK(dn_spconv2d_pre_pair(&d, &d2, dbits, pk, dsc, dsh, pk2, dsc, dsh, o4, NULL) == DN_ERR_ARG, "stride-2 second layer accepted");
+      printf("C ABI stem pair: one launch bit-equal to the two launches\n");
+    }
+    d.math = 3;
     printf("C ABI occupancy words: scatter == host loop, conv output bit-equal to the full form\n");
   }
   /* range guard */

@@ -360,3 +360,58 @@ def test_bit_grid_source_refusals():
             attempt(c_out, k, stride)
     with pytest.raises(_lib.DnError):
         ops.SpTensor(1, 16, 16, 33, device="cuda", bits=True)
+
+
+@pytest.mark.parametrize("n,h,w,c,c_out", [
+    (3, 64, 64, 13, 32),        # the stem's shape at a small map: 2 x 2 tiles per image
+    (2, 37, 70, 13, 32),        # ragged: partial tiles right and bottom, odd sizes
+    (5, 16, 32, 16, 32),        # exactly one tile per image, a full 16-channel chunk of bits
+    (1, 5, 3, 7, 20),           # smaller than a tile, c_out below 32 (second chunk partly empty)
+    (2, 48, 96, 13, 16),        # c_out = 16: one output chunk
+    (40, 32, 64, 13, 32),       # more tiles than workgroups' first round: the persistent loop
+])
+def test_stem_pair_launch_equals_two_launches(n, h, w, c, c_out):
+    """dn_spconv2d_pre_pair (conv_pre_1 -> conv_pre_2 in one launch, the intermediate map in LDS) writes the bytes of
+    dn_spconv2d(math 4) followed by dn_spconv2d, and follows the torch-CPU reference of the two layers"""
+    from disconet_amd import ops
+    g = torch.Generator().manual_seed(h * 131 + c_out)
+    occ = (torch.rand(n, h, w, c, generator=g) < 0.1).float()
+    occ[0, 0, 0, :] = 1.0
+    occ[-1, -1, -1, :] = 1.0
+    w1 = torch.randn(32, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5
+    w2 = torch.randn(c_out, 32, 3, 3, generator=g) * (2.0 / (32 * 9)) ** 0.5
+    s1, t1 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2     # shifts of both signs: ReLU bites
+    s2, t2 = torch.rand(c_out, generator=g) + 0.5, torch.randn(c_out, generator=g) * 0.2
+    x = occ.permute(0, 3, 1, 2)
+    mid = F.relu(F.conv2d(x, w1, None, padding=1) * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1))
+    want = F.relu(F.conv2d(mid, w2, None, padding=1) * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+
+    words = (occ.to(torch.int64) << torch.arange(c, dtype=torch.int64)).sum(-1).to(torch.int32)
+    bits = ops.SpTensor(n, h, w, c, device="cuda", bits=True, data=words.cuda())
+    d1 = ops.conv_desc(n, h, w, c, 32, 3, 1, True, math="sp")
+    d2 = ops.conv_desc(n, h, w, 32, c_out, 3, 1, True, math="sp")
+    p1, m1 = ops.sp_pack_conv_weights(d1, w1.cuda())
+    p2, m2 = ops.sp_pack_conv_weights(d2, w2.cuda())
+    sc1, sh1, sc2, sh2 = (s1 / m1).cuda(), t1.cuda(), (s2 / m2).cuda(), t2.cuda()
+    assert ops.sp_conv2d_pre_pair_supported(d1, d2)
+    two = ops.sp_conv2d(d2, ops.sp_conv2d(d1, bits, p1, sc1, sh1), p2, sc2, sh2)
+    out = ops.SpTensor(n, h, w, c_out, device="cuda")
+    out.data.fill_(255)
+    one = ops.sp_conv2d_pre_pair(d1, d2, bits, p1, sc1, sh1, p2, sc2, sh2, out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(one.data, two.data)
+    assert (one.nhwc().cpu() - want).abs().max().item() <= TOL * max(1.0, want.abs().max().item() / 4)
+
+
+def test_stem_pair_refusals():
+    from disconet_amd import ops, _lib
+    mk = lambda c0, c_out, k=3, s=1, hw=16: ops.conv_desc(2, hw, hw, c0, c_out, k, s, True, math="sp")
+    assert ops.sp_conv2d_pre_pair_supported(mk(13, 32), mk(32, 32))
+    for d1, d2 in ((mk(17, 32), mk(32, 32)), (mk(13, 64), mk(64, 32)), (mk(13, 32), mk(32, 64)), (mk(13, 32), mk(32, 32, s=2)),
+                   (mk(13, 32, k=1), mk(32, 32)), (mk(13, 32), mk(32, 32, hw=32))):
+        assert not ops.sp_conv2d_pre_pair_supported(d1, d2)
+    bits = ops.SpTensor(2, 16, 16, 13, device="cuda", bits=True, data=torch.zeros(2, 16, 16, dtype=torch.int32, device="cuda"))
+    z = torch.zeros(64, device="cuda")
+    pk = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(_lib.DnError):
+        ops.sp_conv2d_pre_pair(mk(13, 32), mk(32, 64), bits, pk, z, z, pk, z, z)

@@ -205,6 +205,15 @@ def test_split_planar_bevs_input_equals_dense_input():
     with torch.no_grad():
         bits = m(ops.scatter_dense_bits(indices, offsets, A * B, dims), trans, na, B)
     assert torch.equal(bits["cls"], sp["cls"]) and torch.equal(bits["loc"], sp["loc"])
+    # ... and with the stem's two layers as two launches instead of one (DN_STEM_PAIR=0): the same bits
+    import os
+    os.environ["DN_STEM_PAIR"] = "0"
+    try:
+        with torch.no_grad():
+            two = m(ops.scatter_dense_bits(indices, offsets, A * B, dims), trans, na, B)
+    finally:
+        del os.environ["DN_STEM_PAIR"]
+    assert torch.equal(two["cls"], bits["cls"]) and torch.equal(two["loc"], bits["loc"])
 
 
 def _trained_like(ref):

@@ -11,11 +11,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F, P = os.path.join(ROOT, "gpurun_out", "r04final"), os.path.join(ROOT, "gpurun_out", "r04prof")
-R3 = {"conv_pre_1": 38, "conv_pre_2": 78, "conv1_1 (s2)": 76, "conv1_2 + Conv3D 1x1": 87, "conv2_1 (s2)": 46, "conv2_2": 60,
+R3 = {"conv_pre_1 + conv_pre_2": 116, "conv1_1 (s2)": 76, "conv1_2 + Conv3D 1x1": 87, "conv2_1 (s2)": 46, "conv2_2": 60,
       "conv3d_2 (1x1)": 21, "conv3_1 (s2)": 44, "conv3_2": 66, "conv4_1 (s2)": 54, "conv4_2": 70, "conv5_1 (up+cat)": 163, "conv5_2": 65,
       "conv6_1 (up+cat)": 134, "conv6_2": 58, "conv7_1 (up+cat)": 131, "conv7_2": 60, "conv8_1 (up+cat)": 164, "conv8_2": 82,
       "heads (3x3 + block-diag 1x1)": 164}
-SHAPE = {"conv_pre_1": "13→32 @256² (occupancy-word source)", "conv_pre_2": "32→32 @256²", "conv1_1 (s2)": "32→64 s2 → 128²",
+SHAPE = {"conv_pre_1 + conv_pre_2": "13→32→32 @256², one launch (occupancy words in, intermediate map in LDS)", "conv1_1 (s2)": "32→64 s2 → 128²",
          "conv1_2 + Conv3D 1x1": "64→64 (+1×1) @128²", "conv2_1 (s2)": "64→128 s2 → 64²", "conv2_2": "128→128 @64²", "conv3d_2 (1x1)": "128→128 1×1 @64²",
          "conv3_1 (s2)": "128→256 s2 → 32²", "conv3_2": "256→256 @32² (+ fp32 NHWC copy)", "conv4_1 (s2)": "256→512 s2 → 16²", "conv4_2": "512→512 @16²",
          "conv5_1 (up+cat)": "768→256 @32² (tap-merged BN 32, 4 K slices)", "conv5_2": "256→256 @32²", "conv6_1 (up+cat)": "384→128 @64² (tap-merged BN 32)",
@@ -33,10 +33,10 @@ def layer_table():
         m = re.match(r"^(\S.*?)\s{2,}([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+(.*)$", line.rstrip())
         if m and m.group(1) in R3:
             layers.append((m.group(1), float(m.group(2)), float(m.group(4))))
-    # counters: the last 25 product launches of the eager pass = zero fill, scatter, 11 encoder convs, warp, fuse, conv5_1 (+ fix-up), 8 more
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_table.py"), P, "25"], capture_output=True, text=True, check=True).stdout
+    # counters: the last 24 product launches of the eager pass = zero fill, scatter, 10 encoder convs, warp, fuse, conv5_1 (+ fix-up), 8 more
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_table.py"), P, "24"], capture_output=True, text=True, check=True).stdout
     rows = [l.split() for l in out.splitlines()[1:]]
-    conv = [r for r in rows if r[0].startswith("sp<") or r[0].startswith("spq<")]
+    conv = [r for r in rows if r[0].startswith("sp<") or r[0].startswith("spq<") or r[0].startswith("conv_pre_pair")]
     merged = []
     for r in conv:       # the K-sliced layer's fix-up launch belongs to the row before it
         name = " ".join(r[:-9])
@@ -45,7 +45,7 @@ def layer_table():
             merged[-1][1][7] += vals[7]; merged[-1][1][8] += vals[8]
             continue
         merged.append([name, vals])
-    assert len(merged) == len(layers) == 20, (len(merged), len(layers))
+    assert len(merged) == len(layers) == 19, (len(merged), len(layers))
     lines = ["| layer (shape at batch 4 × 5 agents) | µs (round 3) | TFLOP/s (alg.) | MFMA busy | clock | busy × GHz ÷ 2.4 | HBM r + w (MB) |", "|---|---|---|---|---|---|---|"]
     for (name, us, tf), (kname, v) in zip(layers, merged):
         lines.append("| %s %s | %.0f (%d) | %.0f | %.0f %% | %.2f GHz | %.2f | %.0f + %.0f |" % (
@@ -103,7 +103,7 @@ def main(dry):
     cp += [(os.path.join(F, "agent_share_b%d.json" % b), "r04_agent_share_b%d.json" % b) for b in (8, 16, 32)]
     for src, dst in cp:
         shutil.copy(src, os.path.join(ROOT, "profiles", dst))
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_table.py"), P, "25"], capture_output=True, text=True, check=True).stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_table.py"), P, "24"], capture_output=True, text=True, check=True).stdout
     open(os.path.join(ROOT, "profiles", "r04_pmc_conv_sp.txt"), "w").write(out)
 
 

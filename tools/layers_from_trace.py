@@ -21,7 +21,12 @@ starts = [i for i, r in enumerate(rows) if "zero_fill_kernel" in r["Kernel_Name"
 skip = 4                                       # the bench ends with an eager check step and extras: go back a few
 sel = rows[starts[-skip]:starts[-skip + 1]]
 def is_conv(r):
-    return "conv_sp_kernel" in r["Kernel_Name"] or "conv_spq_kernel" in r["Kernel_Name"]
+    return any(k in r["Kernel_Name"] for k in ("conv_sp_kernel", "conv_spq_kernel", "conv_pre_pair_kernel"))
+
+
+if any("conv_pre_pair_kernel" in r["Kernel_Name"] for r in sel):      # the stem's two layers in one launch (round 4)
+    LAYERS = [("conv_pre_1 + conv_pre_2", 256 * 256, 0, 0, 3)] + LAYERS[2:]
+    EXTRA = {2: EXTRA[3], 18: EXTRA[19], 0: 2.0 * N * 256 * 256 * 9 * (13 * 32 + 32 * 32)}
 
 
 def is_ksl(r):      # K-sliced launch (template flag KSL = 1): may be followed by its fix-up pass, the same kernel again
@@ -49,6 +54,7 @@ for i, (r, (name, px, cin, cout, k)) in enumerate(zip(conv, LAYERS)):
     gf = (2.0 * N * px * cout * cin * k * k + EXTRA.get(i, 0.0)) / 1e9
     kn = r["Kernel_Name"]
     cfg = ("quad-merged BN=" + kn.split("conv_spq_kernel<")[1].split(">")[0]) if "conv_spq_kernel" in kn else \
+        "one launch: 16 x 32 tile, 8 waves, intermediate map in LDS" if "conv_pre_pair_kernel" in kn else \
         "<" + kn.split("conv_sp_kernel<")[1].split(">")[0].replace(" ", "") + ">"
     if r.get("_fixup"):
         cfg += "  K-sliced: %.1f us of it the fix-up pass" % r["_fixup"]

@@ -21,9 +21,9 @@ timeout 250 rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_LDS_IDX_ACTIVE --output
 for i in 1 2 3; do
   f=$(find /tmp/r04_p$i -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/pmc$i.csv
 done
-python3 $R/tools/pmc_table.py $OUT 30 > $OUT/pmc_table.txt 2>&1
-python3 $R/tools/pmc_traffic.py $OUT sp conv_sp_kernel,conv_spq_kernel 21 20 > $OUT/pmc_traffic_sp.json 2> $OUT/pmc_traffic.err
-python3 $R/tools/rocprof_conv.py $OUT/kernel_trace.csv conv_sp_kernel,conv_spq_kernel 20 4 $V > $OUT/rocprof_conv_sp.json 2> $OUT/rocprof_conv.err
+python3 $R/tools/pmc_table.py $OUT 29 > $OUT/pmc_table.txt 2>&1
+python3 $R/tools/pmc_traffic.py $OUT sp conv_sp_kernel,conv_spq_kernel,conv_pre_pair_kernel 20 19 > $OUT/pmc_traffic_sp.json 2> $OUT/pmc_traffic.err
+python3 $R/tools/rocprof_conv.py $OUT/kernel_trace.csv conv_sp_kernel,conv_spq_kernel,conv_pre_pair_kernel 19 4 $V > $OUT/rocprof_conv_sp.json 2> $OUT/rocprof_conv.err
 # 3. segmentation task (configs[3]): FETCH_SIZE / WRITE_SIZE of its conv launches, same method
 S="python $R/bench.py --task seg --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-events --train-steps 0"
 mkdir -p $OUT/seg
