@@ -15,12 +15,13 @@
 // Every accumulation chain has the order of the two-launch path (stage 1: per tap w_lo.x then w_hi.x, taps 0..8; stage 2:
 // per tap w_lo.x_hi, w_hi.x_lo, w_hi.x_hi, chunks 0, 1) and the same affine4 / split4, so the output is bit-identical to
 // dn_spconv2d(math 4) followed by dn_spconv2d; 19.5 % of stage 1 is halo recompute.
+// A pipelined form (8 x 32 tiles, two patch buffers, four producer waves running stage 1 of the next tile beside four consumer
+// waves on stage 2, one barrier per tile; commit before this one) measured the same 2342 vs 2347 scenes/s in one lease, as did
+// conv_pre_1's weight fragments held in registers: the launch sits at the busy x clock plateau of the engine's other layers
+// (DESIGN.md 3.1e), not on its phase structure.  The simpler two-phase kernel is the one kept.
 // LDS: patch 2 x 39168 + conv_pre_2 weights 36864 + conv_pre_1 weights 18432 + occupancy words 2880 + affines 512 + the
 // byte -> fragment table 4096 = 141120 B.
 
-#ifndef DN_PIPE_W1_REGS
-#define DN_PIPE_W1_REGS 1   // pipelined kernel: conv_pre_1's 18 weight fragments in the producers' registers (0: read from LDS per tap)
-#endif
 #ifndef DN_PRE_LUT
 #define DN_PRE_LUT 1     // tools/ab: 0 = the occupancy bytes expanded with VALU instructions instead of a table in LDS
 #endif
@@ -312,281 +313,6 @@ __global__ void __launch_bounds__(pp::NTHR, 1) conv_pre_pair_kernel(const PrePai
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// The same pair, PIPELINED (the shipped form): an 8 x 32 output tile per step and two patch buffers.  Waves 4..7 (the
-// producers) run stage 1 of tile i + 1 -- 11 pixel tiles of the 10 x 34 patch -- into patch buffer (i + 1) & 1 while waves 0..3
-// (the consumers) run stage 2 and the epilogue of tile i from buffer i & 1; one workgroup barrier per tile hands the buffers
-// over.  Wave w and wave w + 4 share a SIMD, so every SIMD holds one VALU-heavy producer and one MFMA-heavy consumer: the two
-// stages overlap by construction instead of alternating chip-wide as in the two-phase kernel above (kept for A/B:
-// DN_STEM_PIPE=0).  The arithmetic, its order and every output bit are unchanged.
-// LDS: 2 x 43520 (patch buffers) + 36864 + 18432 (weights) + 2 x 1728 (occupancy words, double-buffered) + 512 + 4096 = 150400 B.
-namespace pq {
-constexpr int TH = 8, TW = 32;
-constexpr int MH = TH + 2, MW = TW + 2, MNPIX = MH * MW;          // 10 x 34 = 340 patch pixels
-constexpr int MTILES = (MNPIX + 31) / 32;                         // 11 pixel tiles
-constexpr int BH = TH + 4, BW = TW + 4, BWORDS = BH * BW;         // 12 x 36 = 432 occupancy words
-constexpr int NCONS = 4, NPROD = 4, NTHR = (NCONS + NPROD) * 64;
-constexpr int MID_CHUNK = 4 * MNPIX * 16, MID_BUF = 2 * MID_CHUNK;            // 21760, 43520
-constexpr int OFF_W2 = 2 * MID_BUF, OFF_W1 = OFF_W2 + pp::W2_BYTES, OFF_BITS = OFF_W1 + pp::W1_BYTES;
-constexpr int BITS_BUF = BWORDS * 4, OFF_AFF = OFF_BITS + 2 * BITS_BUF, OFF_LUT = OFF_AFF + 512, LDS_BYTES = OFF_LUT + 4096;
-static_assert(OFF_BITS % 16 == 0 && OFF_AFF % 16 == 0 && OFF_LUT % 16 == 0 && LDS_BYTES <= 160 * 1024, "LDS layout");
-constexpr int K1 = (MTILES + NPROD - 1) / NPROD;                  // 3 (the last producer wave runs 2)
-}  // namespace pq
-
-__global__ void __launch_bounds__(pq::NTHR, 1) conv_pre_pipe_kernel(const PrePairArgs a) {
-  using namespace pq;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const bool producer = wave >= NCONS;
-  const int pw = wave - NCONS, ptid = tid - NCONS * 64;            // producer-relative wave / thread
-  const int G = gridDim.x;
-  const int first = blockIdx.x;
-  if (first >= a.items) return;
-  const int n_mine = (a.items - first + G - 1) / G;                // tiles of this workgroup: first, first + G, ...
-
-  auto piece_of = [&](int i) { return (size_t)(((i >> 7) * 4 + ((i >> 5) & 3)) * a.cout_pad + (i & 31)) * 16; };
-  for (int i = tid; i < pp::W2_BYTES / 16; i += NTHR)
-    *reinterpret_cast<u32x4*>(smem + OFF_W2 + i * 16) = *reinterpret_cast<const u32x4*>(a.w2 + piece_of(i));
-  for (int i = tid; i < pp::W1_BYTES / 16; i += NTHR)
-    *reinterpret_cast<u32x4*>(smem + OFF_W1 + i * 16) = *reinterpret_cast<const u32x4*>(a.w1 + piece_of(i));
-  float* aff = reinterpret_cast<float*>(smem + OFF_AFF);
-  if (tid < 32) {
-    aff[tid] = a.s1[tid];
-    aff[32 + tid] = a.t1[tid];
-    aff[64 + tid] = tid < a.c_out ? a.s2[tid] : 0.f;
-    aff[96 + tid] = tid < a.c_out ? a.t2[tid] : 0.f;
-  }
-  if (tid < 256) *reinterpret_cast<half8*>(smem + OFF_LUT + tid * 16) = expand_octet((unsigned)tid);
-
-  const int sp_full = a.items & ~7;
-  auto decode = [&](int it) {
-    TileCoord tc;
-    int spi = it < sp_full ? (it & 7) * (sp_full >> 3) + (it >> 3) : it;
-    int tx, ty;
-    spi = fdivmod(spi, a.tiles_x, a.rcp_tx, tx);
-    tc.img = fdivmod(spi, a.tiles_y, a.rcp_ty, ty);
-    tc.img = __builtin_amdgcn_readfirstlane(tc.img);
-    tc.ox0 = __builtin_amdgcn_readfirstlane(tx * TW);
-    tc.oy0 = __builtin_amdgcn_readfirstlane(ty * TH);
-    tc.n0 = 0;
-    return tc;
-  };
-  // a barrier of all eight waves with this wave's LDS writes done (raw s_barrier: both roles execute the same count)
-  auto wg_barrier = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-  const float lo_clamp1 = a.relu1 ? 0.f : -65504.f, lo_clamp2 = a.relu2 ? 0.f : -65504.f;
-  const int b_off = (lh * 32 + li) * 16;
-  float amax = 0.f;
-  bool nan_seen = false;
-
-  if (producer) {
-    // ---- occupancy words: word idx of the 12 x 36 block = ptid, ptid + 256 (< 432)
-    const size_t img_words = (size_t)a.h * a.w;
-    int bw_r[2], bw_c[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int idx = ptid + q * 256;
-      bw_r[q] = idx / BW;
-      bw_c[q] = idx % BW;
-    }
-    unsigned wreg[2];
-    auto load_words = [&](const TileCoord& tc) {
-      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.bits + (size_t)tc.img * img_words), 0,
-                                                          (int)(img_words * 4), 0x00020000);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int iy = tc.oy0 - 2 + bw_r[q], ix = tc.ox0 - 2 + bw_c[q];
-        const bool ok = ptid + q * 256 < BWORDS && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
-        wreg[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? (unsigned)(iy * a.w + ix) * 4u : 0xFFFFFFFFu, 0, 0);
-      }
-    };
-    auto store_words = [&](int buf) {
-      unsigned* bl = reinterpret_cast<unsigned*>(smem + OFF_BITS + buf * BITS_BUF);
-      bl[ptid] = wreg[0];
-      if (ptid + 256 < BWORDS) bl[ptid + 256] = wreg[1];
-    };
-    int s1_word[K1], s1_r[K1], s1_c[K1], s1_dst[K1];
-    bool s1_valid[K1];
-#pragma unroll
-    for (int k = 0; k < K1; ++k) {
-      const int pos = 32 * (pw + NPROD * k) + li;
-      s1_valid[k] = pos < MNPIX;
-      const int pc = s1_valid[k] ? pos : MNPIX - 1;
-      s1_r[k] = pc / MW;
-      s1_c[k] = pc % MW;
-      s1_word[k] = (s1_r[k] * BW + s1_c[k]) * 4;
-      s1_dst[k] = (lh * MNPIX + pc) * 16;
-    }
-    // stage 1 of tile `tc` from words buffer wb into patch buffer mb
-    f32x4 sc1[4], sh1[4];
-    half8 w1h[DN_PIPE_W1_REGS ? 9 : 1], w1l[DN_PIPE_W1_REGS ? 9 : 1];      // conv_pre_1's weight fragments: registers of the producers
-    auto stage1 = [&](const TileCoord& tc, int wb, int mb) {
-      unsigned char* mid = smem + mb * MID_BUF;
-#pragma unroll
-      for (int k = 0; k < K1; ++k) {
-        if (pw + NPROD * k >= MTILES) break;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const unsigned char* wp = smem + OFF_BITS + wb * BITS_BUF + s1_word[k];
-        const unsigned char* w1p = smem + OFF_W1 + b_off;
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-          const unsigned word = *reinterpret_cast<const unsigned*>(wp + ((u / 3) * BW + u % 3) * 4);
-          const half8 x = *reinterpret_cast<const half8*>(smem + OFF_LUT + ((word >> (8 * lh)) & 0xffu) * 16);
-#if DN_PIPE_W1_REGS
-          const half8 bh = w1h[u], bl = w1l[u];
-#else
-          const half8 bh = *reinterpret_cast<const half8*>(w1p + u * 2048);
-          const half8 bl = *reinterpret_cast<const half8*>(w1p + u * 2048 + 1024);
-#endif
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, x, acc, 0, 0, 0);
-        }
-        const int iy = tc.oy0 - 1 + s1_r[k], ix = tc.ox0 - 1 + s1_c[k];
-        const bool in_map = iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
-        u32x2 hi[4], lo[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v = affine4(quad_of(acc, g), sc1[g], sh1[g]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = in_map ? v[e] : 0.f;
-          split4(v, hi[g], lo[g], amax, lo_clamp1);
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const u32x4 ph = gather_octet(hi[2 * m], hi[2 * m + 1]);
-          const u32x4 pl = gather_octet(lo[2 * m], lo[2 * m + 1]);
-          if (s1_valid[k]) {
-            *reinterpret_cast<u32x4*>(mid + m * MID_CHUNK + s1_dst[k]) = ph;
-            *reinterpret_cast<u32x4*>(mid + m * MID_CHUNK + s1_dst[k] + 2 * MNPIX * 16) = pl;
-          }
-        }
-      }
-    };
-    // prologue: words of tile 0 -> buffer 0
-    TileCoord t0 = decode(first);
-    load_words(t0);
-    store_words(0);
-    wg_barrier();                                                  // (1) weights, affines, table, words 0 visible
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      sc1[g] = *reinterpret_cast<const f32x4*>(aff + 8 * g + 4 * lh);
-      sh1[g] = *reinterpret_cast<const f32x4*>(aff + 32 + 8 * g + 4 * lh);
-    }
-#if DN_PIPE_W1_REGS
-#pragma unroll
-    for (int u = 0; u < 9; ++u) {
-      w1h[u] = *reinterpret_cast<const half8*>(smem + OFF_W1 + b_off + u * 2048);
-      w1l[u] = *reinterpret_cast<const half8*>(smem + OFF_W1 + b_off + u * 2048 + 1024);
-    }
-#endif
-    TileCoord t1 = t0;
-    if (n_mine > 1) {
-      t1 = decode(first + G);
-      load_words(t1);
-    }
-    stage1(t0, 0, 0);
-    if (n_mine > 1) store_words(1);
-    wg_barrier();                                                  // (2) patch 0 complete, words 1 in place
-    // steady state: iteration i (consumers work on tile i) produces tile i + 1
-    TileCoord tn = t1;
-    for (int i = 0; i < n_mine; ++i) {
-      if (i + 1 < n_mine) {
-        TileCoord t2 = tn;
-        const bool more = i + 2 < n_mine;
-        if (more) {
-          t2 = decode(first + (i + 2) * G);
-          load_words(t2);                                          // lands under this stage 1
-        }
-        stage1(tn, (i + 1) & 1, (i + 1) & 1);
-        if (more) store_words(i & 1);                              // words buffer i & 1 was read by stage 1 of tile i: free
-        tn = t2;
-      }
-      wg_barrier();                                                // (3 + i)
-    }
-  } else {
-    // ---- consumers: stage 2 + epilogue of tile i from patch buffer i & 1
-    int a_off[2];
-#pragma unroll
-    for (int wm = 0; wm < 2; ++wm) a_off[wm] = (lh * MNPIX + (2 * wave + wm) * MW + li) * 16;
-    const int plane = a.h * a.w * 16, img_bytes = a.cog * 4 * plane;
-    wg_barrier();                                                  // (1)
-    f32x4 sc2[4], sh2[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      sc2[g] = *reinterpret_cast<const f32x4*>(aff + 64 + 8 * g + 4 * lh);
-      sh2[g] = *reinterpret_cast<const f32x4*>(aff + 96 + 8 * g + 4 * lh);
-    }
-    wg_barrier();                                                  // (2)
-    for (int i = 0; i < n_mine; ++i) {
-      const TileCoord cur = decode(first + i * G);
-      const unsigned char* mid = smem + (i & 1) * MID_BUF;
-      f32x16 acc2[2];
-#pragma unroll
-      for (int wm = 0; wm < 2; ++wm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[wm][r] = 0.f;
-      {
-        half8 ah[2][2], al[2][2], bh[2], bl[2];
-        auto load = [&](int s, int g, int u) {
-          const unsigned char* As = mid + g * MID_CHUNK + ((u / 3) * MW + u % 3) * 16;
-          const unsigned char* Bs = smem + OFF_W2 + (g * 9 + u) * 2048 + b_off;
-#pragma unroll
-          for (int wm = 0; wm < 2; ++wm) {
-            ah[s][wm] = *reinterpret_cast<const half8*>(As + a_off[wm]);
-            al[s][wm] = *reinterpret_cast<const half8*>(As + a_off[wm] + 2 * MNPIX * 16);
-          }
-          bh[s] = *reinterpret_cast<const half8*>(Bs);
-          bl[s] = *reinterpret_cast<const half8*>(Bs + 1024);
-        };
-        auto mma = [&](int s) {
-#pragma unroll
-          for (int wm = 0; wm < 2; ++wm) acc2[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s], ah[s][wm], acc2[wm], 0, 0, 0);
-#pragma unroll
-          for (int wm = 0; wm < 2; ++wm) acc2[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s], al[s][wm], acc2[wm], 0, 0, 0);
-#pragma unroll
-          for (int wm = 0; wm < 2; ++wm) acc2[wm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s], ah[s][wm], acc2[wm], 0, 0, 0);
-        };
-        load(0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 18; ++q) {
-          if (q + 1 < 18) load((q + 1) & 1, (q + 1) / 9, (q + 1) % 9);
-          __builtin_amdgcn_sched_barrier(0);
-          mma(q & 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      {
-        const auto rsrc_o = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)cur.img * img_bytes, 0, img_bytes, 0x00020000);
-#pragma unroll
-        for (int wm = 0; wm < 2; ++wm) {
-          const int oy = cur.oy0 + 2 * wave + wm, ox = cur.ox0 + li;
-          const bool inside = oy < a.h && ox < a.w;
-          const int voff = inside ? (oy * a.w + ox) * 16 + lh * plane : (int)0x80000000;
-          u32x2 hi[4], lo[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) split4(affine4(quad_of(acc2[wm], g), sc2[g], sh2[g]), hi[g], lo[g], amax, lo_clamp2);
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const u32x4 ph = gather_octet(hi[2 * m], hi[2 * m + 1]);
-            const u32x4 pl = gather_octet(lo[2 * m], lo[2 * m + 1]);
-            if (m < a.cog) {
-              __builtin_amdgcn_raw_buffer_store_b128(ph, rsrc_o, voff + m * 4 * plane, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b128(pl, rsrc_o, voff + (m * 4 + 2) * plane, 0, 0);
-            }
-          }
-        }
-      }
-      wg_barrier();                                                // (3 + i): done reading buffer i & 1; buffer (i + 1) & 1 complete
-    }
-  }
-  note_range(amax, nan_seen);
-}
-
 }  // namespace
 
 extern "C" int dn_spconv2d_pre_pair(const dn_conv_desc* d1, const dn_conv_desc* d2, const uint32_t* bits, const void* packed1,
@@ -603,10 +329,7 @@ extern "C" int dn_spconv2d_pre_pair(const dn_conv_desc* d1, const dn_conv_desc* 
   a.n = d1->n_images; a.h = d1->h_in; a.w = d1->w_in; a.c_out = d2->c_out; a.cog = (d2->c_out + 15) / 16;
   a.relu1 = d1->relu; a.relu2 = d2->relu;
   a.cout_pad = cout_pad_of(32);      // both layers: c_out <= 32 -> the same padded row (dn_spconv_pack_weights)
-  const char* pipe_s = getenv("DN_STEM_PIPE");        // 0: the two-phase kernel (A/B, tests); read per call
-  const int pipe_env = pipe_s ? atoi(pipe_s) : 1;
-  const int th = pipe_env ? pq::TH : pp::TH;
-  a.tiles_x = (a.w + pp::TW - 1) / pp::TW; a.tiles_y = (a.h + th - 1) / th;
+  a.tiles_x = (a.w + pp::TW - 1) / pp::TW; a.tiles_y = (a.h + pp::TH - 1) / pp::TH;
   a.items = a.n * a.tiles_x * a.tiles_y;
   a.rcp_tx = 1.f / a.tiles_x; a.rcp_ty = 1.f / a.tiles_y;
   DN_REQUIRE((size_t)a.cog * 4 * a.h * a.w * 16 < ((size_t)1 << 31) && (size_t)a.h * a.w * 4 < ((size_t)1 << 31) && a.items < (1 << 22),
@@ -616,17 +339,10 @@ extern "C" int dn_spconv2d_pre_pair(const dn_conv_desc* d1, const dn_conv_desc* 
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pre_pair_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pre_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              pq::LDS_BYTES);
     if (e != hipSuccess) return dn::fail(DN_ERR_LAUNCH, "spconv pre pair: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
   const int grid = a.items < kCUs ? a.items : kCUs;
-  if (pipe_env) {
-    hipLaunchKernelGGL(conv_pre_pipe_kernel, dim3(grid), dim3(pq::NTHR), pq::LDS_BYTES, (hipStream_t)stream, a);
-    return dn::check_launch("conv_pre_pipe_kernel");
-  }
   hipLaunchKernelGGL(conv_pre_pair_kernel, dim3(grid), dim3(pp::NTHR), pp::LDS_BYTES, (hipStream_t)stream, a);
   return dn::check_launch("conv_pre_pair_kernel");
 }

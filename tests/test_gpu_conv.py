@@ -370,13 +370,10 @@ def test_bit_grid_source_refusals():
     (2, 48, 96, 13, 16),        # c_out = 16: one output chunk
     (40, 32, 64, 13, 32),       # more tiles than workgroups' first round: the persistent loop
 ])
-@pytest.mark.parametrize("pipe", ["1", "0"])
-def test_stem_pair_launch_equals_two_launches(n, h, w, c, c_out, pipe, monkeypatch):
+def test_stem_pair_launch_equals_two_launches(n, h, w, c, c_out):
     """dn_spconv2d_pre_pair (conv_pre_1 -> conv_pre_2 in one launch, the intermediate map in LDS) writes the bytes of
-    dn_spconv2d(math 4) followed by dn_spconv2d, and follows the torch-CPU reference of the two layers -- in its pipelined
-    form (producer / consumer waves, the default) and in the two-phase form (DN_STEM_PIPE=0)"""
+    dn_spconv2d(math 4) followed by dn_spconv2d, and follows the torch-CPU reference of the two layers"""
     from disconet_amd import ops
-    monkeypatch.setenv("DN_STEM_PIPE", pipe)
     g = torch.Generator().manual_seed(h * 131 + c_out)
     occ = (torch.rand(n, h, w, c, generator=g) < 0.1).float()
     occ[0, 0, 0, :] = 1.0

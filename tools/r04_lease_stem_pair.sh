@@ -8,4 +8,4 @@ run() {
   python3 -c "
 import json; r=json.load(open('gpurun_out/ab/$1.json')); print('%-12s value %.1f  median-of-5 %.1f  conv %.4f ms  launches %s others %s' % ('$1', r['value'], r['repeat']['scenes_per_s']['median'], r['roofline']['kernel_ms_per_step'], r['roofline']['kernel'][-22:], r['roofline']['other_kernels_ms_per_step']))"
 }
-for r in 1 2 3; do run pipe1_$r 1; DN_STEM_PIPE=0 run pipe0_$r 1; run pair0_$r 0; done
+for r in 1 2 3; do run pair1_$r 1; run pair0_$r 0; done
