@@ -7,7 +7,7 @@
 // both launches run near the memory roofline (4.7 / 4.2 TB/s, profiles/r04_pmc_conv_sp.txt) with the MFMA pipe a third busy.
 // Fused, the intermediate never leaves the CU: a workgroup (8 waves, one per CU) owns a 16 x 32 output tile,
 //   stage 1  computes conv_pre_1 on the tile's 18 x 34 halo patch straight from the occupancy words (20 MFMA pixel tiles
-//            of 32, the words expanded to f16 0 / 1 fragments in registers: AHI = 2's arithmetic), applies affine + ReLU +
+//            of 32, a word's byte -> its f16 0 / 1 fragment through a 256-entry table in LDS: AHI = 2's arithmetic), applies affine + ReLU +
 //            hi/lo split and writes the SP pieces into LDS in the patch layout conv_pre_2's K loop reads -- zero where the
 //            patch pixel lies outside the map (that is conv_pre_2's zero padding, not relu(bias));
 //   stage 2  is conv_pre_2's weight-stationary K loop over that patch (both 16-channel chunks resident: no DMA, no stage
@@ -16,7 +16,7 @@
 // per tap w_lo.x_hi, w_hi.x_lo, w_hi.x_hi, chunks 0, 1) and the same affine4 / split4, so the output is bit-identical to
 // dn_spconv2d(math 4) followed by dn_spconv2d; 19.5 % of stage 1 is halo recompute.
 // A pipelined form (8 x 32 tiles, two patch buffers, four producer waves running stage 1 of the next tile beside four consumer
-// waves on stage 2, one barrier per tile; commit before this one) measured the same 2342 vs 2347 scenes/s in one lease, as did
+// waves on stage 2, one barrier per tile; in the repository's history as "Stem pair, pipelined form") measured the same 2342 vs 2347 scenes/s in one lease, as did
 // conv_pre_1's weight fragments held in registers: the launch sits at the busy x clock plateau of the engine's other layers
 // (DESIGN.md 3.1e), not on its phase structure.  The simpler two-phase kernel is the one kept.
 // LDS: patch 2 x 39168 + conv_pre_2 weights 36864 + conv_pre_1 weights 18432 + occupancy words 2880 + affines 512 + the
