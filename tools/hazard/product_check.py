@@ -29,7 +29,7 @@ na = torch.full((BATCH, AGENTS), AGENTS, dtype=torch.int64).cuda()
 
 def step():
     with torch.no_grad():
-        return model(ops.scatter_dense_sp(indices, offsets, AGENTS * BATCH, (HW, HW, 13)), trans, na, BATCH)
+        return model(ops.scatter_dense_bits(indices, offsets, AGENTS * BATCH, (HW, HW, 13)), trans, na, BATCH)
 
 
 def checksum(out):
