@@ -618,7 +618,9 @@ def main():
     model.conv_math = args.math
     if args.in_flight > 1:      # measurement option: every replay is checksummed below
         os.environ["DISCONET_UNSAFE_OVERLAP"] = "1"
-    model.overlap_streams = args.in_flight > 1        # concurrency features together, guarded below
+    # (DISCONET_OVERLAP=1 + DISCONET_UNSAFE_OVERLAP=1: the intra-step side branch alone, a measurement option -- the line says so)
+    intra_overlap = os.environ.get("DISCONET_OVERLAP", "0") == "1" and os.environ.get("DISCONET_UNSAFE_OVERLAP", "0") == "1"
+    model.overlap_streams = args.in_flight > 1 or intra_overlap        # concurrency features together, guarded below
     model.eval().cuda()
     state_dict_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
@@ -874,7 +876,9 @@ def main():
                    "conv_math": args.math,
                    "launch": launch_mode["mode"] + (
                        ", %d steps in flight (alternating streams, one captured graph + buffers each)"
-                       % args.in_flight if (args.in_flight > 1 and launch_mode["mode"] == "hipGraph replay") else ""),
+                       % args.in_flight if (args.in_flight > 1 and launch_mode["mode"] == "hipGraph replay") else "") + (
+                       ", conv4_x as a parallel graph branch beside the fusion block (DISCONET_OVERLAP=1: a measurement option, "
+                       "not the product's one-stream contract)" if (intra_overlap and args.in_flight == 1) else ""),
                    "parallelism": "scene-parallel x%d (no data-path collective)" % world},
     }
 
