@@ -44,6 +44,7 @@ class MlpTailParams(Structure):
 # name -> (restype, argtypes); must list every symbol include/*.h declares
 SIGNATURES = {
     "dn_version": (c_int, []),
+    "dn_build_id": (c_char_p, []),
     "dn_last_error": (c_char_p, []),
     "dn_sp_range_flags": (ctypes.c_uint, [c_int]),
     "dn_sp_range_flags_async": (c_int, [c_void_p, c_int, c_void_p]),
@@ -182,6 +183,15 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing: loud by design
         fn.restype = restype
         fn.argtypes = argtypes
+    # a library that was not built from THIS tree must not run (round 4 shipped one): the id baked into it is the
+    # hash of every source, header and flag (csrc/build.py).  A/B variants (tools/ab) are built with other flags
+    # and therefore other ids: DISCONET_HIP_LIB / DISCONET_ALLOW_STALE_LIB=1 say so explicitly.
+    if not (os.environ.get("DISCONET_HIP_LIB") or os.environ.get("DISCONET_ALLOW_STALE_LIB") == "1"):
+        from .csrc import build as _build
+        have, want = lib.dn_build_id().decode(), _build.tree_hash()
+        if have != want:
+            raise DnError("libdisconet_hip.so is stale: built from tree %s, the sources here hash to %s. "
+                          "Run `python -m disconet_amd.csrc.build`." % (have, want))
     _lib = lib
     return lib
 

@@ -30,7 +30,15 @@ hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
 }
 }  // namespace dn
 
-extern "C" int dn_version(void) { return 120; }  // 0.1.2: round-4 kernels (profiles carry this number)
+extern "C" int dn_version(void) { return 130; }  // 0.1.3: round-5 kernels (profiles carry this number)
+
+// The hash of every source / header / flag this library was built from (csrc/build.py :: tree_hash), behind a marker
+// that build.py also finds in the file without loading it.  _lib.load() refuses a library whose id is not the tree's.
+#ifndef DN_BUILD_ID
+#error "build through disconet_amd/csrc/build.py (it passes -DDN_BUILD_ID)"
+#endif
+static const char dn_build_id_marker[] = "dn-build-id:" DN_BUILD_ID;
+extern "C" const char* dn_build_id(void) { return dn_build_id_marker + 12; }
 
 // Stream-ordered form: every split-f16 translation unit ORs its sticky word into *dst_device (which the caller
 // zeroed) behind whatever the stream holds; kernel launches only, so it is legal inside a capture.

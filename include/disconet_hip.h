@@ -47,6 +47,10 @@ extern "C" {
 #define DN_ERR_UNSUPPORTED (-3)
 
 int dn_version(void);
+/* 16 hex digits: SHA-256 over every csrc source / header, include/*.h and the compiler flags the library was built
+ * from (disconet_amd/csrc/build.py :: tree_hash).  The Python binding refuses a library whose id differs from the
+ * tree it sits in -- a stale .so fails loudly instead of running kernels no commit reproduces. */
+const char* dn_build_id(void);
 const char* dn_last_error(void);
 
 /* Range guard of the split-f16 engines (dn_spconv2d*, dn_sp_from_nhwc, dn_disco_fuse_mlp).  A value is

@@ -22,7 +22,8 @@
 static float frand(unsigned* s) { *s = *s * 1664525u + 1013904223u; return ((*s >> 8) / 8388608.0f) - 1.0f; }
 
 static int errors_only(void) {
-  CHECK(dn_version() >= 100, "version");
+  CHECK(dn_version() >= 130, "version");
+  CHECK(dn_build_id() != NULL && strlen(dn_build_id()) == 16, "build id: %s", dn_build_id() ? dn_build_id() : "(null)");
   dn_conv_desc d;
   memset(&d, 0, sizeof d);
   d.n_images = 1; d.h_in = 8; d.w_in = 8; d.c0 = 32; d.c_out = 32; d.ksize = 7; d.stride = 1;

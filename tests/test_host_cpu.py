@@ -31,6 +31,37 @@ def test_library_exports_every_declared_symbol():
     assert lib.dn_version() >= 100
 
 
+def test_library_build_id_is_the_trees_hash(tmp_path):
+    """the shipped binary must be what HEAD builds.  The id baked into the library is the
+    SHA-256 over every csrc/*.hip|*.inl|*.h, include/*.h and the compiler flags; a stale library refuses to load."""
+    import shutil
+    import subprocess
+    import sys
+    from disconet_amd import _lib
+    from disconet_amd.csrc import build as _build
+    files = _build.tree_files()
+    for must in ("disconet_amd/csrc/conv_pre_pair.inl", "disconet_amd/csrc/sp_device.h", "disconet_amd/csrc/conv_sp.hip",
+                 "include/disconet_hip.h", "include/disconet_train.h", "include/disconet_seg.h"):
+        assert must in files, must
+    want = _build.tree_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", want)
+    assert _lib.load().dn_build_id().decode() == want        # through the C ABI
+    assert _build.built_id() == want                         # from the file, without loading it
+    assert _build.tree_hash(("-DX=1",)) != want              # a variant's flags are part of its id
+    # a library whose id is not the tree's: load() raises, DISCONET_ALLOW_STALE_LIB=1 / DISCONET_HIP_LIB opt in
+    pkg = tmp_path / "disconet_amd"
+    shutil.copytree(os.path.join(ROOT, "disconet_amd"), pkg, ignore=shutil.ignore_patterns("build", "__pycache__"))
+    with open(pkg / "csrc" / "conv_pre_pair.inl", "a") as f:
+        f.write("\n// edited after the build\n")
+    code = "from disconet_amd import _lib; _lib.load(); print('loaded')"
+    env = {k: v for k, v in os.environ.items() if k not in ("DISCONET_HIP_LIB", "DISCONET_ALLOW_STALE_LIB")}
+    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "stale" in r.stderr, r.stderr[-400:]
+    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, env=dict(env, DISCONET_ALLOW_STALE_LIB="1"),
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "loaded" in r.stdout, r.stderr[-400:]
+
+
 def test_struct_layouts_match_header():
     from disconet_amd import _lib
     assert ctypes.sizeof(_lib.ConvDesc) == 14 * 4

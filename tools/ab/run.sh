@@ -2,6 +2,7 @@
 # tools/ab/run.sh ROUNDS VARIANT_DIR...   (on the GPU box): swaps each variant's libdisconet_hip.so into the scratch copy and runs the
 # default bench without extras, ROUNDS interleaved rounds; prints value / median of the repeats / conv ms per variant and round.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+export DISCONET_ALLOW_STALE_LIB=1   # variant libraries carry the tree's id of ANOTHER flag set: say so (csrc/build.py)
 N=$1; shift
 mkdir -p gpurun_out/ab; cp disconet_amd/libdisconet_hip.so /tmp/lib_keep.so
 for r in $(seq 1 $N); do for v in "$@"; do
