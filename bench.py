@@ -176,12 +176,19 @@ def cpu_baseline(state_dict, threads):
         base["sample"] = ("one forward of %d scenes (5 agents, 256x256x13: the bench's batch), eval fwd, fp32, after the "
                           "batch-1 runs as warm-up; torch-CPU oracle (reference source not in the mount)" % BATCH)
     # The timed model carries torch's default init: its logits are ~1e-2, so an error against them
-    # says nothing about the arithmetic.  The parity sample is the SAME scene through a kaiming-initialised copy
-    # (activations and logits of O(1): what the -m gpu parity tests use); the parent runs that state through the HIP path.
+    # says nothing about the arithmetic.  The parity sample runs a kaiming-initialised copy (activations and logits of
+    # O(1): what the -m gpu parity tests use) on the TIMED step's own inputs -- the bench's batch of sparse voxel lists
+    # (as the dense grid they describe) and rank 0's poses; the parent runs that state through the HIP path from the
+    # lists themselves (dn_scatter_dense_bits -> stem pair -> ... -> K-sliced conv5_1: the launches `value` times).
+    from disconet_amd.synthetic import make_sparse_scene_batch, make_trans_matrices
+    pb = BATCH if best * BATCH * 1.5 < 60 else 1
+    _, _, pbevs = make_sparse_scene_batch(pb, AGENTS, MAP_HW)
+    ptrans = make_trans_matrices(pb, AGENTS, jitter_seed=0)
+    pna = torch.full((pb, AGENTS), AGENTS, dtype=torch.int64)
     refk = build_ref_model(RefConfig(MAP_HW), init="kaiming", kd_flag=0, num_agent=AGENTS)
     with torch.no_grad():
-        outk = refk(bevs, trans, na, 1)
-    parity = {"state": refk.state_dict(), "cls": outk["cls"], "loc": outk["loc"]}
+        outk = refk(pbevs, ptrans, pna, pb)
+    parity = {"state": refk.state_dict(), "cls": outk["cls"], "loc": outk["loc"], "batch": pb}
     return base, (bevs, trans, na, out), parity
 
 
@@ -715,6 +722,7 @@ def main():
         launches = sum(v["calls"] for v in conv.values())
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak, factor = MFMA_PEAK_TFLOPS[math], EXECUTED_FLOP_FACTOR[math]
+        exec_flops = sum(v["exec_flops"] if v.get("exec_known") else factor * v["flops"] for v in conv.values())
         traffic, traffic_src = None, None
         try:   # HBM bytes per conv launch from the committed rocprofv3 --pmc passes
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
@@ -756,7 +764,10 @@ def main():
             "frac": round(achieved / peak, 4),
             "note": "achieved = algorithmic FLOP (true channel counts) / HIP-event kernel time",
             "roofline_serial_basis": True,   # every launch timed alone on its stream (eager, event pair around it)
-            "executed_flop_factor": factor, "frac_executed": round(achieved * factor / peak, 4),
+            # executed MFMA work per LAYER (model.py regions): 3 per product, 2 on conv_pre_1's hi-only operand, 4 of 9 taps
+            # on the upsampled chunks of the tap-merged decoder layers -- not a uniform 3 x
+            "executed_flop_factor": round(exec_flops / flops, 3) if flops else factor,
+            "frac_executed": round(exec_flops / (ms * 1e-3) / 1e12 / peak, 4) if ms > 0 else 0.0,
             "hbm_algorithmic_TBps": round(alg_bytes / (ms * 1e-3) / 1e12, 3) if ms > 0 else None,
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
             "traffic_source": traffic_src,
@@ -964,20 +975,35 @@ def main():
                                                     for k in ("cls", "loc")}
                 par = ref_out.get("parity")
                 if par is not None:
-                    # parity of the measured configuration on O(1) activations: the child's kaiming-initialised
-                    # oracle vs the HIP path loaded with the same state, same scene, same math mode
+                    # parity of the measured configuration on O(1) activations, through the measured INPUT FORM at the
+                    # measured batch: the child's kaiming-initialised oracle on the step's own scenes vs the HIP path
+                    # loaded with the same state and fed the sparse voxel lists exactly as the timed step is
+                    from disconet_amd.synthetic import make_sparse_scene_batch, make_trans_matrices
+                    pb = int(par.get("batch", 1))
+                    pidx, poff, _ = make_sparse_scene_batch(pb, AGENTS, MAP_HW)
+                    ptrans = make_trans_matrices(pb, AGENTS, jitter_seed=0).cuda()
+                    pna = torch.full((pb, AGENTS), AGENTS, dtype=torch.int64).cuda()
                     pmodel = DiscoNet(Config(map_hw=MAP_HW), kd_flag=0, num_agent=AGENTS).eval()
                     pmodel.conv_math = args.math
                     pmodel.load_state_dict(par["state"])
                     pmodel.cuda()
+                    pdims = (MAP_HW, MAP_HW, 13)
                     with torch.no_grad():
-                        gotk = pmodel(bevs1.cuda(), trans1.cuda(), na1.cuda(), 1)
+                        if args.math == "sp":
+                            px = _sp_bevs(ops, pidx.cuda(), poff.cuda(), AGENTS * pb, pdims)
+                            form = "sparse voxel lists -> dn_scatter_dense_bits (occupancy words)"
+                        else:
+                            px = ops.scatter_dense(pidx.cuda(), poff.cuda(), AGENTS * pb, pdims)
+                            form = "sparse voxel lists -> dn_scatter_dense (float32 grid)"
+                        gotk = pmodel(px, ptrans, pna, pb)
                     base["parity_max_abs_err"] = {k: float((gotk[k].cpu() - par[k]).abs().max()) for k in ("cls", "loc")}
                     base["parity_ref_max_abs"] = {k: float(par[k].abs().max()) for k in ("cls", "loc")}
-                    base["parity_note"] = ("kaiming-initialised weights (logits of O(1)) for this comparison only; the timed "
-                                           "model keeps torch's default init, whose ~1e-2 logits make an error figure vacuous "
-                                           "(default_init_max_abs_err)")
-                    del pmodel
+                    base["parity_batch"] = pb
+                    base["parity_input_form"] = form
+                    base["parity_note"] = ("kaiming-initialised weights (logits of O(1)) for this comparison only, on the timed "
+                                           "step's own scenes, batch and input form; the timed model keeps torch's default "
+                                           "init, whose ~1e-2 logits make an error figure vacuous (default_init_max_abs_err)")
+                    del pmodel, gotk, px
                 # the metric's accuracy half: mAP of the HIP path's detections scored against
                 # the oracle's detections on the same scene (decode + rotated NMS both ways)
                 try:

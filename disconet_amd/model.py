@@ -202,7 +202,11 @@ class _ConvLayer:
                 self.packed_sig = sig
             # split-planar engine: NHWC inputs (the voxel grid, the fused map) are split once here
             src0, src1 = ops.as_sp(src0), (ops.as_sp(src1) if src1 is not None else None)
-            with region(self.name, "conv_sp_kernel", flops, nbytes):
+            # executed MFMA work: 3 products per MAC (hi*hi, hi*lo, lo*hi); the tap-merged kernel (conv_spq.hip: 3x3 over a
+            # nearest-upsampled first source) runs 4 merged taps instead of 9 on that source's chunks
+            taps0 = {2: 4, 1: 6}.get(ops.sp_upmode(), 9) if (up0 and self.ksize == 3 and self.stride == 1) else self.ksize ** 2
+            xflops = 3.0 * 2.0 * n * ho * wo * self.c_out * (taps0 * c0 + self.ksize ** 2 * c1)
+            with region(self.name, "conv_sp_kernel", flops, nbytes, exec_flops=xflops):
                 dual = nhwc_copy and not up0 and self.c_out % 4 == 0
                 return ops.sp_conv2d(d, src0, self.packed, self.scale, self.shift, src1=src1, nhwc_copy=dual,
                                      kslices=self.kslices)
@@ -525,7 +529,9 @@ class DiscoNet(nn.Module):
             return None
         flops = 2.0 * n * h * w * 9 * (l1.c_out * l1.c_in + l2.c_out * l2.c_in)
         nbytes = 4.0 * (n * h * w + n * h * w * l2.c_out)
-        with region("conv_pre_1+2", "conv_sp_kernel", flops, nbytes):      # (the SP engine's family name: bench.py sums it with the conv launches)
+        # executed: conv_pre_1 reads a hi-only (0 / 1) operand -> 2 MFMAs per product, conv_pre_2 3 (halo recompute not counted)
+        xflops = 2.0 * n * h * w * 9 * (2 * l1.c_out * l1.c_in + 3 * l2.c_out * l2.c_in)
+        with region("conv_pre_1+2", "conv_sp_kernel", flops, nbytes, exec_flops=xflops):      # (the SP engine's family name: bench.py sums it with the conv launches)
             return ops.sp_conv2d_pre_pair(d1, d2, x, l1.packed, l1.scale, l1.shift, l2.packed, l2.scale, l2.shift)
 
     def _enc_group(self, k, x, P, nhwc_copy=False):

@@ -279,10 +279,16 @@ def sp_range_flags(reset=True):
     validation time, not per step (check_sp_range is the asynchronous guard the model uses)."""
     if reset:
         _range_guard.pending.pop(torch.cuda.current_device(), None)
-    return int(_lib.load().dn_sp_range_flags(1 if reset else 0))
+    flags = int(_lib.load().dn_sp_range_flags(1 if reset else 0)) & 0xffffffff
+    if flags & 0x80000000:       # the read itself failed (device sync / allocation / copy): never "no clamp, no NaN"
+        msg = _lib.load().dn_last_error()
+        raise _lib.DnError("dn_sp_range_flags: the flags could not be read (%s)" % (msg.decode() if msg else "HIP error"))
+    return flags
 
 
 def _raise_on_range_flags(flags, what):
+    if flags & 0x80000000:
+        raise _lib.DnError("%s: the split-f16 range flags could not be read" % what)
     if flags & 1:
         raise _lib.DnError("%s: a value was clamped to +-65504 by the split-f16 (hi + lo binary16) activation format; "
                            "the outputs do not follow the fp32 reference%s.  Rescale the layer (fold a power of two into "
@@ -330,7 +336,7 @@ class _RangeGuard:
             return
         del self.pending[dev]
         flags = int(host[0]) & 0xffffffff
-        if flags:
+        if flags & 7:
             _lib.load().dn_sp_range_flags(1)       # the flags are sticky: cleared here, where they are reported
         _raise_on_range_flags(flags, what)
 
@@ -360,6 +366,18 @@ def check_sp_range(what="forward"):
 def drain_sp_range():
     """block until the outstanding asynchronous range-guard read (if any) has landed; raises like check_sp_range"""
     _range_guard.drain()
+
+
+def sp_upmode():
+    """The process's up-conv form as the library reads it (csrc/conv_sp.hip :: sp_upmode): DN_SP_UPMERGE, default 2 = the
+    row- and column-merged kernel (4 of 9 taps on the upsampled source), 1 = row-merged (6 of 9), 0 = plain taps.
+    (dn_spconv_set_upmode() overrides are a tools / test matter and not mirrored here: this only feeds the executed-work
+    figure of the profiling regions.)"""
+    import os
+    try:
+        return int(os.environ.get("DN_SP_UPMERGE", "2"))
+    except ValueError:
+        return 2
 
 
 def as_sp(x):

@@ -10,7 +10,7 @@ _active = None
 
 class KernelTimer:
     def __init__(self):
-        self.records = []          # (tag, kernel, flops, bytes, start_event, end_event)
+        self.records = []          # (tag, kernel, flops, bytes, start_event, end_event, executed MFMA flops or None)
 
     def summary(self):
         """-> {tag: dict(kernel, calls, ms_total, ms_median, flops, bytes)} after a
@@ -19,9 +19,13 @@ class KernelTimer:
         instead of charging that stall to the kernel."""
         torch.cuda.synchronize()
         out, samples = {}, {}
-        for tag, kernel, flops, nbytes, e0, e1 in self.records:
+        for tag, kernel, flops, nbytes, e0, e1, xflops in self.records:
             r = out.setdefault(tag, dict(kernel=kernel, calls=0, ms_total=0.0, ms_mean=0.0,
-                                         flops=0.0, bytes=0.0))
+                                         flops=0.0, bytes=0.0, exec_flops=0.0, exec_known=True))
+            if xflops is None:
+                r["exec_known"] = False
+            else:
+                r["exec_flops"] += xflops
             r["calls"] += 1
             samples.setdefault(tag, []).append(e0.elapsed_time(e1))
             r["flops"] += flops
@@ -46,7 +50,10 @@ def timing(timer):
 
 
 @contextlib.contextmanager
-def region(tag, kernel, flops=0.0, nbytes=0.0):
+def region(tag, kernel, flops=0.0, nbytes=0.0, exec_flops=None):
+    """exec_flops: the MFMA work the launch EXECUTES for `flops` of algorithmic work (split-f16: 3 MFMAs per product, 2 on
+    a hi-only operand; the tap-merged up-convs run 4 of 9 taps on the upsampled source's chunks).  None: the engine's
+    uniform factor (bench.py :: EXECUTED_FLOP_FACTOR)."""
     if _active is None:
         yield
         return
@@ -57,4 +64,4 @@ def region(tag, kernel, flops=0.0, nbytes=0.0):
         yield
     finally:
         e1.record()
-        _active.records.append((tag, kernel, flops, nbytes, e0, e1))
+        _active.records.append((tag, kernel, flops, nbytes, e0, e1, exec_flops))

@@ -71,7 +71,9 @@ const char* dn_last_error(void);
  *              (overflow is clamped and flagged by bit 0) -- the caller must not pack non-finite weights / scale /
  *              shift (the Python host refuses them when it packs a plan).
  * dn_sp_range_flags: the OR over the library's kernels on the current device; with reset != 0 it clears them.
- *   BLOCKING (hipDeviceSynchronize + a device -> host copy): validation time.
+ *   BLOCKING (hipDeviceSynchronize + a device -> host copy): validation time.  Bit 31 (0x80000000) set = the READ
+ *   failed (synchronisation, allocation or copy error): the flags are unknown -- treat as an error, never as "clean"
+ *   (the Python host raises).
  * dn_sp_range_flags_async: the same OR enqueued on `stream` into *dst_device (a device word the caller zeroed):
  *   no synchronisation, legal inside a stream capture.  The Python host enqueues it behind a forward, copies the
  *   word to pinned memory and raises at the next call once the copy has landed: the guard is on by default and

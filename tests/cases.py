@@ -83,6 +83,49 @@ def run_ref(case, model=None):
     return {"cls": res["cls"], "loc": res["loc"], "x8": x8, "x5": x5, "fused": fused}
 
 
+# --- the BENCHMARKED configuration (BASELINE.json configs[1]): 5 agents, batch 4, 256 x 256 x 13, through the step's own
+# input form (sorted sparse voxel lists -> dn_scatter_dense_bits), kaiming weights so that logits are O(1)
+# (the 256^2 5-agent whole-model golden; call site /root/reference/README.md:68-75)
+BENCH_CASE = dict(map_hw=256, agents=5, batch=4, jitter=0)
+
+
+def bench_case_inputs():
+    """(indices [M, 3] int32, offsets [A*B + 1] int32, dense bevs, trans, num_agent) exactly as bench.py builds its step's
+    inputs (make_sparse_scene_batch + make_trans_matrices(jitter_seed = rank 0))"""
+    from disconet_amd.synthetic import make_sparse_scene_batch, make_trans_matrices
+    c = BENCH_CASE
+    indices, offsets, bevs = make_sparse_scene_batch(c["batch"], c["agents"], c["map_hw"])
+    trans = make_trans_matrices(c["batch"], c["agents"], jitter_seed=c["jitter"])
+    na = torch.full((c["batch"], c["agents"]), c["agents"], dtype=torch.int64)
+    return indices, offsets, bevs, trans, na
+
+
+_BENCH_REF = {}
+
+
+def run_ref_bench_case():
+    """The oracle's outputs for BENCH_CASE (memoised per process: ~5 s of CPU) + the state_dict that produced them."""
+    if not _BENCH_REF:
+        c = BENCH_CASE
+        model = ref_model(c["map_hw"], c["agents"])
+        _, _, bevs, trans, na = bench_case_inputs()
+        with torch.no_grad():
+            res, x8, x7, x6, x5, fused = model(bevs, trans, na, c["batch"])
+        _BENCH_REF["outs"] = {"cls": res["cls"], "loc": res["loc"], "x8": x8, "x5": x5, "fused": fused}
+        _BENCH_REF["model"] = model
+    return _BENCH_REF["outs"], _BENCH_REF["model"]
+
+
+def subsample_bench(name, t):
+    """strided slice of a BENCH_CASE output kept in tests/golden/model_256_a5.npz (every image is sampled)"""
+    t = t.detach().cpu().numpy()
+    if name == "cls":
+        return t[:, ::1531, :]
+    if name == "loc":
+        return t[:, ::23, ::29]
+    return t[:, ::7, ::5, ::5]
+
+
 # --- fusion block alone at the BASELINE map size: 5 agents x [256, 32, 32] ---------------
 def fusion_inputs(agents=5, c=256, hw=32, seed=21):
     """post-ReLU-like maps (agent-major, B = 1), the synthetic poses and all agents live"""

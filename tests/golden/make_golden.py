@@ -69,6 +69,17 @@ def main():
     np.savez_compressed(os.path.join(HERE, "fusion_5x256.npz"),
                         fused=fused.numpy()[:, ::4, ::2, ::2], absmax=np.float32(fused.abs().max()))
     print("fusion", tuple(fused.shape), float(fused.abs().max()))
+    # 4b. the benchmarked configuration, whole model: strided slices + SHA-256 of inputs / full outputs
+    outs, _ = cases.run_ref_bench_case()
+    indices, offsets, bevs, trans, na = cases.bench_case_inputs()
+    store = {"indices_sha256": sha(indices.numpy()), "offsets_sha256": sha(offsets.numpy()), "trans_sha256": sha(trans.numpy()),
+             "threads": torch.get_num_threads()}
+    for name, t in outs.items():
+        store[name] = cases.subsample_bench(name, t)
+        store[name + "_absmax"] = np.float32(t.abs().max())
+        store[name + "_sha256"] = sha(t.numpy())        # of THIS run (thread count above): informational, not asserted
+    np.savez_compressed(os.path.join(HERE, "model_256_a5.npz"), **store)
+    print("bench case", {k: (tuple(v.shape), float(v.abs().max())) for k, v in outs.items()})
     # 5. training step (float64 oracle): losses and strided gradient slices, with and without KD
     from oracle.disconet_ref import RefConfig
     from oracle.teacher_ref import build_teacher

@@ -65,6 +65,43 @@ def test_model_256_five_agents_default_init(math):
         assert err <= TOL, "%s max abs err %.3e" % (name, err)
 
 
+@pytest.mark.parametrize("math", MATHS)
+def test_benchmarked_path_256_a5_b4_vs_oracle_and_golden(math, golden_dir):
+    """The configuration bench.py times, through the form it times (missing #1): BASELINE configs[1] --
+    5 agents, batch 4, 256 x 256 x 13 -- kaiming weights (logits of O(1)), the input handed over as sorted sparse voxel lists
+    and rebuilt by dn_scatter_dense_bits, so that on the SP engine the stem pair (dn_spconv2d_pre_pair), the K-sliced conv5_1,
+    the fragment-major warp and the one-launch attention kernel are the launches that run.  Against the oracle on the same
+    inputs and against tests/golden/model_256_a5.npz, 1e-4 absolute.  The fp32-NHWC engines (f32 / f16x3) have no
+    occupancy-word source: they get the float32 grid dn_scatter_dense builds from the same lists."""
+    from disconet_amd import ops
+    c = cases.BENCH_CASE
+    want, ref = cases.run_ref_bench_case()
+    m = _product(ref, c["map_hw"], c["agents"], math=math)
+    indices, offsets, bevs, trans, na = cases.bench_case_inputs()
+    n, dims = c["agents"] * c["batch"], (c["map_hw"], c["map_hw"], bevs.shape[-1])
+    if math == "sp":
+        x = ops.scatter_dense_bits(indices.cuda(), offsets.cuda(), n, dims)
+        assert isinstance(x, ops.SpTensor) and x.bits
+        P = m._get_plan()
+        assert P["conv5_1"].kslices == 4, "conv5_1 must run K-sliced in the benchmarked configuration"
+        assert m._stem_pair(x, P) is not None, "the stem pair launch must be the one that runs"
+    else:
+        x = ops.scatter_dense(indices.cuda(), offsets.cuda(), n, dims)
+        assert torch.equal(x.cpu().reshape(bevs.shape), bevs)
+    with torch.no_grad():
+        res, x8, x7, x6, x5, fused = m(x, trans.cuda(), na.cuda(), c["batch"])
+    torch.cuda.synchronize()
+    assert ops.sp_range_flags() == 0
+    got = {"cls": res["cls"].cpu(), "loc": res["loc"].cpu(), "x8": x8.cpu(), "x5": x5.cpu(), "fused": fused.cpu()}
+    g = np.load(os.path.join(golden_dir, "model_256_a5.npz"))
+    for name in want:
+        assert got[name].shape == want[name].shape, name
+        err = (got[name] - want[name]).abs().max().item()
+        assert err <= TOL, "%s max abs err %.3e (max |ref| %.2f)" % (name, err, want[name].abs().max())
+        gerr = np.abs(cases.subsample_bench(name, got[name]) - g[name]).max()
+        assert gerr <= TOL, "%s golden err %.3e" % (name, gerr)
+
+
 def test_kd_flag_zero_returns_dict_and_only_v2i():
     c = cases.MODEL_CASES["ragged_a4"]
     ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=0, only_v2i=True)

@@ -85,6 +85,31 @@ def test_model_golden(case, golden_dir):
         assert err <= 2e-5, (case, name, err)
 
 
+def test_benchmarked_configuration_golden(golden_dir):
+    """the 256 x 256, 5-agent, batch-4 whole-model golden of the configuration bench.py times
+    (tests/golden/model_256_a5.npz).  The inputs regenerate bit for bit from their seeds (SHA-256); the oracle's outputs
+    agree with the committed strided slices to 2e-5 (summation order moves the last bits with the thread count, so the
+    full-tensor SHA-256 in the file is a record of the generating run, not an assertion)."""
+    g = np.load(os.path.join(golden_dir, "model_256_a5.npz"))
+    indices, offsets, bevs, trans, na = cases.bench_case_inputs()
+    assert _sha(indices.numpy()) == str(g["indices_sha256"])
+    assert _sha(offsets.numpy()) == str(g["offsets_sha256"])
+    assert _sha(trans.numpy()) == str(g["trans_sha256"])
+    # the sparse lists ARE the dense grid the oracle reads
+    dense = torch.zeros(bevs.shape[0], *bevs.shape[2:])
+    img = torch.repeat_interleave(torch.arange(bevs.shape[0]), (offsets[1:] - offsets[:-1]).long())
+    dense[img, indices[:, 0].long(), indices[:, 1].long(), indices[:, 2].long()] = 1.0
+    assert torch.equal(dense, bevs[:, 0])
+    outs, _ = cases.run_ref_bench_case()
+    for name, t in outs.items():
+        want = g[name]
+        got = cases.subsample_bench(name, t)
+        assert got.shape == want.shape
+        assert float(t.abs().max()) > 1.0, name                # O(1) activations: the error bar means something
+        err = np.abs(got - want).max()
+        assert err <= 2e-5, (name, err)
+
+
 def test_ragged_scene_dead_agents_pass_through():
     """num_agent_tensor[b, 0] live agents are fused; padded agents keep their map."""
     c = cases.MODEL_CASES["ragged_a4"]
