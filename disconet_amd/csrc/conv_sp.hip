@@ -594,7 +594,13 @@ conv_sp_kernel(const SpArgs a) {
         for (int g = 0; g < 4; ++g) {
           const int co = ch0 + 8 * g + 4 * lh;
           f32x4 v;
-          affine(g, v, true);
+          affine(g, v, false);
+          // the fp32 copy leaves the engine (fusion kernels, the agent all-gather): the one place where a NaN / Inf test of
+          // the conv stack is free -- one launch per step, behind a uniform branch.  Before the ReLU, which would hide a NaN.
+          nan_seen |= !(fabsf(v[0]) <= 3.4028235e38f) | !(fabsf(v[1]) <= 3.4028235e38f) | !(fabsf(v[2]) <= 3.4028235e38f) |
+                      !(fabsf(v[3]) <= 3.4028235e38f);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);
           if (inside && co < c_lim) *reinterpret_cast<f32x4*>(orow + co) = v;
         }
       }

@@ -28,11 +28,34 @@
 #include <cstdlib>
 #include <type_traits>
 
+// tools/ab (DN_FUSE_PHASES 1): every active wave of the weight-in-LDS form adds its cycles per phase into g_fuse_phase --
+// [0] staging + barriers, [1] ego term, [2] layer-1 passes of the slots, [3] tails, [4] weighted sum + stores, [5] waves, [6] total,
+// [7] first cycle count seen (unused) -- read with dn_fuse_phase_cycles().  Never in the shipped build.
+#ifndef DN_FUSE_PHASES
+#define DN_FUSE_PHASES 0
+#endif
+#if DN_FUSE_PHASES
+__device__ unsigned long long g_fuse_phase[8];
+extern "C" int dn_fuse_phase_cycles(unsigned long long* host8, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (host8 && hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_fuse_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fuse_phase), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
+
 namespace {
 
 constexpr int MAX_AGENTS = 8;
 constexpr size_t kW2Bytes = 8 * 2 * 2 * 32 * 16, kW3Bytes = 2 * 2 * 2 * 32 * 16;
 constexpr int FUSE_G = 3;   // list slots per layer-1 pass: 3 accumulator sets (192 AGPRs) is what hipcc allocates without spilling
+#ifndef DN_FUSE_RING
+#define DN_FUSE_RING 4   // row ring of the weight-in-LDS form's layer-1 loop (k-steps); 8 measured the same (67.5 vs 67.9 us standalone): the loop does not wait for its rows
+#endif
+#ifndef DN_FUSE_GL
+#define DN_FUSE_GL 2      // 3 spills 16 registers there (tools/kernel_resources.py fuse_mlp); the grouping does not change a bit of any slot's chain
+#endif
+constexpr int FUSE_GL = DN_FUSE_GL;   // the same for the weight-in-LDS form (the ego term holds 64 more registers there)
 
 struct FuseMlpArgs {
   const float* feat;
@@ -46,6 +69,7 @@ struct FuseMlpArgs {
   float* fused_nhwc;
   float* weights_out;
   int batch, agents, hw, only_v2i, ego_first, ego_count, tiles;
+  int total_tiles;   // batch * ego_count * tiles (the weight-in-LDS form has workgroups of several tiles)
   int warped_fm;   // `warped` is fragment-major (dn_warp_neighbors_fm): a k-step of a tile is two contiguous 1 KB runs
 };
 // Timing-only ablations (results are garbage), COMPILE-time so that the shipped kernel carries none of it: build a variant
@@ -79,28 +103,42 @@ __device__ inline half8 frag_of(const unsigned char* base, int idx) {
 // wave, the list slots go round-robin to the waves (slot k to wave k % 4, one slot per layer-1 pass), and
 // pass 2 splits the channels (KS / 4 k-steps per wave).  Every output is produced by the same instruction
 // sequence on the same operands as with NW = 1: the results are bit-identical (tests/test_gpu_fusion.py).
-template <int C, int G, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kernel(const FuseMlpArgs a) {
+// WL > 0 (round 5): the WEIGHT-IN-LDS form for launches of at least two tiles per CU (the BASELINE size: 640 tiles).  A workgroup
+// is WL waves, each the whole chain of ITS OWN tile (NW = 1 arithmetic, instruction for instruction), and the layer-1 weights --
+// first W1_ego, then W1_nbr, 128 KB each at C = 256 -- are staged ONCE per workgroup into LDS, from where every k-step's eight
+// fragments come at LDS latency.  In the one-wave form every wave streamed those fragments from L2 for itself (128 KB per layer-1
+// pass, 245 MB per step) with nothing to switch to while a load was in flight: two thirds of the launch was that loop at 30 % MFMA
+// utilisation.  The ego term stays in registers (no e_s), so the static LDS beside the 128 KB is 28 KB.
+template <int C, int G, int NW, int WL = 0>
+__global__ void __launch_bounds__(64 * (WL > 0 ? WL : NW), (NW == 1 || WL > 0) ? 1 : 2) disco_fuse_mlp_kernel(const FuseMlpArgs a) {
+  constexpr bool kWL = WL > 0;
+  constexpr int TWV = kWL ? WL : 1;        // waves of the workgroup that own a tile each
+  static_assert(!kWL || NW == 1, "weight-in-LDS form: one wave per tile");
   constexpr int KS = C / 16;
   constexpr int KSW = KS / NW;             // k-steps (16-channel chunks) of pass 2 / the pass-through per wave
   static_assert(KS % NW == 0, "pass 2 splits the k-steps over the waves");
-  __shared__ float ek_s[MAX_AGENTS][64];   // exp(s_k) of this wave's pixels, per list slot
-  __shared__ float e_s[64][64];            // layer-1 ego term of this wave's pixels: [reg][lane]
-  __shared__ int jl_s[MAX_AGENTS];         // agent of each list slot (slot 0 = the ego)
+  constexpr int kW1MatBytes = 4 * KS * 2 * 2 * 32 * 16;      // one matrix (ego or nbr) of layer 1 as fragments
+  extern __shared__ __attribute__((aligned(16))) unsigned char w1_s[];   // kWL: kW1MatBytes, the matrix in use
+  __shared__ float ek_s[TWV][MAX_AGENTS][64];   // exp(s_k) of a wave's pixels, per list slot
+  __shared__ float e_s[kWL ? 1 : 64][64];       // layer-1 ego term of the tile's pixels: [reg][lane] (kWL: in registers)
+  __shared__ int jl_s[TWV][MAX_AGENTS];         // agent of each list slot (slot 0 = the ego)
   // layers 2-4: weight fragments and affines, read by every tail() -- LDS-resident (an L2 round
   // trip per dependent stage of the tail was ~40 % of the kernel)
   __shared__ __attribute__((aligned(16))) unsigned char w23_s[kW2Bytes + kW3Bytes];
   __shared__ __attribute__((aligned(16))) float aff_s[2 * 128 + 2 * 32 + 3 * 8];   // s1 t1 s2 t2 s3 t3 w4
 
   const int lane = threadIdx.x & 63, wave = NW > 1 ? threadIdx.x >> 6 : 0;
+  const int tw = kWL ? threadIdx.x >> 6 : 0;   // which of the workgroup's tiles this wave owns
   const int ks_first = wave * KSW;
   const int li = lane & 31, lh = lane >> 5;
-  const int wid = blockIdx.x;
+  const int wid_raw = kWL ? blockIdx.x * WL + tw : blockIdx.x;
+  const bool have = wid_raw < a.total_tiles;        // kWL: the last workgroup may hold waves without a tile
+  const int wid = have ? wid_raw : a.total_tiles - 1;
   const int tile = wid % a.tiles, il = (wid / a.tiles) % a.ego_count, b = wid / (a.tiles * a.ego_count);
   const int i = a.ego_first + il;
   const int p = tile * 32 + li;
-  const bool pvalid = p < a.hw;
-  const int pc = pvalid ? p : a.hw - 1;
+  const bool pvalid = p < a.hw && have;
+  const int pc = p < a.hw ? p : a.hw - 1;
   int live = a.num_agent[b];
   live = live < 0 ? 0 : (live < a.agents ? live : a.agents);   // never index past the agents that exist
   const size_t oimg = (size_t)il * a.batch + b;
@@ -143,20 +181,44 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
     }
   };
 
-  if (i < live) {
+  constexpr int NTHR = 64 * (kWL ? WL : NW);
+#if DN_FUSE_PHASES
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = __builtin_readcyclecounter();
+  const unsigned long long t_begin = t_prev;
+  auto mark = [&](int k) { const unsigned long long t = __builtin_readcyclecounter(); ph[k] += t - t_prev; t_prev = t; };
+#else
+  auto mark = [&](int) {};
+#endif
+  if (kWL || i < live) {      // (kWL: the waves of a workgroup own different egos -- everyone stages)
     const int t = threadIdx.x;
-    for (int q = t; q < (int)((kW2Bytes + kW3Bytes) / 16); q += 64 * NW)   // w3 follows w2 in the packed block
+    for (int q = t; q < (int)((kW2Bytes + kW3Bytes) / 16); q += NTHR)   // w3 follows w2 in the packed block
       *reinterpret_cast<u32x4*>(w23_s + q * 16) = *reinterpret_cast<const u32x4*>(a.w2 + (size_t)q * 16);
-    for (int q = t; q < 128; q += 64 * NW) { aff_s[q] = a.s1[q]; aff_s[128 + q] = a.t1[q]; }
+    for (int q = t; q < 128; q += NTHR) { aff_s[q] = a.s1[q]; aff_s[128 + q] = a.t1[q]; }
     if (t < 32) { aff_s[256 + t] = a.s2[t]; aff_s[288 + t] = a.t2[t]; }
     if (t < 8) { aff_s[320 + t] = a.s3[t]; aff_s[328 + t] = a.t3[t]; aff_s[336 + t] = a.w4[t]; }
   }
+  // kWL: one matrix of layer 1 -> LDS, a linear copy (fragment (nt, ks, part) of lane l keeps its place) by LDS-DMA: every wave
+  // issues its share of the 1 KB instructions back to back, so the whole matrix is in flight at once -- one memory latency per
+  // matrix.  (Through registers, 8 x 16 B per thread in flight, the two matrices cost ~25 us of the launch: the copy ran at the
+  // latency of its 11 round trips.)
+  auto stage_w1 = [&](int mat) {
+    if constexpr (kWL) {
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.w1 + (size_t)mat * kW1MatBytes), 0,
+                                                        kW1MatBytes, 0x00020000);
+      constexpr int INSTR = kW1MatBytes / 1024;
+      for (int q = tw; q < INSTR; q += WL) dma16(rs, w1_s + q * 1024, (unsigned)(q * 1024 + lane * 16), 0);
+      wait_vm0();
+    }
+  };
+  stage_w1(0);
   const float b4v = a.b4[0];   // read once: a global load inside every tail() sat on its critical path
   const unsigned char* w2l = w23_s;
   const unsigned char* w3l = w23_s + kW2Bytes;
   const float *s1l = aff_s, *t1l = aff_s + 128, *s2l = aff_s + 256, *t2l = aff_s + 288, *s3l = aff_s + 320,
               *t3l = aff_s + 328, *w4l = aff_s + 336;
 
+  const bool active = have && i < live;      // kWL: a wave without a live ego still meets the workgroup's barriers
   if (i >= live) {   // padded agent: its map passes through un-fused
 #pragma unroll
     for (int u = 0; u < KSW; ++u) {
@@ -164,17 +226,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
       store_piece(ks, *reinterpret_cast<const f32x4*>(xrow + 16 * ks),
                   *reinterpret_cast<const f32x4*>(xrow + 16 * ks + 4));
     }
-    note_range(amax, nan_seen);
-    return;
+    if constexpr (!kWL) {
+      note_range(amax, nan_seen);
+      return;
+    }
   }
 
   // neighbour list, in the reference's order: the ego, then j ascending
   int n = 1;
-  jl_s[0] = i;   // NW > 1: every wave writes the same values
+  jl_s[tw][0] = i;   // NW > 1: every wave writes the same values
   for (int j = 0; j < live; ++j)
-    if (j != i && (!a.only_v2i || i == 0 || j == 0)) jl_s[n++] = j;
-  if constexpr (NW > 1) __syncthreads();   // list, layer 2-4 weights and affines visible to every wave
-  auto row_of = [&](int k) { return k == 0 ? xrow_r : yrow_of(jl_s[k]); };
+    if (j != i && (!a.only_v2i || i == 0 || j == 0)) jl_s[tw][n++] = j;
+  if constexpr (NW > 1 || kWL) __syncthreads();   // list, layer 2-4 weights and affines (kWL: and W1_ego) visible to every wave
+  auto row_of = [&](int k) { return k == 0 ? xrow_r : yrow_of(jl_s[tw][k]); };
 
   auto frag_from = [&](const f32x4 v0, const f32x4 v1, half8& fh, half8& fl) {
     u32x2 h0, l0, h1, l1;
@@ -192,12 +256,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
     const unsigned char* wbase = a.w1 + (size_t)mat * 4 * KS * 2 * 2 * 32 * 16 + (size_t)(lh * 32 + li) * 16;
     // fragment (nt, ks, part) at wbase + (((nt * KS + ks) * 2 + part) * 64) * 16
     half8 wh[kWRing][4], wl[kWRing][4];   // weight fragments: ring of kWRing k-steps, loaded kWAhead k-steps before their MFMAs
-    f32x4 r0[4][NG], r1[4][NG];   // row pieces: ring of 4 k-steps (the maps come from HBM / far L2)
+    // row pieces: ring of RING k-steps (the maps come from HBM / the far L2); DN_FUSE_RING deepens it for the weight-in-LDS form (A/B)
+    constexpr int RING = (kWL && KS % DN_FUSE_RING == 0) ? DN_FUSE_RING : 4;
+    f32x4 r0[RING][NG], r1[RING][NG];
     auto wload = [&](int ks, int s) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        wh[s][nt] = *reinterpret_cast<const half8*>(wbase + (size_t)(((nt * KS + ks) * 2 + 0) * 64) * 16);
-        wl[s][nt] = *reinterpret_cast<const half8*>(wbase + (size_t)(((nt * KS + ks) * 2 + 1) * 64) * 16);
+        if constexpr (kWL) {      // the matrix in use is LDS-resident (stage_w1): the same fragment, at LDS latency
+          wh[s][nt] = *reinterpret_cast<const half8*>(w1_s + (((nt * KS + ks) * 2 + 0) * 64 + lh * 32 + li) * 16);
+          wl[s][nt] = *reinterpret_cast<const half8*>(w1_s + (((nt * KS + ks) * 2 + 1) * 64 + lh * 32 + li) * 16);
+        } else {
+          wh[s][nt] = *reinterpret_cast<const half8*>(wbase + (size_t)(((nt * KS + ks) * 2 + 0) * 64) * 16);
+          wl[s][nt] = *reinterpret_cast<const half8*>(wbase + (size_t)(((nt * KS + ks) * 2 + 1) * 64) * 16);
+        }
       }
     };
     auto rload = [&](int ks, int s) {
@@ -228,18 +299,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
           for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sw][nt], fh, acc[g][nt], 0, 0, 0);
         }
     };
-    static_assert(KS % 4 == 0, "k loop runs four k-steps per trip");
-    rload(0, 0);
-    rload(1, 1);
-    rload(2, 2);
+    static_assert(KS % RING == 0, "k loop runs RING k-steps per trip");
+#pragma unroll
+    for (int q = 0; q < RING - 1; ++q) rload(q, q);
 #pragma unroll
     for (int q = 0; q < kWAhead; ++q) wload(q, q);
 #pragma unroll 1
-    for (int ks0 = 0; ks0 < KS; ks0 += 4) {
+    for (int ks0 = 0; ks0 < KS; ks0 += RING) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RING; ++u) {
         const int ks = ks0 + u;
-        if (ks + 3 < KS) rload(ks + 3, (u + 3) & 3);
+        if (ks + RING - 1 < KS) rload(ks + RING - 1, (u + RING - 1) % RING);
         if (ks + kWAhead < KS) wload(ks + kWAhead, (u + kWAhead) & (kWRing - 1));
         __builtin_amdgcn_sched_barrier(0);
         mma(u & (kWRing - 1), u);
@@ -309,8 +379,32 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
     return expf(s);
   };
 
-  // ---- pass 1a: E = W1_ego . x_ego, parked in LDS between the groups ([reg][lane])
-  if constexpr (NW == 1) {
+  // ---- pass 1a: E = W1_ego . x_ego, parked in LDS between the groups ([reg][lane]); kWL: kept in registers
+  f32x16 Ereg[kWL ? 4 : 1];
+  mark(0);
+  if constexpr (kWL) {
+    if (active) {
+      f32x16 acc[G][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nt][r] = 0.f;
+      Row rows[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) rows[g] = xrow_r;
+      layer1(std::integral_constant<int, 1>{}, rows, 1, 0, acc);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) Ereg[nt] = acc[0][nt];
+#if DN_FUSE_PHASES
+      { float probe = Ereg[0][0]; asm volatile("v_mov_b32 %0, %0" : "+v"(probe)); }
+#endif
+    }
+    mark(1);
+    __syncthreads();      // every wave is done with W1_ego
+    stage_w1(1);
+    __syncthreads();      // W1_nbr in place
+    mark(0);
+  } else if constexpr (NW == 1) {
     f32x16 acc[G][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -364,6 +458,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
     __syncthreads();
   }
   // ---- pass 1b: scores of the list.  NW = 1: G slots at a time; NW = 4: this wave's slots wave, wave + 4, ...
+  if constexpr (kWL) {
+    if (!active) {      // nothing left for this wave (no tile, or a padded agent already passed through); no barrier follows
+      note_range(amax, nan_seen);
+      return;
+    }
+  }
   if constexpr (NW == 1) {
     for (int g0 = 0; g0 < n; g0 += G) {
       const int cnt = n - g0 < G ? n - g0 : G;
@@ -374,15 +474,24 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
         rows[g] = row_of(g0 + g < n ? g0 + g : 0);
         if (g < cnt) {
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
+          for (int nt = 0; nt < 4; ++nt) {
+            if constexpr (kWL) acc[g][nt] = Ereg[nt];
+            else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][nt][r] = e_s[nt * 16 + r][lane];
+              for (int r = 0; r < 16; ++r) acc[g][nt][r] = e_s[nt * 16 + r][lane];
+            }
+          }
         }
       }
       layer1(std::integral_constant<int, G>{}, rows, cnt, 1, acc);
+#if DN_FUSE_PHASES
+      { float probe = acc[0][0][0]; asm volatile("v_mov_b32 %0, %0" : "+v"(probe)); }
+#endif
+      mark(2);
 #pragma unroll
       for (int g = 0; g < G; ++g)
-        if (g < cnt) ek_s[g0 + g][lane] = tail(acc[g]);
+        if (g < cnt) ek_s[tw][g0 + g][lane] = tail(acc[g]);
+      mark(3);
     }
   } else {
     for (int k = wave; k < n; k += NW) {   // one slot per pass: two accumulator sets would spill at 256 registers
@@ -395,12 +504,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][nt][r] = e_s[nt * 16 + r][lane];
       layer1(std::integral_constant<int, 1>{}, rows, 1, 1, acc);
-      ek_s[k][lane] = tail(acc[0]);
+      ek_s[0][k][lane] = tail(acc[0]);
     }
     __syncthreads();
   }
   float den = 0.f;
-  for (int k = 0; k < n; ++k) den += ek_s[k][lane];
+  for (int k = 0; k < n; ++k) den += ek_s[tw][k][lane];
 
   // ---- pass 2: weighted sum in list order; the next slot's row is in flight under the FMAs
   f32x4 f0[KSW], f1[KSW], y0[2][KSW], y1[2][KSW];
@@ -418,7 +527,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
     }
   };
   auto yacc = [&](int k, int s) {
-    const float w = ek_s[k][lane] / den;
+    const float w = ek_s[tw][k][lane] / den;
     if (a.weights_out && pvalid && lh == 0 && wave == 0)
       a.weights_out[(((size_t)b * a.ego_count + il) * a.agents + k) * a.hw + p] = w;
 #pragma unroll
@@ -441,6 +550,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) disco_fuse_mlp_kerne
 #pragma unroll
   for (int ks = 0; ks < KSW; ++ks) store_piece(ks_first + ks, f0[ks], f1[ks]);
   note_range(amax, nan_seen);
+#if DN_FUSE_PHASES
+  mark(4);
+  ph[5] = 1;
+  ph[6] = __builtin_readcyclecounter() - t_begin;
+  if (lane == 0)
+    for (int k = 0; k < 7; ++k) atomicAdd(&g_fuse_phase[k], ph[k]);
+#endif
 }
 
 // weights [rows][cols] * wmul -> A-operand fragments [nt][ks][part][h][32 rows] x 16 B (rows / cols
@@ -471,9 +587,10 @@ namespace dn { void range_collect_fuse_mlp(unsigned* dst, bool reset, hipStream_
 
 int g_fuse_waves = 0;   // 0 = DN_FUSE_MLP_WAVES, else chosen per launch
 
-// tools / tests: 1 or 4 waves per 32-pixel tile (0 = default)
+// tools / tests: the launch form -- 1 or 4 waves per 32-pixel tile, 2 = the weight-in-LDS form (0 = default)
 extern "C" int dn_fuse_mlp_set_waves(int waves) {
-  DN_REQUIRE(waves == 0 || waves == 1 || waves == 4, "fuse_mlp: waves per tile is 1 or 4 (0 = default), got %d", waves);
+  DN_REQUIRE(waves == 0 || waves == 1 || waves == 2 || waves == 4,
+             "fuse_mlp: form is 1 or 4 waves per tile, 2 = layer-1 weights in LDS (0 = default), got %d", waves);
   g_fuse_waves = waves;
   return DN_OK;
 }
@@ -553,17 +670,46 @@ int fuse_mlp_impl(const float* feat, const float* warped, int warped_fm, const i
   a.batch = batch; a.agents = agents; a.hw = hw; a.only_v2i = only_v2i;
   a.ego_first = ego_first; a.ego_count = ego_count;
   a.tiles = (hw + 31) / 32;
+  a.total_tiles = batch * ego_count * a.tiles;
   a.warped_fm = warped_fm;
-  dim3 grid(batch * ego_count * a.tiles);   // one workgroup per 32 pixels of one (sample, ego)
+  dim3 grid(a.total_tiles);   // one workgroup per 32 pixels of one (sample, ego)
   hipStream_t s = (hipStream_t)stream;
-  // Four waves per tile when the launch leaves SIMDs idle (fewer tiles than 2 per CU: 128 tiles for one rank's
-  // share of the agent-sharded step, 87 -> 45 us); at the BASELINE size (640 tiles) the two forms run within
-  // 3 % of each other (85.9 vs 88.6 us) and the one-wave chain stays.  DN_FUSE_MLP_WAVES / dn_fuse_mlp_set_waves
-  // force one form (tools, tests); the results are bit-identical either way.
+  // Three forms, bit-identical results (tests/test_gpu_fusion.py):
+  //   4 -- four waves per tile, when the launch leaves SIMDs idle (fewer tiles than 2 per CU: 128 tiles for one rank's
+  //        share of the agent-sharded step, 87 -> 45 us);
+  //   2 -- layer-1 weights staged in LDS once per workgroup of WL tiles (round 5), from 2 tiles per CU up (the BASELINE
+  //        size: 640 tiles -> 214 workgroups of three one-wave chains);
+  //   1 -- one wave per tile streaming its weight fragments from L2 (rounds 2-4's form at the BASELINE size; kept for A/B).
+  // DN_FUSE_MLP_WAVES / dn_fuse_mlp_set_waves force a form (tools, tests).
   static const int waves_env = [] { const char* e = getenv("DN_FUSE_MLP_WAVES"); return e ? atoi(e) : 0; }();
   const int forced = g_fuse_waves > 0 ? g_fuse_waves : waves_env;
-  const int waves = forced > 0 ? forced : (grid.x < 2u * 256u ? 4 : 1);
-  if (waves == 1) {
+  const int waves = forced > 0 ? forced : (grid.x < 2u * 256u ? 4 : 2);
+  if (waves == 2) {
+    // workgroups of WL tiles so that the launch is one resident generation (one workgroup per CU: 128 KB of LDS at C = 256)
+    const int wl = a.total_tiles <= 2 * 256 ? 2 : a.total_tiles <= 3 * 256 ? 3 : 4;
+    const dim3 g2((a.total_tiles + wl - 1) / wl);
+    const int lds = 4 * (c / 16) * 2 * 2 * 32 * 16;
+    auto go = [&](auto kern) {
+      static dn::PerDeviceFlag flag;      // (one per instantiation: the lambda's operator() is a template)
+      bool& done = flag.here();
+      if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+          return dn::fail(DN_ERR_LAUNCH, "fuse_mlp: cannot reserve %d B of dynamic LDS", lds);
+        done = true;
+      }
+      hipLaunchKernelGGL(kern, g2, dim3(64 * wl), lds, s, a);
+      return DN_OK;
+    };
+    int rc = DN_OK;
+#define DN_FUSE_WL(CC)                                                                        \
+    rc = wl == 2 ? go(disco_fuse_mlp_kernel<CC, FUSE_GL, 1, 2>) : wl == 3 ? go(disco_fuse_mlp_kernel<CC, FUSE_GL, 1, 3>) \
+                                                                 : go(disco_fuse_mlp_kernel<CC, FUSE_GL, 1, 4>)
+    if (c == 256) DN_FUSE_WL(256);
+    else if (c == 128) DN_FUSE_WL(128);
+    else DN_FUSE_WL(64);
+#undef DN_FUSE_WL
+    if (rc) return rc;
+  } else if (waves == 1) {
     if (c == 256) hipLaunchKernelGGL((disco_fuse_mlp_kernel<256, FUSE_G, 1>), grid, dim3(64), 0, s, a);
     else if (c == 128) hipLaunchKernelGGL((disco_fuse_mlp_kernel<128, FUSE_G, 1>), grid, dim3(64), 0, s, a);
     else hipLaunchKernelGGL((disco_fuse_mlp_kernel<64, FUSE_G, 1>), grid, dim3(64), 0, s, a);

@@ -664,8 +664,8 @@ def fuse_mlp_supported(c):
 
 
 def set_fuse_mlp_waves(waves):
-    """tools / tests: 4 or 1 wave(s) per 32-pixel tile of dn_disco_fuse_mlp; 0 = chosen per launch.
-    The two forms give bit-identical results."""
+    """tools / tests: the launch form of dn_disco_fuse_mlp -- 4 or 1 wave(s) per 32-pixel tile, 2 = one wave per tile with
+    the layer-1 weights staged in LDS per workgroup of tiles; 0 = chosen per launch.  Bit-identical results."""
     check(_lib.load().dn_fuse_mlp_set_waves(int(waves)), "dn_fuse_mlp_set_waves")
 
 

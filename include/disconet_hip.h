@@ -375,10 +375,12 @@ typedef struct dn_fuse_mlp_params {
   const float* w4; const float* b4;
 } dn_fuse_mlp_params;
 int dn_fuse_mlp_supported(int c);
-/* tools / tests only: waves per 32-pixel tile of dn_disco_fuse_mlp: 4 (the ego term, the list slots and
- * the channels of the weighted sum are split over four waves) or 1 (one wave does the whole chain);
- * 0 = chosen per launch (4 below 512 tiles) unless DN_FUSE_MLP_WAVES is set.  Both forms give
- * bit-identical results.  Process-wide, not thread-safe. */
+/* tools / tests only: the launch form of dn_disco_fuse_mlp -- 4 (the ego term, the list slots and the channels of the
+ * weighted sum of a 32-pixel tile split over four waves: launches of fewer than 512 tiles), 2 (round 5: one wave per
+ * tile, workgroups of 2-4 tiles that stage the layer-1 weights in LDS once: 512 tiles and more) or 1 (one wave per
+ * tile streaming its weight fragments from L2: rounds 2-4's form for large launches, kept for A/B);
+ * 0 = chosen per launch unless DN_FUSE_MLP_WAVES is set.  All forms give bit-identical results.
+ * Process-wide, not thread-safe. */
 int dn_fuse_mlp_set_waves(int waves);
 size_t dn_fuse_mlp_packed_bytes(int c);
 int dn_fuse_mlp_pack(const float* w1, const float* w2, const float* w3, int c, float wmul1,

@@ -131,6 +131,8 @@ def test_one_launch_fusion_matches_the_three_launch_form(case):
     (4, 2, 20, 28, 128, [4, 3], True),      # ragged last tile, only_v2i
     (3, 1, 12, 16, 64, None, False),        # one k-step per wave in the weighted sum
     (1, 2, 16, 16, 256, None, False),       # the ego alone
+    (5, 4, 32, 32, 256, None, False),       # BASELINE configs[1]: 640 tiles -- workgroups of three tiles in the weight-in-LDS form
+    (6, 4, 32, 32, 256, [6, 3, 6, 1], False),   # 768 tiles: workgroups of four; padded agents inside a workgroup
 ])
 def test_four_wave_attention_launch_is_bit_identical_to_the_one_wave_form(A, B, h, w, C, live, v2i):
     """dn_disco_fuse_mlp with the work of a 32-pixel tile split over four waves (small launches) against the
@@ -152,7 +154,7 @@ def test_four_wave_attention_launch_is_bit_identical_to_the_one_wave_form(A, B, 
     assert "_fuse_mlp" in P
     outs = {}
     try:
-        for waves in (1, 4):
+        for waves in (1, 4, 2):
             ops.set_fuse_mlp_waves(waves)
             fused, weights = m.fuse(feat, trans, na, B, P, want_weights=True)
             sp = m.fuse(feat, trans, na, B, P, sp_out=True)
@@ -163,5 +165,8 @@ def test_four_wave_attention_launch_is_bit_identical_to_the_one_wave_form(A, B, 
         ops.set_fuse_mlp_waves(0)
     assert torch.isfinite(outs[4][0]).all()
     for x, y in zip(outs[1], outs[4]):
+        assert torch.equal(x, y)
+    # the weight-in-LDS form (one wave per tile, the layer-1 matrices staged once per workgroup of 2-4 tiles): same bits
+    for x, y in zip(outs[1], outs[2]):
         assert torch.equal(x, y)
     assert torch.equal(outs[4][3], outs[4][0][(A - 1) * B:])
