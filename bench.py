@@ -297,7 +297,7 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
         return round(1e3 * e0.elapsed_time(e1) / reps, 2)
 
     first, count = sharded.agent_range(agents, world, rank)
-    stepper = sharded.GraphedAgentStep(engine, rank_inputs(first, count), trans, na, batch, first, count)
+    stepper = sharded.GraphedAgentStep(engine, rank_inputs(first, count), trans, na, batch, first, count, range_guard=False)
     elapsed = time_steps(stepper, args.steps, args.warmup)
     # per-phase times on EVERY rank (the exchange is a collective: all ranks must call it the same number of times)
     phases = {"graph_a_encode": phase_us(stepper.graph_a), "allgather": phase_us(stepper.exchange),
@@ -365,13 +365,13 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
                 have_pg = True
             except Exception as e:      # noqa: BLE001 -- the projection then carries no collective (said in the note)
                 print("bench: no one-rank process group for the emulated share (%r)" % (e,), file=sys.stderr)
-        share_plain = sharded.GraphedAgentStep(engine, rank_inputs(0, cnt), trans, na, batch, 0, cnt,
+        share_plain = sharded.GraphedAgentStep(engine, rank_inputs(0, cnt), trans, na, batch, 0, cnt, range_guard=False,
                                                emulate_feat_all=full_feat)
         t_plain = time_steps(share_plain, args.steps, args.warmup)
         share = share_plain
         t_share = t_plain
         if have_pg:
-            share = sharded.GraphedAgentStep(engine, rank_inputs(0, cnt), trans, na, batch, 0, cnt,
+            share = sharded.GraphedAgentStep(engine, rank_inputs(0, cnt), trans, na, batch, 0, cnt, range_guard=False,
                                              emulate_feat_all=full_feat, emulate_collective=True)
             t_share = time_steps(share, args.steps, args.warmup)
         got = share()
@@ -446,7 +446,7 @@ def seg_bench(args, world, rank, dist, use_pg):
     graphed = None
     if not args.no_graph:
         try:
-            graphed = GraphedStep(step)
+            graphed = GraphedStep(step, range_guard=False)
         except Exception as e:      # noqa: BLE001
             print("bench: hipGraph capture failed (%r); launching eagerly" % (e,), file=sys.stderr)
             torch.cuda.synchronize()
@@ -669,7 +669,7 @@ def main():
         if key not in graphed:
             from disconet_amd.graph import GraphedStep
             try:
-                graphed[key] = [(GraphedStep(step), torch.cuda.Stream()) for _ in range(max(1, args.in_flight))]
+                graphed[key] = [(GraphedStep(step, range_guard=False), torch.cuda.Stream()) for _ in range(max(1, args.in_flight))]      # the range flags are read once, blocking, after the timed regions (`range_flags_after_run`)
             except Exception as e:   # capture refused (driver / collective library state): run eagerly
                 print("bench: hipGraph capture failed (%r); launching eagerly" % (e,), file=sys.stderr)
                 torch.cuda.synchronize()
@@ -895,6 +895,12 @@ def main():
 
     if rank == 0:
         result["pre_roll_steps"] = args.pre_roll
+        # split-f16 range guard of the timed replays: the captured step carries no poll (GraphedStep(range_guard=False): no
+        # launch of the timed region is spent on it), so the sticky device flags are read here, once, blocking
+        flags = ops.sp_range_flags(reset=True) if args.math == "sp" else 0
+        result["range_flags_after_run"] = flags
+        if flags & 5:
+            result["invalid"] = "split-f16 range guard: a value was clamped / a NaN was split during the timed replays"
         if repeats is not None:
             result["repeat"] = repeats
         if graph_ok is not None:

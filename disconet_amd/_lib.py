@@ -79,6 +79,7 @@ SIGNATURES = {
     "dn_spconv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_float, c_void_p, c_void_p]),
     "dn_spconv2d": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p]),
+    "dn_spconv_ks_supported": (c_int, [POINTER(ConvDesc), c_int]),
     "dn_spconv_workspace_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
     "dn_spconv2d_ks": (c_int, [POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

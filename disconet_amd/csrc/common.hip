@@ -45,9 +45,13 @@ extern "C" const char* dn_build_id(void) { return dn_build_id_marker + 12; }
 extern "C" int dn_sp_range_flags_async(unsigned* dst_device, int reset, void* stream) {
   DN_REQUIRE(dst_device != nullptr, "sp_range_flags_async: null destination");
   hipStream_t s = (hipStream_t)stream;
-  dn::range_collect_conv_sp(dst_device, reset != 0, s);
-  dn::range_collect_conv_spq(dst_device, reset != 0, s);
-  dn::range_collect_fuse_mlp(dst_device, reset != 0, s);
+  // bit 1 of `reset`: zero *dst first, with a kernel -- a captured step cannot rely on a memset node
+  if ((reset & 2) && dn::zero_fill(dst_device, sizeof(unsigned), s) != hipSuccess)
+    return dn::fail(DN_ERR_LAUNCH, "sp_range_flags_async: zero fill of the destination failed");
+  const bool clear = (reset & 1) != 0;
+  dn::range_collect_conv_sp(dst_device, clear, s);
+  dn::range_collect_conv_spq(dst_device, clear, s);
+  dn::range_collect_fuse_mlp(dst_device, clear, s);
   return dn::check_launch("sp_range_collect_kernel");
 }
 
@@ -57,7 +61,7 @@ extern "C" unsigned dn_sp_range_flags(int reset) {
   unsigned v = 0;
   if (hipDeviceSynchronize() != hipSuccess || hipMalloc((void**)&d, sizeof v) != hipSuccess) return 0x80000000u;
   bool ok = hipMemcpy(d, &v, sizeof v, hipMemcpyHostToDevice) == hipSuccess &&
-            dn_sp_range_flags_async(d, reset, nullptr) == DN_OK &&
+            dn_sp_range_flags_async(d, reset ? 1 : 0, nullptr) == DN_OK &&
             hipMemcpy(&v, d, sizeof v, hipMemcpyDeviceToHost) == hipSuccess;
   (void)hipFree(d);
   return ok ? v : 0x80000000u;

@@ -1698,6 +1698,16 @@ extern "C" int dn_spconv2d_dual(const dn_conv_desc* d, const void* src0, const v
 // K-sliced form: does the layer qualify?  (3x3, no row-merged image, no hi-only source)
 inline bool ks_layer(const dn_conv_desc& d) { return d.ksize == 3 && d.math != 3 && d.math != 4 && up_mode(d) != 1; }
 
+// Can the layer run with `kslices` canonical K slices?  A property of the layer and of the process's up-conv form
+// (DN_SP_UPMERGE / dn_spconv_set_upmode), never of the batch: callers that take the count from a table fall back to 1
+// where this says no, instead of meeting DN_ERR_ARG in dn_spconv2d_ks.
+extern "C" int dn_spconv_ks_supported(const dn_conv_desc* d, int kslices) {
+  if (validate(d) != DN_OK) return 0;
+  if (kslices == 1) return 1;
+  if (kslices != 2 && kslices != 4) return 0;
+  return ks_layer(*d) && chunks_of(d->c0) + chunks_of(d->c1) >= kslices ? 1 : 0;
+}
+
 extern "C" size_t dn_spconv_workspace_bytes(const dn_conv_desc* d, int kslices) {
   if (validate(d) != DN_OK || kslices <= 1 || !ks_layer(*d)) return 0;
   const size_t ho = out_dim(d->h_in, d->ksize, d->stride), wo = out_dim(d->w_in, d->ksize, d->stride);

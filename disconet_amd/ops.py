@@ -286,6 +286,16 @@ def sp_range_flags(reset=True):
     return flags
 
 
+def sp_range_flags_into(word, zero_first=False, reset=False):
+    """Stream-ordered collect of the sticky range flags into the int32 device tensor `word` (dn_sp_range_flags_async): kernel
+    launches only, legal inside a stream capture.  zero_first: the word is zeroed by a kernel of the same call (a captured step
+    cannot rely on a memset node); reset: the sticky flags are cleared once collected."""
+    _need_gpu(word)
+    check(_lib.load().dn_sp_range_flags_async(_ptr(word), (1 if reset else 0) | (2 if zero_first else 0), _stream()),
+          "dn_sp_range_flags_async")
+    return word
+
+
 def _raise_on_range_flags(flags, what):
     if flags & 0x80000000:
         raise _lib.DnError("%s: the split-f16 range flags could not be read" % what)
@@ -435,7 +445,9 @@ def sp_conv2d(d, src0, packed, scale, shift, src1=None, out=None, nhwc_copy=Fals
     lib = _lib.load()
     flat = torch.empty((d.n_images, ho, wo, d.c_out), dtype=torch.float32, device=src0.device) if nhwc_copy else None
     p1 = _ptr(src1.data) if src1 is not None else None
-    if kslices > 1 and d.math not in (3, 4):
+    if kslices > 1 and not lib.dn_spconv_ks_supported(ctypes.byref(d), kslices):
+        kslices = 1      # the process's up-conv form (DN_SP_UPMERGE=1) or a short layer has no K-sliced form: run whole
+    if kslices > 1:
         nbytes = min(int(lib.dn_spconv_workspace_bytes(ctypes.byref(d), kslices)), _KS_WORKSPACE_CAP)
         if os.environ.get("DN_SP_KS_NOSPLIT", "0") == "1":      # A/B runs: every tile whole (the slices folded in registers)
             nbytes = 0

@@ -30,10 +30,25 @@ def rot90_indices(idx, grid_x):
     return np.ascontiguousarray(out[order])
 
 
-def load_sample(path, grid_x=256, rotate=True):
+def _stored_dims(dims):
+    """dims of the STORED grid: (X, Y, Z), (X, Y) or a single int for a square X = Y grid (Z unchecked when absent)"""
+    if isinstance(dims, (int, np.integer)):
+        return int(dims), int(dims), None
+    d = tuple(int(v) for v in dims)
+    if len(d) not in (2, 3) or min(d) <= 0:
+        raise ValueError("dims must be (X, Y[, Z]) of the stored grid or one int for a square grid, got %r" % (dims,))
+    return d[0], d[1], (d[2] if len(d) == 3 else None)
+
+
+def load_sample(path, dims, rotate=True):
     """One `.npy` file -> dict with `indices` [M, 3] int32 (sorted unique, in the MODEL's frame: after the loader's
-    rot90(k=3) when `rotate`; `grid_x` = first dimension of the stored grid), `trans_matrices` [A, 4, 4] float32,
-    `num_agent` int, and `rest` (every other entry, untouched)."""
+    rot90(k=3) when `rotate`), `dims` (the model-frame grid those indices address: (Y, X, Z) after the rotation -- pass THAT
+    to ops.scatter_dense_*), `trans_matrices` [A, 4, 4] float32, `num_agent` int, and `rest` (every other entry, untouched).
+
+    `dims` -- REQUIRED: (X, Y[, Z]) of the STORED grid (an int = a square grid).  The rotation maps x to column X - 1 - x, so
+    a wrong X silently shifts the whole cloud and (with X too large) drops it at the scatter's bounds check; every stored
+    index is therefore checked against `dims` here and a voxel outside raises."""
+    X, Y, Z = _stored_dims(dims)
     raw = np.load(path, allow_pickle=True)
     d = raw.item() if raw.dtype == object and raw.shape == () else dict(raw)
     for k in KEYS.values():
@@ -41,21 +56,33 @@ def load_sample(path, grid_x=256, rotate=True):
             raise KeyError("sample %s has no %r entry (keys: %s); see disconet_amd/sample_format.py :: KEYS"
                            % (path, k, sorted(d)[:12]))
     idx = np.ascontiguousarray(np.asarray(d[KEYS["indices"]]).reshape(-1, 3).astype(np.int32))
+    if idx.size:
+        hi = idx.max(0)
+        if idx.min() < 0 or hi[0] >= X or hi[1] >= Y or (Z is not None and hi[2] >= Z):
+            raise ValueError("sample %s: voxel index range [%d .. (%d, %d, %d)] outside the stored grid %s (pass the stored "
+                             "grid's dims)" % (path, int(idx.min()), int(hi[0]), int(hi[1]), int(hi[2]), (X, Y, Z)))
     if rotate:
-        if idx.size and (idx[:, 0].max() >= grid_x or idx.min() < 0):
-            raise ValueError("sample %s: voxel x index %d outside the %d-row grid (pass grid_x)" % (path, int(idx[:, 0].max()), grid_x))
-        idx = rot90_indices(idx, grid_x)
+        idx = rot90_indices(idx, X)
     rest = {k: v for k, v in d.items() if k not in KEYS.values()}
-    return {"indices": idx, "trans_matrices": np.asarray(d[KEYS["trans"]], dtype=np.float32),
+    return {"indices": idx, "dims": (Y, X, Z) if rotate else (X, Y, Z),
+            "trans_matrices": np.asarray(d[KEYS["trans"]], dtype=np.float32),
             "num_agent": int(np.asarray(d[KEYS["num_agent"]]).reshape(-1)[0]), "rest": rest}
 
 
-def batch_from_samples(samples, num_agent, device="cuda"):
+def batch_from_samples(samples, num_agent, device="cuda", dims=None):
     """samples[b][a] = load_sample(...) of agent a of scene b (None for an absent agent) -> the hot path's inputs in
     the agent-major image order the reference's tools build (image = a * B + b):
         indices [Mtot, 3] int32, offsets [A*B + 1] int32   (for ops.scatter_dense_sp / scatter_dense)
-        trans_matrices [B, A, A, 4, 4] float32, num_agent_tensor [B, A] int64"""
+        trans_matrices [B, A, A, 4, 4] float32, num_agent_tensor [B, A] int64
+    Every sample must address the same model-frame grid (load_sample's `dims`); `dims` = the grid the caller will hand to
+    the scatter (X, Y[, Z]): a mismatch raises here instead of dropping voxels at the scatter's bounds check."""
     B = len(samples)
+    seen = {s["dims"][:2] for row in samples for s in row if s is not None and "dims" in s}
+    if len(seen) > 1:
+        raise ValueError("samples address different grids: %s" % sorted(seen))
+    if dims is not None and seen and tuple(int(v) for v in dims[:2]) != next(iter(seen)):
+        raise ValueError("samples address a %s grid (model frame, after the loader's rotation) but the batch is built for %s "
+                         "-- non-square grids swap X and Y under rot90" % (next(iter(seen)), tuple(dims[:2])))
     lists, offsets = [], [0]
     trans = np.tile(np.eye(4, dtype=np.float32), (B, num_agent, num_agent, 1, 1))
     na = np.zeros((B, num_agent), dtype=np.int64)

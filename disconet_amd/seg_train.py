@@ -171,12 +171,17 @@ class SegTrainStep:
         if self.optimizer is not None:
             eng.lr = float(self.optimizer.param_groups[0]["lr"])
         with torch.no_grad():
-            logits = eng.forward(x, data["trans_matrices"], data["num_agent"], B)
             # the reference drops the images whose BEV is empty (sum <= 1e-4: the padded slots of scenes with fewer
             # live agents than num_agent) from pred and labels before the criterion.  Same loss, divisor and
-            # gradients with their labels set to the ignore index -- on the device, no host sync.
-            labels = data["labels"].to(device=x.device)
+            # gradients with their labels set to the ignore index.  The reference casts with labels.long() first, so
+            # uint8 label maps are legal input: convert BEFORE the ignore index (-100) goes in.
             empty = x.reshape(x.shape[0], -1).sum(1) <= 1e-4
+            if bool(empty.all()):
+                # no live image at all: the criterion's divisor is zero (the reference would produce a NaN loss and NaN
+                # gradients out of an empty batch) -- skip the step, leave the parameters and the optimizer state alone
+                return {"loss": float("nan"), "skipped": True}
+            logits = eng.forward(x, data["trans_matrices"], data["num_agent"], B)
+            labels = data["labels"].to(device=x.device, dtype=torch.int64)
             labels = torch.where(empty.view(-1, 1, 1), torch.full_like(labels, -100), labels)
             loss, dlogits = ops.seg_ce_loss(logits, labels, want_grad=True, check_labels=False)
             eng.backward(dlogits)

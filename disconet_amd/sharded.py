@@ -113,10 +113,12 @@ class GraphedAgentStep:
     """
 
     def __init__(self, engine, make_bevs, trans_matrices, num_agent_tensor, batch_size, first, count,
-                 group=None, emulate_feat_all=None, emulate_collective=False):
+                 group=None, emulate_feat_all=None, emulate_collective=False, range_guard=True):
         """emulate_collective (with emulate_feat_all, needs an initialised process group -- one rank is enough): the
         emulated exchange ALSO runs the real RCCL all_gather_into_tensor of this rank's maps, so that the collective's
-        launch + kernel latency sits between the two graphs as it will on 8 ranks (link time does not)."""
+        launch + kernel latency sits between the two graphs as it will on 8 ranks (link time does not).
+        range_guard: graph B ends with the captured poll of the split-f16 range flags (graph.GraphedStep); False leaves the
+        guard to the caller (bench.py reads the flags once after its timed regions)."""
         from .graph import GraphedStep
         self.engine, self.group, self.first, self.count, self.batch = engine, group, first, count, batch_size
         self.emulated = emulate_feat_all is not None
@@ -124,7 +126,8 @@ class GraphedAgentStep:
         self._own_gather = None
         layer = engine.layer
         with torch.no_grad():
-            self.graph_a = GraphedStep(lambda: engine.encode(make_bevs()))
+            # (the range flags are sticky: graph B's captured poll covers graph A's launches too)
+            self.graph_a = GraphedStep(lambda: engine.encode(make_bevs()), range_guard=False)
         self.enc = list(self.graph_a.outputs)
         x_local = self.enc[layer]
         world = 1 if (self.emulated or not (dist.is_available() and dist.is_initialized())) else dist.get_world_size(group)
@@ -145,7 +148,7 @@ class GraphedAgentStep:
             return engine.decode_heads(enc), fused
 
         with torch.no_grad():
-            self.graph_b = GraphedStep(fuse_decode)
+            self.graph_b = GraphedStep(fuse_decode, range_guard=range_guard)
 
     def exchange(self):
         x_local = self.enc[self.engine.layer]

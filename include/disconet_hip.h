@@ -74,8 +74,11 @@ const char* dn_last_error(void);
  *   BLOCKING (hipDeviceSynchronize + a device -> host copy): validation time.  Bit 31 (0x80000000) set = the READ
  *   failed (synchronisation, allocation or copy error): the flags are unknown -- treat as an error, never as "clean"
  *   (the Python host raises).
- * dn_sp_range_flags_async: the same OR enqueued on `stream` into *dst_device (a device word the caller zeroed):
- *   no synchronisation, legal inside a stream capture.  The Python host enqueues it behind a forward, copies the
+ * dn_sp_range_flags_async: the same OR enqueued on `stream` into *dst_device (a device word the caller zeroed, or
+ *   `reset` bit 1 set: zeroed here first by a kernel launch -- what a CAPTURED step uses, a memset node does not replay
+ *   reliably on ROCm 7.2); `reset` bit 0 clears the sticky flags.  No synchronisation, legal inside a stream capture.
+ *   A flagged forward's OUTPUTS ARE INVALID (bit 0: clamped values; bit 2: a NaN was turned into a finite number): the
+ *   caller must discard them, not only log the flag.  The Python host enqueues it behind a forward, copies the
  *   word to pinned memory and raises at the next call once the copy has landed: the guard is on by default and
  *   costs nothing but four tiny launches (DN_SP_CHECK=0 switches it off, =1 makes every forward block and check). */
 unsigned dn_sp_range_flags(int reset);
@@ -255,6 +258,10 @@ int dn_spconv2d(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp,
  * dn_spconv2d.  Refused (DN_ERR_ARG): 1x1 layers, hi-only and bit-grid sources (math = 3, 4), the row-merged image
  * (dn_spconv_set_upmode(1)), layers with fewer chunks than slices. */
 size_t dn_spconv_workspace_bytes(const dn_conv_desc* d, int kslices);
+/* 1 if the layer can run with `kslices` canonical K slices (1, 2 or 4) in this process -- 3x3, no hi-only / bit-grid
+ * source, not the row-merged up-conv image (DN_SP_UPMERGE=1), at least `kslices` 16-channel chunks -- else 0.  Depends on
+ * the layer and the process-wide up-conv form only, never on the batch. */
+int dn_spconv_ks_supported(const dn_conv_desc* d, int kslices);
 int dn_spconv2d_ks(const dn_conv_desc* d, int kslices, const void* src0, const void* src1, const void* packed,
                    const float* scale, const float* shift, void* out, float* out_nhwc /* may be NULL: the second,
                    fp32 NHWC output of dn_spconv2d_dual (not on the tap-merged up-conv) */, int ld_nhwc,

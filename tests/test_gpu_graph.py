@@ -56,3 +56,46 @@ def test_two_graphs_on_two_streams_replay_identically():
     for i, o in enumerate(kept):
         for k in want:
             assert torch.equal(o[k], want[k]), "replay %d (stream %d): %s differs" % (i, i % 2, k)
+
+
+def test_a_replayed_step_reports_a_clamped_activation():
+    """ops.check_sp_range skips itself under capture, so the replayed step -- the production mode -- never
+    polled the range flags.  GraphedStep now ends its capture with the stream-ordered collect + a pinned copy and looks at the
+    previous replay's word on every call: a clamp raises at the next call (or at drain()), range_guard=False leaves it alone."""
+    from disconet_amd import Config, DiscoNet, ops
+    from disconet_amd._lib import DnError
+    from disconet_amd.graph import GraphedStep
+    from disconet_amd.synthetic import make_scene_batch
+    torch.manual_seed(0)
+    hw, agents = 64, 2
+    model = DiscoNet(Config(map_hw=hw), kd_flag=0, num_agent=agents).eval()
+    with torch.no_grad():
+        model.u_encoder.conv_pre_2.weight.mul_(3.0e6)       # activations far beyond 65504: the split clamps
+    model.cuda()
+    bevs, trans, na = make_scene_batch(1, agents, hw)
+    bevs, trans, na = bevs.cuda(), trans.cuda(), na.cuda()
+
+    def step():
+        with torch.no_grad():
+            return model(bevs, trans, na, 1)
+    import os
+    os.environ["DN_SP_CHECK"] = "0"                          # the eager warm-up inside GraphedStep must not raise first
+    try:
+        ops.sp_range_flags(reset=True)
+        g = GraphedStep(step)
+        ops.sp_range_flags(reset=True)                       # (the warm-up's own clamps)
+        g()
+        torch.cuda.synchronize()
+        with pytest.raises(DnError, match="clamped"):
+            g()                                              # the previous replay's word has landed
+        assert ops.sp_range_flags(reset=True) == 0           # reporting cleared the sticky flags
+        g()
+        with pytest.raises(DnError, match="clamped"):
+            g.drain()
+        quiet = GraphedStep(step, range_guard=False)
+        ops.sp_range_flags(reset=True)
+        quiet(); quiet()
+        torch.cuda.synchronize()
+        assert ops.sp_range_flags(reset=True) & 1            # nothing raised, the flag is there for whoever reads it
+    finally:
+        del os.environ["DN_SP_CHECK"]

@@ -190,3 +190,30 @@ def test_seg_step_drops_the_images_of_padded_agents():
         mod.step(data, B)
         assert mod._trainer.engine.lr == 5e-4
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_seg_step_takes_uint8_labels_and_skips_a_batch_without_live_images():
+    """the reference casts with labels.long(), so uint8 label maps are legal -- the ignore index (-100) used
+    to be written into the caller's dtype (full_like on uint8); and a batch whose images are ALL empty has a zero divisor:
+    the step is skipped, parameters and optimizer state untouched"""
+    from disconet_amd import SegDiscoNet, SegModule
+    from disconet_amd.synthetic import make_scene_batch
+    A, B, hw = 2, 1, 64
+    bevs, trans, na = make_scene_batch(B, A, hw, live=[1])
+    x = bevs[:, 0].permute(0, 3, 1, 2).contiguous()
+    g = torch.Generator().manual_seed(4)
+    labels = torch.randint(0, 8, (A * B, hw, hw), generator=g)
+    losses = []
+    for dtype in (torch.int64, torch.uint8):
+        torch.manual_seed(0)
+        mod = SegModule(SegDiscoNet(num_agent=A).cuda())
+        data = {"bev_seq": x.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(), "labels": labels.to(dtype).cuda()}
+        losses.append((mod.step(data, B)["loss"], mod._trainer.engine.flat_g.clone()))
+    assert losses[0][0] == losses[1][0] and torch.equal(losses[0][1], losses[1][1])
+    assert losses[0][0] == losses[0][0]                                   # not a NaN
+    eng = mod._trainer.engine
+    before, steps = eng.flat_p.clone(), eng.step_count
+    out = mod.step({"bev_seq": torch.zeros_like(x).cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(),
+                    "labels": labels.cuda()}, B)
+    assert out.get("skipped") and out["loss"] != out["loss"]
+    assert torch.equal(eng.flat_p, before) and eng.step_count == steps

@@ -21,7 +21,7 @@ def test_round_trip_through_npy_files(tmp_path):
             path = tmp_path / ("scene%d_agent%d.npy" % (b, a))
             np.save(path, {"voxel_indices_0": idx, "trans_matrices": trans[b, a], "num_sensor": A,
                            "reg_target_sparse": np.zeros((1, 6))}, allow_pickle=True)
-            samples[b][a] = sample_format.load_sample(str(path), grid_x=hw)
+            samples[b][a] = sample_format.load_sample(str(path), (hw, hw, 13))
             assert samples[b][a]["indices"].dtype == np.int32 and "reg_target_sparse" in samples[b][a]["rest"]
     indices, offsets, tr, na = sample_format.batch_from_samples(samples, A, device="cpu")
     assert offsets.dtype == torch.int32 and offsets.shape == (A * B + 1,) and int(offsets[-1]) == indices.shape[0]
@@ -34,7 +34,7 @@ def test_round_trip_through_npy_files(tmp_path):
     want = torch.from_numpy(np.stack([np.rot90(bevs[g, 0].numpy(), 3).copy() for g in range(A * B)]))
     assert torch.equal(dense, want)
     # ... and with rotate=False the stored list is handed through
-    raw = sample_format.load_sample(str(tmp_path / "scene0_agent0.npy"), rotate=False)["indices"]
+    raw = sample_format.load_sample(str(tmp_path / "scene0_agent0.npy"), hw, rotate=False)["indices"]
     assert np.array_equal(raw, np.argwhere(bevs[0, 0].numpy() > 0).astype(np.int32))
 
 
@@ -52,4 +52,26 @@ def test_missing_key_is_reported(tmp_path):
     path = tmp_path / "bad.npy"
     np.save(path, {"voxel_indices": np.zeros((0, 3))}, allow_pickle=True)
     with pytest.raises(KeyError, match="voxel_indices_0"):
-        sample_format.load_sample(str(path))
+        sample_format.load_sample(str(path), 256)
+
+
+def test_grid_dims_are_required_and_checked(tmp_path):
+    """a stored grid smaller than an assumed 256 rows mapped x to 255 - x, outside the real grid, and the scatter's
+    bounds check dropped the voxels silently.  dims is required now, every index is checked, the rotated dims travel with the
+    sample and batch_from_samples refuses a batch built for another grid."""
+    idx = np.array([[0, 1, 2], [31, 47, 12]], dtype=np.int64)           # a 32 x 48 x 13 stored grid
+    path = tmp_path / "s.npy"
+    np.save(path, {"voxel_indices_0": idx, "trans_matrices": np.eye(4)[None], "num_sensor": 1}, allow_pickle=True)
+    with pytest.raises(TypeError):
+        sample_format.load_sample(str(path))                             # no default grid any more
+    with pytest.raises(ValueError, match="outside the stored grid"):
+        sample_format.load_sample(str(path), 32)                         # y = 47 does not fit a square 32 grid
+    with pytest.raises(ValueError, match="outside the stored grid"):
+        sample_format.load_sample(str(path), (32, 48, 12))               # z = 12 does not fit 12 bins
+    s = sample_format.load_sample(str(path), (32, 48, 13))
+    assert s["dims"] == (48, 32, 13)                                     # rot90 swaps X and Y
+    assert np.array_equal(s["indices"], np.array([[1, 31, 2], [47, 0, 12]], dtype=np.int32))
+    assert sample_format.load_sample(str(path), (32, 48, 13), rotate=False)["dims"] == (32, 48, 13)
+    sample_format.batch_from_samples([[s]], 1, device="cpu", dims=(48, 32, 13))
+    with pytest.raises(ValueError, match="swap X and Y"):
+        sample_format.batch_from_samples([[s]], 1, device="cpu", dims=(32, 48, 13))
