@@ -137,6 +137,14 @@ SIGNATURES = {
                                             POINTER(c_int), c_void_p]),
     "dn_bn_train_stats": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                   c_void_p, c_void_p]),
+    "dn_bn_train_stats_partial": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dn_bn_train_stats_finish": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p]),
+    "dn_bn_train_backward_partial": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                                             c_void_p, c_int, c_void_p]),
+    "dn_bn_train_backward_finish": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long,
+                                            c_void_p, c_void_p]),
     "dn_bn_train_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                   c_int, c_long, c_int, c_int, c_void_p, c_void_p]),
     "dn_bn_update_running": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_void_p, c_float,

@@ -281,7 +281,7 @@ bn_bwd_reduce_v4_kernel(GradSrc src, const float* __restrict__ z, const float* _
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_v4_kernel(GradSrc src, const float* __restrict__ z, const float* __restrict__ mean,
                        const float* __restrict__ var, const float* __restrict__ gamma, float eps,
-                       long rows_per_group, const double* __restrict__ sums, long total4,
+                       long rows_per_group, long norm_rows, const double* __restrict__ sums, long total4,
                        float* __restrict__ dz) {
   const int c = src.c, c4n = c >> 2;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total4;
@@ -295,8 +295,8 @@ bn_bwd_apply_v4_kernel(GradSrc src, const float* __restrict__ z, const float* __
     f32x4 m1, m2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      m1[e] = (float)(sg[e] / rows_per_group);
-      m2[e] = (float)(sg[c + e] / rows_per_group);
+      m1[e] = (float)(sg[e] / norm_rows);
+      m2[e] = (float)(sg[c + e] / norm_rows);
     }
     *reinterpret_cast<f32x4*>(dz + row * c + 4 * c4) =
         ldv4(gamma + 4 * c4) * rs * (src.v4(row, c4) - m1 - zh * m2);
@@ -321,7 +321,7 @@ bn_bwd_reduce_kernel(GradSrc src, const float* __restrict__ z, const float* __re
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(GradSrc src, const float* __restrict__ z, const float* __restrict__ mean,
                     const float* __restrict__ var, const float* __restrict__ gamma, float eps,
-                    long rows_per_group, const double* __restrict__ sums, long total,
+                    long rows_per_group, long norm_rows, const double* __restrict__ sums, long total,
                     float* __restrict__ dz) {
   const int c = src.c;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
@@ -331,8 +331,8 @@ bn_bwd_apply_kernel(GradSrc src, const float* __restrict__ z, const float* __res
     const int g = (int)(row / rows_per_group);
     const float rstd = 1.f / sqrtf(var[g * c + cc] + eps);
     const float zh = (z[idx] - mean[g * c + cc]) * rstd;
-    const float m1 = (float)(sums[(size_t)g * 2 * c + cc] / rows_per_group);
-    const float m2 = (float)(sums[(size_t)g * 2 * c + c + cc] / rows_per_group);
+    const float m1 = (float)(sums[(size_t)g * 2 * c + cc] / norm_rows);
+    const float m2 = (float)(sums[(size_t)g * 2 * c + c + cc] / norm_rows);
     dz[idx] = gamma[cc] * rstd * (src(row, cc) - m1 - zh * m2);
   }
 }
@@ -626,9 +626,13 @@ extern "C" size_t dn_reduce_workspace_bytes(int n_groups, long rows_per_group, i
   return sizeof(double) * 2 * c * n_groups * (size_t)(1 + blocks_per_group(rows_per_group, n_groups));
 }
 
-extern "C" int dn_bn_train_stats(const float* z, int n_groups, long rows_per_group, int c, int ldz,
-                                 double* sums, size_t sums_bytes, float* mean, float* var, void* stream) {
-  DN_REQUIRE(z && sums && mean && var, "bn stats: null pointer");
+// Two-phase forms (round 5: agent-parallel training, sharded.py).  A rank that holds only SOME images of a BatchNorm batch
+// reduces its own rows (`_partial`: the folded sums [n_groups][2 c] doubles land at the start of `sums`), the caller
+// all-reduces those doubles over the ranks, and `_finish` normalises by the GLOBAL row count.  The one-call forms below are
+// the two phases back to back with norm_rows = rows_per_group.
+extern "C" int dn_bn_train_stats_partial(const float* z, int n_groups, long rows_per_group, int c, int ldz,
+                                         double* sums, size_t sums_bytes, void* stream) {
+  DN_REQUIRE(z && sums, "bn stats: null pointer");
   DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0 && c <= kMaxC && ldz >= c,
              "bn stats: bad shape (groups %d rows %ld c %d ld %d)", n_groups, rows_per_group, c, ldz);
   DN_REQUIRE(sums_bytes >= dn_reduce_workspace_bytes(n_groups, rows_per_group, c),
@@ -644,10 +648,24 @@ extern "C" int dn_bn_train_stats(const float* z, int n_groups, long rows_per_gro
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, n_groups), dim3(256), 0, s, z, rows_per_group, c, ldz, part);
   hipLaunchKernelGGL(fold_partials_kernel, dim3((n_groups * 2 * c + 3) / 4), dim3(256), 0, s, part, nblk, 2 * c,
                      n_groups, sums);
-  const int n = n_groups * c;
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sums, n, c,
-                     rows_per_group, mean, var);
   return dn::check_launch("bn_stats_kernel");
+}
+
+extern "C" int dn_bn_train_stats_finish(const double* sums, int n_groups, long norm_rows, int c, float* mean, float* var,
+                                        void* stream) {
+  DN_REQUIRE(sums && mean && var, "bn stats finish: null pointer");
+  DN_REQUIRE(n_groups > 0 && norm_rows > 0 && c > 0 && c <= kMaxC, "bn stats finish: bad shape");
+  const int n = n_groups * c;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, n, c,
+                     norm_rows, mean, var);
+  return dn::check_launch("bn_stats_finalize_kernel");
+}
+
+extern "C" int dn_bn_train_stats(const float* z, int n_groups, long rows_per_group, int c, int ldz,
+                                 double* sums, size_t sums_bytes, float* mean, float* var, void* stream) {
+  DN_REQUIRE(mean && var, "bn stats: null pointer");
+  if (int rc = dn_bn_train_stats_partial(z, n_groups, rows_per_group, c, ldz, sums, sums_bytes, stream)) return rc;
+  return dn_bn_train_stats_finish(sums, n_groups, rows_per_group, c, mean, var, stream);
 }
 
 extern "C" int dn_bn_train_apply(const float* z, const float* mean, const float* var,
@@ -677,14 +695,13 @@ extern "C" int dn_bn_update_running(const float* mean, const float* var, int n_g
   return dn::check_launch("bn_update_running_kernel");
 }
 
-extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
-                                    const float* y, const float* z, const float* mean,
-                                    const float* var, const float* gamma, float eps, int relu,
-                                    int n_groups, int h, int w, int images_per_group, int c,
-                                    double* sums, size_t sums_bytes, float* dz, float* dgamma, float* dbeta,
-                                    int accumulate, void* stream) {
-  DN_REQUIRE(dy_a && z && mean && var && gamma && sums && dz && dgamma && dbeta,
-             "bn backward: null pointer");
+// phase 1 of the backward: this rank's sums of g and g * zhat (folded, at the start of `sums`) and the parameter gradients
+// out of THESE rows (dgamma / dbeta are sums over rows: ranks add theirs with the gradient all-reduce)
+extern "C" int dn_bn_train_backward_partial(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
+                                            const float* y, const float* z, const float* mean, const float* var, float eps,
+                                            int relu, int n_groups, int h, int w, int images_per_group, int c, double* sums,
+                                            size_t sums_bytes, float* dgamma, float* dbeta, int accumulate, void* stream) {
+  DN_REQUIRE(dy_a && z && mean && var && sums && dgamma && dbeta, "bn backward: null pointer");
   DN_REQUIRE(!relu || y, "bn backward: relu needs y");
   DN_REQUIRE(n_groups > 0 && h > 0 && w > 0 && images_per_group > 0 && c > 0 && c <= kMaxC &&
                  ld_a >= c && (!dy_b || ld_b >= c),
@@ -695,29 +712,57 @@ extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const
              "bn backward: workspace of %zu bytes, dn_reduce_workspace_bytes() asks for %zu", sums_bytes,
              dn_reduce_workspace_bytes(n_groups, rows_per_group, c));
   GradSrc src{dy_a, dy_b, y, ld_a, up_a, ld_b, relu, h, w, c};
-  const long total = (long)n_groups * rows_per_group * c;
   const int nblk = blocks_per_group(rows_per_group, n_groups);
-  double* part = sums + (size_t)2 * c * n_groups;      // workspace layout: see dn_bn_train_stats
-  auto fold = [&] {
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((n_groups * 2 * c + 3) / 4), dim3(256), 0, s, part, nblk, 2 * c,
-                       n_groups, sums);
-  };
-  if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz})) {
+  double* part = sums + (size_t)2 * c * n_groups;      // workspace layout: see dn_bn_train_stats_partial
+  if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var}))
     hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel, dim3(nblk, n_groups), dim3(256), 0, s, src, z, mean, var, eps,
                        rows_per_group, part);
-    fold();
-    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z,
-                       mean, var, gamma, eps, rows_per_group, sums, total / 4, dz);
-  } else {
+  else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, n_groups), dim3(256), 0, s, src, z, mean, var, eps,
                        rows_per_group, part);
-    fold();
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, src, z, mean,
-                       var, gamma, eps, rows_per_group, sums, total, dz);
-  }
+  hipLaunchKernelGGL(fold_partials_kernel, dim3((n_groups * 2 * c + 3) / 4), dim3(256), 0, s, part, nblk, 2 * c,
+                     n_groups, sums);
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((c + 63) / 64), dim3(64), 0, s, sums, n_groups, c,
                      dgamma, dbeta, accumulate);
-  return dn::check_launch("bn_backward kernels");
+  return dn::check_launch("bn_backward reduce kernels");
+}
+
+// phase 2: dz of this rank's rows from the (all-reduced) sums, means taken over norm_rows rows per group
+extern "C" int dn_bn_train_backward_finish(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
+                                           const float* y, const float* z, const float* mean, const float* var,
+                                           const float* gamma, float eps, int relu, int n_groups, int h, int w,
+                                           int images_per_group, int c, const double* sums, long norm_rows, float* dz,
+                                           void* stream) {
+  DN_REQUIRE(dy_a && z && mean && var && gamma && sums && dz, "bn backward finish: null pointer");
+  DN_REQUIRE(!relu || y, "bn backward: relu needs y");
+  DN_REQUIRE(n_groups > 0 && h > 0 && w > 0 && images_per_group > 0 && c > 0 && c <= kMaxC && norm_rows > 0 &&
+                 ld_a >= c && (!dy_b || ld_b >= c),
+             "bn backward finish: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const long rows_per_group = (long)images_per_group * h * w;
+  GradSrc src{dy_a, dy_b, y, ld_a, up_a, ld_b, relu, h, w, c};
+  const long total = (long)n_groups * rows_per_group * c;
+  if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz}))
+    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z,
+                       mean, var, gamma, eps, rows_per_group, norm_rows, sums, total / 4, dz);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, src, z, mean,
+                       var, gamma, eps, rows_per_group, norm_rows, sums, total, dz);
+  return dn::check_launch("bn_backward apply kernels");
+}
+
+extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
+                                    const float* y, const float* z, const float* mean,
+                                    const float* var, const float* gamma, float eps, int relu,
+                                    int n_groups, int h, int w, int images_per_group, int c,
+                                    double* sums, size_t sums_bytes, float* dz, float* dgamma, float* dbeta,
+                                    int accumulate, void* stream) {
+  DN_REQUIRE(gamma && dz, "bn backward: null pointer");
+  if (int rc = dn_bn_train_backward_partial(dy_a, ld_a, up_a, dy_b, ld_b, y, z, mean, var, eps, relu, n_groups, h, w,
+                                            images_per_group, c, sums, sums_bytes, dgamma, dbeta, accumulate, stream))
+    return rc;
+  return dn_bn_train_backward_finish(dy_a, ld_a, up_a, dy_b, ld_b, y, z, mean, var, gamma, eps, relu, n_groups, h, w,
+                                     images_per_group, c, sums, (long)images_per_group * h * w, dz, stream);
 }
 
 extern "C" int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, size_t sums_bytes, float* out,

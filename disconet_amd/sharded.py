@@ -172,6 +172,94 @@ class GraphedAgentStep:
         return self.graph_b()
 
 
+class AgentShard:
+    """One rank's place in an AGENT-PARALLEL TRAINING step (SURVEY.md 8(e)(ii) + its backward, "Backward of (ii) is a
+    reduce-scatter"): rank r owns the agents [first, first + count) of every scene and holds the replicated parameters.
+    The collectives of a step, all through this object so that the HIP engine (train.TrainEngine(shard=...)) and the CPU
+    oracle twin of the gloo tests (tests/oracle_engine.py) make the same calls:
+
+      forward   sum_()                per BatchNorm layer: this rank's sum z, sum z^2 (float64) -> the batch's
+                gather_rows()         the layer-`layer` maps of the own agents -> every agent's (the V2X exchange)
+                gather_padded()       per-call statistics of the attention MLP's BatchNorms (running-stat replay order)
+      backward  sum_()                per BatchNorm layer: sum g, sum g * zhat
+                reduce_scatter_rows() d(loss terms of this rank) / d(every agent's map) -> d(loss) / d(own maps)
+                sum_()                the flat parameter gradient (ranks hold disjoint terms of ONE loss: summed, not averaged)
+
+    Backends: RCCL ("nccl") on the GPUs; gloo in the CPU tests (its missing reduce_scatter / *_into_tensor forms are
+    rebuilt from all_reduce / all_gather here).  world == 1 (or no process group): every call is the identity."""
+
+    def __init__(self, num_agent, group=None):
+        self.group = group
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.first, self.count = agent_range(num_agent, self.world, self.rank)
+        self.num_agent = num_agent
+
+    # -- sums --------------------------------------------------------------------------------------------------
+    def sum_(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    # -- rows of an agent-major [A*B, ...] buffer ---------------------------------------------------------------
+    def gather_rows(self, all_rows, lo, n):
+        """all_rows[lo:lo + n] holds this rank's rows; afterwards all_rows holds every rank's (rank order == agent order).
+        In place: the input is the rank's own slice of the output (NCCL's in-place all-gather)."""
+        if self.world == 1:
+            return all_rows
+        assert all_rows.shape[0] == n * self.world and lo == self.rank * n
+        try:
+            dist.all_gather_into_tensor(all_rows, all_rows[lo:lo + n], group=self.group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather(list(all_rows.chunk(self.world, 0)), all_rows[lo:lo + n].clone(), group=self.group)
+        return all_rows
+
+    def reduce_scatter_rows(self, all_rows, lo, n):
+        """sum over the ranks of all_rows, of which this rank keeps rows [lo, lo + n) -> [n, ...]"""
+        if self.world == 1:
+            return all_rows[lo:lo + n]
+        assert all_rows.shape[0] == n * self.world and lo == self.rank * n
+        out = all_rows.new_empty((n,) + tuple(all_rows.shape[1:]))
+        try:
+            dist.reduce_scatter_tensor(out, all_rows.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
+        except (RuntimeError, NotImplementedError):      # gloo: no reduce-scatter
+            full = all_rows.clone()
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+            out.copy_(full[lo:lo + n])
+        return out
+
+    def gather_padded(self, x_local, max_rows):
+        """[n_r, C] per rank (n_r <= max_rows) -> [world, max_rows, C] on every rank (rows past n_r are zero)"""
+        pad = x_local.new_zeros((max_rows,) + tuple(x_local.shape[1:]))
+        pad[:x_local.shape[0]] = x_local
+        if self.world == 1:
+            return pad.unsqueeze(0)
+        out = pad.new_empty((self.world * max_rows,) + tuple(pad.shape[1:]))
+        try:
+            dist.all_gather_into_tensor(out, pad, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather(list(out.chunk(self.world, 0)), pad, group=self.group)
+        return out.view((self.world, max_rows) + tuple(pad.shape[1:]))
+
+    def calls_in_reference_order(self, counts, n_local_calls):
+        """counts[b][i] = attention-MLP calls of ego i in scene b (train.fusion_call_counts; replicated knowledge).  Every rank
+        lists its calls scene by scene, ego by ego; the reference's order is scene, then ego over ALL agents -> for each
+        scene the ranks' runs in rank order.  Returns {"total", "max_per_rank", "index"}: `index` (int32) lists, in the
+        reference's call order, the rows of the [world * max_per_rank, C] buffer gather_padded() builds."""
+        per = [[sum(row[r * self.count:(r + 1) * self.count]) for row in counts] for r in range(self.world)]   # [rank][scene]
+        if sum(per[self.rank]) != n_local_calls:
+            raise RuntimeError("agent shard: this rank lists %d attention calls, the scenes' agent counts give %d"
+                               % (n_local_calls, sum(per[self.rank])))
+        max_rows = max(1, max(sum(p) for p in per))
+        index, offs = [], [0] * self.world
+        for b in range(len(counts)):
+            for r in range(self.world):
+                index.extend(r * max_rows + offs[r] + k for k in range(per[r][b]))
+                offs[r] += per[r][b]
+        return {"total": len(index), "max_per_rank": max_rows, "index": torch.tensor(index, dtype=torch.int32)}
+
+
 def average_gradients_(flat_grad):
     """Data-parallel training (upstream: nn.DataParallel / DDP around CoDetModule.step): every rank
     holds the gradient of its own scenes in ONE flat buffer (train.TrainEngine.flat_g, 7.9 M fp32 =

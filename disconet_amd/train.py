@@ -54,12 +54,34 @@ def _param_order(model):
     return first + [p for p in model.parameters() if id(p) not in seen]
 
 
-def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev):
+def fusion_call_counts(agents, only_v2i, num_agent_cpu, B):
+    """counts[b][i] = maps in ego i's list in scene b (the ego itself + its listed neighbours; 0 for a padded agent) = calls
+    of the attention MLP the reference makes for that ego.  Host-side; what the ranks of an agent-parallel step use to put
+    their per-call BatchNorm statistics back into the reference's call order."""
+    out = []
+    for b in range(B):
+        n = int(num_agent_cpu[b])
+        row = []
+        for i in range(agents):
+            if i >= n:
+                row.append(0)
+            else:
+                row.append(1 + sum(1 for j in range(n) if j != i and not (only_v2i and i != 0 and j != 0)))
+        out.append(row)
+    return out
+
+
+def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev, ego_first=0, ego_count=None):
     """Index lists of the DiscoGraph fusion for one batch, in the reference's loop order
     (upstream DiscoNet.forward: for b, for ego i < n_b: [ego] + [warp(j -> i) for j < n_b, j != i],
     honouring only_v2i).  Images are agent-major (agent * B + b); maps / pairs = own maps then warps.
-    Host-side logic only (runs on CPU tensors too)."""
+    Host-side logic only (runs on CPU tensors too).
+
+    ego_first / ego_count (agent-parallel training: a rank fuses ITS egos against every agent's map): the lists cover the
+    egos [ego_first, ego_first + ego_count) only; map / pair indices still address the buffer [all A*B maps | this rank's
+    warps], `ego_out` is the LOCAL image index (i - ego_first) * B + b of the fused output."""
     A = agents
+    E = A if ego_count is None else ego_count
     NI = A * B
     img = lambda a, b: a * B + b
     src_image, poses_idx, warp_ego = [], [], []
@@ -67,8 +89,8 @@ def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev):
     order = []
     for b in range(B):
         n = int(num_agent_cpu[b])
-        for i in range(A):
-            ego_out.append(img(i, b))
+        for i in range(ego_first, ego_first + E):
+            ego_out.append((i - ego_first) * B + b)
             if i >= n:
                 pair_index.append(-1)
                 map_image.append(img(i, b))
@@ -125,8 +147,13 @@ class TrainEngine:
                                lambda self, v: setattr(self, "_overlap_streams",
                                                        ops.check_overlap_request(v, "TrainEngine.overlap_streams")))
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, shard=None):
+        """shard: a sharded.AgentShard -- this process trains the agents [shard.first, shard.first + shard.count) of every
+        scene (agent-parallel training): forward() / backward() then take the LOCAL agent-major images and
+        exchange BatchNorm sums (all-reduce), the layer-`layer` maps (all-gather), the gradient of those maps (reduce-scatter)
+        and the parameter gradients (all-reduce, summed) through it.  None: every agent lives here."""
         self.model = model
+        self.shard = shard
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.generation = 0          # bumped by every forward(): the saved activations belong to it
@@ -248,7 +275,7 @@ class TrainEngine:
         w = lay.w if w is None else w
         b = lay.b if b is None else b
         z, d = self._conv(w, b, src0, src1, up0, lay.stride, lay.ksize)
-        mean, var = T.bn_stats(z, groups)
+        mean, var = T.bn_stats(z, groups, **self._bn_sync(z, groups))
         gamma = lay.bn.weight if gamma is None else gamma
         beta = lay.bn.bias if beta is None else beta
         y = T.bn_apply(z, mean, var, gamma, beta, _EPS, relu=True, out=y_out)
@@ -256,7 +283,17 @@ class TrainEngine:
                        groups=groups, w=w, gamma=gamma)
         return y
 
+    def _bn_sync(self, z, groups):
+        """keyword arguments that make a BatchNorm reduction span every rank's images (agent-parallel training): the batch of
+        a layer's BatchNorm is all A*B images, of which this rank holds count*B -- its sums are all-reduced and normalised by
+        the global row count.  Grouped statistics (the attention MLP: one (ego, neighbour) pair per call) are rank-local."""
+        if self.shard is None or self.shard.world == 1 or groups != 1:
+            return {}
+        return {"sync": self.shard.sum_, "norm_rows": (z.numel() // z.shape[-1]) * self.shard.world}
+
     def _update_running(self, bn, mean, var, rows, order=None, calls=1):
+        if self.shard is not None and order is None:
+            rows = rows * self.shard.world            # the unbiased variance's n / (n - 1) is the global batch's
         T.bn_update_running(mean, var, rows, bn.running_mean, bn.running_var, _MOMENTUM, order)
         bn.num_batches_tracked += calls
 
@@ -269,7 +306,7 @@ class TrainEngine:
         ggamma = self.g(lay.bn.weight, G) if ggamma is None else ggamma
         gbeta = self.g(lay.bn.bias, G) if gbeta is None else gbeta
         dz = T.bn_backward(dy_a, c["y"], c["z"], c["mean"], c["var"], c["gamma"], _EPS, ggamma, gbeta,
-                           relu=True, dy_b=dy_b, up_a=up_a)
+                           relu=True, dy_b=dy_b, up_a=up_a, **self._bn_sync(c["z"], c["groups"]))
         return self._conv_bwd(c["desc"], c["w"], c["src0"], c["src1"], dz, gw, gb, need_dx)
 
     def _conv_bwd(self, d, w, src0, src1, dz, gw, gb, need_dx=True, dw_cin_total=0, w_ci_first=0,
@@ -320,7 +357,9 @@ class TrainEngine:
     # fusion lists (host side, from num_agent / only_v2i)
     # ------------------------------------------------------------------
     def _fusion_lists(self, trans, num_agent_cpu, B, dev):
-        return fusion_lists(self.model.agent_num, self.model.only_v2i, trans, num_agent_cpu, B, dev)
+        sh = self.shard
+        return fusion_lists(self.model.agent_num, self.model.only_v2i, trans, num_agent_cpu, B, dev,
+                            ego_first=sh.first if sh is not None else 0, ego_count=sh.count if sh is not None else None)
 
     # ------------------------------------------------------------------
     # forward (training mode)
@@ -345,14 +384,18 @@ class TrainEngine:
         if m.layer != 3 and m.u_encoder.compress_level > 0:
             raise NotImplementedError("compress_level > 0 in training needs layer = 3")
         n = bevs.shape[0] * bevs.shape[1]
-        if n != A * B:
-            raise ValueError("bevs has %d images, expected num_agent*batch_size = %d" % (n, A * B))
+        sh = self.shard
+        A_loc = A if sh is None else sh.count            # agents whose images this rank holds (agent-parallel training)
+        if n != A_loc * B:
+            raise ValueError("bevs has %d images, expected %d (this rank's agents) * batch_size %d = %d"
+                             % (n, A_loc, B, A_loc * B))
         dev = bevs.device
         x = bevs.reshape(n, bevs.shape[2], bevs.shape[3], bevs.shape[4])
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
         trans = trans_matrices.to(device=dev, dtype=torch.float32).contiguous()
-        F = self._fusion_lists(trans, num_agent_tensor[:, 0].cpu(), B, dev)
+        self._num_agent_cpu, self._batch = num_agent_tensor[:, 0].cpu(), B
+        F = self._fusion_lists(trans, self._num_agent_cpu, B, dev)
         self.F = F
 
         # encoder: groups of layers, the last one of group k yields e[k]; the maps of the fusion layer
@@ -360,11 +403,15 @@ class TrainEngine:
         lay_k = m.layer
         C = LAYER_CHANNEL[lay_k]
         hk, wk = x.shape[1] >> lay_k, x.shape[2] >> lay_k
-        NI, NW = n, F["n_warps"]
+        # pair buffer [every agent's map (A * B, agent-major) | this rank's warps]; this rank's own maps are rows
+        # [lo, lo + n) of it -- all of it without a shard -- and the other ranks' arrive by the all-gather below
+        NI, NW = A * B, F["n_warps"]
+        lo = 0 if sh is None else sh.first * B
         maps = torch.empty((NI + NW, hk, wk, C), dtype=torch.float32, device=dev)
+        own = maps[lo:lo + n]
         def group(k, a):
             for name in _ENC_GROUPS[k]:
-                into = maps[:NI] if (name == _ENC_GROUPS[k][-1] and k == lay_k and "compress" not in L) else None
+                into = own if (name == _ENC_GROUPS[k][-1] and k == lay_k and "compress" not in L) else None
                 a = self._layer_fwd(L[name], a, y_out=into)
             return a
 
@@ -386,7 +433,9 @@ class TrainEngine:
         if "compress" in L:
             # the encoder goes on from the uncompressed x3; what is exchanged (and what the decoder's
             # skip sees) goes through the 1x1 compress / decompress pair
-            self._layer_fwd(L["decompress"], self._layer_fwd(L["compress"], e[3]), y_out=maps[:NI])
+            self._layer_fwd(L["decompress"], self._layer_fwd(L["compress"], e[3]), y_out=own)
+        if sh is not None:
+            sh.gather_rows(maps[:NI], lo, n)             # the V2X exchange: every agent's layer-`layer` map on every rank
         fused = self._fusion_fwd(maps, NI, NW, F)
         main.wait_stream(side)
         for t in e[lay_k + 1:]:
@@ -427,7 +476,7 @@ class TrainEngine:
             c = lay.ctx
             self._update_running(lay.bn, c["mean"], c["var"], c["z"].numel() // c["z"].shape[-1])
         hc = self.head1.ctx
-        rows = hc["z"].numel() // 64
+        rows = (hc["z"].numel() // 64) * (sh.world if sh is not None else 1)
         T.bn_update_running(hc["mean"][:, :32], hc["var"][:, :32], rows, cls.bn1.running_mean,
                             cls.bn1.running_var, _MOMENTUM)
         T.bn_update_running(hc["mean"][:, 32:], hc["var"][:, 32:], rows, reg[1].running_mean,
@@ -459,14 +508,28 @@ class TrainEngine:
         h2 = self._layer_fwd(L["mlp2"], h1, groups=P)
         h3 = self._layer_fwd(L["mlp3"], h2, groups=P)
         z4, d4 = self._conv(f.conv1_4.weight, f.conv1_4.bias, h3, ksize=1)
-        fused = torch.empty((NI,) + tuple(maps.shape[1:]), dtype=torch.float32, device=maps.device)
+        n_ego = F["ego_out"].numel()                          # fused maps of this rank's egos (all of them without a shard)
+        fused = torch.empty((n_ego,) + tuple(maps.shape[1:]), dtype=torch.float32, device=maps.device)
         weights = T.fuse_combine(z4, maps, F["first"], F["pair_index"], F["map_image"], F["ego_out"], fused)
         self.fctx = dict(maps=maps, NI=NI, NW=NW, z1=z1, mean1=mean1, var1=var1, h1=h1, d_e=d_e, d_f=d_f,
                          w_ego=w_ego, w_nbr=w_nbr, h3=h3, z4=z4, d4=d4, weights=weights)
-        if F["n_calls"]:
-            for bn, mean, var in ((f.bn1_1, mean1, var1),
-                                  (f.bn1_2, L["mlp2"].ctx["mean"], L["mlp2"].ctx["var"]),
-                                  (f.bn1_3, L["mlp3"].ctx["mean"], L["mlp3"].ctx["var"])):
+        stats = ((f.bn1_1, mean1, var1), (f.bn1_2, L["mlp2"].ctx["mean"], L["mlp2"].ctx["var"]),
+                 (f.bn1_3, L["mlp3"].ctx["mean"], L["mlp3"].ctx["var"]))
+        if self.shard is not None and self.shard.world > 1:
+            # the reference updates the MLP's running statistics once per CALL, in its loop order (scene, then ego): every
+            # rank owns some egos' calls, so the per-call statistics travel (all-gather) and every rank replays all of them
+            calls = self.shard.calls_in_reference_order(
+                fusion_call_counts(m.agent_num, m.only_v2i, self._num_agent_cpu, self._batch), F["n_calls"])
+            if calls["total"]:
+                local = F["order"][:F["n_calls"]].long()
+                for bn, mean, var in stats:
+                    allm = self.shard.gather_padded(mean[local], calls["max_per_rank"])
+                    allv = self.shard.gather_padded(var[local], calls["max_per_rank"])
+                    T.bn_update_running(allm.reshape(-1, mean.shape[1]), allv.reshape(-1, var.shape[1]), hw, bn.running_mean,
+                                        bn.running_var, _MOMENTUM, calls["index"].to(mean.device))
+                    bn.num_batches_tracked += calls["total"]
+        elif F["n_calls"]:
+            for bn, mean, var in stats:
                 T.bn_update_running(mean, var, hw, bn.running_mean, bn.running_var, _MOMENTUM,
                                     F["order"][:F["n_calls"]].contiguous())
                 bn.num_batches_tracked += F["n_calls"]
@@ -560,7 +623,9 @@ class TrainEngine:
         maps, NI, NW = c["maps"], c["NI"], c["NW"]
         C = maps.shape[-1]
         P = NI + NW
-        dmaps = torch.empty_like(maps)
+        # (agent-parallel: the other ranks' maps are in no list of this rank's egos -- only their warps are -- so their rows
+        # of dmaps are written by nothing before the adds below: start from zero)
+        dmaps = torch.empty_like(maps) if self.shard is None else torch.zeros_like(maps)
         dz4 = T.fuse_combine_backward(dfused, c["z4"], c["weights"], maps, F["first"], F["pair_index"],
                                       F["map_image"], F["ego_out"], dmaps)
         dh3 = self._conv_bwd(c["d4"], f.conv1_4.weight, c["h3"], None, dz4, self.g(f.conv1_4.weight, G),
@@ -578,6 +643,11 @@ class TrainEngine:
         T.add_rows(dmaps[:NI], self._dgrad(c["d_e"], c["w_ego"].view(128, C, 1, 1), dE))
         if NW:
             T.warp_backward(dmaps[NI:], F["poses"], F["src_image"], dmaps[:NI], rigid=F["rigid"])
+        if self.shard is not None:
+            # dmaps[:NI] = d(this rank's loss terms) / d(EVERY agent's map): the backward of the all-gather is a
+            # reduce-scatter -- each rank receives the sum, over the ranks, of the gradient of its own agents' maps
+            n_loc = self.shard.count * (NI // m.agent_num)
+            return self.shard.reduce_scatter_rows(dmaps[:NI], self.shard.first * (NI // m.agent_num), n_loc)
         return dmaps[:NI]
 
     # ------------------------------------------------------------------
@@ -607,7 +677,11 @@ class TrainEngine:
             self.flat_v[off:off + p.numel()].view(p.shape).copy_(sd["exp_avg_sq"][n])
 
     def allreduce_grads(self):
-        """DDP's gradient averaging as ONE collective over the flat buffer (RCCL over xGMI)"""
+        """DDP's gradient averaging as ONE collective over the flat buffer (RCCL over xGMI).  Agent-parallel training: the
+        ranks hold DISJOINT terms of one loss (normalised by the global image count), so their gradients are SUMMED."""
+        if self.shard is not None:
+            self.shard.sum_(self.flat_g)
+            return
         from .sharded import average_gradients_
         average_gradients_(self.flat_g)
 
@@ -676,9 +750,13 @@ class CoDetModule:
     layer-3 map (vs the teacher's x3) joins the loss."""
 
     def __init__(self, model, teacher=None, config=None, optimizer=None, kd_flag=0, lr=1e-3,
-                 alpha=0.25, gamma=2.0, sigma=3.0):
+                 alpha=0.25, gamma=2.0, sigma=3.0, shard=None):
+        """shard (sharded.AgentShard): agent-parallel training -- step() then takes THIS rank's agents' images, labels and
+        targets (agent-major, [count * B, ...]); trans_matrices / num_agent stay the whole scenes'.  Not with kd_flag."""
         if kd_flag and teacher is None:
             raise ValueError("kd_flag = 1 needs the teacher network")
+        if kd_flag and shard is not None:
+            raise NotImplementedError("agent-parallel training does not carry the KD teacher (it sees every agent's points)")
         self.model, self.teacher, self.kd_flag = model, teacher, int(bool(kd_flag))
         if self.kd_flag:
             teacher.eval()
@@ -688,7 +766,7 @@ class CoDetModule:
             lr = grp["lr"]
             kw = {"betas": tuple(grp.get("betas", (0.9, 0.999))), "eps": grp.get("eps", 1e-8),
                   "weight_decay": grp.get("weight_decay", 0.0)}
-        self.engine = TrainEngine(model, lr=lr, **kw)
+        self.engine = TrainEngine(model, lr=lr, shard=shard, **kw)
         model.__dict__["_train_engine"] = self.engine
         self.alpha, self.gamma, self.sigma = alpha, gamma, sigma
 
@@ -711,7 +789,8 @@ class CoDetModule:
             losses, dcls, dloc = T.det_loss(
                 res["cls"].reshape(-1, 2), f32(data["labels"], (-1, 2)), res["loc"].reshape(-1, code),
                 f32(data["reg_targets"], (-1, code)), f32(data["reg_loss_mask"], (-1,)),
-                norm=bev_seq.shape[0], alpha=self.alpha, gamma=self.gamma, sigma=self.sigma)
+                norm=bev_seq.shape[0] * (eng.shard.world if eng.shard is not None else 1),      # the reference's N: all A * B images
+                alpha=self.alpha, gamma=self.gamma, sigma=self.sigma)
             dkd, kd = None, None
             if self.kd_flag:
                 kd_weight = float(data["kd_weight"]) if "kd_weight" in data else 1e5
@@ -723,6 +802,8 @@ class CoDetModule:
             eng.backward(dcls, dloc, dkd=dkd)
             eng.allreduce_grads()
             eng.optimizer_step()
+        if eng.shard is not None:
+            eng.shard.sum_(losses)                    # reported losses: the whole scenes', as without a shard
         l = losses.tolist()
         out = {"loss": l[0] + l[1], "cls_loss": l[0], "loc_loss": l[1]}
         if kd is not None:

@@ -70,17 +70,32 @@ def dgrad_class_weights(w, py, px, ci_first=0, c_in=None):
 
 
 # ---- batch norm, training mode ------------------------------------------------------------
-def bn_stats(z, n_groups=1):
-    """z [..., c] dense NHWC rows -> (mean, biased var) each [n_groups, c]"""
+def _folded(sums, n_groups, c):
+    """the folded sums [n_groups, 2, c] float64 at the start of a reduction workspace (what a SyncBN exchange all-reduces)"""
+    return sums[:n_groups * 2 * c * 8].view(torch.float64)
+
+
+def bn_stats(z, n_groups=1, sync=None, norm_rows=None):
+    """z [..., c] dense NHWC rows -> (mean, biased var) each [n_groups, c].
+    sync (agent-parallel training): callable that all-reduces a float64 tensor in place -- this rank's sums are reduced,
+    `sync` adds the other ranks', and the statistics are normalised by `norm_rows` rows per group (the global count)."""
     _need_gpu(z)
     c = z.shape[-1]
     rows = z.numel() // c
     assert rows % n_groups == 0
     mean = torch.empty((n_groups, c), dtype=torch.float32, device=z.device)
     var = torch.empty_like(mean)
-    sums = _ws(z.device, _lib.load().dn_reduce_workspace_bytes(n_groups, rows // n_groups, c))
-    check(_lib.load().dn_bn_train_stats(_ptr(z), n_groups, rows // n_groups, c, c, _ptr(sums), sums.numel(),
-                                        _ptr(mean), _ptr(var), _stream()), "dn_bn_train_stats")
+    lib = _lib.load()
+    sums = _ws(z.device, lib.dn_reduce_workspace_bytes(n_groups, rows // n_groups, c))
+    if sync is None:
+        check(lib.dn_bn_train_stats(_ptr(z), n_groups, rows // n_groups, c, c, _ptr(sums), sums.numel(),
+                                    _ptr(mean), _ptr(var), _stream()), "dn_bn_train_stats")
+        return mean, var
+    check(lib.dn_bn_train_stats_partial(_ptr(z), n_groups, rows // n_groups, c, c, _ptr(sums), sums.numel(), _stream()),
+          "dn_bn_train_stats_partial")
+    sync(_folded(sums, n_groups, c))
+    check(lib.dn_bn_train_stats_finish(_ptr(sums), n_groups, int(norm_rows if norm_rows is not None else rows // n_groups), c,
+                                       _ptr(mean), _ptr(var), _stream()), "dn_bn_train_stats_finish")
     return mean, var
 
 
@@ -106,20 +121,33 @@ def bn_update_running(mean, var, rows_per_group, running_mean, running_var, mome
 
 
 def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_b=None, up_a=False,
-                accumulate=False, out=None):
+                accumulate=False, out=None, sync=None, norm_rows=None):
     """z, y [n, h, w, c] dense.  dy_a: [n, h, w, c'] view (or [n, 2h, 2w, c'] when up_a), dy_b
-    optional second gradient (same resolution as y).  Returns dz; fills dgamma / dbeta."""
+    optional second gradient (same resolution as y).  Returns dz; fills dgamma / dbeta.
+    sync / norm_rows (agent-parallel training, see bn_stats): dgamma / dbeta are then THIS rank's share (sums over its rows)."""
     _need_gpu(dy_a, dy_b, y, z, mean, var, gamma)
     n, h, w, c = z.shape
     n_groups = mean.shape[0]
     assert n % n_groups == 0
     dz = torch.empty_like(z) if out is None else out
-    sums = _ws(z.device, _lib.load().dn_reduce_workspace_bytes(n_groups, (n // n_groups) * h * w, c))
-    check(_lib.load().dn_bn_train_backward(
-        _ptr(dy_a), _ld(dy_a), int(bool(up_a)), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0,
-        _ptr(y), _ptr(z), _ptr(mean), _ptr(var), _ptr(gamma), float(eps), int(relu), n_groups, h, w,
-        n // n_groups, c, _ptr(sums), sums.numel(), _ptr(dz), _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)),
-        _stream()), "dn_bn_train_backward")
+    lib = _lib.load()
+    sums = _ws(z.device, lib.dn_reduce_workspace_bytes(n_groups, (n // n_groups) * h * w, c))
+    if sync is None:
+        check(lib.dn_bn_train_backward(
+            _ptr(dy_a), _ld(dy_a), int(bool(up_a)), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0,
+            _ptr(y), _ptr(z), _ptr(mean), _ptr(var), _ptr(gamma), float(eps), int(relu), n_groups, h, w,
+            n // n_groups, c, _ptr(sums), sums.numel(), _ptr(dz), _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)),
+            _stream()), "dn_bn_train_backward")
+        return dz
+    src = (_ptr(dy_a), _ld(dy_a), int(bool(up_a)), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0, _ptr(y), _ptr(z),
+           _ptr(mean), _ptr(var))
+    check(lib.dn_bn_train_backward_partial(*src, float(eps), int(relu), n_groups, h, w, n // n_groups, c, _ptr(sums),
+                                           sums.numel(), _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)), _stream()),
+          "dn_bn_train_backward_partial")
+    sync(_folded(sums, n_groups, c))
+    rows = int(norm_rows if norm_rows is not None else (n // n_groups) * h * w)
+    check(lib.dn_bn_train_backward_finish(*src, _ptr(gamma), float(eps), int(relu), n_groups, h, w, n // n_groups, c,
+                                          _ptr(sums), rows, _ptr(dz), _stream()), "dn_bn_train_backward_finish")
     return dz
 
 

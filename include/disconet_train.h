@@ -68,6 +68,15 @@ int dn_conv_dgrad_class_weights(const float* w_oihw, int c_out, int cin_total, i
 int dn_bn_train_stats(const float* z, int n_groups, long rows_per_group, int c, int ldz,
                       double* sums, size_t sums_bytes, float* mean, float* var, void* stream);
 
+/* Two-phase form for a BatchNorm batch that is spread over several ranks (agent-parallel training, disconet_amd/sharded.py):
+ *   dn_bn_train_stats_partial   this rank's rows -> the folded sums [n_groups][2 c] doubles (sum z, sum z^2) at the START of `sums`
+ *   (the caller all-reduces those n_groups * 2 * c doubles over the ranks)
+ *   dn_bn_train_stats_finish    mean / biased var from the sums over `norm_rows` rows per group (the GLOBAL count).
+ * dn_bn_train_stats is the two phases back to back with norm_rows = rows_per_group. */
+int dn_bn_train_stats_partial(const float* z, int n_groups, long rows_per_group, int c, int ldz,
+                              double* sums, size_t sums_bytes, void* stream);
+int dn_bn_train_stats_finish(const double* sums, int n_groups, long norm_rows, int c, float* mean, float* var, void* stream);
+
 /* y = act((z - mean) * rsqrt(var + eps) * gamma + beta), act = ReLU if relu */
 int dn_bn_train_apply(const float* z, const float* mean, const float* var, const float* gamma,
                       const float* beta, float eps, int relu, int n_groups, long rows_per_group,
@@ -91,6 +100,19 @@ int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const float* dy_
                          const float* gamma, float eps, int relu, int n_groups, int h, int w,
                          int images_per_group, int c, double* sums, size_t sums_bytes, float* dz,
                          float* dgamma, float* dbeta, int accumulate, void* stream);
+
+/* Two-phase form of the backward (see dn_bn_train_stats_partial): `_partial` leaves this rank's folded sums of g and
+ * g * zhat at the start of `sums` and writes dgamma / dbeta out of THESE rows (they are plain sums over rows: the ranks'
+ * shares meet in the gradient all-reduce); the caller all-reduces the n_groups * 2 * c doubles; `_finish` writes dz of this
+ * rank's rows with the means taken over `norm_rows` rows per group. */
+int dn_bn_train_backward_partial(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b, const float* y,
+                                 const float* z, const float* mean, const float* var, float eps, int relu, int n_groups,
+                                 int h, int w, int images_per_group, int c, double* sums, size_t sums_bytes, float* dgamma,
+                                 float* dbeta, int accumulate, void* stream);
+int dn_bn_train_backward_finish(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b, const float* y,
+                                const float* z, const float* mean, const float* var, const float* gamma, float eps, int relu,
+                                int n_groups, int h, int w, int images_per_group, int c, const double* sums, long norm_rows,
+                                float* dz, void* stream);
 
 /* out[c] (+)= sum over rows of x[row][c] (bias gradients); sums: dn_reduce_workspace_bytes(1, rows, c) bytes */
 int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, size_t sums_bytes, float* out,

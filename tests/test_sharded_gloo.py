@@ -109,3 +109,117 @@ def test_flat_gradient_average_is_the_mean_over_ranks():
         assert abs(got[r] - want.numpy()).max() < 1e-6
     t = torch.ones(5)
     assert sharded.average_gradients_(t) is t and float(t.sum()) == 5.0     # no process group: no-op
+
+
+# ---- agent-parallel TRAINING: all-gather forward, reduce-scatter backward, BatchNorm sums all-reduced ---------------------
+_ATRAIN = dict(map_hw=64, agents=4, batch=2, live=[3, 2], jitter=7, lr=0.02)
+
+
+def _atrain_setup():
+    """float64 oracle + inputs of the agent-parallel training case (every rank and the parent build the same)"""
+    import torch.nn.functional as F
+    from disconet_amd.synthetic import make_scene_batch, make_train_targets
+    c = _ATRAIN
+    ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=0).double()
+    ref.u_encoder.conv_pre_1.register_forward_pre_hook(lambda m, inp: (inp[0].double(),))
+    bevs, trans, na = make_scene_batch(c["batch"], c["agents"], c["map_hw"], live=c["live"], jitter_seed=c["jitter"])
+    labels, targets, mask = make_train_targets(bevs.shape[0], c["map_hw"], p_fg=0.02)
+    if not getattr(F.grid_sample, "_dn_f64", False):      # the oracle builds float32 grids (as upstream): cast to the map's dtype
+        orig = F.grid_sample
+        def patched(inp, grid, **kw):
+            return orig(inp, grid.to(inp.dtype), **kw)
+        patched._dn_f64 = True
+        F.grid_sample = patched
+    return ref, (bevs, trans, na), (labels, targets, mask)
+
+
+def _state(ref):
+    return {k.replace(".bn.", "."): v.detach().clone() for k, v in ref.state_dict().items()}
+
+
+def _atrain_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disconet_amd import sharded
+        from tests.oracle_engine import oracle_agent_sharded_train_step
+        c = _ATRAIN
+        ref, (bevs, trans, na), (labels, targets, mask) = _atrain_setup()
+        shard = sharded.AgentShard(c["agents"])
+        mine = lambda t: sharded.local_bevs(t, c["agents"], c["batch"], world, rank)
+        opt = torch.optim.SGD(ref.parameters(), lr=c["lr"])      # (why not Adam: see the test)
+        losses = [oracle_agent_sharded_train_step(ref, shard, opt, mine(bevs), trans, na, c["batch"], mine(labels),
+                                                  mine(targets), mine(mask)) for _ in range(2)]
+        q.put((rank, losses, {k: v.numpy() for k, v in _state(ref).items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_agent_sharded_training_step_matches_unsharded_oracle():
+    """"Backward of (ii) is a reduce-scatter".  Two gloo ranks, two agents each of 4-agent scenes (one scene
+    with 3 live agents, one with 2: rank 1 holds a padded agent in one scene and nothing live in the other), TWO consecutive
+    steps of the oracle twin (tests/oracle_engine.py) through disconet_amd.sharded.AgentShard -- the collectives the HIP
+    engine makes -- in float64: the losses, EVERY parameter after the update and EVERY BatchNorm buffer (the attention MLP's
+    running statistics replayed in the reference's call order) equal the un-sharded oracle's on both ranks."""
+    from oracle.train_ref import train_step
+    world, c = 2, _ATRAIN
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_atrain_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    torch.set_num_threads(2)
+    ref, (bevs, trans, na), (labels, targets, mask) = _atrain_setup()
+    # Plain SGD on purpose: a conv bias in front of a BatchNorm has a gradient that is exactly zero in mathematics and rounding
+    # noise (~1e-17) in any backward; Adam normalises that noise into a +-lr step whose sign depends on the summation order,
+    # which would force a loose comparison.  The collectives under test do not depend on the optimizer.
+    opt = torch.optim.SGD(ref.parameters(), lr=c["lr"])
+    want_losses = [train_step(ref, opt, bevs, trans, na, c["batch"], labels, targets, mask) for _ in range(2)]
+    want = _state(ref)
+    got = {}
+    for _ in range(world):
+        rank, losses, state = q.get(timeout=600)
+        got[rank] = (losses, state)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    moved = 0
+    for r in range(world):
+        losses, state = got[r]
+        for (a0, a1), (b0, b1) in zip(losses, want_losses):
+            assert abs(a0 - b0) <= 1e-9 * abs(b0) and abs(a1 - b1) <= 1e-9 * abs(b1), (r, losses, want_losses)
+        assert set(state) == set(want)
+        for k, w in want.items():
+            g = torch.from_numpy(state[k])
+            scale = float(w.abs().max()) if w.numel() else 0.0
+            assert float((g - w).abs().max()) <= 1e-8 * max(scale, 1e-3), (r, k, float((g - w).abs().max()), scale)
+    # the step did move the parameters of every part (encoder, fusion MLP, decoder, heads)
+    init = _state(_atrain_setup()[0])
+    for key in ("u_encoder.conv1_1.weight", "pixel_weighted_fusion.conv1_1.weight", "decoder.conv5_1.weight",
+                "classification.conv2.weight", "pixel_weighted_fusion.bn1_2.running_mean"):
+        assert float((want[key] - init[key]).abs().max()) > 0, key
+
+
+def test_agent_shard_helpers_without_a_process_group():
+    from disconet_amd import sharded
+    from disconet_amd.train import fusion_call_counts
+    sh = sharded.AgentShard(6)
+    assert (sh.world, sh.rank, sh.first, sh.count) == (1, 0, 0, 6)
+    x = torch.arange(12.0).view(6, 2)
+    assert sh.gather_rows(x, 0, 6) is x and torch.equal(sh.reduce_scatter_rows(x, 0, 6), x) and sh.sum_(x) is x
+    assert tuple(sh.gather_padded(x[:4], 5).shape) == (1, 5, 2)
+    counts = fusion_call_counts(4, False, torch.tensor([3, 2]), 2)
+    assert counts == [[3, 3, 3, 0], [2, 2, 0, 0]]
+    assert fusion_call_counts(4, True, torch.tensor([3, 1]), 2) == [[3, 2, 2, 0], [1, 0, 0, 0]]
+    order = sh.calls_in_reference_order(counts, 13)
+    assert order["total"] == 13 and order["index"].tolist() == list(range(13))
+    # two ranks of two agents: per scene the ranks' runs in rank order (rank 1's rows live behind max_per_rank)
+    two = sharded.AgentShard.__new__(sharded.AgentShard)
+    two.world, two.rank, two.first, two.count, two.group, two.num_agent = 2, 1, 2, 2, None, 4
+    o = two.calls_in_reference_order(counts, 3)
+    assert o["max_per_rank"] == 10 and o["index"].tolist() == [0, 1, 2, 3, 4, 5, 10, 11, 12, 6, 7, 8, 9]
+    with pytest.raises(RuntimeError):
+        two.calls_in_reference_order(counts, 4)
