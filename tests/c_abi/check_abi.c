@@ -44,6 +44,21 @@ static int errors_only(void) {
   CHECK(dn_adam_step(NULL, NULL, NULL, NULL, 10, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 1, NULL) == DN_ERR_ARG,
         "adam null");
   CHECK(dn_bn_train_stats(NULL, 1, 10, 600, 600, NULL, 0, NULL, NULL, NULL) == DN_ERR_ARG, "bn null");
+  /* round 5: two-phase BatchNorm reductions (agent-parallel training) and the K-slice query */
+  CHECK(dn_bn_train_stats_partial(NULL, 1, 10, 8, 8, NULL, 0, NULL) == DN_ERR_ARG, "bn stats partial null");
+  CHECK(dn_bn_train_stats_finish(NULL, 1, 10, 8, NULL, NULL, NULL) == DN_ERR_ARG, "bn stats finish null");
+  CHECK(dn_bn_train_stats_finish((const double*)16, 1, 0, 8, (float*)16, (float*)16, NULL) == DN_ERR_ARG, "bn stats finish: zero rows");
+  CHECK(dn_bn_train_backward_partial(NULL, 8, 0, NULL, 0, NULL, NULL, NULL, NULL, 1e-5f, 0, 1, 4, 4, 1, 8, NULL, 0, NULL, NULL, 0,
+                                     NULL) == DN_ERR_ARG, "bn bwd partial null");
+  CHECK(dn_bn_train_backward_finish(NULL, 8, 0, NULL, 0, NULL, NULL, NULL, NULL, NULL, 1e-5f, 0, 1, 4, 4, 1, 8, NULL, 16, NULL,
+                                    NULL) == DN_ERR_ARG, "bn bwd finish null");
+  memset(&d, 0, sizeof d);
+  d.n_images = 4; d.h_in = 32; d.w_in = 32; d.c0 = 256; d.c_out = 256; d.ksize = 3; d.stride = 1; d.math = 2;
+  CHECK(dn_spconv_ks_supported(&d, 1) == 1 && dn_spconv_ks_supported(&d, 4) == 1 && dn_spconv_ks_supported(&d, 3) == 0, "ks supported");
+  d.c0 = 32;      /* two chunks: not four slices */
+  CHECK(dn_spconv_ks_supported(&d, 4) == 0 && dn_spconv_ks_supported(&d, 2) == 1, "ks: fewer chunks than slices");
+  d.ksize = 1;
+  CHECK(dn_spconv_ks_supported(&d, 2) == 0, "ks: 1x1 layers have no sliced form");
   printf("C ABI error behaviour: ok\n");
   return 0;
 }

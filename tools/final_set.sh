@@ -1,19 +1,20 @@
 #!/bin/bash
-# Round-4 validation + profile set on the GPU box:  bash tools/r04_final.sh  -> gpurun_out/r04final/
-#   full -m gpu suite, smoke(), tools/r04_profile.sh (its summaries are copied into profiles/ of the box's copy so
+# Validation + profile set of a round on the GPU box:  bash tools/final_set.sh r05  -> gpurun_out/r05final/
+#   full -m gpu suite, smoke(), tools/profile_set.sh $RD (its summaries are copied into profiles/ of the box's copy so
 #   that the bench lines quote the profile of THIS build), then the bench lines that profiles/ keeps.
+RD=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r04final
+O=$R/gpurun_out/${RD}final
 mkdir -p $O
 cd $R
 ( timeout 1200 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.log )
 tail -3 $O/pytest_gpu.log
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?" >> $O/smoke.log ); tail -2 $O/smoke.log
-bash tools/r04_profile.sh > $O/profile.log 2>&1
-P=$R/gpurun_out/r04prof
-cp $P/rocprof_conv_sp.json profiles/r04_rocprof_conv_sp.json
-cp $P/pmc_traffic_sp.json profiles/r04_pmc_traffic_sp.json
-[ -s $P/pmc_traffic_seg.json ] && cp $P/pmc_traffic_seg.json profiles/r04_pmc_traffic_seg.json
+bash tools/profile_set.sh $RD > $O/profile.log 2>&1
+P=$R/gpurun_out/${RD}prof
+cp $P/rocprof_conv_sp.json profiles/${RD}_rocprof_conv_sp.json
+cp $P/pmc_traffic_sp.json profiles/${RD}_pmc_traffic_sp.json
+[ -s $P/pmc_traffic_seg.json ] && cp $P/pmc_traffic_seg.json profiles/${RD}_pmc_traffic_seg.json
 cd $R
 timeout 600 python bench.py 2> $O/bench_default.err | tail -1 > $O/bench_default.json
 timeout 400 python bench.py --mode agent --no-pg --emulate-world 8 --agent-check 1000 2> $O/agent_share.err | tail -1 > $O/agent_share.json
