@@ -183,24 +183,35 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise DnError(
-            "libdisconet_hip.so is not built (%s). Run `python -m disconet_amd.csrc.build` "
-            "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+    # A library that was not built from THIS tree must not run (round 4 shipped one): the id baked into it is the hash of
+    # every source, header and flag (csrc/build.py), read from the FILE before anything is mapped.  Missing or stale and the
+    # sources + hipcc are here: rebuilt, loudly, under a file lock (several processes may import at once) -- what runs is always
+    # what the tree says.  DISCONET_NO_AUTOBUILD=1: raise instead.  A/B variants (tools/ab) carry other flags and therefore
+    # other ids: DISCONET_HIP_LIB / DISCONET_ALLOW_STALE_LIB=1 say so explicitly and skip the check.
+    variant = bool(os.environ.get("DISCONET_HIP_LIB")) or os.environ.get("DISCONET_ALLOW_STALE_LIB") == "1"
+    if not variant:
+        from .csrc import build as _build
+        want, have = _build.tree_hash(), _build.built_id(LIB_PATH)
+        if have != want:
+            why = ("libdisconet_hip.so is not built (%s)" % LIB_PATH if have is None and not os.path.exists(LIB_PATH) else
+                   "libdisconet_hip.so is stale: built from tree %s, the sources here hash to %s" % (have, want))
+            if os.environ.get("DISCONET_NO_AUTOBUILD") == "1" or os.path.abspath(LIB_PATH) != os.path.abspath(_build.LIB_PATH):
+                raise DnError(why + ". Run `python -m disconet_amd.csrc.build` (needs hipcc); there is no CPU fallback.")
+            import sys
+            print("disconet_amd: %s -- rebuilding with hipcc (python -m disconet_amd.csrc.build)" % why, file=sys.stderr, flush=True)
+            try:
+                _build.build_locked(verbose=False)
+            except Exception as e:      # noqa: BLE001 -- no hipcc, a compile error: never run the stale binary
+                raise DnError("%s, and the rebuild failed (%r). There is no CPU fallback." % (why, e)) from e
+    elif not os.path.exists(LIB_PATH):
+        raise DnError("libdisconet_hip.so variant %s does not exist" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing: loud by design
         fn.restype = restype
         fn.argtypes = argtypes
-    # a library that was not built from THIS tree must not run (round 4 shipped one): the id baked into it is the
-    # hash of every source, header and flag (csrc/build.py).  A/B variants (tools/ab) are built with other flags
-    # and therefore other ids: DISCONET_HIP_LIB / DISCONET_ALLOW_STALE_LIB=1 say so explicitly.
-    if not (os.environ.get("DISCONET_HIP_LIB") or os.environ.get("DISCONET_ALLOW_STALE_LIB") == "1"):
-        from .csrc import build as _build
-        have, want = lib.dn_build_id().decode(), _build.tree_hash()
-        if have != want:
-            raise DnError("libdisconet_hip.so is stale: built from tree %s, the sources here hash to %s. "
-                          "Run `python -m disconet_amd.csrc.build`." % (have, want))
+    if not variant and lib.dn_build_id().decode() != want:
+        raise DnError("libdisconet_hip.so reports build id %s, the tree hashes to %s" % (lib.dn_build_id().decode(), want))
     _lib = lib
     return lib
 

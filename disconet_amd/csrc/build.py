@@ -9,8 +9,9 @@ and the compiler flags.  It is
   * the basis of every object file's key (`build/<name>.o.key` = hash of the unit's own .hip + every header /
     .inl + flags: any header or .inl edit recompiles every unit; common.o, which carries the id, is keyed by
     the whole tree),
-  * checked by `_lib.load()`: a library whose id is not the tree's raises instead of running
-    (`DISCONET_ALLOW_STALE_LIB=1` is for A/B runs of a variant library only).
+  * checked by `_lib.load()` BEFORE the library is mapped: a library whose id is not the tree's never runs -- it is rebuilt
+    (loudly, under a file lock) when hipcc is there, else the import raises; `DISCONET_NO_AUTOBUILD=1` always raises;
+    `DISCONET_ALLOW_STALE_LIB=1` / `DISCONET_HIP_LIB` are for A/B runs of a variant library only.
 Round 4 shipped a conv_pre_pair_kernel that HEAD's source did not build because conv_pre_pair.inl was
 missing from a dependency list; that cannot happen with this scheme.
 """
@@ -114,6 +115,19 @@ def build(force=False, verbose=True, extra_flags=(), lib_path=None, objdir=None)
     if got != key:
         raise RuntimeError("built %s reports id %r, the tree is %r" % (lib_path, got, key))
     return lib_path
+
+
+def build_locked(**kw):
+    """build() under an exclusive file lock: several processes (pytest workers, the ranks of a multi-process test) may find
+    the library stale at once; the first one builds, the others wait and find it current."""
+    import fcntl
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return build(**kw)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 if __name__ == "__main__":

@@ -48,17 +48,21 @@ def test_library_build_id_is_the_trees_hash(tmp_path):
     assert _lib.load().dn_build_id().decode() == want        # through the C ABI
     assert _build.built_id() == want                         # from the file, without loading it
     assert _build.tree_hash(("-DX=1",)) != want              # a variant's flags are part of its id
-    # a library whose id is not the tree's: load() raises, DISCONET_ALLOW_STALE_LIB=1 / DISCONET_HIP_LIB opt in
+    # a library whose id is not the tree's never runs: DISCONET_NO_AUTOBUILD=1 -> load() raises; a failing rebuild raises too
+    # (never the stale binary); DISCONET_ALLOW_STALE_LIB=1 / DISCONET_HIP_LIB opt in to a variant
     pkg = tmp_path / "disconet_amd"
     shutil.copytree(os.path.join(ROOT, "disconet_amd"), pkg, ignore=shutil.ignore_patterns("build", "__pycache__"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")
     with open(pkg / "csrc" / "conv_pre_pair.inl", "a") as f:
         f.write("\n// edited after the build\n")
     code = "from disconet_amd import _lib; _lib.load(); print('loaded')"
-    env = {k: v for k, v in os.environ.items() if k not in ("DISCONET_HIP_LIB", "DISCONET_ALLOW_STALE_LIB")}
-    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, env=env, capture_output=True, text=True)
-    assert r.returncode != 0 and "stale" in r.stderr, r.stderr[-400:]
-    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, env=dict(env, DISCONET_ALLOW_STALE_LIB="1"),
-                       capture_output=True, text=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("DISCONET_HIP_LIB", "DISCONET_ALLOW_STALE_LIB", "DISCONET_NO_AUTOBUILD")}
+    run = lambda extra: subprocess.run([sys.executable, "-c", code], cwd=tmp_path, env=dict(env, **extra), capture_output=True, text=True)
+    r = run({"DISCONET_NO_AUTOBUILD": "1"})
+    assert r.returncode != 0 and "stale" in r.stderr and "loaded" not in r.stdout, r.stderr[-400:]
+    r = run({"HIPCC": "/bin/false"})                     # the automatic rebuild cannot succeed: still no stale binary
+    assert r.returncode != 0 and "rebuild failed" in r.stderr and "loaded" not in r.stdout, r.stderr[-400:]
+    r = run({"DISCONET_ALLOW_STALE_LIB": "1"})
     assert r.returncode == 0 and "loaded" in r.stdout, r.stderr[-400:]
 
 
