@@ -1,6 +1,6 @@
-"""Fills DESIGN.md's @@PLACEHOLDERS@@ and the per-layer table from the round's final GPU run (tools/r04_final.sh ->
-gpurun_out/r04final, gpurun_out/r04prof) and copies that run's summaries into profiles/r04_*.  Run once, at the end:
-    python tools/fill_design.py [--dry]"""
+"""Fills DESIGN.md's @@PLACEHOLDERS@@ and the per-layer table from the round's final GPU run (tools/final_set.sh r05 ->
+gpurun_out/r05final, gpurun_out/r05prof) and copies that run's summaries into profiles/r05_*.  Run once, at the end:
+    python tools/fill_design.py [--dry]      (RD below names the round; PREV = the previous round's per-layer microseconds)"""
 import csv
 import json
 import os
@@ -10,11 +10,12 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F, P = os.path.join(ROOT, "gpurun_out", "r04final"), os.path.join(ROOT, "gpurun_out", "r04prof")
-R3 = {"conv_pre_1 + conv_pre_2": 116, "conv1_1 (s2)": 76, "conv1_2 + Conv3D 1x1": 87, "conv2_1 (s2)": 46, "conv2_2": 60,
-      "conv3d_2 (1x1)": 21, "conv3_1 (s2)": 44, "conv3_2": 66, "conv4_1 (s2)": 54, "conv4_2": 70, "conv5_1 (up+cat)": 163, "conv5_2": 65,
-      "conv6_1 (up+cat)": 134, "conv6_2": 58, "conv7_1 (up+cat)": 131, "conv7_2": 60, "conv8_1 (up+cat)": 164, "conv8_2": 82,
-      "heads (3x3 + block-diag 1x1)": 164}
+RD = "r05"
+F, P = os.path.join(ROOT, "gpurun_out", RD + "final"), os.path.join(ROOT, "gpurun_out", RD + "prof")
+R3 = {"conv_pre_1 + conv_pre_2": 98, "conv1_1 (s2)": 52, "conv1_2 + Conv3D 1x1": 82, "conv2_1 (s2)": 47, "conv2_2": 55,      # round 4 (its fastest lease)
+      "conv3d_2 (1x1)": 20, "conv3_1 (s2)": 42, "conv3_2": 61, "conv4_1 (s2)": 54, "conv4_2": 65, "conv5_1 (up+cat)": 132, "conv5_2": 60,
+      "conv6_1 (up+cat)": 123, "conv6_2": 54, "conv7_1 (up+cat)": 122, "conv7_2": 56, "conv8_1 (up+cat)": 152, "conv8_2": 89,
+      "heads (3x3 + block-diag 1x1)": 151}
 SHAPE = {"conv_pre_1 + conv_pre_2": "13→32→32 @256², one launch (occupancy words in, intermediate map in LDS)", "conv1_1 (s2)": "32→64 s2 → 128²",
          "conv1_2 + Conv3D 1x1": "64→64 (+1×1) @128²", "conv2_1 (s2)": "64→128 s2 → 64²", "conv2_2": "128→128 @64²", "conv3d_2 (1x1)": "128→128 1×1 @64²",
          "conv3_1 (s2)": "128→256 s2 → 32²", "conv3_2": "256→256 @32² (+ fp32 NHWC copy)", "conv4_1 (s2)": "256→512 s2 → 16²", "conv4_2": "512→512 @16²",
@@ -46,7 +47,7 @@ def layer_table():
             continue
         merged.append([name, vals])
     assert len(merged) == len(layers) == 19, (len(merged), len(layers))
-    lines = ["| layer (shape at batch 4 × 5 agents) | µs (round 3) | TFLOP/s (alg.) | MFMA busy | clock | busy × GHz ÷ 2.4 | HBM r + w (MB) |", "|---|---|---|---|---|---|---|"]
+    lines = ["| layer (shape at batch 4 × 5 agents) | µs (round 4, its fastest lease) | TFLOP/s (alg.) | MFMA busy | clock | busy × GHz ÷ 2.4 | HBM r + w (MB) |", "|---|---|---|---|---|---|---|"]
     for (name, us, tf), (kname, v) in zip(layers, merged):
         lines.append("| %s %s | %.0f (%d) | %.0f | %.0f %% | %.2f GHz | %.2f | %.0f + %.0f |" % (
             name.split(" (")[0].replace(" + Conv3D 1x1", "+Conv3D"), SHAPE[name], us, R3[name], tf, v[3], v[2], v[3] / 100 * v[2] / 2.4, v[7], v[8]))
@@ -94,17 +95,17 @@ def main(dry):
         print(json.dumps(v, indent=1))
         return
     open(os.path.join(ROOT, "DESIGN.md"), "w").write(text)
-    cp = [(os.path.join(F, "bench_default.json"), "r04_bench_default.json"), (os.path.join(F, "bench_seg.json"), "r04_bench_seg.json"),
-          (os.path.join(F, "agent_share.json"), "r04_agent_share.json"), (os.path.join(P, "kernel_stats.csv"), "r04_bench_kernel_stats.csv"),
-          (os.path.join(P, "kernel_trace.csv"), "r04_bench_kernel_trace.csv"), (os.path.join(P, "bench_layers.txt"), "r04_bench_layers.txt"),
-          (os.path.join(P, "step_timeline.txt"), "r04_step_timeline.txt"), (os.path.join(P, "rocprof_conv_sp.json"), "r04_rocprof_conv_sp.json"),
-          (os.path.join(P, "pmc_traffic_sp.json"), "r04_pmc_traffic_sp.json"), (os.path.join(P, "pmc_traffic_seg.json"), "r04_pmc_traffic_seg.json"),
-          (os.path.join(P, "train_step_kernel_stats.csv"), "r04_train_step_kernel_stats.csv")]
-    cp += [(os.path.join(F, "agent_share_b%d.json" % b), "r04_agent_share_b%d.json" % b) for b in (8, 16, 32)]
+    cp = [(os.path.join(F, "bench_default.json"), RD + "_bench_default.json"), (os.path.join(F, "bench_seg.json"), RD + "_bench_seg.json"),
+          (os.path.join(F, "agent_share.json"), RD + "_agent_share.json"), (os.path.join(P, "kernel_stats.csv"), RD + "_bench_kernel_stats.csv"),
+          (os.path.join(P, "kernel_trace.csv"), RD + "_bench_kernel_trace.csv"), (os.path.join(P, "bench_layers.txt"), RD + "_bench_layers.txt"),
+          (os.path.join(P, "step_timeline.txt"), RD + "_step_timeline.txt"), (os.path.join(P, "rocprof_conv_sp.json"), RD + "_rocprof_conv_sp.json"),
+          (os.path.join(P, "pmc_traffic_sp.json"), RD + "_pmc_traffic_sp.json"), (os.path.join(P, "pmc_traffic_seg.json"), RD + "_pmc_traffic_seg.json"),
+          (os.path.join(P, "train_step_kernel_stats.csv"), RD + "_train_step_kernel_stats.csv")]
+    cp += [(os.path.join(F, "agent_share_b%d.json" % b), RD + "_agent_share_b%d.json" % b) for b in (8, 16, 32)]
     for src, dst in cp:
         shutil.copy(src, os.path.join(ROOT, "profiles", dst))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_table.py"), P, "24"], capture_output=True, text=True, check=True).stdout
-    open(os.path.join(ROOT, "profiles", "r04_pmc_conv_sp.txt"), "w").write(out)
+    open(os.path.join(ROOT, "profiles", RD + "_pmc_conv_sp.txt"), "w").write(out)
 
 
 if __name__ == "__main__":

@@ -1,4 +1,4 @@
-"""HBM traffic of the conv kernel per launch from the rocprofv3 counter passes (tools/r04_profile.sh): FETCH_SIZE (KiB, x2 on gfx950 per MI355X_MICROARCH.md) and WRITE_SIZE (KiB) of the LAST
+"""HBM traffic of the conv kernel per launch from the rocprofv3 counter passes (tools/profile_set.sh): FETCH_SIZE (KiB, x2 on gfx950 per MI355X_MICROARCH.md) and WRITE_SIZE (KiB) of the LAST
 step's conv launches (the eager bench launches one step at a time).
 
     python tools/pmc_traffic.py gpurun_out/r02prof sp conv_sp_kernel > profiles/r02_pmc_traffic_sp.json
@@ -17,10 +17,14 @@ def per_dispatch(path, counter, kernel):
     return [out[k] for k in sorted(out)]
 
 
-def main(d, math, kernel, launches=0, layers=0, rnd=4):
+def main(d, math, kernel, launches=0, layers=0, rnd=None):
     """launches: conv kernel launches of ONE step (a K-sliced layer counts twice: main + fix-up pass); 0 = the run
     was 3 identical eager steps (rounds 1-3).  layers: LAYER launches of one step (what bench.py's algorithmic bytes per
     launch are divided by); 0 = launches"""
+    if rnd is None:      # gpurun_out/r05prof[/seg] -> 5
+        import re
+        m = re.search(r"r(\d+)prof", d)
+        rnd = int(m.group(1)) if m else 0
     fetch = per_dispatch("%s/pmc2.csv" % d, "FETCH_SIZE", kernel)
     write = per_dispatch("%s/pmc3.csv" % d, "WRITE_SIZE", kernel)
     launches = launches or len(fetch) // 3
@@ -32,7 +36,7 @@ def main(d, math, kernel, launches=0, layers=0, rnd=4):
         "fetch_bytes_per_step": fb, "write_bytes_per_step": wb,
         "kernel_launches_per_step": launches, "hbm_bytes_per_launch": (fb + wb) / (layers or launches),
         "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over the eager bench "
-                "(tools/r04_profile.sh); FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; "
+                "(tools/profile_set.sh); FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; "
                 "WRITE_SIZE as reported; last step's launches"}, indent=1))
 
 
