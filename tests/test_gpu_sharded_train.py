@@ -53,14 +53,14 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, case, math, q):
+def _worker(rank, world, port, case, math, q, kw=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from disconet_amd import CoDetModule, sharded
-        c, ref, model, inputs, targets = _setup(case, math)
+        c, ref, model, inputs, targets = _setup(case, math, **(kw or {}))
         shard = sharded.AgentShard(c["agents"])
         per = shard.count * c["batch"]
         sl = slice(shard.first * c["batch"], shard.first * c["batch"] + per)
@@ -77,11 +77,12 @@ def _worker(rank, world, port, case, math, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("math", ["f32", "f16x3"])
-def test_two_ranks_agent_parallel_step_matches_oracle(math, monkeypatch):
+@pytest.mark.parametrize("math,kw", [("f32", {}), ("f16x3", {}),
+                                     ("f32", dict(only_v2i=True, compress_level=1))])      # the 1x1 compress / decompress pair around the exchange
+def test_two_ranks_agent_parallel_step_matches_oracle(math, kw, monkeypatch):
     from oracle.train_ref import train_step
     case, world = "ragged_a4", 2              # 4 agent slots, batch 2, live agents [3, 2]: rank 1 = agents 2, 3
-    c, ref, _, inputs, targets = _setup(case, math)
+    c, ref, _, inputs, targets = _setup(case, math, **kw)
     bevs, trans, na = inputs
     g64 = _fp64_grads(ref, inputs, targets, c["batch"], monkeypatch)
     opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
@@ -89,7 +90,7 @@ def test_two_ranks_agent_parallel_step_matches_oracle(math, monkeypatch):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, math, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, math, q, kw)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}

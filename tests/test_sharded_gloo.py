@@ -115,12 +115,12 @@ def test_flat_gradient_average_is_the_mean_over_ranks():
 _ATRAIN = dict(map_hw=64, agents=4, batch=2, live=[3, 2], jitter=7, lr=0.02)
 
 
-def _atrain_setup():
+def _atrain_setup(only_v2i=False):
     """float64 oracle + inputs of the agent-parallel training case (every rank and the parent build the same)"""
     import torch.nn.functional as F
     from disconet_amd.synthetic import make_scene_batch, make_train_targets
     c = _ATRAIN
-    ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=0).double()
+    ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=0, only_v2i=only_v2i).double()
     ref.u_encoder.conv_pre_1.register_forward_pre_hook(lambda m, inp: (inp[0].double(),))
     bevs, trans, na = make_scene_batch(c["batch"], c["agents"], c["map_hw"], live=c["live"], jitter_seed=c["jitter"])
     labels, targets, mask = make_train_targets(bevs.shape[0], c["map_hw"], p_fg=0.02)
@@ -137,7 +137,7 @@ def _state(ref):
     return {k.replace(".bn.", "."): v.detach().clone() for k, v in ref.state_dict().items()}
 
 
-def _atrain_worker(rank, world, port, q):
+def _atrain_worker(rank, world, port, q, only_v2i=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
@@ -146,7 +146,7 @@ def _atrain_worker(rank, world, port, q):
         from disconet_amd import sharded
         from tests.oracle_engine import oracle_agent_sharded_train_step
         c = _ATRAIN
-        ref, (bevs, trans, na), (labels, targets, mask) = _atrain_setup()
+        ref, (bevs, trans, na), (labels, targets, mask) = _atrain_setup(only_v2i)
         shard = sharded.AgentShard(c["agents"])
         mine = lambda t: sharded.local_bevs(t, c["agents"], c["batch"], world, rank)
         opt = torch.optim.SGD(ref.parameters(), lr=c["lr"])      # (why not Adam: see the test)
@@ -157,7 +157,8 @@ def _atrain_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_agent_sharded_training_step_matches_unsharded_oracle():
+@pytest.mark.parametrize("only_v2i", [False, True])
+def test_agent_sharded_training_step_matches_unsharded_oracle(only_v2i):
     """"Backward of (ii) is a reduce-scatter".  Two gloo ranks, two agents each of 4-agent scenes (one scene
     with 3 live agents, one with 2: rank 1 holds a padded agent in one scene and nothing live in the other), TWO consecutive
     steps of the oracle twin (tests/oracle_engine.py) through disconet_amd.sharded.AgentShard -- the collectives the HIP
@@ -168,11 +169,11 @@ def test_agent_sharded_training_step_matches_unsharded_oracle():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_atrain_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_atrain_worker, args=(r, world, port, q, only_v2i)) for r in range(world)]
     for p in procs:
         p.start()
     torch.set_num_threads(2)
-    ref, (bevs, trans, na), (labels, targets, mask) = _atrain_setup()
+    ref, (bevs, trans, na), (labels, targets, mask) = _atrain_setup(only_v2i)
     # Plain SGD on purpose: a conv bias in front of a BatchNorm has a gradient that is exactly zero in mathematics and rounding
     # noise (~1e-17) in any backward; Adam normalises that noise into a +-lr step whose sign depends on the summation order,
     # which would force a loose comparison.  The collectives under test do not depend on the optimizer.
@@ -197,10 +198,59 @@ def test_agent_sharded_training_step_matches_unsharded_oracle():
             scale = float(w.abs().max()) if w.numel() else 0.0
             assert float((g - w).abs().max()) <= 1e-8 * max(scale, 1e-3), (r, k, float((g - w).abs().max()), scale)
     # the step did move the parameters of every part (encoder, fusion MLP, decoder, heads)
-    init = _state(_atrain_setup()[0])
+    init = _state(_atrain_setup(only_v2i)[0])
     for key in ("u_encoder.conv1_1.weight", "pixel_weighted_fusion.conv1_1.weight", "decoder.conv5_1.weight",
                 "classification.conv2.weight", "pixel_weighted_fusion.bn1_2.running_mean"):
         assert float((want[key] - init[key]).abs().max()) > 0, key
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disconet_amd import sharded
+        sh = sharded.AgentShard(4)                      # two agents per rank
+        B, n = 3, 2 * 3                                 # rows per rank = count * B
+        rows = torch.zeros(2 * n, 5)
+        rows[rank * n:(rank + 1) * n] = torch.arange(n * 5, dtype=torch.float32).view(n, 5) + 100 * rank
+        sh.gather_rows(rows, rank * n, n)               # in place: own slice of the gathered buffer
+        contrib = torch.arange(2 * n * 5, dtype=torch.float32).view(2 * n, 5) * (rank + 1)
+        mine = sh.reduce_scatter_rows(contrib, rank * n, n)
+        pad = sh.gather_padded(torch.full((rank + 1, 2), float(rank + 1)), 3)
+        t = sh.sum_(torch.tensor([1.0 + rank, 10.0], dtype=torch.float64))
+        q.put((rank, rows.numpy(), mine.numpy(), pad.numpy(), t.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_agent_shard_collectives_on_two_gloo_ranks():
+    """AgentShard's row collectives where gloo has no native form (reduce_scatter, *_into_tensor): rebuilt from all_reduce /
+    all_gather, checked value by value"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=120)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    n = 6
+    own = lambda r: torch.arange(n * 5, dtype=torch.float32).view(n, 5) + 100 * r
+    full = torch.cat([own(0), own(1)])
+    total = torch.arange(2 * n * 5, dtype=torch.float32).view(2 * n, 5) * 3          # rank 0's + rank 1's contribution
+    for r in range(world):
+        rows, mine, pad, t = got[r]
+        assert torch.equal(torch.from_numpy(rows), full)
+        assert torch.equal(torch.from_numpy(mine), total[r * n:(r + 1) * n])
+        assert pad.shape == (2, 3, 2) and pad[0, 0, 0] == 1 and pad[0, 1, 0] == 0 and pad[1, 1, 1] == 2 and pad[1, 2, 0] == 0
+        assert t.tolist() == [3.0, 20.0]
 
 
 def test_agent_shard_helpers_without_a_process_group():
