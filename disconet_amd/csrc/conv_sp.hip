@@ -110,8 +110,11 @@ struct TileCoord {
 // dn_scatter_dense_bits): the patch's words are loaded to registers and expanded to the hi-only stage's 0x3C00 / 0 halves
 // with VALU + ds_write, so the MFMA loop, its operands and every result are those of AHI = 1 on the expanded grid;
 // the source is 1/8 of the hi-only bytes (1/32 of the float32 grid).  Weight-stationary form only.
+// NB: weight stages of the streaming form -- 2 (a step's weights are requested one step ahead) or 3 (round 5: two steps ahead, for the
+// tiles whose steps are much shorter than the loaded L2 latency and whose LDS has room: the stride-2 8 x 8 tile, 78 KB, still two
+// workgroups per CU).
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST, int BSTAT = 0, int UPM = 0, int AHI = 0, int KSL = 0>
+          int WTM, int WTN, int POST, int BSTAT = 0, int UPM = 0, int AHI = 0, int KSL = 0, int NB = 2>
 struct SpTile {
   using P = sp::Patch<KS, STRIDE, TH, TW>;
   static constexpr int NW = WAVES_M * WAVES_N;
@@ -142,7 +145,9 @@ struct SpTile {
   static constexpr int STG_ROW = 68;                                    // floats, fp32 staging row (max)
   static constexpr int STG_BYTES = POST == 1 ? NW * 32 * STG_ROW * 4 : 0;
   static constexpr int OFF_B = 2 * A_STAGE;
-  static constexpr int OFF_W2 = OFF_B + 2 * B_STAGE;        // streaming form (stationary: runtime)
+  static constexpr int OFF_W2 = OFF_B + NB * B_STAGE;       // streaming form (stationary: runtime)
+  static_assert(NB == 2 || (NB == 3 && KS == 3 && CA == 1 && TG == 3 && POST == 0 && BSTAT == 0 && UPM == 0 && AHI == 0 && KSL == 0),
+                "three weight stages: plain streaming 3x3 tiles, three taps per step");
   static constexpr int OFF_STG = OFF_W2 + W2_BYTES;
   static constexpr int LDS_BYTES = BSTAT ? OFF_B + W2_BYTES : OFF_STG + STG_BYTES;   // stationary (1): + weights
   // stationary form: LDS bytes for `nsteps` weight steps and (POST, fp32 out) staging rows of
@@ -179,12 +184,12 @@ struct SpTile {
 // 1 = no weight DMA after the first step, 2 = no patch DMA after the first group, 3 = neither,
 // 4 = no epilogue stores, 5 = 3 + operands from registers (pure MFMA stream).
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST, int ABL = 0, int BSTAT = 0, int UPM = 0, int AHI = 0, int KSL = 0>
+          int WTM, int WTN, int POST, int ABL = 0, int BSTAT = 0, int UPM = 0, int AHI = 0, int KSL = 0, int NB = 2>
 __global__ void __launch_bounds__(
     (WAVES_M * WAVES_N * 64),
-    (SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI, KSL>::WPS))
+    (SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI, KSL, NB>::WPS))
 conv_sp_kernel(const SpArgs a) {
-  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI, KSL>;
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI, KSL, NB>;
   using P = typename T::P;
   constexpr bool kNoB = ABL == 1 || ABL == 3 || ABL >= 5, kNoA = ABL == 2 || ABL == 3 || ABL >= 5;
   constexpr bool kNoStore = ABL == 4 || ABL == 6 || ABL == 7, kNoLds = ABL >= 5;
@@ -1054,10 +1059,20 @@ conv_sp_kernel(const SpArgs a) {
   setup_rsrc(cur);
   setup_voff_b(cur);
   setup_voff_a(cur, first_group(cw) * CA >= a.c0g);
-  issue_b(first_group(cw), 0, 0, false);
-  issue_a(first_group(cw), 0, false);
   int sb = 0;
   bool a_pending = true;   // A DMAs issued after the B DMAs the next step waits for
+  // NB == 3: DMA instructions THIS wave issued behind the weights of the step it will wait for next -- the patch issued two steps
+  // ago (hist_a2), the weights issued one step ago (hist_b1), the patch issued one step ago (hist_a1): the counted wait of a step
+  int hist_a2 = 0, hist_b1 = 0, hist_a1 = 0;
+  if constexpr (NB == 3) {
+    issue_a(first_group(cw), 0, false);              // the patch first: the first step waits for it together with its weights
+    issue_b(first_group(cw), 0, 0, false);
+    issue_b(first_group(cw), 1, 1, false);
+    hist_b1 = B_IT;
+  } else {
+    issue_b(first_group(cw), 0, 0, false);
+    issue_a(first_group(cw), 0, false);
+  }
 
   while (true) {
     zero_acc();
@@ -1086,9 +1101,32 @@ conv_sp_kernel(const SpArgs a) {
         // group) ago.  At ST == 1 the A patch of the NEXT group may still be in flight behind B.
         // Raw s_barrier: __syncthreads() would add a fence that drains vmcnt to 0 (the LDS-DMA
         // counts as a pending LDS write) and with it the patch still in flight at ST == 1.
-        if (ST == 1 && a_pending) wait_vm<A_IT>(); else wait_vm0();
+        if constexpr (NB == 3) {
+          // this step's weights were requested TWO steps ago; behind them this wave issued hist_a2 + hist_b1 + hist_a1
+          // instructions (wave-uniform; every wave issues A_IT / B_IT per stage in the streaming form)
+          const int young = hist_a2 + hist_b1 + hist_a1;
+          if (young == 0) wait_vm0();
+          else if (young == B_IT) wait_vm<B_IT>();
+          else if (young == A_IT) wait_vm<A_IT>();
+          else wait_vm<A_IT + B_IT>();
+        } else {
+          if (ST == 1 && a_pending) wait_vm<A_IT>(); else wait_vm0();
+        }
         if (!kNoBarrier) __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is done with the previous step
         asm volatile("" ::: "memory");
+        int cnt_b = 0, cnt_a = 0;
+        if constexpr (NB == 3) {
+          // the weights of the step after next -> the stage the previous step just released
+          const int sb2 = sb >= 1 ? sb - 1 : 2;      // (sb + 2) % 3
+          if (ST + 2 < NSG) {
+            issue_b(g, ST + 2, sb2); cnt_b = B_IT;
+          } else if (!last_g) {
+            issue_b(g + 1, ST + 2 - NSG, sb2); cnt_b = B_IT;
+          } else if (has_next) {
+            setup_voff_b(nxt);
+            issue_b(ng0, ST + 2 - NSG, sb2); cnt_b = B_IT;
+          }
+        } else {
         // issue the next step's weights, then (first step of a group) the next group's patch
         if (ST + 1 < NSG) {
           issue_b(g, ST + 1, sb ^ 1);
@@ -1098,19 +1136,21 @@ conv_sp_kernel(const SpArgs a) {
           setup_voff_b(nxt);
           issue_b(ng0, 0, sb ^ 1);
         }
+        }
         if (ST == 0) {
           a_pending = true;
           if (!last_g) {
             if ((g + 1) * CA == a.c0g && a.c1g) setup_voff_a(cur, true);   // concat: switch source
-            issue_a(g + 1, sa ^ 1);
+            issue_a(g + 1, sa ^ 1); cnt_a = A_IT;
           } else if (has_next) {
             setup_rsrc(nxt);
             setup_voff_a(nxt, ng0 * CA >= a.c0g);
-            issue_a(ng0, sa ^ 1);
+            issue_a(ng0, sa ^ 1); cnt_a = A_IT;
           } else {
             a_pending = false;
           }
         }
+        hist_a2 = hist_a1; hist_b1 = cnt_b; hist_a1 = cnt_a;
         if constexpr (MERGED) {
           // row-tap ST of an output row of parity pi reads patch row r + ST + (pi & ST); this wave's
           // parity block of the stage's six weight blocks
@@ -1122,7 +1162,7 @@ conv_sp_kernel(const SpArgs a) {
           compute(std::integral_constant<int, ST * TG>{}, std::integral_constant<int, SUB>{},
                   smem + sa * T::A_STAGE, smem + T::OFF_B + sb * T::B_STAGE);
         }
-        sb ^= 1;
+        if constexpr (NB == 3) sb = sb == 2 ? 0 : sb + 1; else sb ^= 1;
       };
       using Plain = std::false_type;
       if (UPM != 0 && g < a.c0g) {
@@ -1455,10 +1495,10 @@ inline long ks_plan(long T, long R, int S, size_t ws_bytes, size_t bytes_per_til
 }
 
 template <int KS, int STRIDE, int TH, int TW, int BN, int TG, int CA, int WAVES_M, int WAVES_N,
-          int WTM, int WTN, int POST = 0, int ABL = 0, int BSTAT = 0, int UPM = 0, int AHI = 0, int KSL = 0>
+          int WTM, int WTN, int POST = 0, int ABL = 0, int BSTAT = 0, int UPM = 0, int AHI = 0, int KSL = 0, int NB = 2>
 int launch(SpArgs& a, const dn_conv_desc& d, hipStream_t stream) {
-  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI, KSL>;
-  auto kern = conv_sp_kernel<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, ABL, BSTAT, UPM, AHI, KSL>;
+  using T = SpTile<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, BSTAT, UPM, AHI, KSL, NB>;
+  auto kern = conv_sp_kernel<KS, STRIDE, TH, TW, BN, TG, CA, WAVES_M, WAVES_N, WTM, WTN, POST, ABL, BSTAT, UPM, AHI, KSL, NB>;
   const int nchunks = a.c0g + a.c1g;
   DN_REQUIRE(nchunks % CA == 0, "spconv: chunk count %d not a multiple of %d", nchunks, CA);
   a.ngroups = nchunks / CA;
@@ -1824,6 +1864,14 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
       return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1>(a, *d, s);
   }
   if (g_sp_force == S3_256x32_ST) return launch<3, 1, 8, 32, 32, 3, 1, 4, 1, 2, 1, 0, 0, 1>(a, *d, s);
+  // Three weight stages (round 5) on the 8 x 8-pixel tiles, whose steps (9 MFMAs per wave) are far shorter than the loaded L2 latency
+  // and whose LDS has the room (stride 2: 78 KB, two workgroups per CU as before; stride 1: 53 KB, three as before).  DN_SP_B3: bit 0 =
+  // the stride-2 tile, bit 1 = the stride-1 tile (A/B runs; the results are bit-identical -- same operands, same MFMA order).
+  static const int b3_env = [] { const char* e = getenv("DN_SP_B3"); return e ? atoi(e) : 3; }();
+  if (g_sp_force < 0 && c.id == S3S2_64x64 && (b3_env & 1))
+    return launch<3, 2, 8, 8, 64, 3, 1, 2, 2, 1, 1, 0, 0, 0, 0, 0, 0, 3>(a, *d, s);
+  if (g_sp_force < 0 && c.id == S3_64x64 && (b3_env & 2))
+    return launch<3, 1, 8, 8, 64, 3, 1, 2, 2, 1, 1, 0, 0, 0, 0, 0, 0, 3>(a, *d, s);
   switch (c.id) {
     //                               KS S  TH TW  BN TG CA WM WN WTM WTN
     case S3_256x64:   return launch<3, 1, 8, 32, 64, 3, 1, 4, 1, 2, 2>(a, *d, s);
