@@ -36,6 +36,9 @@
 #ifndef DN_PHASE_TIMING
 #define DN_PHASE_TIMING 0
 #endif
+#ifndef DN_S2_ABL
+#define DN_S2_ABL 0      // tools/ab: 1 = instantiate the timing-only ablations of the stride-2 8 x 8 tile (dn_spconv_force_config(400..407))
+#endif
 #ifndef DN_UNIFORM_TILE
 #define DN_UNIFORM_TILE 0   // tools/ab: 1 = every kernel's tile coordinates through v_readfirstlane (scalar registers)
 #endif
@@ -1851,6 +1854,20 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
       default: break;
     }
   }
+#if DN_S2_ABL   // tools/ab build only (AB_FILES=conv_sp tools/ab/build.sh DN_S2_ABL 1): timing-only ablations of the stride-2 8 x 8 tile
+  if (g_sp_force >= 400 && d->ksize == 3 && d->stride == 2) {
+    switch (g_sp_force) {
+      case 400: return launch<3, 2, 8, 8, 64, 3, 1, 2, 2, 1, 1, 0, 0>(a, *d, s);   // as shipped in round 4 (two weight stages)
+      case 401: return launch<3, 2, 8, 8, 64, 3, 1, 2, 2, 1, 1, 0, 1>(a, *d, s);   // no weight DMA after the first step
+      case 402: return launch<3, 2, 8, 8, 64, 3, 1, 2, 2, 1, 1, 0, 2>(a, *d, s);   // no patch DMA after the first chunk
+      case 403: return launch<3, 2, 8, 8, 64, 3, 1, 2, 2, 1, 1, 0, 3>(a, *d, s);   // neither
+      case 404: return launch<3, 2, 8, 8, 64, 3, 1, 2, 2, 1, 1, 0, 4>(a, *d, s);   // no epilogue stores
+      case 405: return launch<3, 2, 8, 8, 64, 3, 1, 2, 2, 1, 1, 0, 5>(a, *d, s);   // 3 + operands from registers: the MFMA stream alone
+      case 407: return launch<3, 2, 8, 8, 64, 3, 1, 2, 2, 1, 1, 0, 7>(a, *d, s);   // 5 + no stores, no barriers
+      default: break;
+    }
+  }
+#endif
   // weight-stationary forms (short-K full-resolution layers): two workgroups per CU
   // DN_SP_STATIONARY=0: weights streamed per step everywhere (A/B runs)
   static const int stat_env = [] { const char* e = getenv("DN_SP_STATIONARY"); return e ? atoi(e) : 1; }();

@@ -415,3 +415,36 @@ def test_stem_pair_refusals():
     pk = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
     with pytest.raises(_lib.DnError):
         ops.sp_conv2d_pre_pair(mk(13, 32), mk(32, 64), bits, pk, z, z, pk, z, z)
+
+
+def test_three_weight_stages_are_bit_identical_to_two():
+    """round 5: the 8 x 8-pixel tiles request a step's weights two steps ahead through a third LDS stage (SpTile NB = 3, counted
+    vmcnt waits from an issue history).  Same operands, same MFMA order: the outputs of the layers that take those tiles -- stride-2
+    layers, a 16 x 16 long-K layer, ragged maps, one- and many-chunk K loops, more tiles than resident workgroups -- must equal the
+    two-stage form's bit for bit.  DN_SP_B3 is read once per process, so each form runs in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import torch
+from disconet_amd import ops
+out = []
+for (n, h, w, c0, c_out, stride) in [(20, 64, 64, 128, 256, 2), (3, 40, 72, 32, 96, 2), (20, 16, 16, 512, 512, 1), (2, 24, 24, 16, 64, 2),
+                                      (5, 16, 24, 64, 128, 1), (64, 32, 32, 32, 64, 2)]:
+    g = torch.Generator().manual_seed(n * 100 + c0)
+    d = ops.conv_desc(n, h, w, c0, c_out, 3, stride, True, math="sp")
+    wt = (torch.randn(c_out, c0, 3, 3, generator=g) * (2.0 / (9 * c0)) ** 0.5).cuda()
+    packed, wmul = ops.sp_pack_conv_weights(d, wt)
+    x = ops.SpTensor.from_nhwc(torch.randn(n, h, w, c0, generator=g).clamp_(min=0).cuda())
+    y = ops.sp_conv2d(d, x, packed, (torch.ones(c_out) / wmul).cuda(), (torch.randn(c_out, generator=g) * 0.1).cuda())
+    torch.cuda.synchronize()
+    out.append(int(y.data.view(torch.int32).long().sum()) ^ (int(y.data.view(torch.int32)[::7].long().sum()) << 1))
+print("CHECKSUMS", out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = {}
+    for b3 in ("0", "3"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, DN_SP_B3=b3), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-600:]
+        sums[b3] = [l for l in r.stdout.splitlines() if l.startswith("CHECKSUMS")][0]
+    assert sums["0"] == sums["3"], sums

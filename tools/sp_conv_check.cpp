@@ -159,6 +159,7 @@ static void run_layer(const char* name, int n, int h, int w, int c0, int c1, int
     if (ks == 1) cfgs.insert(cfgs.end(), {6, 7});
     else if (stride == 2) cfgs.insert(cfgs.end(), {4, 5, 15, 16});
     else cfgs.insert(cfgs.end(), {0, 1, 2, 3, 8, 9, 10, 12, 13, 14});
+    if (g_mode == 2 && ks == 3 && stride == 2 && getenv("SPCHECK_S2_ABL")) cfgs.insert(cfgs.end(), {400, 401, 402, 403, 404, 405, 407});   // a -DDN_S2_ABL=1 library
     if (g_mode == 2 && ks == 3 && stride == 1) cfgs.insert(cfgs.end(), {101, 102, 103, 104, 105, 201, 202, 203, 204, 205, 206, 207, 301, 302, 303, 304, 305});
   }
   if (!g_only_cfgs.empty()) {
