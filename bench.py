@@ -543,6 +543,7 @@ def seg_bench(args, world, rank, dist, use_pg):
             x = ops.scatter_dense(indices, offsets, n_img, dims).view(n_img, MAP_HW, MAP_HW, 13)
             tdata = {"bev_seq": x, "trans_matrices": trans, "num_agent": na, "labels": labels}
             first = tmod.step(tdata, BATCH)
+            tmod.step(tdata, BATCH)        # (the first step measures the gradient maps' lifts, this one warms the split-f16 data gradients)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.train_steps):
@@ -552,6 +553,8 @@ def seg_bench(args, world, rank, dist, use_pg):
             result["train_step"] = {"ms_per_step": round(1e3 * dt, 3), "scenes_per_s": round(BATCH / dt, 2),
                                     "steps": args.train_steps, "batch_per_gpu": BATCH,
                                     "loss_first": round(first["loss"], 5), "loss_last": round(last["loss"], 5),
+                                    "dgrad_math": tmod.engine.dgrad_math,
+                                    "data_gradients_on_the_split_f16_engine": len(tmod.engine._dz_lift),
                                     "note": "SegModule.step: train() forward + cross entropy + explicit HIP backward + Adam, "
                                             "eager launches, wall clock"}
         except Exception as e:
@@ -1041,7 +1044,8 @@ def main():
                         "trans_matrices": trans, "num_agent": na, "labels": labels.cuda(),
                         "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda()}
                 mod = CoDetModule(tmodel, lr=1e-3)
-                first = mod.step(data, BATCH)          # warm-up (allocator, LDS attributes)
+                first = mod.step(data, BATCH)          # warm-up (allocator, LDS attributes); with the default dgrad_math = "sp" also
+                mod.step(data, BATCH)                  # the calibration pass (lifts of the gradient maps), then the split-f16 path's own warm-up
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(args.train_steps):
@@ -1051,9 +1055,31 @@ def main():
                 result["train_step"] = {
                     "ms_per_step": round(1e3 * dt, 3), "scenes_per_s": round(BATCH / dt, 2),
                     "steps": args.train_steps, "batch_per_gpu": BATCH, "loss_first": round(first["loss"], 4),
-                    "loss_last": round(last["loss"], 4),
-                    "note": "train() forward (batch-stat BN) + focal/smooth-L1 loss + explicit HIP backward "
-                            "(dgrad/wgrad on the fp32 MFMA) + Adam, eager launches, wall clock"}
+                    "loss_last": round(last["loss"], 4), "dgrad_math": mod.engine.dgrad_math,
+                    "data_gradients_on_the_split_f16_engine": len(mod.engine._dz_lift),
+                    "note": "train() forward (batch-stat BN) + focal/smooth-L1 loss + explicit HIP backward (3x3 stride-1 data "
+                            "gradients: split-f16 LDS-DMA engine on a lifted, pre-split dz; stride-2 / 1x1 data gradients and "
+                            "every weight gradient: fp32 MFMA) + Adam, eager launches, wall clock"}
+                del mod
+                # the same step with every data gradient on the exact-fp32 MFMA (rounds 2-4's step)
+                try:
+                    fmodel = DiscoNet(Config(map_hw=MAP_HW), kd_flag=0, num_agent=AGENTS)
+                    fmodel.conv_math = args.math
+                    fmodel.cuda()
+                    fmod = CoDetModule(fmodel, lr=1e-3, dgrad_math="f32")
+                    fmod.step(data, BATCH)
+                    fmod.step(data, BATCH)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(args.train_steps):
+                        flast = fmod.step(data, BATCH)
+                    torch.cuda.synchronize()
+                    dtf = (time.perf_counter() - t0) / args.train_steps
+                    result["train_step"]["dgrad_f32"] = {"ms_per_step": round(1e3 * dtf, 3), "scenes_per_s": round(BATCH / dtf, 2),
+                                                         "loss_last": round(flast["loss"], 4)}
+                    del fmod, fmodel
+                except Exception as e:
+                    result["train_step"]["dgrad_f32"] = {"error": repr(e)}
                 # BASELINE configs[2]'s per-GPU step: + frozen teacher forward and the KD KL terms
                 from disconet_amd import TeacherNet
                 from disconet_amd.synthetic import make_bevs
@@ -1065,6 +1091,7 @@ def main():
                 data["bev_seq_teacher"] = make_bevs(BATCH, AGENTS, MAP_HW, p=0.05).cuda()
                 data["kd_weight"] = 1e5
                 kmod = CoDetModule(kmodel, teacher, None, None, kd_flag=1, lr=1e-3)
+                kmod.step(data, BATCH)
                 kmod.step(data, BATCH)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()

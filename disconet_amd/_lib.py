@@ -88,6 +88,8 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "dn_spconv2d_dual": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_int, c_void_p]),
+    "dn_spconv2d_nhwc": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_void_p]),
     "dn_sp_post1x1_packed_bytes": (c_size_t, []),
     "dn_sp_post1x1_pack_weights": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "dn_sp_post1x1_pack_heads": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
@@ -145,6 +147,9 @@ SIGNATURES = {
     "dn_bn_train_backward_finish": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long,
                                             c_void_p, c_void_p]),
+    "dn_bn_train_backward_finish_sp": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long,
+                                               c_void_p, c_void_p, c_float, c_void_p]),
     "dn_bn_train_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                   c_int, c_long, c_int, c_int, c_void_p, c_void_p]),
     "dn_bn_update_running": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_void_p, c_float,

@@ -611,6 +611,9 @@ conv_sp_kernel(const SpArgs a) {
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);
           if (inside && co < c_lim) *reinterpret_cast<f32x4*>(orow + co) = v;
         }
+        // dn_spconv2d_nhwc (the training step's split-f16 data gradient): the fp32 rows are the ONLY output -- nothing is
+        // split, no magnitude is tracked (a gradient may exceed the f16 range: it never becomes an f16 pair here)
+        if (out == nullptr) return;
       }
     }
     u32x2 hi[4], lo[4];
@@ -1605,6 +1608,14 @@ int fill_args(const dn_conv_desc* d, const void* src0, const void* src1, const v
 }  // namespace
 
 namespace dn { void range_collect_conv_sp(unsigned* dst, bool reset, hipStream_t s) { sp_range_collect_here(dst, reset, s); } }
+// device address (current device) of this unit's flag word: kernels of OTHER units that split values (the BatchNorm backward's SP
+// copy of dz, train_ops.hip) report into it instead of growing the list of collectors a captured step replays
+namespace dn {
+unsigned* sp_range_word() {
+  void* p = nullptr;
+  return hipGetSymbolAddress(&p, HIP_SYMBOL(g_sp_range_flags)) == hipSuccess ? (unsigned*)p : nullptr;
+}
+}
 
 extern "C" size_t dn_sp_tensor_bytes(int n_images, int h, int w, int channels) {
   return (size_t)n_images * chunks_of(channels) * 4 * h * w * 16;
@@ -1738,6 +1749,14 @@ extern "C" int dn_spconv2d_dual(const dn_conv_desc* d, const void* src0, const v
   return spconv2d_impl(d, src0, src1, packed, scale, shift, out_sp, out_nhwc, ld_nhwc, stream);
 }
 
+extern "C" int dn_spconv2d_nhwc(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed,
+                                const float* scale, const float* shift, float* out_nhwc, int ld_nhwc, void* stream) {
+  DN_REQUIRE(d && out_nhwc && ld_nhwc >= d->c_out && ld_nhwc % 4 == 0 && d->c_out % 4 == 0 &&
+                 (reinterpret_cast<uintptr_t>(out_nhwc) & 15) == 0,
+             "spconv nhwc: the fp32 NHWC output needs c_out %% 4 == 0, ld >= c_out, ld %% 4 == 0, 16-byte alignment");
+  return spconv2d_impl(d, src0, src1, packed, scale, shift, nullptr, out_nhwc, ld_nhwc, stream);
+}
+
 // K-sliced form: does the layer qualify?  (3x3, no row-merged image, no hi-only source)
 inline bool ks_layer(const dn_conv_desc& d) { return d.ksize == 3 && d.math != 3 && d.math != 4 && up_mode(d) != 1; }
 
@@ -1774,7 +1793,7 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
                   const float* shift, void* out, float* out_nhwc, int ld_nhwc, void* stream, int kslices,
                   void* workspace, size_t workspace_bytes) {
   if (int rc = validate(d)) return rc;
-  DN_REQUIRE(src0 && packed && scale && shift && out, "spconv: null pointer");
+  DN_REQUIRE(src0 && packed && scale && shift && (out || out_nhwc), "spconv: null pointer");
   DN_REQUIRE(d->c1 == 0 || src1, "spconv: c1 > 0 but src1 is null");
   SpArgs a;
   if (int rc = fill_args(d, src0, src1, packed, scale, shift, out, a)) return rc;

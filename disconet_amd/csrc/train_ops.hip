@@ -12,6 +12,7 @@
 // torch.optim.Adam).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <initializer_list>
 
 #include "disconet_train.h"
@@ -278,12 +279,21 @@ bn_bwd_reduce_v4_kernel(GradSrc src, const float* __restrict__ z, const float* _
                            });
 }
 
+// SP: a second copy of dz, multiplied by the power of two `sp_lift`, as the split-planar f16 hi / lo tensor of the inference conv
+// engine (include/disconet_hip.h "SP tensor": [image][c / 16][4 quarters][h][w] x 16 bytes, quarter = 2 * part + octet) -- the
+// operand of the split-f16 data gradient (dn_spconv2d_nhwc).  A piece is 8 channels of one pixel = the values of TWO adjacent
+// threads (c % 16 == 0: an even / odd pair never straddles a wavefront or the end of the loop): they swap halves, the even thread
+// writes the hi piece, the odd one the lo piece.  The split is dn_sp_from_nhwc's (clamp to +-65504, hi = half(x), lo = half(x - hi)),
+// magnitudes reported into the conv engine's sticky range word (`flags`).
+template <bool SP>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_v4_kernel(GradSrc src, const float* __restrict__ z, const float* __restrict__ mean,
                        const float* __restrict__ var, const float* __restrict__ gamma, float eps,
                        long rows_per_group, long norm_rows, const double* __restrict__ sums, long total4,
-                       float* __restrict__ dz) {
+                       float* __restrict__ dz, unsigned char* __restrict__ dz_sp, float sp_lift, unsigned hw,
+                       unsigned* __restrict__ flags) {
   const int c = src.c, c4n = c >> 2;
+  float amax = 0.f;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total4;
        idx += (long)gridDim.x * blockDim.x) {
     const long row = idx / c4n;
@@ -298,8 +308,33 @@ bn_bwd_apply_v4_kernel(GradSrc src, const float* __restrict__ z, const float* __
       m1[e] = (float)(sg[e] / norm_rows);
       m2[e] = (float)(sg[c + e] / norm_rows);
     }
-    *reinterpret_cast<f32x4*>(dz + row * c + 4 * c4) =
-        ldv4(gamma + 4 * c4) * rs * (src.v4(row, c4) - m1 - zh * m2);
+    const f32x4 v = ldv4(gamma + 4 * c4) * rs * (src.v4(row, c4) - m1 - zh * m2);
+    *reinterpret_cast<f32x4*>(dz + row * c + 4 * c4) = v;
+    if constexpr (SP) {
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      f32x4 x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[e] = fminf(fmaxf(v[e] * sp_lift, -65504.f), 65504.f);
+        amax = fmaxf(amax, fabsf(x[e]));
+      }
+      const h4 hi = __builtin_convertvector(x, h4);
+      const h4 lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), h4);
+      const u2 hu = __builtin_bit_cast(u2, hi), lu = __builtin_bit_cast(u2, lo);
+      const bool odd = c4 & 1;
+      // the even thread needs its partner's hi halves, the odd one its partner's lo halves
+      const unsigned t0 = __shfl_xor(odd ? hu[0] : lu[0], 1), t1 = __shfl_xor(odd ? hu[1] : lu[1], 1);
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      const u4 piece = odd ? u4{t0, t1, lu[0], lu[1]} : u4{hu[0], hu[1], t0, t1};
+      const unsigned urow = (unsigned)row, img = urow / hw, px = urow - img * hw;
+      const int oct8 = c4 >> 1, cg = oct8 >> 1, oct = oct8 & 1, cg_total = c >> 4;      // (c % 16 == 0: no padded octet to zero)
+      const size_t q = ((size_t)img * cg_total + cg) * 4 + (odd ? 2 : 0) + oct;
+      *reinterpret_cast<u4*>(dz_sp + (q * hw + px) * 16) = piece;
+    }
+  }
+  if constexpr (SP) {
+    if (amax > 16384.f && flags) atomicOr(flags, amax >= 65504.f ? 3u : 2u);
   }
 }
 
@@ -728,11 +763,12 @@ extern "C" int dn_bn_train_backward_partial(const float* dy_a, int ld_a, int up_
 }
 
 // phase 2: dz of this rank's rows from the (all-reduced) sums, means taken over norm_rows rows per group
-extern "C" int dn_bn_train_backward_finish(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
-                                           const float* y, const float* z, const float* mean, const float* var,
-                                           const float* gamma, float eps, int relu, int n_groups, int h, int w,
-                                           int images_per_group, int c, const double* sums, long norm_rows, float* dz,
-                                           void* stream) {
+namespace {
+int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
+                            const float* y, const float* z, const float* mean, const float* var,
+                            const float* gamma, float eps, int relu, int n_groups, int h, int w,
+                            int images_per_group, int c, const double* sums, long norm_rows, float* dz,
+                            void* dz_sp, float sp_lift, void* stream) {
   DN_REQUIRE(dy_a && z && mean && var && gamma && sums && dz, "bn backward finish: null pointer");
   DN_REQUIRE(!relu || y, "bn backward: relu needs y");
   DN_REQUIRE(n_groups > 0 && h > 0 && w > 0 && images_per_group > 0 && c > 0 && c <= kMaxC && norm_rows > 0 &&
@@ -742,13 +778,44 @@ extern "C" int dn_bn_train_backward_finish(const float* dy_a, int ld_a, int up_a
   const long rows_per_group = (long)images_per_group * h * w;
   GradSrc src{dy_a, dy_b, y, ld_a, up_a, ld_b, relu, h, w, c};
   const long total = (long)n_groups * rows_per_group * c;
+  if (dz_sp) {
+    DN_REQUIRE(n_groups == 1 && c % 16 == 0 && vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz}) &&
+                   (reinterpret_cast<uintptr_t>(dz_sp) & 15) == 0 && rows_per_group < (1L << 31),
+               "bn backward: the SP copy of dz needs one group, c %% 16 == 0, 16-byte aligned tensors (c = %d, groups = %d)", c, n_groups);
+    DN_REQUIRE(sp_lift > 0.f && std::isfinite(sp_lift), "bn backward: sp_lift must be a positive finite power of two");
+    unsigned* flags = dn::sp_range_word();
+    DN_REQUIRE(flags, "bn backward: the range word of the split-f16 engine is not addressable");
+    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel<true>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z, mean, var, gamma,
+                       eps, rows_per_group, norm_rows, sums, total / 4, dz, (unsigned char*)dz_sp, sp_lift, (unsigned)(h * w), flags);
+    return dn::check_launch("bn backward apply kernel (SP copy)");
+  }
   if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz}))
-    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z,
-                       mean, var, gamma, eps, rows_per_group, norm_rows, sums, total / 4, dz);
+    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel<false>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z,
+                       mean, var, gamma, eps, rows_per_group, norm_rows, sums, total / 4, dz, nullptr, 1.f, 1u, nullptr);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, src, z, mean,
                        var, gamma, eps, rows_per_group, norm_rows, sums, total, dz);
   return dn::check_launch("bn_backward apply kernels");
+}
+}  // namespace
+
+extern "C" int dn_bn_train_backward_finish(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
+                                           const float* y, const float* z, const float* mean, const float* var,
+                                           const float* gamma, float eps, int relu, int n_groups, int h, int w,
+                                           int images_per_group, int c, const double* sums, long norm_rows, float* dz,
+                                           void* stream) {
+  return bn_backward_finish_impl(dy_a, ld_a, up_a, dy_b, ld_b, y, z, mean, var, gamma, eps, relu, n_groups, h, w,
+                                 images_per_group, c, sums, norm_rows, dz, nullptr, 1.f, stream);
+}
+
+extern "C" int dn_bn_train_backward_finish_sp(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
+                                              const float* y, const float* z, const float* mean, const float* var,
+                                              const float* gamma, float eps, int relu, int n_groups, int h, int w,
+                                              int images_per_group, int c, const double* sums, long norm_rows, float* dz,
+                                              void* dz_sp, float sp_lift, void* stream) {
+  DN_REQUIRE(dz_sp, "bn backward finish (SP copy): null pointer");
+  return bn_backward_finish_impl(dy_a, ld_a, up_a, dy_b, ld_b, y, z, mean, var, gamma, eps, relu, n_groups, h, w,
+                                 images_per_group, c, sums, norm_rows, dz, dz_sp, sp_lift, stream);
 }
 
 extern "C" int dn_bn_train_backward(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,

@@ -408,15 +408,17 @@ def _pow2_lift(weight):
     return float(2.0 ** max(-20, min(30, 12 - math.floor(math.log2(m)))))
 
 
-def sp_pack_conv_weights(d, weight):
-    """-> (packed uint8 buffer, wmul)"""
+def sp_pack_conv_weights(d, weight, wmul=None):
+    """-> (packed uint8 buffer, wmul).  wmul: the power-of-two lift, when the caller already knows it (the training engine
+    caches it per parameter: _pow2_lift reads max |w| back from the device)"""
     _need_gpu(weight)
     w = weight.detach().reshape(d.c_out, d.c0 + d.c1, d.ksize, d.ksize).contiguous().float()
     lib = _lib.load()
     nbytes = lib.dn_spconv_packed_weight_bytes(ctypes.byref(d))
     if nbytes == 0:
         check(-1, "dn_spconv_packed_weight_bytes")
-    wmul = _pow2_lift(w)
+    if wmul is None:
+        wmul = _pow2_lift(w)
     packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     check(lib.dn_spconv_pack_weights(ctypes.byref(d), _ptr(w), wmul, _ptr(packed), _stream()),
           "dn_spconv_pack_weights")
@@ -464,6 +466,22 @@ def sp_conv2d(d, src0, packed, scale, shift, src1=None, out=None, nhwc_copy=Fals
     check(_lib.load().dn_spconv2d(ctypes.byref(d), _ptr(src0.data), _ptr(src1.data) if src1 is not None else None,
                                   _ptr(packed), _ptr(scale), _ptr(shift), _ptr(out.data), _stream()),
           "dn_spconv2d")
+    return out
+
+
+def sp_conv2d_nhwc(d, src0, packed, scale, shift, out, src1=None):
+    """SP conv whose only output is float32 NHWC rows (dn_spconv2d_nhwc): `out` [n_images, h_out, w_out, c_out], possibly a
+    channel slice of a wider tensor (pixel stride out.stride(2)).  The training step's split-f16 data gradient."""
+    _need_gpu(src0, packed, scale, shift, src1, out)
+    ho, wo = conv_out_hw(d)
+    if (tuple(out.shape) != (d.n_images, ho, wo, d.c_out) or out.dtype != torch.float32 or out.stride(3) != 1
+            or out.stride(1) != wo * out.stride(2) or out.stride(0) != ho * out.stride(1)):
+        raise _lib.DnError("sp_conv2d_nhwc: out must be float32 [n, h_out, w_out, c_out] rows (a channel slice is fine)")
+    if src0.hi_only or src0.bits or (src1 is not None and (src1.hi_only or src1.bits)):
+        raise _lib.DnError("sp_conv2d_nhwc: full SP sources only")
+    check(_lib.load().dn_spconv2d_nhwc(ctypes.byref(d), _ptr(src0.data), _ptr(src1.data) if src1 is not None else None,
+                                       _ptr(packed), _ptr(scale), _ptr(shift), _ptr(out), out.stride(2), _stream()),
+          "dn_spconv2d_nhwc")
     return out
 
 

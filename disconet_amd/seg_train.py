@@ -136,6 +136,7 @@ class SegTrainEngine(TrainEngine):
         dp2 = double_bwd("down2", T.maxpool2_backward(c["x3"], dp3), dy_b=dskip3)
         dp1 = double_bwd("down1", T.maxpool2_backward(c["x2"], dp2), dy_b=dskip2)
         double_bwd("inc", T.maxpool2_backward(c["x1"], dp1), dy_b=dskip1, need_dx=False)
+        self._check_dz_range()
         return G
 
 

@@ -202,6 +202,11 @@ class AgentShard:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def max_(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
     # -- rows of an agent-major [A*B, ...] buffer ---------------------------------------------------------------
     def gather_rows(self, all_rows, lo, n):
         """all_rows[lo:lo + n] holds this rank's rows; afterwards all_rows holds every rank's (rank order == agent order).

@@ -31,6 +31,7 @@ from .model import LAYER_CHANNEL, _bn_name
 _ENC_GROUPS = (("conv_pre_1", "conv_pre_2"), ("conv1_1", "conv1_2", "conv3d_1"),
                ("conv2_1", "conv2_2", "conv3d_2"), ("conv3_1", "conv3_2"), ("conv4_1", "conv4_2"))
 _EPS = 1e-5          # nn.BatchNorm default
+_DGRAD_MATH_DEFAULT = "sp"        # measured (round 5): per-tensor gradient error vs the float64 oracle equal to the fp32 form's to 3 digits
 _MOMENTUM = 0.1
 
 
@@ -147,13 +148,20 @@ class TrainEngine:
                                lambda self, v: setattr(self, "_overlap_streams",
                                                        ops.check_overlap_request(v, "TrainEngine.overlap_streams")))
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, shard=None):
-        """shard: a sharded.AgentShard -- this process trains the agents [shard.first, shard.first + shard.count) of every
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, shard=None, dgrad_math=None):
+        """dgrad_math: arithmetic of the 3x3 stride-1 data gradients -- "f32" (the exact fp32 MFMA) or "sp" (the inference
+        engine's split-f16 LDS-DMA kernels on a dz the BatchNorm backward writes pre-split and lifted, see _dz_sp_plan);
+        None: DISCONET_DGRAD_MATH, default _DGRAD_MATH_DEFAULT.
+        shard: a sharded.AgentShard -- this process trains the agents [shard.first, shard.first + shard.count) of every
         scene (agent-parallel training): forward() / backward() then take the LOCAL agent-major images and
         exchange BatchNorm sums (all-reduce), the layer-`layer` maps (all-gather), the gradient of those maps (reduce-scatter)
         and the parameter gradients (all-reduce, summed) through it.  None: every agent lives here."""
         self.model = model
         self.shard = shard
+        self.dgrad_math = dgrad_math if dgrad_math is not None else os.environ.get("DISCONET_DGRAD_MATH", _DGRAD_MATH_DEFAULT)
+        if self.dgrad_math not in ("f32", "sp"):
+            raise ValueError("dgrad_math must be 'f32' or 'sp' (got %r)" % (self.dgrad_math,))
+        self._dz_lift = {}           # layer name -> (power-of-two lift of its dz, step it was measured at)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.generation = 0          # bumped by every forward(): the saved activations belong to it
@@ -305,26 +313,76 @@ class TrainEngine:
         gb = self.g(lay.b, G) if gb is None else gb
         ggamma = self.g(lay.bn.weight, G) if ggamma is None else ggamma
         gbeta = self.g(lay.bn.bias, G) if gbeta is None else gbeta
+        sp, lift = self._dz_sp_plan(lay, c, need_dx)
         dz = T.bn_backward(dy_a, c["y"], c["z"], c["mean"], c["var"], c["gamma"], _EPS, ggamma, gbeta,
-                           relu=True, dy_b=dy_b, up_a=up_a, **self._bn_sync(c["z"], c["groups"]))
-        return self._conv_bwd(c["desc"], c["w"], c["src0"], c["src1"], dz, gw, gb, need_dx)
+                           relu=True, dy_b=dy_b, up_a=up_a, sp_out=sp, sp_lift=lift, **self._bn_sync(c["z"], c["groups"]))
+        if lift is not None:
+            self._dz_lift_refresh(lay, dz)
+        return self._conv_bwd(c["desc"], c["w"], c["src0"], c["src1"], dz, gw, gb, need_dx, dz_sp=sp, dz_lift=lift)
+
+    def _dz_sp_plan(self, lay, c, need_dx):
+        """-> (SpTensor that shall receive dz * lift, lift) when this layer's data gradient runs on the split-f16 engine, else
+        (None, None) / (None, 1.0) while the lift is still unknown.  The engine's operands are f16 hi + lo pairs: 2^-22 relative
+        only while 2^-3 <= |x| <= 65504, and a gradient's magnitude is anything -- so dz is LIFTED by a power of two that puts its
+        largest element near 2^8 (19 binades of full precision below it, 256 x of head room above; include/disconet_train.h ::
+        dn_bn_train_backward_finish_sp).  The lift of a layer is measured (max |dz|, a host read) on the first step, which runs
+        that layer's data gradient in fp32, and again every 64 steps; a dz that outgrows it is clamped AND flagged (the range
+        guard polled at the end of the step raises: the step's gradients are invalid)."""
+        d = c["desc"]
+        if (self.dgrad_math != "sp" or not need_dx or d.ksize != 3 or d.stride != 1 or c["groups"] != 1
+                or d.c_out % 16 != 0 or (d.c0 + d.c1) % 4 != 0):
+            return None, None
+        ent = self._dz_lift.get(lay.name)
+        if ent is None:
+            return None, 1.0            # not measured yet: fp32 this step, _dz_lift_refresh measures
+        z = c["z"]
+        return ops.SpTensor(z.shape[0], z.shape[1], z.shape[2], z.shape[3], device=z.device), ent[0]
+
+    def _dz_lift_refresh(self, lay, dz):
+        ent = self._dz_lift.get(lay.name)
+        if ent is not None and abs(self.step_count - ent[1]) < 64:
+            return
+        m = float(dz.abs().max())        # host read: first step and every 64th only
+        if self.shard is not None and self.shard.world > 1:
+            t = torch.tensor([m], dtype=torch.float64, device=dz.device)
+            m = float(self.shard.max_(t)[0])         # one lift for all ranks: the replicas must stay bit-identical
+        if not (m > 0.0) or m != m or m == float("inf"):
+            self._dz_lift.pop(lay.name, None)
+            return
+        import math
+        self._dz_lift[lay.name] = (float(2.0 ** max(-100, min(100, 8 - math.floor(math.log2(m))))), self.step_count)
 
     def _conv_bwd(self, d, w, src0, src1, dz, gw, gb, need_dx=True, dw_cin_total=0, w_ci_first=0,
-                  w_c_in=None, dx_out=None):
+                  w_c_in=None, dx_out=None, dz_sp=None, dz_lift=None):
         T.conv_wgrad(d, src0, src1, dz, gw, dw_cin_total=dw_cin_total)
         if gb is not None:
             T.channel_sum(dz, gb)
         if not need_dx:
             return None
-        return self._dgrad(d, w, dz, w_ci_first, w_c_in, dx_out)
+        return self._dgrad(d, w, dz, w_ci_first, w_c_in, dx_out, dz_sp, dz_lift)
 
-    def _dgrad(self, d, w, dz, ci_first=0, c_in=None, dx_out=None):
-        """data gradient = forward engine on dz with flipped / transposed weights.  Always the
-        exact-fp32 MFMA mode: a split-f16 product carries 22 mantissa bits against fp32's 24, and
-        this backward amplifies relative error by ~1e5 (BatchNorm's mean subtraction, see
-        tests/test_gpu_train_step.py) -- measured 3.6 % error on conv5_1.weight's gradient with
-        split-f16 dgrad against 1 % with fp32 (= ATen's own fp32 autograd)."""
+    def _dgrad(self, d, w, dz, ci_first=0, c_in=None, dx_out=None, dz_sp=None, dz_lift=None):
+        """data gradient = a forward engine on dz with flipped / transposed weights.
+        fp32 form (dgrad_math = "f32", and always: 1x1 layers, the parity-phase stride-2 form, a layer whose lift is not
+        measured yet): the exact-fp32 MFMA.  This backward amplifies relative error by ~1e5 (BatchNorm's mean subtraction,
+        tests/test_gpu_train_step.py), and the NHWC engine's split-f16 mode, which splits dz as it stages it WITHOUT a lift,
+        measured 3.6 % error on conv5_1.weight's gradient against fp32's 1 % (rounds 2-4: most of a small gradient's lo halves
+        are f16 subnormals there).
+        split-f16 form (dz_sp given: dz * dz_lift pre-split by the BatchNorm backward): the inference engine's LDS-DMA kernels
+        (dn_spconv2d_nhwc), 1 / (dz_lift * wmul) in the scale vector."""
         w4 = w.reshape(w.shape[0], w.shape[1], d.ksize, d.ksize)
+        if dz_sp is not None:
+            wt = T.dgrad_weights(w4, ci_first, c_in)
+            n_in = wt.shape[0]
+            dev = dz.device
+            dd = ops.conv_desc(d.n_images, d.h_in, d.w_in, d.c_out, n_in, 3, 1, False)
+            wmul = self._wmul_of(w)
+            packed, _ = ops.sp_pack_conv_weights(dd, wt, wmul)
+            if dx_out is None:
+                dx_out = torch.empty((d.n_images, d.h_in, d.w_in, n_in), dtype=torch.float32, device=dev)
+            ops.sp_conv2d_nhwc(dd, dz_sp, packed, self._const(dev, n_in, 1.0 / (dz_lift * wmul)), self._const(dev, n_in, 0.0),
+                               dx_out)
+            return dx_out
         if (d.stride == 2 and d.ksize == 3 and d.h_in % 2 == 0 and d.w_in % 2 == 0
                 and os.environ.get("DN_DGRAD_PARITY", "1") != "0"):
             # parity-phase form: four stride-1 convs over dz of 1 / 2 / 2 / 4 taps, each writing one parity class of dx
@@ -615,7 +673,24 @@ class TrainEngine:
             d.record_stream(main)
         for k in range(lay_k, -1, -1):
             d = group_bwd(k, d)
+        self._check_dz_range()
         return G
+
+    def _check_dz_range(self):
+        """dgrad_math = "sp": did a dz outgrow its lift?  A blocking read of the engine's sticky range flags BEFORE the optimizer
+        step (the step ends in a host read of the losses anyway): a clamped dz means wrong gradients -- the lifts are dropped
+        (the next backward measures them again, in fp32) and the step is refused with the parameters untouched."""
+        if self.dgrad_math != "sp" or not self._dz_lift:
+            return
+        flags = ops.sp_range_flags(reset=True)
+        if flags & 1:
+            self._dz_lift.clear()
+            raise ops._lib.DnError(
+                "backward: a gradient map outgrew the power-of-two lift of its split-f16 copy (|dz| * lift > 65504); the "
+                "gradients of this step are invalid and were NOT applied.  The lifts are re-measured by the next step; a run "
+                "that keeps tripping this wants dgrad_math = 'f32'.")
+        if flags & 4:
+            raise ops._lib.DnError("backward: a NaN reached a split-f16 epilogue")
 
     def _fusion_bwd(self, dfused, G):
         m, L, F, c = self.model, self.L, self.F, self.fctx
@@ -750,7 +825,7 @@ class CoDetModule:
     layer-3 map (vs the teacher's x3) joins the loss."""
 
     def __init__(self, model, teacher=None, config=None, optimizer=None, kd_flag=0, lr=1e-3,
-                 alpha=0.25, gamma=2.0, sigma=3.0, shard=None):
+                 alpha=0.25, gamma=2.0, sigma=3.0, shard=None, dgrad_math=None):
         """shard (sharded.AgentShard): agent-parallel training -- step() then takes THIS rank's agents' images, labels and
         targets (agent-major, [count * B, ...]); trans_matrices / num_agent stay the whole scenes'.  Not with kd_flag."""
         if kd_flag and teacher is None:
@@ -766,7 +841,7 @@ class CoDetModule:
             lr = grp["lr"]
             kw = {"betas": tuple(grp.get("betas", (0.9, 0.999))), "eps": grp.get("eps", 1e-8),
                   "weight_decay": grp.get("weight_decay", 0.0)}
-        self.engine = TrainEngine(model, lr=lr, shard=shard, **kw)
+        self.engine = TrainEngine(model, lr=lr, shard=shard, dgrad_math=dgrad_math, **kw)
         model.__dict__["_train_engine"] = self.engine
         self.alpha, self.gamma, self.sigma = alpha, gamma, sigma
 
@@ -777,7 +852,9 @@ class CoDetModule:
             self.engine.lr *= gamma
         return self.engine.lr
 
-    def step(self, data, batch_size):
+    def step(self, data, batch_size, update=True):
+        """update = False: forward, losses and every gradient (engine.flat_g), but no gradient exchange and no Adam step --
+        tests, and the calibration pass of dgrad_math = "sp" (the first backward measures the gradient maps' lifts)"""
         bev_seq = data["bev_seq"]
         eng = self.engine
         self.model.train()
@@ -800,8 +877,9 @@ class CoDetModule:
                 dkd = {k: T.kd_kl_loss(o[k], t, kd_weight, kd)
                        for k, t in (("x5", t5), ("x6", t6), ("x7", t7), ("fused", t3))}
             eng.backward(dcls, dloc, dkd=dkd)
-            eng.allreduce_grads()
-            eng.optimizer_step()
+            if update:
+                eng.allreduce_grads()
+                eng.optimizer_step()
         if eng.shard is not None:
             eng.shard.sum_(losses)                    # reported losses: the whole scenes', as without a shard
         l = losses.tolist()

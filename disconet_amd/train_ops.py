@@ -121,10 +121,12 @@ def bn_update_running(mean, var, rows_per_group, running_mean, running_var, mome
 
 
 def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_b=None, up_a=False,
-                accumulate=False, out=None, sync=None, norm_rows=None):
+                accumulate=False, out=None, sync=None, norm_rows=None, sp_out=None, sp_lift=1.0):
     """z, y [n, h, w, c] dense.  dy_a: [n, h, w, c'] view (or [n, 2h, 2w, c'] when up_a), dy_b
     optional second gradient (same resolution as y).  Returns dz; fills dgamma / dbeta.
-    sync / norm_rows (agent-parallel training, see bn_stats): dgamma / dbeta are then THIS rank's share (sums over its rows)."""
+    sync / norm_rows (agent-parallel training, see bn_stats): dgamma / dbeta are then THIS rank's share (sums over its rows).
+    sp_out / sp_lift: an ops.SpTensor [n, h, w, c] that also receives dz * sp_lift as f16 hi / lo planes
+    (dn_bn_train_backward_finish_sp: the operand of the split-f16 data gradient; one group, c % 16 == 0)."""
     _need_gpu(dy_a, dy_b, y, z, mean, var, gamma)
     n, h, w, c = z.shape
     n_groups = mean.shape[0]
@@ -132,6 +134,21 @@ def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_
     dz = torch.empty_like(z) if out is None else out
     lib = _lib.load()
     sums = _ws(z.device, lib.dn_reduce_workspace_bytes(n_groups, (n // n_groups) * h * w, c))
+    if sp_out is not None:
+        if tuple(sp_out.shape) != (n, h, w, c) or sp_out.hi_only or sp_out.bits:
+            raise _lib.DnError("bn_backward: sp_out must be a full SP tensor of z's shape")
+        src = (_ptr(dy_a), _ld(dy_a), int(bool(up_a)), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0, _ptr(y), _ptr(z),
+               _ptr(mean), _ptr(var))
+        check(lib.dn_bn_train_backward_partial(*src, float(eps), int(relu), n_groups, h, w, n // n_groups, c, _ptr(sums),
+                                               sums.numel(), _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)), _stream()),
+              "dn_bn_train_backward_partial")
+        if sync is not None:
+            sync(_folded(sums, n_groups, c))
+        rows = int(norm_rows if norm_rows is not None else (n // n_groups) * h * w)
+        check(lib.dn_bn_train_backward_finish_sp(*src, _ptr(gamma), float(eps), int(relu), n_groups, h, w, n // n_groups, c,
+                                                 _ptr(sums), rows, _ptr(dz), _ptr(sp_out.data), float(sp_lift), _stream()),
+              "dn_bn_train_backward_finish_sp")
+        return dz
     if sync is None:
         check(lib.dn_bn_train_backward(
             _ptr(dy_a), _ld(dy_a), int(bool(up_a)), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0,

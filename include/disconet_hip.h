@@ -284,6 +284,12 @@ int dn_spconv2d_pre_pair(const dn_conv_desc* d1, const dn_conv_desc* d2, const u
 int dn_spconv2d_dual(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp, const void* packed,
                      const float* scale, const float* shift, void* out_sp, float* out_nhwc, int ld_nhwc,
                      void* stream);
+/* dn_spconv2d whose ONLY output is the float32 NHWC copy (no SP tensor is written, nothing is split, no magnitude is
+ * tracked): the training step's split-f16 data gradient -- src0 = dz as an SP tensor (dn_bn_train_backward_finish_sp),
+ * packed = the flipped / transposed weights, scale = 1 / (sp_lift * wmul), shift = 0, relu = 0.  Same restrictions as
+ * dn_spconv2d_dual (not on the tap-merged up-conv kernel). */
+int dn_spconv2d_nhwc(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp, const void* packed,
+                     const float* scale, const float* shift, float* out_nhwc, int ld_nhwc, void* stream);
 /* Fused 3x3 (64 channels) + affine + ReLU, then 1x1 + affine (+ReLU): the 64-channel tile
  * never leaves the registers between the two layers (cf. dn_conv2d_post1x1).
  * out_f32 == 0: out_a is an SP tensor of c_out2 channels (p->split, ldo_* ignored);

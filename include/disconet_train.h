@@ -114,6 +114,18 @@ int dn_bn_train_backward_finish(const float* dy_a, int ld_a, int up_a, const flo
                                 int n_groups, int h, int w, int images_per_group, int c, const double* sums, long norm_rows,
                                 float* dz, void* stream);
 
+/* dn_bn_train_backward_finish that ALSO writes dz * sp_lift as the SP tensor [n][c / 16][4][h][w] x 16 bytes of the inference conv
+ * engine (disconet_hip.h "SP tensor") -- the pre-split operand of the split-f16 data gradient (dn_spconv2d_nhwc): the split is
+ * paid once, by the kernel that produces dz, not by the conv's staging.  One group, c % 16 == 0, 16-byte aligned tensors.
+ * sp_lift: a power of two that brings max |dz| * sp_lift to ~2^8 -- a value is stored as half(x) + half(x - half(x)): 2^-22
+ * relative while 2^-3 <= |x| <= 65504, so the top 19 binades of the tensor keep full precision, smaller elements an absolute floor
+ * of 2^-25 / sp_lift, and 256 x of head room remains before the clamp (which sets bit 0 of dn_sp_range_flags: the gradients of
+ * that step are invalid).  The caller folds 1 / sp_lift into the data gradient's scale vector (exact). */
+int dn_bn_train_backward_finish_sp(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b, const float* y,
+                                   const float* z, const float* mean, const float* var, const float* gamma, float eps, int relu,
+                                   int n_groups, int h, int w, int images_per_group, int c, const double* sums, long norm_rows,
+                                   float* dz, void* dz_sp, float sp_lift, void* stream);
+
 /* out[c] (+)= sum over rows of x[row][c] (bias gradients); sums: dn_reduce_workspace_bytes(1, rows, c) bytes */
 int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, size_t sums_bytes, float* out,
                    int accumulate, void* stream);

@@ -222,6 +222,84 @@ def test_bn_backward_of_upsampled_gradient_and_running_stats():
     assert rel_err(rm, bn.running_mean) < 1e-6 and rel_err(rv, bn.running_var) < 1e-6
 
 
+@pytest.mark.parametrize("shape,up_a,lift", [((3, 16, 32, 64), False, 2.0 ** 9), ((2, 8, 8, 512), False, 2.0 ** 12),
+                                             ((2, 32, 32, 32), True, 2.0 ** 14)])
+def test_bn_backward_sp_copy_is_the_split_of_the_lifted_dz(shape, up_a, lift):
+    """dn_bn_train_backward_finish_sp: dz itself is bit for bit the plain call's, and the SP copy holds exactly the f16 hi / lo
+    split of dz * lift (what dn_sp_from_nhwc makes of it) -- pieces of two threads' values, ragged wavefronts, the x2 gradient."""
+    from disconet_amd import ops, train_ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(21)
+    z = (torch.randn(shape, generator=g) * 2 + 0.5).to(_dev())
+    gm = (torch.rand(c, generator=g) + 0.5).to(_dev())
+    bt = (torch.randn(c, generator=g) * 0.2).to(_dev())
+    mean, var = train_ops.bn_stats(z)
+    y = train_ops.bn_apply(z, mean, var, gm, bt, 1e-5, relu=True)
+    dy = (torch.randn((n, 2 * h, 2 * w, c + 16) if up_a else (n, h, w, c + 16), generator=g) * 1e-3).to(_dev())[..., 16:]
+    dg0, db0 = torch.empty(c, device=_dev()), torch.empty(c, device=_dev())
+    dg1, db1 = torch.empty(c, device=_dev()), torch.empty(c, device=_dev())
+    dz0 = train_ops.bn_backward(dy, y, z, mean, var, gm, 1e-5, dg0, db0, up_a=up_a)
+    sp = ops.SpTensor(n, h, w, c, device=_dev())
+    sp.data.fill_(7.0)
+    dz1 = train_ops.bn_backward(dy, y, z, mean, var, gm, 1e-5, dg1, db1, up_a=up_a, sp_out=sp, sp_lift=lift)
+    assert torch.equal(dz0, dz1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    want = ops.SpTensor.from_nhwc(dz0 * lift)
+    assert torch.equal(sp.data.view(torch.int16), want.data.view(torch.int16))
+    assert float((sp.nhwc() / lift - dz0).abs().max()) <= 2.0 ** -21 * float(dz0.abs().max())
+
+
+def test_bn_backward_sp_copy_flags_a_gradient_that_outgrows_its_lift():
+    from disconet_amd import ops, train_ops
+    n, h, w, c = 1, 8, 8, 32
+    g = torch.Generator().manual_seed(22)
+    z = torch.randn(n, h, w, c, generator=g).to(_dev())
+    gm, bt = torch.ones(c, device=_dev()), torch.zeros(c, device=_dev())
+    mean, var = train_ops.bn_stats(z)
+    y = train_ops.bn_apply(z, mean, var, gm, bt, 1e-5, relu=True)
+    dy = torch.randn(n, h, w, c, generator=g).to(_dev())
+    dg, db = torch.empty(c, device=_dev()), torch.empty(c, device=_dev())
+    ops.sp_range_flags(reset=True)
+    sp = ops.SpTensor(n, h, w, c, device=_dev())
+    train_ops.bn_backward(dy, y, z, mean, var, gm, 1e-5, dg, db, sp_out=sp, sp_lift=2.0 ** 8)
+    assert ops.sp_range_flags(reset=True) & 1 == 0
+    train_ops.bn_backward(dy, y, z, mean, var, gm, 1e-5, dg, db, sp_out=sp, sp_lift=2.0 ** 20)
+    assert ops.sp_range_flags(reset=True) & 1 == 1          # clamped to +-65504: the caller must discard the gradients
+
+
+@pytest.mark.parametrize("n,h,w,c_out,c_in", [(2, 16, 16, 256, 768), (3, 32, 64, 32, 96), (1, 64, 64, 64, 64), (2, 8, 8, 512, 512)])
+def test_split_f16_data_gradient_through_the_inference_engine(n, h, w, c_out, c_in):
+    """dx = conv(dz; flipped / transposed weights) on the split-planar engine with fp32 rows as its only output
+    (dn_spconv2d_nhwc), dz lifted and pre-split: against float64 autograd at the engine's 2^-22-per-operand accuracy, written
+    into a channel slice, and bit for bit the fp32 copy of dn_spconv2d_dual."""
+    from disconet_amd import ops, train_ops
+    g = torch.Generator().manual_seed(31)
+    wgt = torch.randn(c_out, c_in, 3, 3, generator=g) * (2.0 / (9 * c_in)) ** 0.5
+    dz = torch.randn(n, h, w, c_out, generator=g) * 3e-4                  # a gradient map's magnitudes: f16 subnormal lo halves without a lift
+    x = torch.zeros(n, c_in, h, w, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, wgt.double(), padding=1).backward(dz.permute(0, 3, 1, 2).double())
+    want = x.grad.permute(0, 2, 3, 1)
+    import math
+    lift = 2.0 ** (8 - math.floor(math.log2(float(dz.abs().max()))))
+    dzd = dz.to(_dev())
+    sp = ops.SpTensor.from_nhwc(dzd * lift)
+    wt = train_ops.dgrad_weights(wgt.to(_dev()), 0, None)
+    dd = ops.conv_desc(n, h, w, c_out, c_in, 3, 1, False)
+    packed, wmul = ops.sp_pack_conv_weights(dd, wt)
+    scale = torch.full((c_in,), 1.0 / (lift * wmul), device=_dev())
+    shift = torch.zeros(c_in, device=_dev())
+    wide = torch.full((n, h, w, c_in + 8), 5.0, device=_dev())
+    dx = ops.sp_conv2d_nhwc(dd, sp, packed, scale, shift, wide[..., 8:])
+    assert rel_err(dx, want) < 3e-6
+    assert float(wide[..., :8].min()) == 5.0 and float(wide[..., :8].max()) == 5.0
+    _, flat = ops.sp_conv2d(dd, sp, packed, scale, shift, nhwc_copy=True)
+    assert torch.equal(flat, dx)
+    # without the lift the same engine loses the lo halves (f16 subnormals): the measurement behind rounds 2-4's "fp32 only"
+    sp0 = ops.SpTensor.from_nhwc(dzd)
+    dx0 = ops.sp_conv2d_nhwc(dd, sp0, packed, torch.full((c_in,), 1.0 / wmul, device=_dev()), shift,
+                             torch.empty(n, h, w, c_in, device=_dev()))
+    assert rel_err(dx0, want) > 20 * rel_err(dx, want)
+
+
 def test_channel_sum_add_rows_and_pair_kernels():
     from disconet_amd import train_ops
     g = torch.Generator().manual_seed(2)
