@@ -30,7 +30,7 @@ hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
 }
 }  // namespace dn
 
-extern "C" int dn_version(void) { return 130; }  // 0.1.3: round-5 kernels (profiles carry this number)
+extern "C" int dn_version(void) { return 131; }  // 0.1.3: round-5 kernels (profiles carry this number; 131: dn_conv_wgrad_sp)
 
 // The hash of every source / header / flag this library was built from (csrc/build.py :: tree_hash), behind a marker
 // that build.py also finds in the file without loading it.  _lib.load() refuses a library whose id is not the tree's.
@@ -52,6 +52,7 @@ extern "C" int dn_sp_range_flags_async(unsigned* dst_device, int reset, void* st
   dn::range_collect_conv_sp(dst_device, clear, s);
   dn::range_collect_conv_spq(dst_device, clear, s);
   dn::range_collect_fuse_mlp(dst_device, clear, s);
+  dn::range_collect_conv_wgrad(dst_device, clear, s);
   return dn::check_launch("sp_range_collect_kernel");
 }
 

@@ -18,13 +18,14 @@
 // slices in a fixed order (deterministic, no float atomics in HBM) into OIHW.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+#include <cstdint>
+
 #include "disconet_train.h"
 #include "dn_internal.h"
+#include "sp_device.h"
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct WgradArgs {
   const float* src0;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad64_kernel(const WgradArgs a)
 // partial [slice][cot][cit][tap][ct co][ct ci] -> dW [c_out][c_in][taps] (OIHW), slices summed in order
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                     int n_slices, int n_cot, int n_cit, int taps, int c_out, int c_in,
-                                    int cin_total, int accumulate, int ct) {
+                                    int cin_total, int accumulate, int ct, float scale) {
   const long per_slice = (long)n_cot * n_cit * taps * ct * ct;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < per_slice;
        idx += (long)gridDim.x * blockDim.x) {
@@ -357,11 +358,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
       s3 += partial[(sl + 3) * per_slice + idx];
     }
     for (; sl < n_slices; ++sl) s0 += partial[sl * per_slice + idx];
-    const float s = (s0 + s1) + (s2 + s3);
+    const float s = ((s0 + s1) + (s2 + s3)) * scale;      // 1 (fp32 kernels) or 1 / (dz_lift * x_lift), a power of two: exact
     float* dst = dw + ((size_t)co * cin_total + ci) * taps + t;
     *dst = accumulate ? *dst + s : s;
   }
 }
+
+#include "wgrad_sp.inl"
 
 int out_dim(int in, int k, int stride) { return (in + 2 * (k / 2) - k) / stride + 1; }
 
@@ -481,9 +484,100 @@ extern "C" int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const flo
   const int blocks = (int)((per_slice + 255) / 256 < 2048 ? (per_slice + 255) / 256 : 2048);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, dw_oihw, p.n_slices,
                      p.n_cot, p.n_cit, p.taps, d->c_out, d->c0 + d->c1,
-                     dw_cin_total ? dw_cin_total : d->c0 + d->c1, accumulate, p.ct);
+                     dw_cin_total ? dw_cin_total : d->c0 + d->c1, accumulate, p.ct, 1.0f);
   return dn::check_launch("wgrad_reduce_kernel");
 }
+
+// ---- split-f16 form (wgrad_sp.inl) ------------------------------------------------------------------------
+namespace {
+// channels per side of a workgroup's block: 64, 32, or 0 = the layer has no split-f16 kernel
+int sp_block(const dn_conv_desc& d) {
+  if (d.ksize != 3 || d.stride != 1 || d.c_out % 4 != 0 || d.ld0 % 4 != 0 || (d.c1 != 0 && d.ld1 % 4 != 0) || d.ldo % 4 != 0) return 0;
+  if (d.c_out >= 64 && d.c0 % 64 == 0 && d.c1 % 64 == 0) return 64;
+  if (d.c_out >= 32 && d.c0 % 32 == 0 && d.c1 % 32 == 0) return 32;
+  return 0;
+}
+Plan make_plan_sp(const dn_conv_desc& d, int cb) {
+  Plan p;
+  p.ct = cb;
+  p.h_out = d.h_in;
+  p.w_out = d.w_in;
+  const int th = cb == 64 ? WspShape<64>::TH : WspShape<32>::TH;
+  p.tiles_x = (p.w_out + 15) / 16;
+  p.tiles_y = (p.h_out + th - 1) / th;
+  p.n_tiles = d.n_images * p.tiles_x * p.tiles_y;
+  p.n_cot = (d.c_out + cb - 1) / cb;
+  p.n_cit = d.c0 / cb + d.c1 / cb;
+  p.taps = 9;
+  // one resident generation (2 workgroups per CU).  The slice is the fast index of a work item and workgroups go round the
+  // 8 XCDs by index: with a multiple of 8 slices every (co, ci) block of one slice -- the workgroups that read the same pixel
+  // tiles at about the same time -- sits on ONE XCD, behind one L2.
+  int s = 512 / (p.n_cot * p.n_cit);
+  if (s > p.n_tiles / 4) s = p.n_tiles / 4;
+  if (s >= 8) s &= ~7;
+  if (s < 1) s = 1;
+  p.n_slices = s;
+  return p;
+}
+template <int CB>
+int launch_sp(const WgradSpArgs& a, const Plan& p, hipStream_t stream) {
+  constexpr int lds = WspShape<CB>::LDS_DWORDS * 4;
+  auto kern = conv_wgrad_sp_kernel<CB>;
+  static dn::PerDeviceFlag ready_flag;
+  bool& ready = ready_flag.here();
+  if (!ready) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return dn::fail(DN_ERR_LAUNCH, "wgrad_sp: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+    ready = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.n_cot * p.n_cit * p.n_slices), dim3(256), lds, stream, a);
+  return dn::check_launch("conv_wgrad_sp_kernel");
+}
+}  // namespace
+
+extern "C" int dn_conv_wgrad_sp_supported(const dn_conv_desc* d) {
+  return d != nullptr && validate(d) == DN_OK ? sp_block(*d) : 0;
+}
+
+extern "C" size_t dn_conv_wgrad_sp_workspace(const dn_conv_desc* d) {
+  const int cb = dn_conv_wgrad_sp_supported(d);
+  if (!cb) return 0;
+  const Plan p = make_plan_sp(*d, cb);
+  return (size_t)p.n_slices * p.n_cot * p.n_cit * 9 * cb * cb * sizeof(float);
+}
+
+extern "C" int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz, void* workspace,
+                                float* dw_oihw, int dw_cin_total, int accumulate, float dz_lift, float x_lift, void* stream) {
+  if (int rc = validate(d)) return rc;
+  const int cb = sp_block(*d);
+  DN_REQUIRE(cb != 0, "wgrad_sp: 3x3 stride-1 layers with c_out >= 32 and sources of 32 k channels only (dn_conv_wgrad_sp_supported)");
+  DN_REQUIRE(src0 && dz && workspace && dw_oihw, "wgrad_sp: null pointer");
+  DN_REQUIRE(dw_cin_total == 0 || dw_cin_total >= d->c0 + d->c1, "wgrad_sp: dw_cin_total %d < c_in", dw_cin_total);
+  DN_REQUIRE(d->c1 == 0 || src1, "wgrad_sp: c1 > 0 needs src1");
+  auto pow2 = [](float v) { int e; return v > 0.f && std::isfinite(v) && std::frexp(v, &e) == 0.5f; };
+  DN_REQUIRE(pow2(dz_lift) && pow2(x_lift), "wgrad_sp: the lifts must be powers of two (got %g, %g)", dz_lift, x_lift);
+  auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+  DN_REQUIRE(al16(src0) && al16(dz) && (d->c1 == 0 || al16(src1)), "wgrad_sp: sources must be 16-byte aligned");
+  const Plan p = make_plan_sp(*d, cb);
+  WgradSpArgs a;
+  a.src0 = src0; a.src1 = src1; a.dz = dz; a.partial = static_cast<float*>(workspace);
+  a.n_images = d->n_images; a.h_in = d->h_in; a.w_in = d->w_in;
+  a.c0 = d->c0; a.c1 = d->c1; a.up0 = d->up0; a.c_out = d->c_out;
+  a.ld0 = d->ld0; a.ld1 = d->ld1; a.ldz = d->ldo;
+  a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles;
+  a.n_cot = p.n_cot; a.n_cit = p.n_cit; a.n_slices = p.n_slices;
+  a.dz_lift = dz_lift; a.x_lift = x_lift;
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = cb == 64 ? launch_sp<64>(a, p, s) : launch_sp<32>(a, p, s)) return rc;
+  const long per_slice = (long)p.n_cot * p.n_cit * 9 * cb * cb;
+  const int blocks = (int)((per_slice + 255) / 256 < 2048 ? (per_slice + 255) / 256 : 2048);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, dw_oihw, p.n_slices, p.n_cot, p.n_cit, 9,
+                     d->c_out, d->c0 + d->c1, dw_cin_total ? dw_cin_total : d->c0 + d->c1, accumulate, cb,
+                     1.0f / (dz_lift * x_lift));
+  return dn::check_launch("wgrad_reduce_kernel");
+}
+
+namespace dn { void range_collect_conv_wgrad(unsigned* dst, bool reset, hipStream_t s) { sp_range_collect_here(dst, reset, s); } }
 
 namespace {
 // wt[ci][co][kk - 1 - t] = w[co][ci_first + ci][t]

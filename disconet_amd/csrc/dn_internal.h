@@ -52,6 +52,7 @@ int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const vo
 void range_collect_conv_sp(unsigned* dst, bool reset, hipStream_t stream);
 void range_collect_conv_spq(unsigned* dst, bool reset, hipStream_t stream);
 void range_collect_fuse_mlp(unsigned* dst, bool reset, hipStream_t stream);
+void range_collect_conv_wgrad(unsigned* dst, bool reset, hipStream_t stream);
 unsigned* sp_range_word();   // conv_sp.hip's word on the current device (nullptr on error)
 
 }  // namespace dn

@@ -32,6 +32,8 @@ _ENC_GROUPS = (("conv_pre_1", "conv_pre_2"), ("conv1_1", "conv1_2", "conv3d_1"),
                ("conv2_1", "conv2_2", "conv3d_2"), ("conv3_1", "conv3_2"), ("conv4_1", "conv4_2"))
 _EPS = 1e-5          # nn.BatchNorm default
 _DGRAD_MATH_DEFAULT = "sp"        # measured (round 5): per-tensor gradient error vs the float64 oracle equal to the fp32 form's to 3 digits
+_WGRAD_MATH_DEFAULT = "sp"        # the weight gradients of the layers dn_conv_wgrad_sp takes on the f16 MFMA with split operands
+_WGRAD_X_LIFT = 16.0              # power-of-two lift of the activations in that kernel (post-BatchNorm maps: |x| << 4094)
 _MOMENTUM = 0.1
 
 
@@ -148,8 +150,12 @@ class TrainEngine:
                                lambda self, v: setattr(self, "_overlap_streams",
                                                        ops.check_overlap_request(v, "TrainEngine.overlap_streams")))
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, shard=None, dgrad_math=None):
-        """dgrad_math: arithmetic of the 3x3 stride-1 data gradients -- "f32" (the exact fp32 MFMA) or "sp" (the inference
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, shard=None, dgrad_math=None,
+                 wgrad_math=None):
+        """wgrad_math: arithmetic of the weight gradients -- "f32" (the exact fp32 MFMA kernels) or "sp" (dn_conv_wgrad_sp where
+        it takes the layer: f16 hi + lo operands split while staging, dz lifted by the same measured power of two as below; the
+        other layers stay fp32); None: DISCONET_WGRAD_MATH, default _WGRAD_MATH_DEFAULT.
+        dgrad_math: arithmetic of the 3x3 stride-1 data gradients -- "f32" (the exact fp32 MFMA) or "sp" (the inference
         engine's split-f16 LDS-DMA kernels on a dz the BatchNorm backward writes pre-split and lifted, see _dz_sp_plan);
         None: DISCONET_DGRAD_MATH, default _DGRAD_MATH_DEFAULT.
         shard: a sharded.AgentShard -- this process trains the agents [shard.first, shard.first + shard.count) of every
@@ -161,6 +167,9 @@ class TrainEngine:
         self.dgrad_math = dgrad_math if dgrad_math is not None else os.environ.get("DISCONET_DGRAD_MATH", _DGRAD_MATH_DEFAULT)
         if self.dgrad_math not in ("f32", "sp"):
             raise ValueError("dgrad_math must be 'f32' or 'sp' (got %r)" % (self.dgrad_math,))
+        self.wgrad_math = wgrad_math if wgrad_math is not None else os.environ.get("DISCONET_WGRAD_MATH", _WGRAD_MATH_DEFAULT)
+        if self.wgrad_math not in ("f32", "sp"):
+            raise ValueError("wgrad_math must be 'f32' or 'sp' (got %r)" % (self.wgrad_math,))
         self._dz_lift = {}           # layer name -> (power-of-two lift of its dz, step it was measured at)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
@@ -314,11 +323,19 @@ class TrainEngine:
         ggamma = self.g(lay.bn.weight, G) if ggamma is None else ggamma
         gbeta = self.g(lay.bn.bias, G) if gbeta is None else gbeta
         sp, lift = self._dz_sp_plan(lay, c, need_dx)
+        wsp = self._wgrad_sp_layer(c)
+        ent = self._dz_lift.get(lay.name)
         dz = T.bn_backward(dy_a, c["y"], c["z"], c["mean"], c["var"], c["gamma"], _EPS, ggamma, gbeta,
                            relu=True, dy_b=dy_b, up_a=up_a, sp_out=sp, sp_lift=lift, **self._bn_sync(c["z"], c["groups"]))
-        if lift is not None:
+        if lift is not None or wsp:
             self._dz_lift_refresh(lay, dz)
-        return self._conv_bwd(c["desc"], c["w"], c["src0"], c["src1"], dz, gw, gb, need_dx, dz_sp=sp, dz_lift=lift)
+        return self._conv_bwd(c["desc"], c["w"], c["src0"], c["src1"], dz, gw, gb, need_dx, dz_sp=sp, dz_lift=lift,
+                              wgrad_lift=ent[0] if (wsp and ent is not None) else None)
+
+    def _wgrad_sp_layer(self, c):
+        """does this layer's weight gradient run on the split-f16 kernel (wgrad_math = "sp")?  Like the data gradient it needs the
+        layer's measured lift: the first step (and a layer whose lift was dropped) runs the fp32 kernel and measures."""
+        return self.wgrad_math == "sp" and c["groups"] == 1 and T.conv_wgrad_sp_supported(c["desc"])
 
     def _dz_sp_plan(self, lay, c, need_dx):
         """-> (SpTensor that shall receive dz * lift, lift) when this layer's data gradient runs on the split-f16 engine, else
@@ -353,8 +370,8 @@ class TrainEngine:
         self._dz_lift[lay.name] = (float(2.0 ** max(-100, min(100, 8 - math.floor(math.log2(m))))), self.step_count)
 
     def _conv_bwd(self, d, w, src0, src1, dz, gw, gb, need_dx=True, dw_cin_total=0, w_ci_first=0,
-                  w_c_in=None, dx_out=None, dz_sp=None, dz_lift=None):
-        T.conv_wgrad(d, src0, src1, dz, gw, dw_cin_total=dw_cin_total)
+                  w_c_in=None, dx_out=None, dz_sp=None, dz_lift=None, wgrad_lift=None):
+        T.conv_wgrad(d, src0, src1, dz, gw, dw_cin_total=dw_cin_total, sp_lift=wgrad_lift, x_lift=_WGRAD_X_LIFT)
         if gb is not None:
             T.channel_sum(dz, gb)
         if not need_dx:
@@ -680,15 +697,16 @@ class TrainEngine:
         """dgrad_math = "sp": did a dz outgrow its lift?  A blocking read of the engine's sticky range flags BEFORE the optimizer
         step (the step ends in a host read of the losses anyway): a clamped dz means wrong gradients -- the lifts are dropped
         (the next backward measures them again, in fp32) and the step is refused with the parameters untouched."""
-        if self.dgrad_math != "sp" or not self._dz_lift:
+        if (self.dgrad_math != "sp" and self.wgrad_math != "sp") or not self._dz_lift:
             return
         flags = ops.sp_range_flags(reset=True)
         if flags & 1:
             self._dz_lift.clear()
             raise ops._lib.DnError(
-                "backward: a gradient map outgrew the power-of-two lift of its split-f16 copy (|dz| * lift > 65504); the "
-                "gradients of this step are invalid and were NOT applied.  The lifts are re-measured by the next step; a run "
-                "that keeps tripping this wants dgrad_math = 'f32'.")
+                "backward: a gradient map outgrew the power-of-two lift of its split-f16 copy (|dz| * lift > 65504; or an "
+                "activation times %g did, in the split-f16 weight gradient); the gradients of this step are invalid and were NOT "
+                "applied.  The lifts are re-measured by the next step; a run that keeps tripping this wants dgrad_math = 'f32' "
+                "and wgrad_math = 'f32'." % _WGRAD_X_LIFT)
         if flags & 4:
             raise ops._lib.DnError("backward: a NaN reached a split-f16 epilogue")
 
@@ -825,7 +843,7 @@ class CoDetModule:
     layer-3 map (vs the teacher's x3) joins the loss."""
 
     def __init__(self, model, teacher=None, config=None, optimizer=None, kd_flag=0, lr=1e-3,
-                 alpha=0.25, gamma=2.0, sigma=3.0, shard=None, dgrad_math=None):
+                 alpha=0.25, gamma=2.0, sigma=3.0, shard=None, dgrad_math=None, wgrad_math=None):
         """shard (sharded.AgentShard): agent-parallel training -- step() then takes THIS rank's agents' images, labels and
         targets (agent-major, [count * B, ...]); trans_matrices / num_agent stay the whole scenes'.  Not with kd_flag."""
         if kd_flag and teacher is None:
@@ -841,7 +859,7 @@ class CoDetModule:
             lr = grp["lr"]
             kw = {"betas": tuple(grp.get("betas", (0.9, 0.999))), "eps": grp.get("eps", 1e-8),
                   "weight_decay": grp.get("weight_decay", 0.0)}
-        self.engine = TrainEngine(model, lr=lr, shard=shard, dgrad_math=dgrad_math, **kw)
+        self.engine = TrainEngine(model, lr=lr, shard=shard, dgrad_math=dgrad_math, wgrad_math=wgrad_math, **kw)
         model.__dict__["_train_engine"] = self.engine
         self.alpha, self.gamma, self.sigma = alpha, gamma, sigma
 

@@ -31,11 +31,21 @@ def _ld(t):
 
 
 # ---- conv backward ------------------------------------------------------------------------
-def conv_wgrad(desc, src0, src1, dz, dw, dw_cin_total=0, accumulate=False):
+def conv_wgrad(desc, src0, src1, dz, dw, dw_cin_total=0, accumulate=False, sp_lift=None, x_lift=16.0):
     """dw [c_out, c_in(, k, k)] (a column block of a [c_out, dw_cin_total, k, k] tensor when
-    dw_cin_total is given) = weight gradient of the layer `desc` (desc.ldo = row stride of dz)."""
+    dw_cin_total is given) = weight gradient of the layer `desc` (desc.ldo = row stride of dz).
+    sp_lift: the power-of-two lift of dz (max |dz| * sp_lift ~ 2^8) -> the split-f16 kernel (dn_conv_wgrad_sp; the layer must
+    pass conv_wgrad_sp_supported); None: the exact-fp32 MFMA kernels."""
     _need_gpu(src0, src1, dz, dw)
     lib = _lib.load()
+    if sp_lift is not None:
+        nbytes = lib.dn_conv_wgrad_sp_workspace(ctypes.byref(desc))
+        if nbytes == 0:
+            raise _lib.DnError("conv_wgrad: this layer has no split-f16 weight-gradient kernel (conv_wgrad_sp_supported)")
+        ws = _ws(dz.device, nbytes)
+        check(lib.dn_conv_wgrad_sp(ctypes.byref(desc), _ptr(src0), _ptr(src1), _ptr(dz), _ptr(ws), _ptr(dw), int(dw_cin_total),
+                                   int(bool(accumulate)), float(sp_lift), float(x_lift), _stream()), "dn_conv_wgrad_sp")
+        return dw
     nbytes = lib.dn_conv_wgrad_workspace(ctypes.byref(desc))
     if nbytes == 0:
         check(-1, "dn_conv_wgrad_workspace")
@@ -43,6 +53,10 @@ def conv_wgrad(desc, src0, src1, dz, dw, dw_cin_total=0, accumulate=False):
     check(lib.dn_conv_wgrad(ctypes.byref(desc), _ptr(src0), _ptr(src1), _ptr(dz), _ptr(ws), _ptr(dw),
                             int(dw_cin_total), int(bool(accumulate)), _stream()), "dn_conv_wgrad")
     return dw
+
+
+def conv_wgrad_sp_supported(desc):
+    return bool(_lib.load().dn_conv_wgrad_sp_supported(ctypes.byref(desc)))
 
 
 def dgrad_weights(w, ci_first=0, c_in=None):

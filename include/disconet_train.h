@@ -41,6 +41,24 @@ size_t dn_reduce_workspace_bytes(int n_groups, long rows_per_group, int c);
 int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz,
                   void* workspace, float* dw, int dw_cin_total, int accumulate, void* stream);
 
+/* dn_conv_wgrad on the f16 MFMA with split operands (csrc/wgrad_sp.inl): every dz and x value enters as an f16 hi + lo pair
+ * (half(v) + half(v - half(v)), 22 significand bits) and a product is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with
+ * fp32 accumulation -- 5.3 x the fp32 MFMA's rate per product.  The maps stay what dn_conv_wgrad takes (float32 NHWC, same
+ * descriptor, same gather: x2 upsample of source 0, concat); the kernel multiplies by the lifts, splits and transposes while
+ * it stages (K = pixels: a lane's fragment is 8 consecutive pixels of one channel).
+ *   dz_lift, x_lift: powers of two.  dz_lift brings max |dz| * dz_lift to ~2^8 (the lift of dn_bn_train_backward_finish_sp);
+ *   x_lift (activations: 16) keeps the lo halves of small activations out of the f16 subnormal range.  A lifted value beyond
+ *   +-65504 is clamped and sets bit 0 of dn_sp_range_flags: that step's gradients are invalid.  1 / (dz_lift * x_lift) is
+ *   applied by the fixed-order slice sum (exact).
+ * Layers: 3x3, stride 1, 16-byte aligned sources, and either c_out >= 64 with c0 and c1 multiples of 64 (a workgroup owns a
+ * 64 x 64 (co, ci) block) or c_out >= 32 with c0 and c1 multiples of 32 (32 x 32 blocks: the 32-channel layers of the full-
+ * resolution maps).  dn_conv_wgrad_sp_supported returns that block size, 0 = no such kernel for the layer.  Deterministic
+ * like dn_conv_wgrad.  Workspace: dn_conv_wgrad_sp_workspace(d) bytes. */
+int dn_conv_wgrad_sp_supported(const dn_conv_desc* d);
+size_t dn_conv_wgrad_sp_workspace(const dn_conv_desc* d);
+int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz, void* workspace, float* dw,
+                     int dw_cin_total, int accumulate, float dz_lift, float x_lift, void* stream);
+
 /* Weights of the data-gradient conv: wt[ci][co][2-ky][2-kx] = w[co][ci][ky][kx] for the
  * c_in columns starting at `ci_first` of a [c_out][cin_total][k][k] tensor.  dx is then
  * dn_conv2d(dz; pack(wt)) with stride 1 -- for a stride-2 layer with src0 read zero-stuffed

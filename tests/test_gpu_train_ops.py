@@ -70,6 +70,77 @@ def test_conv_wgrad_matches_autograd(case):
     assert rel_err(dw, 2 * wgt.grad) < 2e-5
 
 
+WGRAD_SP_CASES = [
+    # n, h, w, c0, c1, up0, c_out -- 3x3 stride 1; the split-f16 kernel's block (64 / 32) follows the channel counts
+    (2, 32, 32, 64, 0, 0, 64),
+    (2, 20, 24, 128, 0, 0, 64),         # ragged tiles: 24 = 1.5 x 16 columns, 20 = 5 x 4 rows
+    (2, 16, 16, 512, 256, 1, 256),      # conv5_1's channel structure: up(512) || skip(256)
+    (2, 32, 32, 64, 64, 1, 192),        # c_out = 3 x 64
+    (1, 64, 64, 64, 32, 1, 32),         # conv8_1's structure -> 32-channel blocks, up + concat
+    (2, 20, 40, 32, 0, 0, 32),          # 32 -> 32, ragged (20 = 2.5 x 8 rows, 40 = 2.5 x 16 columns)
+    (1, 32, 32, 32, 0, 0, 64),          # the heads' first convs
+    (1, 256, 256, 32, 0, 0, 32),        # full-resolution layer, many slices
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_SP_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_wgrad_split_f16_matches_autograd(case):
+    """dn_conv_wgrad_sp (f16 hi + lo operands split while staging, three MFMAs per product) against float64 autograd: the
+    fp32 kernels' 2e-5, with a gradient map of training-like magnitude (1e-4) under the engine's lift rule."""
+    import math
+    from disconet_amd import ops, train_ops
+    n, h, w, c0, c1, up0, c_out = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    hs, ws = (h // 2, w // 2) if up0 else (h, w)
+    x0 = torch.randn(n, c0, hs, ws, generator=g)
+    x1 = torch.randn(n, c1, h, w, generator=g) if c1 else None
+    wgt = (torch.randn(c_out, c0 + c1, 3, 3, generator=g) * 0.1).double().requires_grad_(True)
+    xin = F.interpolate(x0, scale_factor=2) if up0 else x0
+    if c1:
+        xin = torch.cat([xin, x1], 1)
+    z = F.conv2d(xin.double(), wgt, None, 1, 1)
+    dz = torch.randn(z.shape, generator=g) * 1e-4
+    z.backward(dz.double())
+    d = ops.conv_desc(n, h, w, c0, c_out, ksize=3, stride=1, c1=c1, up0=up0, relu=False)
+    assert train_ops.conv_wgrad_sp_supported(d)
+    lift = float(2.0 ** (8 - math.floor(math.log2(float(dz.abs().max())))))
+    a0, a1, adz = nhwc(x0).to(_dev()), nhwc(x1).to(_dev()) if c1 else None, nhwc(dz).to(_dev())
+    dw = torch.full((c_out, c0 + c1, 3, 3), 7.0, device=_dev())
+    train_ops.conv_wgrad(d, a0, a1, adz, dw, sp_lift=lift)
+    ref = wgt.grad
+    per_tap = [rel_err(dw[:, :, t // 3, t % 3], ref[:, :, t // 3, t % 3]) for t in range(9)]
+    per_src = [rel_err(dw[:, :c0], ref[:, :c0])] + ([rel_err(dw[:, c0:], ref[:, c0:])] if c1 else [])
+    assert rel_err(dw, ref) < 2e-5, (per_tap, per_src)
+    first = dw.clone()
+    train_ops.conv_wgrad(d, a0, a1, adz, dw, sp_lift=lift)
+    assert torch.equal(dw, first)                       # fixed summation order: bitwise repeatable
+    train_ops.conv_wgrad(d, a0, a1, adz, dw, accumulate=True, sp_lift=lift)
+    assert rel_err(dw, 2 * ref) < 2e-5
+    fp32 = torch.empty_like(dw)
+    train_ops.conv_wgrad(d, a0, a1, adz, fp32)
+    assert rel_err(dw, 2 * fp32.double().cpu()) < 2e-5      # and against the exact-fp32 kernels
+    assert ops.sp_range_flags(reset=True) & 5 == 0
+
+
+def test_conv_wgrad_split_f16_refuses_other_layers_and_flags_an_outgrown_lift():
+    from disconet_amd import _lib, ops, train_ops
+    for kw in (dict(c0=13, c_out=32), dict(c0=64, c_out=64, stride=2), dict(c0=64, c_out=64, ksize=1), dict(c0=64, c_out=16)):
+        d = ops.conv_desc(1, 32, 32, kw["c0"], kw["c_out"], ksize=kw.get("ksize", 3), stride=kw.get("stride", 1), relu=False)
+        assert not train_ops.conv_wgrad_sp_supported(d)
+    d = ops.conv_desc(1, 32, 32, 13, 32, ksize=3, relu=False)
+    with pytest.raises(_lib.DnError):
+        train_ops.conv_wgrad(d, torch.zeros(1, 32, 32, 13, device=_dev()), None, torch.zeros(1, 32, 32, 32, device=_dev()),
+                             torch.zeros(32, 13, 3, 3, device=_dev()), sp_lift=1.0)
+    d = ops.conv_desc(1, 32, 32, 64, 64, ksize=3, relu=False)
+    x, dz, dw = (torch.ones(1, 32, 32, 64, device=_dev()), torch.ones(1, 32, 32, 64, device=_dev()),
+                 torch.zeros(64, 64, 3, 3, device=_dev()))
+    with pytest.raises(_lib.DnError):
+        train_ops.conv_wgrad(d, x, None, dz, dw, sp_lift=3.0)            # not a power of two
+    ops.sp_range_flags(reset=True)
+    train_ops.conv_wgrad(d, x, None, dz, dw, sp_lift=2.0 ** 17)          # 1 * 2^17 > 65504: clamped and flagged
+    assert ops.sp_range_flags(reset=True) & 1
+
+
 def test_conv_wgrad_column_block_and_strided_dz():
     """the attention MLP's W1 = [W_ego | W_nbr]: dW written into a column block; dz as a
     channel slice of a wider tensor"""

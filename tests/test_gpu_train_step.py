@@ -160,13 +160,15 @@ def test_train_step_matches_oracle(case, math, monkeypatch):
         assert float((g[k].cpu() - r[k]).abs().max()) < tol, (k, float(r[k].abs().max()))
 
 
-@pytest.mark.parametrize("case", ["cfg1", "ragged_a4"])
-def test_split_f16_data_gradients_meet_the_fp32_criteria(case, monkeypatch):
+@pytest.mark.parametrize("case,dgrad,wgrad", [("cfg1", "sp", "f32"), ("cfg1", "f32", "sp"), ("cfg1", "sp", "sp"), ("ragged_a4", "sp", "sp")])
+def test_split_f16_data_gradients_meet_the_fp32_criteria(case, dgrad, wgrad, monkeypatch):
     """dgrad_math = "sp": the 3x3 stride-1 data gradients on the inference engine's split-f16 kernels, dz pre-split and LIFTED by
-    the BatchNorm backward.  Same parameters, three backward passes: the calibration pass (lifts unknown: every data gradient in
-    fp32 -- bit for bit the "f32" engine's gradients), then the split-f16 pass, which must meet the criteria the fp32 step is
-    held to (float64 oracle run as the truth, _assert_grads) and stay within 2.5 x of the fp32 pass's own error per tensor;
-    the per-tensor errors of both go to gpurun_out/dgrad_sp_errors_<case>.json."""
+    the BatchNorm backward.  wgrad_math = "sp": the 3x3 stride-1 weight gradients (>= 32 channels a side) on the f16 MFMA, dz
+    (same lift) and x split while they are staged (dn_conv_wgrad_sp).  Same parameters, three backward passes: the calibration
+    pass (lifts unknown: every gradient in fp32 -- bit for bit the "f32" engine's gradients), then the split-f16 pass, which
+    must meet the criteria the fp32 step is held to (float64 oracle run as the truth, _assert_grads) and stay within 2.5 x of
+    the fp32 pass's own error per tensor; the per-tensor errors of both go to gpurun_out/sp_grad_errors_<case>_<dgrad>_<wgrad>.json
+    (DESIGN.md 8)."""
     import json
     import os
     from disconet_amd import CoDetModule
@@ -178,11 +180,11 @@ def test_split_f16_data_gradients_meet_the_fp32_criteria(case, monkeypatch):
     (l_cls + l_loc).backward()                      # the fp32 oracle's own gradients (the yardstick of _grad_report)
     data = {"bev_seq": bevs.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(),
             "labels": labels.cuda(), "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda()}
-    plain = CoDetModule(model, lr=1e-3, dgrad_math="f32")
+    plain = CoDetModule(model, lr=1e-3, dgrad_math="f32", wgrad_math="f32")
     plain.step(data, c["batch"], update=False)
     g_plain = plain.engine.flat_g.clone()
     buffers = {k: v.clone() for k, v in model.named_buffers()}
-    mod = CoDetModule(model, lr=1e-3, dgrad_math="sp")       # (a new engine over the same parameters: flat_p is re-pointed)
+    mod = CoDetModule(model, lr=1e-3, dgrad_math=dgrad, wgrad_math=wgrad)       # (a new engine over the same parameters: flat_p is re-pointed)
     for k, v in model.named_buffers():
         v.copy_(buffers[k])
     o1 = mod.step(data, c["batch"], update=False)
@@ -195,8 +197,8 @@ def test_split_f16_data_gradients_meet_the_fp32_criteria(case, monkeypatch):
     rows_sp = _grad_report(g64, ref, mod.engine, model)
     worst = {k: (e_sp, rows_f32[k][0], e_ora, cos) for k, (e_sp, e_ora, cos, real) in rows_sp.items() if real}
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/dgrad_sp_errors_%s.json" % case, "w") as f:
-        json.dump({"case": case, "columns": ["err split-f16 dgrad", "err fp32 dgrad", "err fp32 oracle (ATen)", "cosine (split-f16)"],
+    with open("gpurun_out/sp_grad_errors_%s_%s_%s.json" % (case, dgrad, wgrad), "w") as f:
+        json.dump({"case": case, "dgrad_math": dgrad, "wgrad_math": wgrad, "columns": ["err split-f16", "err fp32", "err fp32 oracle (ATen)", "cosine (split-f16)"],
                    "note": "max |g - g64| / max |g64| per parameter tensor; g64 = the oracle run in float64",
                    "lifts": {k: v[0] for k, v in mod.engine._dz_lift.items()},
                    "tensors": {k: [float("%.3g" % x) for x in v] for k, v in sorted(worst.items())}}, f, indent=1)

@@ -1,7 +1,7 @@
 """One CoDetModule.step configuration, timed alone (so that a rocprofv3 --kernel-trace --stats of this process holds the
 training step's kernels and nothing else):
 
-    python tools/train_step_probe.py [--dgrad f32|sp] [--math sp|f16x3|f32] [--steps 6] [--kd]
+    python tools/train_step_probe.py [--dgrad f32|sp] [--wgrad f32|sp] [--math sp|f16x3|f32] [--steps 6]
 
 BASELINE configs[1]'s batch (5 agents x batch 4, 256 x 256 x 13, synthetic).  Prints one JSON line."""
 import argparse
@@ -18,6 +18,7 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dgrad", default="f32", choices=["f32", "sp"])
+    ap.add_argument("--wgrad", default="f32", choices=["f32", "sp"])
     ap.add_argument("--math", default="sp")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--batch", type=int, default=4)
@@ -34,7 +35,7 @@ def main():
     labels, targets, mask = make_train_targets(bevs.shape[0], args.map)
     data = {"bev_seq": bevs.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(), "labels": labels.cuda(),
             "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda()}
-    mod = CoDetModule(model, lr=1e-3, dgrad_math=args.dgrad)
+    mod = CoDetModule(model, lr=1e-3, dgrad_math=args.dgrad, wgrad_math=args.wgrad)
     first = mod.step(data, args.batch)
     mod.step(data, args.batch)
     torch.cuda.synchronize()
@@ -43,7 +44,7 @@ def main():
         last = mod.step(data, args.batch)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"dgrad": args.dgrad, "math": args.math, "ms_per_step": round(1e3 * dt, 3), "loss_first": first["loss"],
+    print(json.dumps({"dgrad": args.dgrad, "wgrad": args.wgrad, "math": args.math, "ms_per_step": round(1e3 * dt, 3), "loss_first": first["loss"],
                       "loss_last": last["loss"], "lifts": {k: v[0] for k, v in mod.engine._dz_lift.items()},
                       "range_flags": ops.sp_range_flags(reset=False)}))
 
