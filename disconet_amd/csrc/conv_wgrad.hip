@@ -492,9 +492,11 @@ extern "C" int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const flo
 namespace {
 // channels per side of a workgroup's block: 64, 32, or 0 = the layer has no split-f16 kernel
 int sp_block(const dn_conv_desc& d) {
-  if (d.ksize != 3 || d.stride != 1 || d.c_out % 4 != 0 || d.ld0 % 4 != 0 || (d.c1 != 0 && d.ld1 % 4 != 0) || d.ldo % 4 != 0) return 0;
-  if (d.c_out >= 64 && d.c0 % 64 == 0 && d.c1 % 64 == 0) return 64;
-  if (d.c_out >= 32 && d.c0 % 32 == 0 && d.c1 % 32 == 0) return 32;
+  if (d.ksize != 3 || d.stride != 1 || d.c_out % 4 != 0 || d.ldo % 4 != 0) return 0;
+  const bool vec = d.c0 % 4 == 0 && d.ld0 % 4 == 0 && d.c1 % 4 == 0 && (d.c1 == 0 || d.ld1 % 4 == 0);
+  if (vec && d.c_out >= 64 && d.c0 % 64 == 0 && d.c1 % 64 == 0) return 64;
+  // 32 x 32 blocks; a single source may end in a partial block and need not be 16-byte loadable (the 13-channel voxel grid)
+  if (d.c_out >= 32 && (d.c1 == 0 || (vec && d.c0 % 32 == 0))) return 32;
   return 0;
 }
 Plan make_plan_sp(const dn_conv_desc& d, int cb) {
@@ -507,7 +509,7 @@ Plan make_plan_sp(const dn_conv_desc& d, int cb) {
   p.tiles_y = (p.h_out + th - 1) / th;
   p.n_tiles = d.n_images * p.tiles_x * p.tiles_y;
   p.n_cot = (d.c_out + cb - 1) / cb;
-  p.n_cit = d.c0 / cb + d.c1 / cb;
+  p.n_cit = (d.c0 + cb - 1) / cb + (d.c1 + cb - 1) / cb;
   p.taps = 9;
   // one resident generation (2 workgroups per CU).  The slice is the fast index of a work item and workgroups go round the
   // 8 XCDs by index: with a multiple of 8 slices every (co, ci) block of one slice -- the workgroups that read the same pixel
@@ -550,14 +552,16 @@ extern "C" int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const 
                                 float* dw_oihw, int dw_cin_total, int accumulate, float dz_lift, float x_lift, void* stream) {
   if (int rc = validate(d)) return rc;
   const int cb = sp_block(*d);
-  DN_REQUIRE(cb != 0, "wgrad_sp: 3x3 stride-1 layers with c_out >= 32 and sources of 32 k channels only (dn_conv_wgrad_sp_supported)");
+  DN_REQUIRE(cb != 0, "wgrad_sp: 3x3 stride-1 layers with c_out >= 32 only; two sources: 32 k channels each (dn_conv_wgrad_sp_supported)");
   DN_REQUIRE(src0 && dz && workspace && dw_oihw, "wgrad_sp: null pointer");
   DN_REQUIRE(dw_cin_total == 0 || dw_cin_total >= d->c0 + d->c1, "wgrad_sp: dw_cin_total %d < c_in", dw_cin_total);
   DN_REQUIRE(d->c1 == 0 || src1, "wgrad_sp: c1 > 0 needs src1");
   auto pow2 = [](float v) { int e; return v > 0.f && std::isfinite(v) && std::frexp(v, &e) == 0.5f; };
   DN_REQUIRE(pow2(dz_lift) && pow2(x_lift), "wgrad_sp: the lifts must be powers of two (got %g, %g)", dz_lift, x_lift);
   auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
-  DN_REQUIRE(al16(src0) && al16(dz) && (d->c1 == 0 || al16(src1)), "wgrad_sp: sources must be 16-byte aligned");
+  const bool vecx = d->c0 % 4 == 0 && d->ld0 % 4 == 0 && al16(src0) && (d->c1 == 0 || (d->c1 % 4 == 0 && d->ld1 % 4 == 0 && al16(src1)));
+  DN_REQUIRE(al16(dz) && (vecx || (cb == 32 && d->c1 == 0)), "wgrad_sp: dz (and, but for a single-source 32-channel-block layer, "
+             "the sources) must be 16-byte aligned with rows of 4 k floats");
   const Plan p = make_plan_sp(*d, cb);
   WgradSpArgs a;
   a.src0 = src0; a.src1 = src1; a.dz = dz; a.partial = static_cast<float*>(workspace);
@@ -566,7 +570,7 @@ extern "C" int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const 
   a.ld0 = d->ld0; a.ld1 = d->ld1; a.ldz = d->ldo;
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles;
   a.n_cot = p.n_cot; a.n_cit = p.n_cit; a.n_slices = p.n_slices;
-  a.dz_lift = dz_lift; a.x_lift = x_lift;
+  a.dz_lift = dz_lift; a.x_lift = x_lift; a.vecx = vecx ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (int rc = cb == 64 ? launch_sp<64>(a, p, s) : launch_sp<32>(a, p, s)) return rc;
   const long per_slice = (long)p.n_cot * p.n_cit * 9 * cb * cb;

@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256)
 bn_apply_v4_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                    const float* __restrict__ var, const float* __restrict__ gamma,
                    const float* __restrict__ beta, float eps, int relu, long rows_per_group, int c,
-                   int ldz, long total4, float* __restrict__ y) {
+                   int ldz, long total4, float* __restrict__ y, unsigned char* __restrict__ relu_mask) {
   const int c4n = c >> 2;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total4;
        idx += (long)gridDim.x * blockDim.x) {
@@ -157,6 +157,8 @@ bn_apply_v4_kernel(const float* __restrict__ z, const float* __restrict__ mean,
     const f32x4 rs = rstd4(var + g * c + 4 * c4, eps);
     f32x4 v = (ldv4(z + row * ldz + 4 * c4) - ldv4(mean + g * c + 4 * c4)) * rs * ldv4(gamma + 4 * c4) +
               ldv4(beta + 4 * c4);
+    // one byte per four channels: bit e = (y[4 c4 + e] > 0), what the backward's ReLU gate asks of y -- 1/16 of y's bytes
+    if (relu_mask) relu_mask[idx] = (unsigned char)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
     if (relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
     *reinterpret_cast<f32x4*>(y + row * (long)c + 4 * c4) = v;
   }
@@ -239,7 +241,9 @@ struct GradSrc {
       g = dy_a[row * ld_a + cc];
     }
     if (dy_b) g += dy_b[row * ld_b + cc];
-    if (relu && !(y[row * c + cc] > 0.f)) g = 0.f;
+    if (relu == 2) {          // y is the byte mask of dn_bn_train_apply_mask (c % 4 == 0)
+      if (!((reinterpret_cast<const unsigned char*>(y)[(row * c + cc) >> 2] >> (cc & 3)) & 1)) g = 0.f;
+    } else if (relu && !(y[row * c + cc] > 0.f)) g = 0.f;
     return g;
   }
   __device__ inline f32x4 v4(long row, int c4) const {
@@ -254,7 +258,12 @@ struct GradSrc {
       g = ldv4(dy_a + row * ld_a + 4 * c4);
     }
     if (dy_b) g += ldv4(dy_b + row * ld_b + 4 * c4);
-    if (relu) {
+    if (relu == 2) {
+      const unsigned m = reinterpret_cast<const unsigned char*>(y)[row * (long)(c >> 2) + c4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!((m >> e) & 1)) g[e] = 0.f;
+    } else if (relu) {
       const f32x4 yv = ldv4(y + row * (long)c + 4 * c4);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -713,11 +722,23 @@ extern "C" int dn_bn_train_apply(const float* z, const float* mean, const float*
   if (vec4_ok(c, {ldz}, {z, y, mean, var, gamma, beta}))
     hipLaunchKernelGGL(bn_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0,
                        (hipStream_t)stream, z, mean, var, gamma, beta, eps, relu, rows_per_group, c, ldz,
-                       total / 4, y);
+                       total / 4, y, (unsigned char*)nullptr);
   else
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, z,
                        mean, var, gamma, beta, eps, relu, rows_per_group, c, ldz, total, y);
   return dn::check_launch("bn_apply_kernel");
+}
+
+extern "C" int dn_bn_train_apply_mask(const float* z, const float* mean, const float* var, const float* gamma,
+                                      const float* beta, float eps, int n_groups, long rows_per_group, int c, int ldz,
+                                      float* y, unsigned char* relu_mask, void* stream) {
+  DN_REQUIRE(z && mean && var && gamma && beta && y && relu_mask, "bn apply (mask): null pointer");
+  DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0 && ldz >= c, "bn apply (mask): bad shape");
+  DN_REQUIRE(vec4_ok(c, {ldz}, {z, y, mean, var, gamma, beta}), "bn apply (mask): needs c %% 4 == 0 and 16-byte aligned tensors");
+  const long total = (long)n_groups * rows_per_group * c;
+  hipLaunchKernelGGL(bn_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, z, mean, var,
+                     gamma, beta, eps, 1, rows_per_group, c, ldz, total / 4, y, relu_mask);
+  return dn::check_launch("bn_apply_kernel (mask)");
 }
 
 extern "C" int dn_bn_update_running(const float* mean, const float* var, int n_groups,
@@ -738,6 +759,7 @@ extern "C" int dn_bn_train_backward_partial(const float* dy_a, int ld_a, int up_
                                             size_t sums_bytes, float* dgamma, float* dbeta, int accumulate, void* stream) {
   DN_REQUIRE(dy_a && z && mean && var && sums && dgamma && dbeta, "bn backward: null pointer");
   DN_REQUIRE(!relu || y, "bn backward: relu needs y");
+  DN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || c % 4 == 0), "bn backward: relu = 2 (y is the byte mask) needs c %% 4 == 0");
   DN_REQUIRE(n_groups > 0 && h > 0 && w > 0 && images_per_group > 0 && c > 0 && c <= kMaxC &&
                  ld_a >= c && (!dy_b || ld_b >= c),
              "bn backward: bad shape");
@@ -771,6 +793,7 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
                             void* dz_sp, float sp_lift, void* stream) {
   DN_REQUIRE(dy_a && z && mean && var && gamma && sums && dz, "bn backward finish: null pointer");
   DN_REQUIRE(!relu || y, "bn backward: relu needs y");
+  DN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || c % 4 == 0), "bn backward: relu = 2 (y is the byte mask) needs c %% 4 == 0");
   DN_REQUIRE(n_groups > 0 && h > 0 && w > 0 && images_per_group > 0 && c > 0 && c <= kMaxC && norm_rows > 0 &&
                  ld_a >= c && (!dy_b || ld_b >= c),
              "bn backward finish: bad shape");

@@ -21,6 +21,7 @@ struct WgradSpArgs {
   int ld0, ld1, ldz;
   int tiles_x, tiles_y, n_tiles;
   int n_cot, n_cit, n_slices;
+  int vecx;            // 0: the sources' rows are not 16-byte loadable (13 input channels): four dword loads, each with its own bound
   float dz_lift, x_lift;
 };
 
@@ -86,6 +87,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_kernel(const WgradSpArgs
   auto ld128 = [](auto rsrc, unsigned voff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
   };
+  auto ld32x4 = [](auto rsrc, unsigned voff, int nvalid) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                           rsrc, (voff == 0xFFFFFFFFu || e >= nvalid) ? 0xFFFFFFFFu : voff + 4 * e, 0, 0));
+    return v;
+  };
   auto load_tile = [&](int tile) {
     int sp = tile;
     const int ox0 = (sp % a.tiles_x) * TW;
@@ -107,7 +116,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_kernel(const WgradSpArgs
         const int ix = ox0 - 1 + 2 * pp + e;
         const bool ok = rowok && ix >= 0 && ix < a.w_in;
         const int sx = up ? ix >> 1 : ix;
-        rx[it][e] = ld128(rsx, ok ? (unsigned)(((sy * ws + sx) * ld + c) * 4) : OOB);
+        const unsigned off = ok ? (unsigned)(((sy * ws + sx) * ld + c) * 4) : OOB;
+        rx[it][e] = a.vecx ? ld128(rsx, off) : ld32x4(rsx, off, csrc - c);
       }
     }
 #pragma unroll

@@ -295,9 +295,11 @@ class TrainEngine:
         mean, var = T.bn_stats(z, groups, **self._bn_sync(z, groups))
         gamma = lay.bn.weight if gamma is None else gamma
         beta = lay.bn.bias if beta is None else beta
-        y = T.bn_apply(z, mean, var, gamma, beta, _EPS, relu=True, out=y_out)
+        # the backward's ReLU gate as one byte per four channels: its two passes then do not read y (1/16 of the bytes)
+        mask = torch.empty(z.numel() // 4, dtype=torch.uint8, device=z.device) if z.shape[-1] % 4 == 0 else None
+        y = T.bn_apply(z, mean, var, gamma, beta, _EPS, relu=True, out=y_out, relu_mask=mask)
         lay.ctx = dict(src0=src0, src1=src1, up0=up0, z=z, y=y, mean=mean, var=var, desc=d,
-                       groups=groups, w=w, gamma=gamma)
+                       groups=groups, w=w, gamma=gamma, mask=mask)
         return y
 
     def _bn_sync(self, z, groups):
@@ -326,7 +328,8 @@ class TrainEngine:
         wsp = self._wgrad_sp_layer(c)
         ent = self._dz_lift.get(lay.name)
         dz = T.bn_backward(dy_a, c["y"], c["z"], c["mean"], c["var"], c["gamma"], _EPS, ggamma, gbeta,
-                           relu=True, dy_b=dy_b, up_a=up_a, sp_out=sp, sp_lift=lift, **self._bn_sync(c["z"], c["groups"]))
+                           relu=True, dy_b=dy_b, up_a=up_a, sp_out=sp, sp_lift=lift, relu_mask=c.get("mask"),
+                           **self._bn_sync(c["z"], c["groups"]))
         if lift is not None or wsp:
             self._dz_lift_refresh(lay, dz)
         return self._conv_bwd(c["desc"], c["w"], c["src0"], c["src1"], dz, gw, gb, need_dx, dz_sp=sp, dz_lift=lift,
@@ -699,7 +702,12 @@ class TrainEngine:
         (the next backward measures them again, in fp32) and the step is refused with the parameters untouched."""
         if (self.dgrad_math != "sp" and self.wgrad_math != "sp") or not self._dz_lift:
             return
-        flags = ops.sp_range_flags(reset=True)
+        # stream-ordered collect into a word this engine keeps + one host read: the blocking dn_sp_range_flags synchronises the
+        # whole device and allocates / frees its scratch word per call (measured ~2 ms per step inside a large process)
+        word = self.__dict__.get("_range_word")
+        if word is None or word.device != self.flat_p.device:
+            word = self._range_word = torch.zeros(1, dtype=torch.int32, device=self.flat_p.device)
+        flags = int(ops.sp_range_flags_into(word, zero_first=True, reset=True).item()) & 0xffffffff
         if flags & 1:
             self._dz_lift.clear()
             raise ops._lib.DnError(

@@ -113,12 +113,21 @@ def bn_stats(z, n_groups=1, sync=None, norm_rows=None):
     return mean, var
 
 
-def bn_apply(z, mean, var, gamma, beta, eps, relu=True, out=None):
-    _need_gpu(z, mean, var, gamma, beta)
+def bn_apply(z, mean, var, gamma, beta, eps, relu=True, out=None, relu_mask=None):
+    """relu_mask: a uint8 tensor of z.numel() / 4 bytes that receives the backward's ReLU gate, one byte per four channels
+    (dn_bn_train_apply_mask; relu must be on, c % 4 == 0) -- bn_backward(relu_mask=...) reads it instead of y."""
+    _need_gpu(z, mean, var, gamma, beta, relu_mask)
     c = z.shape[-1]
     n_groups = mean.shape[0]
     rows = z.numel() // c
     y = torch.empty_like(z) if out is None else out
+    if relu_mask is not None:
+        if not relu or relu_mask.dtype != torch.uint8 or relu_mask.numel() * 4 != z.numel() or not relu_mask.is_contiguous():
+            raise _lib.DnError("bn_apply: relu_mask must be a contiguous uint8 tensor of z.numel() / 4 bytes, with relu on")
+        check(_lib.load().dn_bn_train_apply_mask(_ptr(z), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), float(eps), n_groups,
+                                                 rows // n_groups, c, c, _ptr(y), _ptr(relu_mask), _stream()),
+              "dn_bn_train_apply_mask")
+        return y
     check(_lib.load().dn_bn_train_apply(_ptr(z), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta),
                                         float(eps), int(relu), n_groups, rows // n_groups, c, c,
                                         _ptr(y), _stream()), "dn_bn_train_apply")
@@ -135,14 +144,19 @@ def bn_update_running(mean, var, rows_per_group, running_mean, running_var, mome
 
 
 def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_b=None, up_a=False,
-                accumulate=False, out=None, sync=None, norm_rows=None, sp_out=None, sp_lift=1.0):
+                accumulate=False, out=None, sync=None, norm_rows=None, sp_out=None, sp_lift=1.0, relu_mask=None):
     """z, y [n, h, w, c] dense.  dy_a: [n, h, w, c'] view (or [n, 2h, 2w, c'] when up_a), dy_b
     optional second gradient (same resolution as y).  Returns dz; fills dgamma / dbeta.
     sync / norm_rows (agent-parallel training, see bn_stats): dgamma / dbeta are then THIS rank's share (sums over its rows).
     sp_out / sp_lift: an ops.SpTensor [n, h, w, c] that also receives dz * sp_lift as f16 hi / lo planes
-    (dn_bn_train_backward_finish_sp: the operand of the split-f16 data gradient; one group, c % 16 == 0)."""
-    _need_gpu(dy_a, dy_b, y, z, mean, var, gamma)
+    (dn_bn_train_backward_finish_sp: the operand of the split-f16 data gradient; one group, c % 16 == 0).
+    relu_mask: bn_apply's byte mask of (y > 0) -- read in place of y by both passes (relu = 2 of the C entry points)."""
+    _need_gpu(dy_a, dy_b, y, z, mean, var, gamma, relu_mask)
     n, h, w, c = z.shape
+    if relu_mask is not None:
+        if not relu or relu_mask.dtype != torch.uint8 or relu_mask.numel() * 4 != z.numel():
+            raise _lib.DnError("bn_backward: relu_mask must be bn_apply's uint8 mask of z.numel() / 4 bytes")
+        y, relu = relu_mask, 2
     n_groups = mean.shape[0]
     assert n % n_groups == 0
     dz = torch.empty_like(z) if out is None else out

@@ -50,10 +50,11 @@ int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const float* src1, c
  *   x_lift (activations: 16) keeps the lo halves of small activations out of the f16 subnormal range.  A lifted value beyond
  *   +-65504 is clamped and sets bit 0 of dn_sp_range_flags: that step's gradients are invalid.  1 / (dz_lift * x_lift) is
  *   applied by the fixed-order slice sum (exact).
- * Layers: 3x3, stride 1, 16-byte aligned sources, and either c_out >= 64 with c0 and c1 multiples of 64 (a workgroup owns a
- * 64 x 64 (co, ci) block) or c_out >= 32 with c0 and c1 multiples of 32 (32 x 32 blocks: the 32-channel layers of the full-
- * resolution maps).  dn_conv_wgrad_sp_supported returns that block size, 0 = no such kernel for the layer.  Deterministic
- * like dn_conv_wgrad.  Workspace: dn_conv_wgrad_sp_workspace(d) bytes. */
+ * Layers: 3x3, stride 1, 16-byte aligned dz (and sources, with the exception below), and either c_out >= 64 with c0 and c1 multiples of 64 (a workgroup owns a
+ * 64 x 64 (co, ci) block) or c_out >= 32 (32 x 32 blocks: the 32-channel layers of the full-resolution maps) with either two
+ * sources of 32 k channels each or ONE source of any width, which then need not be 16-byte loadable (the 13-channel voxel
+ * grid of conv_pre_1: dword loads, the last block partial).  dn_conv_wgrad_sp_supported returns that block size, 0 = no such
+ * kernel for the layer.  Deterministic like dn_conv_wgrad.  Workspace: dn_conv_wgrad_sp_workspace(d) bytes. */
 int dn_conv_wgrad_sp_supported(const dn_conv_desc* d);
 size_t dn_conv_wgrad_sp_workspace(const dn_conv_desc* d);
 int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz, void* workspace, float* dw,
@@ -100,6 +101,14 @@ int dn_bn_train_apply(const float* z, const float* mean, const float* var, const
                       const float* beta, float eps, int relu, int n_groups, long rows_per_group,
                       int c, int ldz, float* y, void* stream);
 
+/* dn_bn_train_apply with ReLU that also writes the ReLU gate of the backward as ONE BYTE PER FOUR CHANNELS:
+ * relu_mask[(row * c + ch) / 4] bit (ch % 4) = (y[row][ch] > 0) -- rows * c / 4 bytes, 1/16 of y.  The backward entry points
+ * below take it in place of y with relu = 2: their two passes then read 1/4 byte per element where y costs 4 (same gate, same
+ * results bit for bit).  c % 4 == 0, 16-byte aligned tensors. */
+int dn_bn_train_apply_mask(const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
+                           float eps, int n_groups, long rows_per_group, int c, int ldz, float* y,
+                           unsigned char* relu_mask, void* stream);
+
 /* running = (1 - momentum) * running + momentum * batch stat, group after group in the order
  * `order` lists them (null = 0..n_groups-1); running_var takes the unbiased variance. */
 int dn_bn_update_running(const float* mean, const float* var, int n_groups, long rows_per_group,
@@ -110,6 +119,7 @@ int dn_bn_update_running(const float* mean, const float* var, int n_groups, long
  * its own row stride, and dy_a may live at twice the resolution (up_a != 0: the 2 x 2 block
  * sum, i.e. the backward of the decoder's nearest upsample; h, w are then y's dims).
  *   g = (dy_a + dy_b) * (y > 0)      dbeta = sum g      dgamma = sum g * zhat
+ *   (relu = 2: `y` is not the map but dn_bn_train_apply_mask's byte mask of (y > 0), cast to const float*)
  *   dz = gamma * rstd * (g - mean(g) - zhat * mean(g * zhat))       (means per group)
  * dgamma / dbeta are summed over groups and ADDED when accumulate != 0.
  * sums: workspace of dn_reduce_workspace_bytes(n_groups, images_per_group * h * w, c) bytes. */

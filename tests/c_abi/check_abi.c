@@ -44,9 +44,11 @@ static int errors_only(void) {
   /* the split-f16 weight gradient: 32 -> 32 channels takes the 32-channel block form; a 13-channel source has none */
   CHECK(dn_conv_wgrad_sp_supported(&d) == 32 && dn_conv_wgrad_sp_workspace(&d) > 0, "wgrad_sp supported");
   CHECK(dn_conv_wgrad_sp(&d, NULL, NULL, NULL, NULL, NULL, 0, 0, 256.f, 16.f, NULL) == DN_ERR_ARG, "wgrad_sp null");
-  d.c0 = 13; d.ld0 = 13;
-  CHECK(dn_conv_wgrad_sp_supported(&d) == 0 && dn_conv_wgrad_sp_workspace(&d) == 0, "wgrad_sp: 13 channels");
-  d.c0 = 32; d.ld0 = 32;
+  d.c0 = 13; d.ld0 = 13;     /* the voxel grid: one source of any width takes the 32-channel blocks too (dword loads) */
+  CHECK(dn_conv_wgrad_sp_supported(&d) == 32, "wgrad_sp: 13 channels");
+  d.stride = 2;
+  CHECK(dn_conv_wgrad_sp_supported(&d) == 0 && dn_conv_wgrad_sp_workspace(&d) == 0, "wgrad_sp: stride 2");
+  d.stride = 1; d.c0 = 32; d.ld0 = 32;
   CHECK(dn_adam_step(NULL, NULL, NULL, NULL, 10, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 1, NULL) == DN_ERR_ARG,
         "adam null");
   CHECK(dn_bn_train_stats(NULL, 1, 10, 600, 600, NULL, 0, NULL, NULL, NULL) == DN_ERR_ARG, "bn null");

@@ -80,6 +80,8 @@ WGRAD_SP_CASES = [
     (2, 20, 40, 32, 0, 0, 32),          # 32 -> 32, ragged (20 = 2.5 x 8 rows, 40 = 2.5 x 16 columns)
     (1, 32, 32, 32, 0, 0, 64),          # the heads' first convs
     (1, 256, 256, 32, 0, 0, 32),        # full-resolution layer, many slices
+    (2, 40, 48, 13, 0, 0, 32),          # conv_pre_1: the 13-channel voxel grid (rows not 16-byte loadable: dword loads)
+    (1, 32, 32, 72, 0, 0, 40),          # one source ending in a partial block; c_out = 32 + 8
 ]
 
 
@@ -124,13 +126,13 @@ def test_conv_wgrad_split_f16_matches_autograd(case):
 
 def test_conv_wgrad_split_f16_refuses_other_layers_and_flags_an_outgrown_lift():
     from disconet_amd import _lib, ops, train_ops
-    for kw in (dict(c0=13, c_out=32), dict(c0=64, c_out=64, stride=2), dict(c0=64, c_out=64, ksize=1), dict(c0=64, c_out=16)):
+    for kw in (dict(c0=64, c_out=64, stride=2), dict(c0=64, c_out=64, ksize=1), dict(c0=64, c_out=16)):
         d = ops.conv_desc(1, 32, 32, kw["c0"], kw["c_out"], ksize=kw.get("ksize", 3), stride=kw.get("stride", 1), relu=False)
         assert not train_ops.conv_wgrad_sp_supported(d)
-    d = ops.conv_desc(1, 32, 32, 13, 32, ksize=3, relu=False)
+    d = ops.conv_desc(1, 32, 32, 64, 64, ksize=3, stride=2, relu=False)
     with pytest.raises(_lib.DnError):
-        train_ops.conv_wgrad(d, torch.zeros(1, 32, 32, 13, device=_dev()), None, torch.zeros(1, 32, 32, 32, device=_dev()),
-                             torch.zeros(32, 13, 3, 3, device=_dev()), sp_lift=1.0)
+        train_ops.conv_wgrad(d, torch.zeros(1, 32, 32, 64, device=_dev()), None, torch.zeros(1, 16, 16, 64, device=_dev()),
+                             torch.zeros(64, 64, 3, 3, device=_dev()), sp_lift=1.0)
     d = ops.conv_desc(1, 32, 32, 64, 64, ksize=3, relu=False)
     x, dz, dw = (torch.ones(1, 32, 32, 64, device=_dev()), torch.ones(1, 32, 32, 64, device=_dev()),
                  torch.zeros(64, 64, 3, 3, device=_dev()))
@@ -317,6 +319,37 @@ def test_bn_backward_sp_copy_is_the_split_of_the_lifted_dz(shape, up_a, lift):
     want = ops.SpTensor.from_nhwc(dz0 * lift)
     assert torch.equal(sp.data.view(torch.int16), want.data.view(torch.int16))
     assert float((sp.nhwc() / lift - dz0).abs().max()) <= 2.0 ** -21 * float(dz0.abs().max())
+
+
+@pytest.mark.parametrize("shape,up_a,sp", [((3, 16, 32, 64), False, False), ((2, 9, 7, 36), False, False), ((2, 32, 32, 32), True, True)])
+def test_bn_relu_byte_mask_replaces_y_in_the_backward_bit_for_bit(shape, up_a, sp):
+    """dn_bn_train_apply_mask: y is the plain call's, the mask is (y > 0) packed four channels to a byte; the backward reading
+    the mask (relu = 2) equals the backward reading y bit for bit -- dz, the SP copy, dgamma, dbeta; ragged sizes included."""
+    from disconet_amd import ops, train_ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(31)
+    z = (torch.randn(shape, generator=g) * 2 + 0.5).to(_dev())
+    gm = (torch.rand(c, generator=g) + 0.5).to(_dev())
+    bt = (torch.randn(c, generator=g) * 0.2).to(_dev())
+    mean, var = train_ops.bn_stats(z)
+    y0 = train_ops.bn_apply(z, mean, var, gm, bt, 1e-5, relu=True)
+    mask = torch.full((z.numel() // 4,), 0xAA, dtype=torch.uint8, device=_dev())
+    y1 = train_ops.bn_apply(z, mean, var, gm, bt, 1e-5, relu=True, relu_mask=mask)
+    assert torch.equal(y0, y1)
+    bits = (y0.reshape(-1, 4) > 0).to(torch.uint8)
+    assert torch.equal(mask, bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3))
+    dy = (torch.randn((n, 2 * h, 2 * w, c + 16) if up_a else (n, h, w, c + 16), generator=g) * 1e-3).to(_dev())[..., 16:]
+    dyb = None if up_a else torch.randn(shape, generator=g).to(_dev()) * 1e-3
+    out = []
+    for m in (None, mask):
+        dg, db = torch.empty(c, device=_dev()), torch.empty(c, device=_dev())
+        spt = ops.SpTensor(n, h, w, c, device=_dev()) if sp else None
+        dz = train_ops.bn_backward(dy, y0, z, mean, var, gm, 1e-5, dg, db, up_a=up_a, dy_b=dyb, sp_out=spt, sp_lift=2.0 ** 12,
+                                   relu_mask=m)
+        out.append((dz, dg, db, spt.data.clone() if sp else dz))
+    for a, b in zip(*out):
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a.view(torch.int16),
+                           b.view(torch.int32) if b.dtype == torch.float32 else b.view(torch.int16))
 
 
 def test_bn_backward_sp_copy_flags_a_gradient_that_outgrows_its_lift():
