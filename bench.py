@@ -94,7 +94,7 @@ def parse():
                          "with the serial replay's checksum; one mismatch and the serial figure is reported")
     ap.add_argument("--no-voxelize", action="store_true", help="skip the K1 (raw points) timing extra")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
-    ap.add_argument("--train-steps", type=int, default=4,
+    ap.add_argument("--train-steps", type=int, default=6,
                     help="also time this many training steps (forward + loss + backward + Adam) of the "
                          "same batch; 0 = skip (reported next to the headline value, never in it)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -410,6 +410,25 @@ def agent_sharded_bench(args, world, rank, dist):
         dist.destroy_process_group()
 
 
+def _time_train_steps(mod, data, batch, steps, warm=4):
+    """-> (first, last, mean seconds per step, per-step milliseconds).  `warm` untimed steps first: the calibration pass (the
+    first backward measures the gradient maps' lifts in fp32), then the split-f16 path's own warm-up (allocator, LDS
+    attributes, clocks after the idle CPU-baseline phase).  A step ends in a host read of its losses, so the per-step wall
+    times cost nothing extra; the reported mean is over the whole timed region, synchronised on both sides."""
+    first = mod.step(data, batch)
+    for _ in range(max(warm - 1, 0)):
+        mod.step(data, batch)
+    torch.cuda.synchronize()
+    per = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        last = mod.step(data, batch)
+        per.append(round(1e3 * (time.perf_counter() - t1), 3))
+    torch.cuda.synchronize()
+    return first, last, (time.perf_counter() - t0) / steps, per
+
+
 def seg_bench(args, world, rank, dist, use_pg):
     """BASELINE configs[3]: DiscoNet seg, 5-agent, 256x256 BEV; scene-parallel like the det bench.
     One step = dense rebuild of the voxel lists (into the conv engine's layout) + the UNet forward with
@@ -542,18 +561,11 @@ def seg_bench(args, world, rank, dist, use_pg):
             tmod = SegModule(tmodel, lr=1e-3)
             x = ops.scatter_dense(indices, offsets, n_img, dims).view(n_img, MAP_HW, MAP_HW, 13)
             tdata = {"bev_seq": x, "trans_matrices": trans, "num_agent": na, "labels": labels}
-            first = tmod.step(tdata, BATCH)
-            tmod.step(tdata, BATCH)        # (the first step measures the gradient maps' lifts, this one warms the split-f16 data gradients)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.train_steps):
-                last = tmod.step(tdata, BATCH)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / args.train_steps
+            first, last, dt, per = _time_train_steps(tmod, tdata, BATCH, args.train_steps)
             result["train_step"] = {"ms_per_step": round(1e3 * dt, 3), "scenes_per_s": round(BATCH / dt, 2),
                                     "steps": args.train_steps, "batch_per_gpu": BATCH,
                                     "loss_first": round(first["loss"], 5), "loss_last": round(last["loss"], 5),
-                                    "dgrad_math": tmod.engine.dgrad_math, "wgrad_math": tmod.engine.wgrad_math,
+                                    "step_ms": per, "dgrad_math": tmod.engine.dgrad_math, "wgrad_math": tmod.engine.wgrad_math,
                                     "layers_with_a_measured_gradient_lift": len(tmod.engine._dz_lift),
                                     "note": "SegModule.step: train() forward + cross entropy + explicit HIP backward + Adam, "
                                             "eager launches, wall clock"}
@@ -1044,18 +1056,11 @@ def main():
                         "trans_matrices": trans, "num_agent": na, "labels": labels.cuda(),
                         "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda()}
                 mod = CoDetModule(tmodel, lr=1e-3)
-                first = mod.step(data, BATCH)          # warm-up (allocator, LDS attributes); with the default dgrad_math = "sp" also
-                mod.step(data, BATCH)                  # the calibration pass (lifts of the gradient maps), then the split-f16 path's own warm-up
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.train_steps):
-                    last = mod.step(data, BATCH)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / args.train_steps
+                first, last, dt, per = _time_train_steps(mod, data, BATCH, args.train_steps)
                 result["train_step"] = {
                     "ms_per_step": round(1e3 * dt, 3), "scenes_per_s": round(BATCH / dt, 2),
                     "steps": args.train_steps, "batch_per_gpu": BATCH, "loss_first": round(first["loss"], 4),
-                    "loss_last": round(last["loss"], 4), "dgrad_math": mod.engine.dgrad_math,
+                    "loss_last": round(last["loss"], 4), "step_ms": per, "warmup_steps": 4, "dgrad_math": mod.engine.dgrad_math,
                     "wgrad_math": mod.engine.wgrad_math,
                     "layers_with_a_measured_gradient_lift": len(mod.engine._dz_lift),
                     "note": "train() forward (batch-stat BN) + focal/smooth-L1 loss + explicit HIP backward (3x3 stride-1 data "
@@ -1069,16 +1074,9 @@ def main():
                     fmodel.conv_math = args.math
                     fmodel.cuda()
                     fmod = CoDetModule(fmodel, lr=1e-3, dgrad_math="f32", wgrad_math="f32")
-                    fmod.step(data, BATCH)
-                    fmod.step(data, BATCH)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for _ in range(args.train_steps):
-                        flast = fmod.step(data, BATCH)
-                    torch.cuda.synchronize()
-                    dtf = (time.perf_counter() - t0) / args.train_steps
+                    _, flast, dtf, perf32 = _time_train_steps(fmod, data, BATCH, args.train_steps)
                     result["train_step"]["all_gradients_f32"] = {"ms_per_step": round(1e3 * dtf, 3), "scenes_per_s": round(BATCH / dtf, 2),
-                                                         "loss_last": round(flast["loss"], 4)}
+                                                         "loss_last": round(flast["loss"], 4), "step_ms": perf32}
                     del fmod, fmodel
                 except Exception as e:
                     result["train_step"]["all_gradients_f32"] = {"error": repr(e)}
@@ -1093,17 +1091,10 @@ def main():
                 data["bev_seq_teacher"] = make_bevs(BATCH, AGENTS, MAP_HW, p=0.05).cuda()
                 data["kd_weight"] = 1e5
                 kmod = CoDetModule(kmodel, teacher, None, None, kd_flag=1, lr=1e-3)
-                kmod.step(data, BATCH)
-                kmod.step(data, BATCH)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.train_steps):
-                    klast = kmod.step(data, BATCH)
-                torch.cuda.synchronize()
-                dtk = (time.perf_counter() - t0) / args.train_steps
+                _, klast, dtk, perkd = _time_train_steps(kmod, data, BATCH, args.train_steps)
                 result["train_step"]["with_kd"] = {"ms_per_step": round(1e3 * dtk, 3),
                                                    "scenes_per_s": round(BATCH / dtk, 2),
-                                                   "kd_loss": round(klast["kd_loss"], 4)}
+                                                   "kd_loss": round(klast["kd_loss"], 4), "step_ms": perkd}
             except Exception as e:
                 result.setdefault("train_step", {})["error"] = repr(e)
         emit(result)

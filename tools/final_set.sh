@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${RD}final
 mkdir -p $O
 cd $R
-( timeout 1200 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.log )
-tail -3 $O/pytest_gpu.log
+( timeout 1500 python -m pytest tests -q -m gpu --durations=12 > $O/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.log )
+tail -22 $O/pytest_gpu.log | cut -c1-200
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?" >> $O/smoke.log ); tail -2 $O/smoke.log
 bash tools/profile_set.sh $RD > $O/profile.log 2>&1
 P=$R/gpurun_out/${RD}prof
