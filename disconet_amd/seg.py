@@ -208,6 +208,9 @@ class SegModule:
         self.model = model
         self._optimizer, self._lr, self._trainer = optimizer, lr, None
 
+    # the training engine behind step() (seg_train.SegTrainEngine; None until the first step built it)
+    engine = property(lambda self: self._trainer.engine if self._trainer is not None else None)
+
     def step(self, data, batch_size=None):
         """upstream SegModule.step: one training step (train-mode forward with batch statistics, cross entropy,
         explicit HIP reverse pass, Adam) -> {"loss": float}.  The training engine is built on first use (its flat
