@@ -334,33 +334,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad64_kernel(const WgradArgs a)
     }
 }
 
-// partial [slice][cot][cit][tap][ct co][ct ci] -> dW [c_out][c_in][taps] (OIHW), slices summed in order
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                    int n_slices, int n_cot, int n_cit, int taps, int c_out, int c_in,
-                                    int cin_total, int accumulate, int ct, float scale) {
-  const long per_slice = (long)n_cot * n_cit * taps * ct * ct;
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < per_slice;
-       idx += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(idx % ct), i = (int)((idx / ct) % ct);
-    long r = idx / (ct * ct);
-    const int t = r % taps;
-    r /= taps;
-    const int cit = r % n_cit, cot = (int)(r / n_cit);
-    const int co = cot * ct + i, ci = cit * ct + j;
-    if (co >= c_out || ci >= c_in) continue;
-    // four independent chains keep the loads in flight; the order is fixed, so still deterministic
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int sl = 0;
-    for (; sl + 4 <= n_slices; sl += 4) {
-      s0 += partial[(sl + 0) * per_slice + idx];
-      s1 += partial[(sl + 1) * per_slice + idx];
-      s2 += partial[(sl + 2) * per_slice + idx];
-      s3 += partial[(sl + 3) * per_slice + idx];
+// partial [slice][cot][cit][tap][ct co][ct ci] -> dW [c_out][c_in][taps] (OIHW), slices summed in a FIXED order: a workgroup owns
+// 64 consecutive elements; wave g adds slices g, g + 4, g + 8, ... (two alternating chains, each wave-load 256 contiguous bytes),
+// then the four waves' sums meet in LDS as (w0 + w1) + (w2 + w3).  (Round 5: one thread per element walked all -- up to 512 --
+// slices alone; the launches behind the 256 x 256 layers were latency-bound at 20-40 us each.)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           int n_slices, int n_cot, int n_cit, int taps, int c_out, int c_in,
+                                                           int cin_total, int accumulate, int ct, float scale) {
+  __shared__ float red[4][64];
+  const long per_slice = (long)n_cot * n_cit * taps * ct * ct;        // a multiple of 64 (ct * ct is)
+  const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (long base = blockIdx.x * 64L; base < per_slice; base += gridDim.x * 64L) {
+    const long idx = base + i;
+    float s0 = 0.f, s1 = 0.f;
+    int sl = g;
+    for (; sl + 4 < n_slices; sl += 8) {
+      s0 += partial[sl * per_slice + idx];
+      s1 += partial[(sl + 4) * per_slice + idx];
     }
-    for (; sl < n_slices; ++sl) s0 += partial[sl * per_slice + idx];
-    const float s = ((s0 + s1) + (s2 + s3)) * scale;      // 1 (fp32 kernels) or 1 / (dz_lift * x_lift), a power of two: exact
-    float* dst = dw + ((size_t)co * cin_total + ci) * taps + t;
-    *dst = accumulate ? *dst + s : s;
+    if (sl < n_slices) s0 += partial[sl * per_slice + idx];
+    red[g][i] = s0 + s1;
+    __syncthreads();
+    if (g == 0) {
+      const float s = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) * scale;   // scale: 1 (fp32 kernels) or 1 / (dz_lift * x_lift), a power of two: exact
+      const int j = (int)(idx % ct), ii = (int)((idx / ct) % ct);
+      long r = idx / (ct * ct);
+      const int t = (int)(r % taps);
+      r /= taps;
+      const int cit = (int)(r % n_cit), cot = (int)(r / n_cit);
+      const int co = cot * ct + ii, ci = cit * ct + j;
+      if (co < c_out && ci < c_in) {
+        float* dst = dw + ((size_t)co * cin_total + ci) * taps + t;
+        *dst = accumulate ? *dst + s : s;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -481,7 +489,7 @@ extern "C" int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const flo
   else rc = launch<1, 1>(a, p, s);
   if (rc) return rc;
   const long per_slice = (long)p.n_cot * p.n_cit * p.taps * p.ct * p.ct;
-  const int blocks = (int)((per_slice + 255) / 256 < 2048 ? (per_slice + 255) / 256 : 2048);
+  const int blocks = (int)(per_slice / 64 < 8192 ? per_slice / 64 : 8192);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, dw_oihw, p.n_slices,
                      p.n_cot, p.n_cit, p.taps, d->c_out, d->c0 + d->c1,
                      dw_cin_total ? dw_cin_total : d->c0 + d->c1, accumulate, p.ct, 1.0f);
@@ -492,8 +500,12 @@ extern "C" int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const flo
 namespace {
 // channels per side of a workgroup's block: 64, 32, or 0 = the layer has no split-f16 kernel
 int sp_block(const dn_conv_desc& d) {
-  if (d.ksize != 3 || d.stride != 1 || d.c_out % 4 != 0 || d.ldo % 4 != 0) return 0;
+  if (d.ksize != 3 || (d.stride != 1 && d.stride != 2) || d.c_out % 4 != 0 || d.ldo % 4 != 0) return 0;
   const bool vec = d.c0 % 4 == 0 && d.ld0 % 4 == 0 && d.c1 % 4 == 0 && (d.c1 == 0 || d.ld1 % 4 == 0);
+  if (d.stride == 2) {      // one 16-byte loadable source, no upsample (the encoder's four down-sampling layers)
+    if (!vec || d.c1 != 0 || d.up0 != 0) return 0;
+    return d.c_out >= 64 && d.c0 % 64 == 0 ? 64 : d.c_out >= 32 && d.c0 % 32 == 0 ? 32 : 0;
+  }
   if (vec && d.c_out >= 64 && d.c0 % 64 == 0 && d.c1 % 64 == 0) return 64;
   // 32 x 32 blocks; a single source may end in a partial block and need not be 16-byte loadable (the 13-channel voxel grid)
   if (d.c_out >= 32 && (d.c1 == 0 || (vec && d.c0 % 32 == 0))) return 32;
@@ -502,9 +514,9 @@ int sp_block(const dn_conv_desc& d) {
 Plan make_plan_sp(const dn_conv_desc& d, int cb) {
   Plan p;
   p.ct = cb;
-  p.h_out = d.h_in;
-  p.w_out = d.w_in;
-  const int th = cb == 64 ? WspShape<64>::TH : WspShape<32>::TH;
+  p.h_out = out_dim(d.h_in, 3, d.stride);
+  p.w_out = out_dim(d.w_in, 3, d.stride);
+  const int th = d.stride == 2 ? (cb == 64 ? WspShape2<64>::TH : WspShape2<32>::TH) : (cb == 64 ? WspShape<64>::TH : WspShape<32>::TH);
   p.tiles_x = (p.w_out + 15) / 16;
   p.tiles_y = (p.h_out + th - 1) / th;
   p.n_tiles = d.n_images * p.tiles_x * p.tiles_y;
@@ -521,10 +533,10 @@ Plan make_plan_sp(const dn_conv_desc& d, int cb) {
   p.n_slices = s;
   return p;
 }
-template <int CB>
+template <int CB, int STRIDE>
 int launch_sp(const WgradSpArgs& a, const Plan& p, hipStream_t stream) {
-  constexpr int lds = WspShape<CB>::LDS_DWORDS * 4;
-  auto kern = conv_wgrad_sp_kernel<CB>;
+  constexpr int lds = (STRIDE == 2 ? WspShape2<CB>::LDS_DWORDS : WspShape<CB>::LDS_DWORDS) * 4;
+  auto kern = STRIDE == 2 ? conv_wgrad_sp_s2_kernel<CB> : conv_wgrad_sp_kernel<CB>;
   static dn::PerDeviceFlag ready_flag;
   bool& ready = ready_flag.here();
   if (!ready) {
@@ -552,7 +564,7 @@ extern "C" int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const 
                                 float* dw_oihw, int dw_cin_total, int accumulate, float dz_lift, float x_lift, void* stream) {
   if (int rc = validate(d)) return rc;
   const int cb = sp_block(*d);
-  DN_REQUIRE(cb != 0, "wgrad_sp: 3x3 stride-1 layers with c_out >= 32 only; two sources: 32 k channels each (dn_conv_wgrad_sp_supported)");
+  DN_REQUIRE(cb != 0, "wgrad_sp: 3x3 layers with c_out >= 32 only; two sources: 32 k channels each, stride 1 (dn_conv_wgrad_sp_supported)");
   DN_REQUIRE(src0 && dz && workspace && dw_oihw, "wgrad_sp: null pointer");
   DN_REQUIRE(dw_cin_total == 0 || dw_cin_total >= d->c0 + d->c1, "wgrad_sp: dw_cin_total %d < c_in", dw_cin_total);
   DN_REQUIRE(d->c1 == 0 || src1, "wgrad_sp: c1 > 0 needs src1");
@@ -560,8 +572,8 @@ extern "C" int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const 
   DN_REQUIRE(pow2(dz_lift) && pow2(x_lift), "wgrad_sp: the lifts must be powers of two (got %g, %g)", dz_lift, x_lift);
   auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
   const bool vecx = d->c0 % 4 == 0 && d->ld0 % 4 == 0 && al16(src0) && (d->c1 == 0 || (d->c1 % 4 == 0 && d->ld1 % 4 == 0 && al16(src1)));
-  DN_REQUIRE(al16(dz) && (vecx || (cb == 32 && d->c1 == 0)), "wgrad_sp: dz (and, but for a single-source 32-channel-block layer, "
-             "the sources) must be 16-byte aligned with rows of 4 k floats");
+  DN_REQUIRE(al16(dz) && (vecx || (cb == 32 && d->c1 == 0 && d->stride == 1)), "wgrad_sp: dz (and, but for a single-source stride-1 "
+             "32-channel-block layer, the sources) must be 16-byte aligned with rows of 4 k floats");
   const Plan p = make_plan_sp(*d, cb);
   WgradSpArgs a;
   a.src0 = src0; a.src1 = src1; a.dz = dz; a.partial = static_cast<float*>(workspace);
@@ -572,9 +584,11 @@ extern "C" int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const 
   a.n_cot = p.n_cot; a.n_cit = p.n_cit; a.n_slices = p.n_slices;
   a.dz_lift = dz_lift; a.x_lift = x_lift; a.vecx = vecx ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = cb == 64 ? launch_sp<64>(a, p, s) : launch_sp<32>(a, p, s)) return rc;
+  if (int rc = d->stride == 2 ? (cb == 64 ? launch_sp<64, 2>(a, p, s) : launch_sp<32, 2>(a, p, s))
+                              : (cb == 64 ? launch_sp<64, 1>(a, p, s) : launch_sp<32, 1>(a, p, s)))
+    return rc;
   const long per_slice = (long)p.n_cot * p.n_cit * 9 * cb * cb;
-  const int blocks = (int)((per_slice + 255) / 256 < 2048 ? (per_slice + 255) / 256 : 2048);
+  const int blocks = (int)(per_slice / 64 < 8192 ? per_slice / 64 : 8192);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, dw_oihw, p.n_slices, p.n_cot, p.n_cit, 9,
                      d->c_out, d->c0 + d->c1, dw_cin_total ? dw_cin_total : d->c0 + d->c1, accumulate, cb,
                      1.0f / (dz_lift * x_lift));

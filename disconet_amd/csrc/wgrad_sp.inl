@@ -237,3 +237,199 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_kernel(const WgradSpArgs
     for (int i = tid * 4; i < 9 * 1024; i += 1024) *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(&R[i]);
   }
 }
+
+// ---- stride 2 ------------------------------------------------------------------------------------------------------------
+// dW[co][ci][ty][tx] = sum dz[oy][ox][co] * x[2 oy + ty - 1][2 ox + tx - 1][ci]: a fragment is still 8 consecutive OUTPUT pixels of a
+// row, i.e. every second input column -- so a patch row is staged as two column-parity planes, O (input columns 2 (ox0 + j) - 1,
+// j = 0..16: tap columns 0 and 2) and E (columns 2 (ox0 + j), j = 0..15: tap column 1), 9 + 8 pixel pairs per row.  Tap column 0
+// reads O pairs 4 kb .. 4 kb + 3, tap column 1 the same E pairs, tap column 2 is O one entry on: v_alignbit of neighbouring dwords,
+// as tap column 1 of the stride-1 kernel.  Output row r sees patch rows 2 r + ty.  The patch of a tile is ~4 x the stride-1 kernel's
+// per output pixel, so the tiles are short: CB = 64: 1 x 16 outputs (3 patch rows), the four waves = the four quadrants;
+// CB = 32: 4 x 16 outputs (9 patch rows), one output row per wave, fixed-order LDS sum at the end.  No upsample / concat (the
+// stride-2 layers have one source).
+template <int CB>
+struct WspShape2 {
+  static constexpr int TH = CB == 64 ? 1 : 4, TW = 16, PH = 2 * TH + 1;
+  static constexpr int QN = CB / 4;
+  static constexpr int RP = 17;                                     // pixel pairs per patch row: 9 of plane O, 8 of plane E
+  static constexpr int XPAIRS = PH * RP;
+  static constexpr int DPAIRS = TH * 8;
+  static constexpr int PITCH = CB + 8;
+  static constexpr int X_IT = (XPAIRS * QN + 255) / 256;
+  static constexpr int D_IT = (DPAIRS * QN + 255) / 256;
+  static constexpr int LDS_DWORDS = 2 * (XPAIRS + DPAIRS) * PITCH;
+  static_assert(CB == 64 || LDS_DWORDS >= 9 * 1024, "reduction buffer");
+};
+
+template <int CB>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_sp_s2_kernel(const WgradSpArgs a) {
+  using S = WspShape2<CB>;
+  constexpr int PITCH = S::PITCH, QN = S::QN, TW = S::TW, TH = S::TH, RP = S::RP;
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  extern __shared__ __attribute__((aligned(16))) unsigned wsp_smem[];
+  unsigned* Xh = wsp_smem;
+  unsigned* Xl = Xh + S::XPAIRS * PITCH;
+  unsigned* Dh = Xl + S::XPAIRS * PITCH;
+  unsigned* Dl = Dh + S::DPAIRS * PITCH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = CB == 64 ? wave >> 1 : 0, wn = CB == 64 ? wave & 1 : 0;
+  const int row0 = CB == 64 ? 0 : wave;                    // the output row of the tile this wave works on
+
+  int item = blockIdx.x;
+  const int slice = item % a.n_slices;
+  item /= a.n_slices;
+  const int cit = item % a.n_cit;
+  const int cot = item / a.n_cit;
+  const int co0 = cot * CB, ci0 = cit * CB;
+  const int h_out = (a.h_in - 1) / 2 + 1, w_out = (a.w_in - 1) / 2 + 1;
+  const size_t img_x = (size_t)a.h_in * a.w_in * a.ld0, img_z = (size_t)h_out * w_out * a.ldz;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  f32x4 rx[S::X_IT][2], rd[S::D_IT][2];
+  float amax = 0.f;
+
+  auto ld128 = [](auto rsrc, unsigned voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+  };
+  auto load_tile = [&](int tile) {
+    int sp = tile;
+    const int ox0 = (sp % a.tiles_x) * TW;
+    sp /= a.tiles_x;
+    const int oy0 = (sp % a.tiles_y) * TH;
+    const int img = sp / a.tiles_y;
+    const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0 + img * img_x), 0, (int)(img_x * 4), 0x00020000);
+    const auto rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz + img * img_z), 0, (int)(img_z * 4), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < S::X_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int pr = idx / QN, q = idx % QN;
+      const int prow = pr / RP, pp = pr - prow * RP;
+      const int iy = 2 * oy0 - 1 + prow, c = ci0 + 4 * q;
+      const bool rowok = idx < S::XPAIRS * QN && iy >= 0 && iy < a.h_in && c < a.c0;
+      // plane O (pp < 9): entries j = 2 pp, 2 pp + 1 at input column 2 (ox0 + j) - 1; plane E: j = 2 (pp - 9), + 1 at 2 (ox0 + j)
+      const int ixb = pp < 9 ? 2 * (ox0 + 2 * pp) - 1 : 2 * (ox0 + 2 * (pp - 9));
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ix = ixb + 2 * e;
+        const bool ok = rowok && ix >= 0 && ix < a.w_in;
+        rx[it][e] = ld128(rsx, ok ? (unsigned)(((iy * a.w_in + ix) * a.ld0 + c) * 4) : OOB);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < S::D_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int pr = idx / QN, q = idx % QN;
+      const int oy = oy0 + (pr >> 3), c = co0 + 4 * q;
+      const bool rowok = idx < S::DPAIRS * QN && oy < h_out && c < a.c_out;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ox = ox0 + 2 * (pr & 7) + e;
+        rd[it][e] = ld128(rsz, (rowok && ox < w_out) ? (unsigned)(((oy * w_out + ox) * a.ldz + c) * 4) : OOB);
+      }
+    }
+  };
+  auto put = [&](unsigned* H, unsigned* L, int slot, const f32x4 p0, const f32x4 p1, float lift) {
+    u32x2 h01, l01, h23, l23;
+    split4(f32x4{p0[0] * lift, p1[0] * lift, p0[1] * lift, p1[1] * lift}, h01, l01, amax);
+    split4(f32x4{p0[2] * lift, p1[2] * lift, p0[3] * lift, p1[3] * lift}, h23, l23, amax);
+    *reinterpret_cast<u32x4*>(&H[slot]) = u32x4{h01[0], h01[1], h23[0], h23[1]};
+    *reinterpret_cast<u32x4*>(&L[slot]) = u32x4{l01[0], l01[1], l23[0], l23[1]};
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < S::X_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < S::XPAIRS * QN) put(Xh, Xl, (idx / QN) * PITCH + 4 * (idx % QN), rx[it][0], rx[it][1], a.x_lift);
+    }
+#pragma unroll
+    for (int it = 0; it < S::D_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < S::DPAIRS * QN) put(Dh, Dl, (idx / QN) * PITCH + 4 * (idx % QN), rd[it][0], rd[it][1], a.dz_lift);
+    }
+  };
+
+  int tile = slice;
+  if (tile < a.n_tiles) {
+    load_tile(tile);
+    store_tile();
+  }
+  __syncthreads();
+  const int bcol = wn * 32 + li + (lh * 4 + 2 * row0 * RP) * PITCH;     // patch row 2 row0 (+ ty), this lane's pixel-pair group
+  const int acol = wm * 32 + li + (lh * 4 + row0 * 8) * PITCH;
+  for (; tile < a.n_tiles; tile += a.n_slices) {
+    const bool more = tile + a.n_slices < a.n_tiles;
+    if (more) load_tile(tile + a.n_slices);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      const unsigned* X = part ? Xl : Xh;
+      u32x4 ah;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ah[i] = Dh[i * PITCH + acol];
+      const half8 ahh = __builtin_bit_cast(half8, ah);
+      half8 alh = ahh;
+      if (part == 0) {
+        u32x4 al;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) al[i] = Dl[i * PITCH + acol];
+        alh = __builtin_bit_cast(half8, al);
+      }
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        unsigned o[5], ev[4];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) o[i] = X[(ty * RP + i) * PITCH + bcol];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ev[i] = X[(ty * RP + 9 + i) * PITCH + bcol];
+        half8 f[3];
+        f[0] = __builtin_bit_cast(half8, u32x4{o[0], o[1], o[2], o[3]});
+        f[1] = __builtin_bit_cast(half8, u32x4{ev[0], ev[1], ev[2], ev[3]});
+        f[2] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(o[1], o[0], 16), __builtin_amdgcn_alignbit(o[2], o[1], 16),
+                                               __builtin_amdgcn_alignbit(o[3], o[2], 16), __builtin_amdgcn_alignbit(o[4], o[3], 16)});
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahh, f[tx], acc[ty * 3 + tx], 0, 0, 0);
+        if (part == 0) {
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alh, f[tx], acc[ty * 3 + tx], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (more) store_tile();
+    __syncthreads();
+  }
+  note_range(amax);
+
+  float* out = a.partial + ((size_t)(slice * a.n_cot + cot) * a.n_cit + cit) * (9 * CB * CB);
+  if constexpr (CB == 64) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = lh * 4 + (r & 3) + 8 * (r >> 2);
+        out[t * 4096 + (wm * 32 + i) * 64 + wn * 32 + li] = acc[t][r];
+      }
+  } else {
+    float* R = reinterpret_cast<float*>(wsp_smem);
+    for (int wv = 0; wv < 4; ++wv) {
+      if (wave == wv) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = lh * 4 + (r & 3) + 8 * (r >> 2);
+            float* slot = &R[t * 1024 + i * 32 + li];
+            *slot = (wv == 0 ? 0.f : *slot) + acc[t][r];
+          }
+      }
+      __syncthreads();
+    }
+    for (int i = tid * 4; i < 9 * 1024; i += 1024) *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(&R[i]);
+  }
+}

@@ -50,7 +50,9 @@ int dn_conv_wgrad(const dn_conv_desc* d, const float* src0, const float* src1, c
  *   x_lift (activations: 16) keeps the lo halves of small activations out of the f16 subnormal range.  A lifted value beyond
  *   +-65504 is clamped and sets bit 0 of dn_sp_range_flags: that step's gradients are invalid.  1 / (dz_lift * x_lift) is
  *   applied by the fixed-order slice sum (exact).
- * Layers: 3x3, stride 1, 16-byte aligned dz (and sources, with the exception below), and either c_out >= 64 with c0 and c1 multiples of 64 (a workgroup owns a
+ * Layers: 3x3; stride 2 with ONE 16-byte loadable source of 32 k channels and c_out >= 32 (the encoder's down-sampling layers: the
+ * patch is staged as two column-parity planes so that a fragment is still consecutive dwords); stride 1 with 16-byte aligned dz
+ * (and sources, with the exception below), and either c_out >= 64 with c0 and c1 multiples of 64 (a workgroup owns a
  * 64 x 64 (co, ci) block) or c_out >= 32 (32 x 32 blocks: the 32-channel layers of the full-resolution maps) with either two
  * sources of 32 k channels each or ONE source of any width, which then need not be 16-byte loadable (the 13-channel voxel
  * grid of conv_pre_1: dword loads, the last block partial).  dn_conv_wgrad_sp_supported returns that block size, 0 = no such

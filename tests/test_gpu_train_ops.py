@@ -82,6 +82,10 @@ WGRAD_SP_CASES = [
     (1, 256, 256, 32, 0, 0, 32),        # full-resolution layer, many slices
     (2, 40, 48, 13, 0, 0, 32),          # conv_pre_1: the 13-channel voxel grid (rows not 16-byte loadable: dword loads)
     (1, 32, 32, 72, 0, 0, 40),          # one source ending in a partial block; c_out = 32 + 8
+    (2, 32, 32, 64, 0, 0, 128, 2),      # stride 2 (conv2_1's structure): 64-channel blocks, 1 x 16 output tiles
+    (2, 18, 22, 32, 0, 0, 64, 2),       # stride 2, 32-channel blocks (conv1_1), ragged: 9 x 11 outputs
+    (1, 17, 33, 128, 0, 0, 64, 2),      # stride 2, odd input sizes
+    (3, 16, 64, 32, 0, 0, 32, 2),       # stride 2, 32 -> 32
 ]
 
 
@@ -91,7 +95,8 @@ def test_conv_wgrad_split_f16_matches_autograd(case):
     fp32 kernels' 2e-5, with a gradient map of training-like magnitude (1e-4) under the engine's lift rule."""
     import math
     from disconet_amd import ops, train_ops
-    n, h, w, c0, c1, up0, c_out = case
+    n, h, w, c0, c1, up0, c_out = case[:7]
+    stride = case[7] if len(case) > 7 else 1
     g = torch.Generator().manual_seed(hash(case) % 1000)
     hs, ws = (h // 2, w // 2) if up0 else (h, w)
     x0 = torch.randn(n, c0, hs, ws, generator=g)
@@ -100,10 +105,10 @@ def test_conv_wgrad_split_f16_matches_autograd(case):
     xin = F.interpolate(x0, scale_factor=2) if up0 else x0
     if c1:
         xin = torch.cat([xin, x1], 1)
-    z = F.conv2d(xin.double(), wgt, None, 1, 1)
+    z = F.conv2d(xin.double(), wgt, None, stride, 1)
     dz = torch.randn(z.shape, generator=g) * 1e-4
     z.backward(dz.double())
-    d = ops.conv_desc(n, h, w, c0, c_out, ksize=3, stride=1, c1=c1, up0=up0, relu=False)
+    d = ops.conv_desc(n, h, w, c0, c_out, ksize=3, stride=stride, c1=c1, up0=up0, relu=False)
     assert train_ops.conv_wgrad_sp_supported(d)
     lift = float(2.0 ** (8 - math.floor(math.log2(float(dz.abs().max())))))
     a0, a1, adz = nhwc(x0).to(_dev()), nhwc(x1).to(_dev()) if c1 else None, nhwc(dz).to(_dev())
@@ -126,13 +131,13 @@ def test_conv_wgrad_split_f16_matches_autograd(case):
 
 def test_conv_wgrad_split_f16_refuses_other_layers_and_flags_an_outgrown_lift():
     from disconet_amd import _lib, ops, train_ops
-    for kw in (dict(c0=64, c_out=64, stride=2), dict(c0=64, c_out=64, ksize=1), dict(c0=64, c_out=16)):
+    for kw in (dict(c0=48, c_out=64, stride=2), dict(c0=64, c_out=64, ksize=1), dict(c0=64, c_out=16)):
         d = ops.conv_desc(1, 32, 32, kw["c0"], kw["c_out"], ksize=kw.get("ksize", 3), stride=kw.get("stride", 1), relu=False)
         assert not train_ops.conv_wgrad_sp_supported(d)
-    d = ops.conv_desc(1, 32, 32, 64, 64, ksize=3, stride=2, relu=False)
+    d = ops.conv_desc(1, 32, 32, 64, 64, ksize=1, relu=False)
     with pytest.raises(_lib.DnError):
-        train_ops.conv_wgrad(d, torch.zeros(1, 32, 32, 64, device=_dev()), None, torch.zeros(1, 16, 16, 64, device=_dev()),
-                             torch.zeros(64, 64, 3, 3, device=_dev()), sp_lift=1.0)
+        train_ops.conv_wgrad(d, torch.zeros(1, 32, 32, 64, device=_dev()), None, torch.zeros(1, 32, 32, 64, device=_dev()),
+                             torch.zeros(64, 64, 1, 1, device=_dev()), sp_lift=1.0)
     d = ops.conv_desc(1, 32, 32, 64, 64, ksize=3, relu=False)
     x, dz, dw = (torch.ones(1, 32, 32, 64, device=_dev()), torch.ones(1, 32, 32, 64, device=_dev()),
                  torch.zeros(64, 64, 3, 3, device=_dev()))
