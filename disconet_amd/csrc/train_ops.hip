@@ -12,6 +12,8 @@
 // torch.optim.Adam).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <cmath>
 #include <initializer_list>
 
@@ -655,9 +657,21 @@ bool vec4_ok(int c, std::initializer_list<int> lds, std::initializer_list<const 
   return true;
 }
 
+// Workgroups of a per-channel reduction over all groups.  1024 since round 5 (2048 before): measured in one lease
+// (tools/r05_reduce_blocks.sh, profiles/r05_reduce_blocks.txt) the folds of a training step cost 0.69 / 0.48 / 0.36 ms at 2048 / 1024 /
+// 512 and the reductions themselves 2.13 / 2.02 / 2.64 ms -- four workgroups per CU still saturate the HBM, two do not.
+// DN_REDUCE_BLOCKS overrides (tools).
+int reduce_blocks_total() {
+  static const int n = [] {
+    const char* e = getenv("DN_REDUCE_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 64 && v <= 8192 ? v : 1024;
+  }();
+  return n;
+}
 int blocks_per_group(long rows_per_group, int n_groups) {
-  // ~2048 workgroups over all groups, at least 64 rows each
-  long b = 2048 / n_groups;
+  // ~1024 workgroups over all groups, at least 64 rows each
+  long b = reduce_blocks_total() / n_groups;
   if (b > rows_per_group / 64) b = rows_per_group / 64;
   return (int)(b < 1 ? 1 : b);
 }
