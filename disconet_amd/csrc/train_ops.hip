@@ -233,7 +233,15 @@ struct GradSrc {
   int ld_a, up_a, ld_b, relu, h, w, c;
   __device__ inline float operator()(long row, int cc) const {
     float g;
-    if (up_a) {
+    if (up_a == 2) {
+      // dy_a is the space-to-depth image of the gradient: [img][h / 2][w / 2][4 c], pixel (y, x) channel cc at
+      // (y / 2, x / 2), channel ((y & 1) * 2 + (x & 1)) * c + cc -- what ONE split-f16 launch over the four parity classes of a
+      // stride-2 layer's data gradient writes (train.py :: _dgrad)
+      const long img = row / ((long)h * w);
+      const int p = (int)(row % ((long)h * w));
+      const int py = p / w, px = p % w;
+      g = dy_a[((img * (h >> 1) + (py >> 1)) * (long)(w >> 1) + (px >> 1)) * ld_a + ((py & 1) * 2 + (px & 1)) * c + cc];
+    } else if (up_a) {
       const long img = row / ((long)h * w);
       const int p = (int)(row % ((long)h * w));
       const int py = p / w, px = p % w;
@@ -250,7 +258,12 @@ struct GradSrc {
   }
   __device__ inline f32x4 v4(long row, int c4) const {
     f32x4 g;
-    if (up_a) {
+    if (up_a == 2) {
+      const long img = row / ((long)h * w);
+      const int p = (int)(row % ((long)h * w));
+      const int py = p / w, px = p % w;
+      g = ldv4(dy_a + ((img * (h >> 1) + (py >> 1)) * (long)(w >> 1) + (px >> 1)) * ld_a + ((py & 1) * 2 + (px & 1)) * c + 4 * c4);
+    } else if (up_a) {
       const long img = row / ((long)h * w);
       const int p = (int)(row % ((long)h * w));
       const int py = p / w, px = p % w;
@@ -774,6 +787,8 @@ extern "C" int dn_bn_train_backward_partial(const float* dy_a, int ld_a, int up_
   DN_REQUIRE(dy_a && z && mean && var && sums && dgamma && dbeta, "bn backward: null pointer");
   DN_REQUIRE(!relu || y, "bn backward: relu needs y");
   DN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || c % 4 == 0), "bn backward: relu = 2 (y is the byte mask) needs c %% 4 == 0");
+  DN_REQUIRE(up_a >= 0 && up_a <= 2 && (up_a != 2 || (h % 2 == 0 && w % 2 == 0 && ld_a >= 4 * c)),
+             "bn backward: up_a = 2 (dy_a is the space-to-depth image [h / 2][w / 2][4 c]) needs even h, w and ld_a >= 4 c");
   DN_REQUIRE(n_groups > 0 && h > 0 && w > 0 && images_per_group > 0 && c > 0 && c <= kMaxC &&
                  ld_a >= c && (!dy_b || ld_b >= c),
              "bn backward: bad shape");
@@ -808,6 +823,8 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
   DN_REQUIRE(dy_a && z && mean && var && gamma && sums && dz, "bn backward finish: null pointer");
   DN_REQUIRE(!relu || y, "bn backward: relu needs y");
   DN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || c % 4 == 0), "bn backward: relu = 2 (y is the byte mask) needs c %% 4 == 0");
+  DN_REQUIRE(up_a >= 0 && up_a <= 2 && (up_a != 2 || (h % 2 == 0 && w % 2 == 0 && ld_a >= 4 * c)),
+             "bn backward: up_a = 2 (dy_a is the space-to-depth image [h / 2][w / 2][4 c]) needs even h, w and ld_a >= 4 c");
   DN_REQUIRE(n_groups > 0 && h > 0 && w > 0 && images_per_group > 0 && c > 0 && c <= kMaxC && norm_rows > 0 &&
                  ld_a >= c && (!dy_b || ld_b >= c),
              "bn backward finish: bad shape");

@@ -317,14 +317,20 @@ class TrainEngine:
         bn.num_batches_tracked += calls
 
     def _layer_bwd(self, lay, dy_a, G, dy_b=None, up_a=False, need_dx=True, gw=None, gb=None,
-                   ggamma=None, gbeta=None):
-        """-> gradient w.r.t. the layer's (concatenated) input, [n, h_in, w_in, c_in]"""
+                   ggamma=None, gbeta=None, s2d_ok=False):
+        """-> gradient w.r.t. the layer's (concatenated) input, [n, h_in, w_in, c_in].
+        s2d_ok: the caller hands the result to another _layer_bwd as dy_a and to nothing else -- a stride-2 layer may then
+        return its data gradient as the SPACE-TO-DEPTH image [n, h_in / 2, w_in / 2, 4 c_in] (marked `_dn_s2d`; one split-f16
+        launch over the four parity classes, _dgrad), which the next BatchNorm backward reads in place (up_a = 2)."""
         c = lay.ctx
+        if getattr(dy_a, "_dn_s2d", False):
+            assert not up_a, "a space-to-depth gradient is not also an upsampled one"
+            up_a = 2
         gw = self.g(lay.w, G) if gw is None else gw
         gb = self.g(lay.b, G) if gb is None else gb
         ggamma = self.g(lay.bn.weight, G) if ggamma is None else ggamma
         gbeta = self.g(lay.bn.bias, G) if gbeta is None else gbeta
-        sp, lift = self._dz_sp_plan(lay, c, need_dx)
+        sp, lift = self._dz_sp_plan(lay, c, need_dx, s2d_ok)
         wsp = self._wgrad_sp_layer(c)
         ent = self._dz_lift.get(lay.name)
         dz = T.bn_backward(dy_a, c["y"], c["z"], c["mean"], c["var"], c["gamma"], _EPS, ggamma, gbeta,
@@ -340,7 +346,7 @@ class TrainEngine:
         layer's measured lift: the first step (and a layer whose lift was dropped) runs the fp32 kernel and measures."""
         return self.wgrad_math == "sp" and c["groups"] == 1 and T.conv_wgrad_sp_supported(c["desc"])
 
-    def _dz_sp_plan(self, lay, c, need_dx):
+    def _dz_sp_plan(self, lay, c, need_dx, s2d_ok=False):
         """-> (SpTensor that shall receive dz * lift, lift) when this layer's data gradient runs on the split-f16 engine, else
         (None, None) / (None, 1.0) while the lift is still unknown.  The engine's operands are f16 hi + lo pairs: 2^-22 relative
         only while 2^-3 <= |x| <= 65504, and a gradient's magnitude is anything -- so dz is LIFTED by a power of two that puts its
@@ -349,9 +355,12 @@ class TrainEngine:
         that layer's data gradient in fp32, and again every 64 steps; a dz that outgrows it is clamped AND flagged (the range
         guard polled at the end of the step raises: the step's gradients are invalid)."""
         d = c["desc"]
-        if (self.dgrad_math != "sp" or not need_dx or d.ksize != 3 or d.stride != 1 or c["groups"] != 1
+        if (self.dgrad_math != "sp" or not need_dx or d.ksize != 3 or c["groups"] != 1
                 or d.c_out % 16 != 0 or (d.c0 + d.c1) % 4 != 0):
             return None, None
+        if d.stride != 1 and not (s2d_ok and d.stride == 2 and d.c1 == 0 and not d.up0 and d.h_in % 2 == 0 and d.w_in % 2 == 0
+                                  and os.environ.get("DN_DGRAD_S2D", "1") != "0"):
+            return None, None       # (a stride-2 layer: only as the one-launch space-to-depth form, where the caller can take it)
         ent = self._dz_lift.get(lay.name)
         if ent is None:
             return None, 1.0            # not measured yet: fp32 this step, _dz_lift_refresh measures
@@ -391,6 +400,27 @@ class TrainEngine:
         split-f16 form (dz_sp given: dz * dz_lift pre-split by the BatchNorm backward): the inference engine's LDS-DMA kernels
         (dn_spconv2d_nhwc), 1 / (dz_lift * wmul) in the scale vector."""
         w4 = w.reshape(w.shape[0], w.shape[1], d.ksize, d.ksize)
+        if dz_sp is not None and d.stride == 2:
+            # all four parity classes of the stride-2 layer's data gradient (include/disconet_train.h ::
+            # dn_conv_dgrad_class_weights) as ONE stride-1 launch of the split-f16 engine over dz: the classes are the output
+            # channel groups, [n, h_in / 2, w_in / 2, 4 c_in] -- the space-to-depth image of dx, read in place by the next
+            # BatchNorm backward (up_a = 2).  27 of its 36 (class, tap) weight blocks are zero: 4 x the MFMAs the masked fp32
+            # form runs, on an engine 16 x as fast per MFMA -- and dz is read once instead of four times.
+            n_in = (w4.shape[1] - ci_first) if c_in is None else c_in
+            dev = dz.device
+            wt = torch.empty((4 * n_in, d.c_out, 3, 3), dtype=torch.float32, device=dev)
+            for py in (0, 1):
+                for px in (0, 1):
+                    k = py * 2 + px
+                    T.dgrad_class_weights(w4, py, px, ci_first, n_in, out=wt[k * n_in:(k + 1) * n_in])
+            dd = ops.conv_desc(d.n_images, d.h_in // 2, d.w_in // 2, d.c_out, 4 * n_in, 3, 1, False)
+            wmul = self._wmul_of(w)
+            packed, _ = ops.sp_pack_conv_weights(dd, wt, wmul)
+            out = torch.empty((d.n_images, d.h_in // 2, d.w_in // 2, 4 * n_in), dtype=torch.float32, device=dev)
+            ops.sp_conv2d_nhwc(dd, dz_sp, packed, self._const(dev, 4 * n_in, 1.0 / (dz_lift * wmul)),
+                               self._const(dev, 4 * n_in, 0.0), out)
+            out._dn_s2d = True
+            return out
         if dz_sp is not None:
             wt = T.dgrad_weights(w4, ci_first, c_in)
             n_in = wt.shape[0]
@@ -672,7 +702,8 @@ class TrainEngine:
                 elif last:
                     d = self._layer_bwd(L[name], d, G, dy_b=d_dec[k])
                 else:
-                    d = self._layer_bwd(L[name], d, G, need_dx=name != "conv_pre_1")
+                    # (the group's first layer, for k >= 1 the stride-2 one: its dx goes to the level below's last layer and nowhere else)
+                    d = self._layer_bwd(L[name], d, G, need_dx=name != "conv_pre_1", s2d_ok=name == names[0] and k >= 1)
             return d
 
         # the levels above the exchanged one do not wait for the fusion's backward: second stream

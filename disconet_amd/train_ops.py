@@ -71,12 +71,15 @@ def dgrad_weights(w, ci_first=0, c_in=None):
     return wt
 
 
-def dgrad_class_weights(w, py, px, ci_first=0, c_in=None):
-    """parity class (py, px) of a stride-2 3x3 layer's data gradient: -> (v [c_in, c_out, 3, 3], tap mask)"""
-    _need_gpu(w)
+def dgrad_class_weights(w, py, px, ci_first=0, c_in=None, out=None):
+    """parity class (py, px) of a stride-2 3x3 layer's data gradient: -> (v [c_in, c_out, 3, 3], tap mask).
+    out: write v there (a contiguous [c_in, c_out, 3, 3] view, e.g. one class's rows of the four-class weight tensor)"""
+    _need_gpu(w, out)
     c_out, cin_total = w.shape[0], w.shape[1]
     c_in = cin_total - ci_first if c_in is None else c_in
-    v = torch.empty((c_in, c_out, 3, 3), dtype=torch.float32, device=w.device)
+    if out is not None and (tuple(out.shape) != (c_in, c_out, 3, 3) or not out.is_contiguous() or out.dtype != torch.float32):
+        raise _lib.DnError("dgrad_class_weights: out must be a contiguous float32 [c_in, c_out, 3, 3] tensor")
+    v = torch.empty((c_in, c_out, 3, 3), dtype=torch.float32, device=w.device) if out is None else out
     mask = ctypes.c_int(0)
     check(_lib.load().dn_conv_dgrad_class_weights(_ptr(w), c_out, cin_total, ci_first, c_in, py, px, _ptr(v),
                                                   ctypes.byref(mask), _stream()), "dn_conv_dgrad_class_weights")
@@ -145,7 +148,8 @@ def bn_update_running(mean, var, rows_per_group, running_mean, running_var, mome
 
 def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_b=None, up_a=False,
                 accumulate=False, out=None, sync=None, norm_rows=None, sp_out=None, sp_lift=1.0, relu_mask=None):
-    """z, y [n, h, w, c] dense.  dy_a: [n, h, w, c'] view (or [n, 2h, 2w, c'] when up_a), dy_b
+    """z, y [n, h, w, c] dense.  dy_a: [n, h, w, c'] view (or [n, 2h, 2w, c'] when up_a = 1 / True; up_a = 2: the
+    space-to-depth image [n, h/2, w/2, 4c] of the gradient, train.py :: _dgrad's one-launch stride-2 data gradient), dy_b
     optional second gradient (same resolution as y).  Returns dz; fills dgamma / dbeta.
     sync / norm_rows (agent-parallel training, see bn_stats): dgamma / dbeta are then THIS rank's share (sums over its rows).
     sp_out / sp_lift: an ops.SpTensor [n, h, w, c] that also receives dz * sp_lift as f16 hi / lo planes
@@ -165,7 +169,7 @@ def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_
     if sp_out is not None:
         if tuple(sp_out.shape) != (n, h, w, c) or sp_out.hi_only or sp_out.bits:
             raise _lib.DnError("bn_backward: sp_out must be a full SP tensor of z's shape")
-        src = (_ptr(dy_a), _ld(dy_a), int(bool(up_a)), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0, _ptr(y), _ptr(z),
+        src = (_ptr(dy_a), _ld(dy_a), int(up_a), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0, _ptr(y), _ptr(z),
                _ptr(mean), _ptr(var))
         check(lib.dn_bn_train_backward_partial(*src, float(eps), int(relu), n_groups, h, w, n // n_groups, c, _ptr(sums),
                                                sums.numel(), _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)), _stream()),
@@ -179,12 +183,12 @@ def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_
         return dz
     if sync is None:
         check(lib.dn_bn_train_backward(
-            _ptr(dy_a), _ld(dy_a), int(bool(up_a)), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0,
+            _ptr(dy_a), _ld(dy_a), int(up_a), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0,
             _ptr(y), _ptr(z), _ptr(mean), _ptr(var), _ptr(gamma), float(eps), int(relu), n_groups, h, w,
             n // n_groups, c, _ptr(sums), sums.numel(), _ptr(dz), _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)),
             _stream()), "dn_bn_train_backward")
         return dz
-    src = (_ptr(dy_a), _ld(dy_a), int(bool(up_a)), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0, _ptr(y), _ptr(z),
+    src = (_ptr(dy_a), _ld(dy_a), int(up_a), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0, _ptr(y), _ptr(z),
            _ptr(mean), _ptr(var))
     check(lib.dn_bn_train_backward_partial(*src, float(eps), int(relu), n_groups, h, w, n // n_groups, c, _ptr(sums),
                                            sums.numel(), _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)), _stream()),

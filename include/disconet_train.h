@@ -118,8 +118,11 @@ int dn_bn_update_running(const float* mean, const float* var, int n_groups, long
                          float* running_var, void* stream);
 
 /* Backward of y = act(bn(z)).  The incoming gradient is dy_a (+ dy_b if not null); each has
- * its own row stride, and dy_a may live at twice the resolution (up_a != 0: the 2 x 2 block
+ * its own row stride, and dy_a may live at twice the resolution (up_a = 1: the 2 x 2 block
  * sum, i.e. the backward of the decoder's nearest upsample; h, w are then y's dims).
+ *   up_a = 2: dy_a is the SPACE-TO-DEPTH image of the gradient, [img][h / 2][w / 2][4 c] with pixel (y, x), channel ch at
+ *   (y / 2, x / 2), channel ((y & 1) * 2 + (x & 1)) * c + ch -- what one split-f16 launch over the four parity classes of a
+ *   stride-2 layer's data gradient writes (round 5; even h, w; ld_a >= 4 c).
  *   g = (dy_a + dy_b) * (y > 0)      dbeta = sum g      dgamma = sum g * zhat
  *   (relu = 2: `y` is not the map but dn_bn_train_apply_mask's byte mask of (y > 0), cast to const float*)
  *   dz = gamma * rstd * (g - mean(g) - zhat * mean(g * zhat))       (means per group)

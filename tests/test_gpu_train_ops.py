@@ -357,6 +357,34 @@ def test_bn_relu_byte_mask_replaces_y_in_the_backward_bit_for_bit(shape, up_a, s
                            b.view(torch.int32) if b.dtype == torch.float32 else b.view(torch.int16))
 
 
+@pytest.mark.parametrize("shape,sp", [((2, 16, 24, 32), True), ((3, 8, 8, 6), False), ((1, 32, 32, 64), False)])
+def test_bn_backward_reads_a_space_to_depth_gradient_in_place(shape, sp):
+    """up_a = 2: dy_a as [n, h/2, w/2, 4c] with pixel (y, x) in channel group (y & 1) * 2 + (x & 1) -- the layout of the one-launch
+    stride-2 data gradient -- gives bit for bit what the dense gradient gives (vector and scalar kernels, SP copy, second consumer)."""
+    from disconet_amd import ops, train_ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(41)
+    z = (torch.randn(shape, generator=g) * 2 + 0.5).to(_dev())
+    gm = (torch.rand(c, generator=g) + 0.5).to(_dev())
+    bt = (torch.randn(c, generator=g) * 0.2).to(_dev())
+    mean, var = train_ops.bn_stats(z)
+    y = train_ops.bn_apply(z, mean, var, gm, bt, 1e-5, relu=True)
+    dy = (torch.randn(shape, generator=g) * 1e-3).to(_dev())
+    dyb = (torch.randn(shape, generator=g) * 1e-3).to(_dev())
+    s2d = dy.view(n, h // 2, 2, w // 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, h // 2, w // 2, 4 * c).contiguous()
+    out = []
+    for src, up in ((dy, 0), (s2d, 2)):
+        dg, db = torch.empty(c, device=_dev()), torch.empty(c, device=_dev())
+        spt = ops.SpTensor(n, h, w, c, device=_dev()) if sp else None
+        dz = train_ops.bn_backward(src, y, z, mean, var, gm, 1e-5, dg, db, up_a=up, dy_b=dyb, sp_out=spt, sp_lift=2.0 ** 12)
+        out.append((dz, dg, db, spt.data.clone().view(torch.int16) if sp else dz))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    with pytest.raises(ops._lib.DnError):       # odd maps have no space-to-depth image
+        zz = z[:, :h - 1].contiguous()
+        train_ops.bn_backward(s2d, y[:, :h - 1].contiguous(), zz, mean, var, gm, 1e-5, dg, db, up_a=2)
+
+
 def test_bn_backward_sp_copy_flags_a_gradient_that_outgrows_its_lift():
     from disconet_amd import ops, train_ops
     n, h, w, c = 1, 8, 8, 32
