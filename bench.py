@@ -1065,9 +1065,10 @@ def main():
                     "wgrad_math": mod.engine.wgrad_math,
                     "layers_with_a_measured_gradient_lift": len(mod.engine._dz_lift),
                     "note": "train() forward (batch-stat BN) + focal/smooth-L1 loss + explicit HIP backward (3x3 stride-1 data "
-                            "gradients: split-f16 LDS-DMA engine on a lifted, pre-split dz; 3x3 weight gradients, stride 1 and 2: f16 "
-                            "MFMA on operands lifted / split / transposed while staged, dn_conv_wgrad_sp; stride-2 data gradients "
-                            "and 1x1 gradients: fp32 MFMA) + Adam, eager launches, wall clock"}
+                            "gradients: split-f16 LDS-DMA engine on a lifted, pre-split dz; stride-2 data gradients: one launch of "
+                            "that engine over the four parity classes, read in place by the next BatchNorm backward; 3x3 weight "
+                            "gradients, stride 1 and 2: f16 MFMA on operands lifted / split / transposed while staged, "
+                            "dn_conv_wgrad_sp; 1x1 gradients: fp32 MFMA) + Adam, eager launches, wall clock"}
                 del mod
                 # the same step with every data and weight gradient on the exact-fp32 MFMA (rounds 2-4's step)
                 try:
