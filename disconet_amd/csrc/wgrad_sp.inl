@@ -1,4 +1,6 @@
-// Weight gradient on the f16 MFMA with split operands (3x3 stride-1 layers; 64 x 64 or 32 x 32 (co, ci) blocks per workgroup).
+// Weight gradient on the f16 MFMA with split operands: 3x3 layers, 64 x 64 or 32 x 32 (co, ci) blocks per workgroup; the stride-1
+// kernel first, the stride-2 kernel (column-parity planes of the patch) at the end of the file.  include/disconet_train.h ::
+// dn_conv_wgrad_sp; replaces autograd's weight gradient of the nn.Conv2d layers (upstream:coperception/utils/CoDetModule.py :: step).
 //
 // Same GEMM as conv_wgrad64_kernel -- D[co][ci] += dz^T . x_shifted per tap, K = pixels -- but every value is an
 // f16 hi + lo pair (x = hi + lo, 22 significand bits) and a product is three v_mfma_f32_32x32x16_f16
@@ -9,7 +11,7 @@
 // (ds_write_b128 per part): LDS image [pixel pair][channel] dwords.  A fragment is then 4 dword reads (pairs
 // 4 kb .. 4 kb + 3 of the lane's channel); the x fragment of tap column 2 starts one pair later, and tap column 1 is
 // v_alignbit of neighbouring dwords -- 5 reads per patch row and part serve the three tap columns.
-// The dz tile [4 rows][16 pixels] and the x patch [6][18] of one pixel tile are prefetched into registers under the
+// The dz tile ([4 | 8 rows][16 pixels]) and the x patch ([6 | 10][18]) of one pixel tile are prefetched into registers under the
 // previous tile's MFMAs, as in the fp32 kernels; the per-slice partial blocks and their fixed-order sum are shared with them.
 struct WgradSpArgs {
   const float* src0;

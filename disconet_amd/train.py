@@ -155,8 +155,9 @@ class TrainEngine:
         """wgrad_math: arithmetic of the weight gradients -- "f32" (the exact fp32 MFMA kernels) or "sp" (dn_conv_wgrad_sp where
         it takes the layer: f16 hi + lo operands split while staging, dz lifted by the same measured power of two as below; the
         other layers stay fp32); None: DISCONET_WGRAD_MATH, default _WGRAD_MATH_DEFAULT.
-        dgrad_math: arithmetic of the 3x3 stride-1 data gradients -- "f32" (the exact fp32 MFMA) or "sp" (the inference
-        engine's split-f16 LDS-DMA kernels on a dz the BatchNorm backward writes pre-split and lifted, see _dz_sp_plan);
+        dgrad_math: arithmetic of the 3x3 data gradients -- "f32" (the exact fp32 MFMA) or "sp" (the inference engine's
+        split-f16 LDS-DMA kernels on a dz the BatchNorm backward writes pre-split and lifted, see _dz_sp_plan; a stride-2 layer
+        as ONE launch over its four parity classes where the next BatchNorm backward can read the space-to-depth result);
         None: DISCONET_DGRAD_MATH, default _DGRAD_MATH_DEFAULT.
         shard: a sharded.AgentShard -- this process trains the agents [shard.first, shard.first + shard.count) of every
         scene (agent-parallel training): forward() / backward() then take the LOCAL agent-major images and
