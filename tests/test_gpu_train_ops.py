@@ -129,6 +129,47 @@ def test_conv_wgrad_split_f16_matches_autograd(case):
     assert ops.sp_range_flags(reset=True) & 5 == 0
 
 
+BASELINE_LAYERS = [
+    # name, map, c0, c1, up0, c_out, stride: every 3x3 layer of the detector at BASELINE configs[1]'s size (20 images of 256 x 256)
+    ("conv_pre_1", 256, 13, 0, 0, 32, 1), ("conv_pre_2", 256, 32, 0, 0, 32, 1), ("conv1_1", 256, 32, 0, 0, 64, 2),
+    ("conv1_2", 128, 64, 0, 0, 64, 1), ("conv2_1", 128, 64, 0, 0, 128, 2), ("conv2_2", 64, 128, 0, 0, 128, 1),
+    ("conv3_1", 64, 128, 0, 0, 256, 2), ("conv3_2", 32, 256, 0, 0, 256, 1), ("conv4_1", 32, 256, 0, 0, 512, 2),
+    ("conv4_2", 16, 512, 0, 0, 512, 1), ("conv5_1", 32, 512, 256, 1, 256, 1), ("conv6_1", 64, 256, 128, 1, 128, 1),
+    ("conv7_1", 128, 128, 64, 1, 64, 1), ("conv8_1", 256, 64, 32, 1, 32, 1), ("heads1", 256, 32, 0, 0, 64, 1),
+]
+
+
+@pytest.mark.parametrize("layer", BASELINE_LAYERS, ids=lambda l: l[0])
+def test_conv_wgrad_split_f16_equals_the_fp32_kernels_at_baseline_size(layer):
+    """the benchmarked batch (5 agents x batch 4, 256 x 256): every 3x3 layer's weight gradient by dn_conv_wgrad_sp against the
+    exact-fp32 kernels on the same operands (2e-5 of the largest entry: both sit ~1e-6 from the float64 sum), bitwise repeatable,
+    no range flag -- post-ReLU-like activations, a 1e-4-sized gradient map under the engine's lift rule"""
+    import math
+    from disconet_amd import ops, train_ops
+    name, hw, c0, c1, up0, c_out, stride = layer
+    n = 20
+    g = torch.Generator(device=_dev()).manual_seed(hash(name) % 1000)
+    hs = hw // 2 if up0 else hw
+    x0 = torch.randn(n, hs, hs, c0, generator=g, device=_dev()).clamp_(min=0) if c0 != 13 else \
+        (torch.rand(n, hs, hs, c0, generator=g, device=_dev()) < 0.05).float()
+    x1 = torch.randn(n, hw, hw, c1, generator=g, device=_dev()).clamp_(min=0) if c1 else None
+    ho = hw // stride
+    dz = torch.randn(n, ho, ho, c_out, generator=g, device=_dev()) * 1e-4
+    d = ops.conv_desc(n, hw, hw, c0, c_out, ksize=3, stride=stride, c1=c1, up0=up0, relu=False)
+    assert train_ops.conv_wgrad_sp_supported(d)
+    lift = float(2.0 ** (8 - math.floor(math.log2(float(dz.abs().max())))))
+    ops.sp_range_flags(reset=True)
+    want = torch.empty(c_out, c0 + c1, 3, 3, device=_dev())
+    train_ops.conv_wgrad(d, x0, x1, dz, want)
+    got = torch.empty_like(want)
+    train_ops.conv_wgrad(d, x0, x1, dz, got, sp_lift=lift)
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    again = torch.empty_like(want)
+    train_ops.conv_wgrad(d, x0, x1, dz, again, sp_lift=lift)
+    assert torch.equal(got, again)
+    assert ops.sp_range_flags(reset=True) & 5 == 0
+
+
 def test_conv_wgrad_split_f16_refuses_other_layers_and_flags_an_outgrown_lift():
     from disconet_amd import _lib, ops, train_ops
     for kw in (dict(c0=48, c_out=64, stride=2), dict(c0=64, c_out=64, ksize=1), dict(c0=64, c_out=16)):
