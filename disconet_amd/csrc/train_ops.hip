@@ -166,6 +166,31 @@ bn_apply_v4_kernel(const float* __restrict__ z, const float* __restrict__ mean,
   }
 }
 
+// One group, c / 4 a power of two, fewer than 2^31 float4s (every BatchNorm of the conv stack): the general kernel above spends
+// ~300 VALU instructions per float4 on two 64-bit divisions and four 1 / sqrtf -- it is instruction-bound at ~4.8 TB/s, not
+// HBM-bound (round 5: rocprofv3 counters, profiles/r05_train_pmc.txt).  Here 1 / sqrtf(var + eps) is computed once per workgroup
+// into LDS (the same expression: the same bits) and (row, channel quad) come from a shift and a mask.  DN_BN_LEGACY=1 routes
+// every call to the general kernels (tests: bitwise A/B).
+__global__ void __launch_bounds__(256)
+bn_apply_v4_fast_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ var,
+                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu, int c, int sh,
+                        int ldz, unsigned total4, float* __restrict__ y, unsigned char* __restrict__ relu_mask) {
+  __shared__ __attribute__((aligned(16))) float rstd_s[kMaxC];
+  for (int i = threadIdx.x; i < c; i += 256) rstd_s[i] = 1.f / sqrtf(var[i] + eps);
+  __syncthreads();
+  const unsigned c4m = (1u << sh) - 1u;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total4; idx += gridDim.x * 256u) {
+    const unsigned row = idx >> sh;
+    const int c4 = (int)(idx & c4m);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(&rstd_s[4 * c4]);
+    f32x4 v = (ldv4(z + (size_t)row * ldz + 4 * c4) - ldv4(mean + 4 * c4)) * rs * ldv4(gamma + 4 * c4) +
+              ldv4(beta + 4 * c4);
+    if (relu_mask) relu_mask[idx] = (unsigned char)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
+    if (relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+    *reinterpret_cast<f32x4*>(y + (size_t)row * c + 4 * c4) = v;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 bn_stats_kernel(const float* __restrict__ z, long rows_per_group, int c, int ldz,
                 double* __restrict__ sums) {
@@ -254,6 +279,36 @@ struct GradSrc {
     if (relu == 2) {          // y is the byte mask of dn_bn_train_apply_mask (c % 4 == 0)
       if (!((reinterpret_cast<const unsigned char*>(y)[(row * c + cc) >> 2] >> (cc & 3)) & 1)) g = 0.f;
     } else if (relu && !(y[row * c + cc] > 0.f)) g = 0.f;
+    return g;
+  }
+  // v4 for rows below 2^31 (the one-group fast kernels): the same values, the pixel decode in 32-bit arithmetic
+  __device__ inline f32x4 v4u(unsigned row, int c4) const {
+    f32x4 g;
+    if (up_a) {
+      const unsigned hw = (unsigned)h * (unsigned)w;
+      const unsigned img = row / hw, p = row - img * hw;
+      const unsigned py = p / (unsigned)w, px = p - py * (unsigned)w;
+      if (up_a == 2) {
+        g = ldv4(dy_a + (((size_t)img * (h >> 1) + (py >> 1)) * (size_t)(w >> 1) + (px >> 1)) * ld_a + ((py & 1) * 2 + (px & 1)) * c + 4 * c4);
+      } else {
+        const float* b = dy_a + (((size_t)img * 2 * h + 2 * py) * (2L * w) + 2 * px) * ld_a + 4 * c4;
+        g = (ldv4(b) + ldv4(b + ld_a)) + (ldv4(b + 2L * w * ld_a) + ldv4(b + (2L * w + 1) * ld_a));
+      }
+    } else {
+      g = ldv4(dy_a + (size_t)row * ld_a + 4 * c4);
+    }
+    if (dy_b) g += ldv4(dy_b + (size_t)row * ld_b + 4 * c4);
+    if (relu == 2) {
+      const unsigned m = reinterpret_cast<const unsigned char*>(y)[(size_t)row * (c >> 2) + c4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!((m >> e) & 1)) g[e] = 0.f;
+    } else if (relu) {
+      const f32x4 yv = ldv4(y + (size_t)row * c + 4 * c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!(yv[e] > 0.f)) g[e] = 0.f;
+    }
     return g;
   }
   __device__ inline f32x4 v4(long row, int c4) const {
@@ -353,6 +408,60 @@ bn_bwd_apply_v4_kernel(GradSrc src, const float* __restrict__ z, const float* __
       const u4 piece = odd ? u4{t0, t1, lu[0], lu[1]} : u4{hu[0], hu[1], t0, t1};
       const unsigned urow = (unsigned)row, img = urow / hw, px = urow - img * hw;
       const int oct8 = c4 >> 1, cg = oct8 >> 1, oct = oct8 & 1, cg_total = c >> 4;      // (c % 16 == 0: no padded octet to zero)
+      const size_t q = ((size_t)img * cg_total + cg) * 4 + (odd ? 2 : 0) + oct;
+      *reinterpret_cast<u4*>(dz_sp + (q * hw + px) * 16) = piece;
+    }
+  }
+  if constexpr (SP) {
+    if (amax > 16384.f && flags) atomicOr(flags, amax >= 65504.f ? 3u : 2u);
+  }
+}
+
+// The one-group fast form of bn_bwd_apply_v4_kernel (see bn_apply_v4_fast_kernel): per channel 1 / sqrtf(var + eps) and the two
+// means (double sum / norm_rows, rounded to float -- eight fp64 divisions per float4 in the general kernel) once per workgroup
+// into LDS, the same expressions; (row, channel quad) by shift and mask; the pixel decode of the incoming gradient in 32 bits.
+template <bool SP>
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_v4_fast_kernel(GradSrc src, const float* __restrict__ z, const float* __restrict__ mean,
+                            const float* __restrict__ var, const float* __restrict__ gamma, float eps, long norm_rows,
+                            const double* __restrict__ sums, int sh, unsigned total4, float* __restrict__ dz,
+                            unsigned char* __restrict__ dz_sp, float sp_lift, unsigned hw, unsigned* __restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) float rstd_s[kMaxC], m1_s[kMaxC], m2_s[kMaxC];
+  const int c = src.c;
+  for (int i = threadIdx.x; i < c; i += 256) {
+    rstd_s[i] = 1.f / sqrtf(var[i] + eps);
+    m1_s[i] = (float)(sums[i] / norm_rows);
+    m2_s[i] = (float)(sums[c + i] / norm_rows);
+  }
+  __syncthreads();
+  const unsigned c4m = (1u << sh) - 1u;
+  float amax = 0.f;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total4; idx += gridDim.x * 256u) {
+    const unsigned row = idx >> sh;
+    const int c4 = (int)(idx & c4m);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(&rstd_s[4 * c4]);
+    const f32x4 zh = (ldv4(z + (size_t)row * c + 4 * c4) - ldv4(mean + 4 * c4)) * rs;
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(&m1_s[4 * c4]), m2 = *reinterpret_cast<const f32x4*>(&m2_s[4 * c4]);
+    const f32x4 v = ldv4(gamma + 4 * c4) * rs * (src.v4u(row, c4) - m1 - zh * m2);
+    *reinterpret_cast<f32x4*>(dz + (size_t)row * c + 4 * c4) = v;
+    if constexpr (SP) {
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      f32x4 x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[e] = fminf(fmaxf(v[e] * sp_lift, -65504.f), 65504.f);
+        amax = fmaxf(amax, fabsf(x[e]));
+      }
+      const h4 hi = __builtin_convertvector(x, h4);
+      const h4 lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), h4);
+      const u2 hu = __builtin_bit_cast(u2, hi), lu = __builtin_bit_cast(u2, lo);
+      const bool odd = c4 & 1;
+      const unsigned t0 = __shfl_xor(odd ? hu[0] : lu[0], 1), t1 = __shfl_xor(odd ? hu[1] : lu[1], 1);
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      const u4 piece = odd ? u4{t0, t1, lu[0], lu[1]} : u4{hu[0], hu[1], t0, t1};
+      const unsigned img = row / hw, px = row - img * hw;
+      const int oct8 = c4 >> 1, cg = oct8 >> 1, oct = oct8 & 1, cg_total = c >> 4;
       const size_t q = ((size_t)img * cg_total + cg) * 4 + (odd ? 2 : 0) + oct;
       *reinterpret_cast<u4*>(dz_sp + (q * hw + px) * 16) = piece;
     }
@@ -656,6 +765,16 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// the one-group fast kernels (bn_apply_v4_fast_kernel, bn_bwd_apply_v4_fast_kernel): log2(c / 4) when they apply, else -1
+int bn_fast_shift(int n_groups, int c, long total) {
+  static const bool legacy = [] { const char* e = getenv("DN_BN_LEGACY"); return e && e[0] == '1'; }();
+  const int c4n = c >> 2;
+  if (legacy || n_groups != 1 || c % 4 != 0 || c > kMaxC || c4n <= 0 || (c4n & (c4n - 1)) != 0 || total / 4 >= (1L << 31)) return -1;
+  int sh = 0;
+  while ((1 << sh) < c4n) ++sh;
+  return sh;
+}
+
 int grid_for(long total, int cap = 4096) {
   const long b = (total + 255) / 256;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -746,7 +865,11 @@ extern "C" int dn_bn_train_apply(const float* z, const float* mean, const float*
   DN_REQUIRE(z && mean && var && gamma && beta && y, "bn apply: null pointer");
   DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0 && ldz >= c, "bn apply: bad shape");
   const long total = (long)n_groups * rows_per_group * c;
-  if (vec4_ok(c, {ldz}, {z, y, mean, var, gamma, beta}))
+  const int fsh = bn_fast_shift(n_groups, c, total);
+  if (vec4_ok(c, {ldz}, {z, y, mean, var, gamma, beta}) && fsh >= 0)
+    hipLaunchKernelGGL(bn_apply_v4_fast_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, z, mean, var,
+                       gamma, beta, eps, relu, c, fsh, ldz, (unsigned)(total / 4), y, (unsigned char*)nullptr);
+  else if (vec4_ok(c, {ldz}, {z, y, mean, var, gamma, beta}))
     hipLaunchKernelGGL(bn_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0,
                        (hipStream_t)stream, z, mean, var, gamma, beta, eps, relu, rows_per_group, c, ldz,
                        total / 4, y, (unsigned char*)nullptr);
@@ -763,8 +886,13 @@ extern "C" int dn_bn_train_apply_mask(const float* z, const float* mean, const f
   DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0 && ldz >= c, "bn apply (mask): bad shape");
   DN_REQUIRE(vec4_ok(c, {ldz}, {z, y, mean, var, gamma, beta}), "bn apply (mask): needs c %% 4 == 0 and 16-byte aligned tensors");
   const long total = (long)n_groups * rows_per_group * c;
-  hipLaunchKernelGGL(bn_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, z, mean, var,
-                     gamma, beta, eps, 1, rows_per_group, c, ldz, total / 4, y, relu_mask);
+  const int fsh = bn_fast_shift(n_groups, c, total);
+  if (fsh >= 0)
+    hipLaunchKernelGGL(bn_apply_v4_fast_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, z, mean, var,
+                       gamma, beta, eps, 1, c, fsh, ldz, (unsigned)(total / 4), y, relu_mask);
+  else
+    hipLaunchKernelGGL(bn_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, z, mean, var,
+                       gamma, beta, eps, 1, rows_per_group, c, ldz, total / 4, y, relu_mask);
   return dn::check_launch("bn_apply_kernel (mask)");
 }
 
@@ -839,11 +967,20 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
     DN_REQUIRE(sp_lift > 0.f && std::isfinite(sp_lift), "bn backward: sp_lift must be a positive finite power of two");
     unsigned* flags = dn::sp_range_word();
     DN_REQUIRE(flags, "bn backward: the range word of the split-f16 engine is not addressable");
-    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel<true>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z, mean, var, gamma,
-                       eps, rows_per_group, norm_rows, sums, total / 4, dz, (unsigned char*)dz_sp, sp_lift, (unsigned)(h * w), flags);
+    const int fsh = bn_fast_shift(n_groups, c, total);
+    if (fsh >= 0)
+      hipLaunchKernelGGL(bn_bwd_apply_v4_fast_kernel<true>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z, mean, var, gamma,
+                         eps, norm_rows, sums, fsh, (unsigned)(total / 4), dz, (unsigned char*)dz_sp, sp_lift, (unsigned)(h * w), flags);
+    else
+      hipLaunchKernelGGL(bn_bwd_apply_v4_kernel<true>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z, mean, var, gamma,
+                         eps, rows_per_group, norm_rows, sums, total / 4, dz, (unsigned char*)dz_sp, sp_lift, (unsigned)(h * w), flags);
     return dn::check_launch("bn backward apply kernel (SP copy)");
   }
-  if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz}))
+  const int fsh = bn_fast_shift(n_groups, c, total);
+  if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz}) && fsh >= 0)
+    hipLaunchKernelGGL(bn_bwd_apply_v4_fast_kernel<false>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z, mean, var, gamma,
+                       eps, norm_rows, sums, fsh, (unsigned)(total / 4), dz, nullptr, 1.f, 1u, nullptr);
+  else if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz}))
     hipLaunchKernelGGL(bn_bwd_apply_v4_kernel<false>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z,
                        mean, var, gamma, eps, rows_per_group, norm_rows, sums, total / 4, dz, nullptr, 1.f, 1u, nullptr);
   else

@@ -426,6 +426,56 @@ def test_bn_backward_reads_a_space_to_depth_gradient_in_place(shape, sp):
         train_ops.bn_backward(s2d, y[:, :h - 1].contiguous(), zz, mean, var, gm, 1e-5, dg, db, up_a=2)
 
 
+_BN_AB_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from disconet_amd import ops, train_ops
+dev = torch.device("cuda:0")
+out = []
+for shape, up_a, sp, two in (((20, 64, 64, 128), 0, True, True), ((3, 16, 32, 64), 1, True, False), ((2, 32, 32, 32), 2, True, True),
+                             ((4, 32, 32, 512), 0, False, False), ((2, 16, 24, 16), 0, True, True), ((1, 256, 256, 32), 0, True, False)):
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(51)
+    z = (torch.randn(shape, generator=g) * 2 + 0.5).to(dev)
+    gm = (torch.rand(c, generator=g) + 0.5).to(dev)
+    bt = (torch.randn(c, generator=g) * 0.2).to(dev)
+    mean, var = train_ops.bn_stats(z)
+    mask = torch.zeros(z.numel() // 4, dtype=torch.uint8, device=dev)
+    y = train_ops.bn_apply(z, mean, var, gm, bt, 1e-5, relu=True, relu_mask=mask)
+    y2 = train_ops.bn_apply(z, mean, var, gm, bt, 1e-5, relu=False)
+    dshape = {0: (n, h, w, c), 1: (n, 2 * h, 2 * w, c), 2: (n, h // 2, w // 2, 4 * c)}[up_a]
+    dy = (torch.randn(dshape, generator=g) * 1e-3).to(dev)
+    dyb = (torch.randn(shape, generator=g) * 1e-3).to(dev) if two else None
+    dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    spt = ops.SpTensor(n, h, w, c, device=dev) if sp else None
+    dz = train_ops.bn_backward(dy, y, z, mean, var, gm, 1e-5, dg, db, up_a=up_a, dy_b=dyb, sp_out=spt, sp_lift=2.0 ** 12, relu_mask=mask)
+    dz2 = train_ops.bn_backward(dy, y, z, mean, var, gm, 1e-5, dg, db, up_a=up_a, dy_b=dyb)
+    out += [t.cpu() for t in (y, y2, mask, dz, dz2, dg, db)] + ([spt.data.view(torch.int16).cpu()] if sp else [])
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_bn_fast_kernels_equal_the_general_kernels_bit_for_bit(tmp_path):
+    """The one-group fast forms of the BatchNorm apply / backward-apply kernels (per-channel constants once per workgroup in LDS,
+    shift-and-mask indexing) against the general kernels (DN_BN_LEGACY=1, a child process: the switch is read once): y, the ReLU
+    byte mask, dz, the SP copy, dgamma, dbeta -- bit for bit, over the gradient forms (dense, x2 block sum, space-to-depth, second
+    consumer) and layer shapes incl. a 20-image batch and a full-resolution map."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    files = []
+    for legacy in ("0", "1"):
+        f = str(tmp_path / ("bn_%s.pt" % legacy))
+        env = dict(os.environ, DN_BN_LEGACY=legacy)
+        subprocess.run([sys.executable, "-c", _BN_AB_SCRIPT % ROOT, f], check=True, env=env, timeout=600)
+        files.append(torch.load(f))
+    assert len(files[0]) == len(files[1]) > 40
+    for a, b in zip(*files):
+        assert a.dtype == b.dtype and a.shape == b.shape
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+
+
 def test_bn_backward_sp_copy_flags_a_gradient_that_outgrows_its_lift():
     from disconet_amd import ops, train_ops
     n, h, w, c = 1, 8, 8, 32
