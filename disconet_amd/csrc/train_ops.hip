@@ -73,8 +73,11 @@ __device__ inline void group_channel_sums(int c, long rows_per_group, double* pa
   }
 }
 
-// float4 form: lanes over groups of 4 channels (c % 4 == 0, 16-byte aligned rows)
-template <int NQ, class F>
+// float4 form: lanes over groups of 4 channels (c % 4 == 0, 16-byte aligned rows).
+// U: rows a thread fetches before it adds them.  The adds stay in row order (the same sums, bit for bit, as U = 1), but U rows'
+// loads are in flight at once: with one row per iteration the kernels moved 3.8-4.5 TB/s, bound by bytes in flight per CU
+// (16 waves x 64 lanes x 2 loads of 16 B against ~2 us of HBM latency), not by the HBM (round 5, profiles/r05_train_pmc.txt).
+template <int NQ, int U = 4, class F>
 __device__ inline void group_channel_sums_v4(int c, long rows_per_group, double* part_g, F f) {
   __shared__ double red[2][kRedSlots];
   const int c4n = c >> 2;
@@ -85,7 +88,25 @@ __device__ inline void group_channel_sums_v4(int c, long rows_per_group, double*
   const long r1 = r0 + chunk < rows_per_group ? r0 + chunk : rows_per_group;
   for (int c4 = tx; c4 < c4n; c4 += tx_n) {
     double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
-    for (long r = r0 + ty; r < r1; r += ty_n) {
+    long r = r0 + ty;
+    if constexpr (U > 1) {
+      for (; r + (long)(U - 1) * ty_n < r1; r += (long)U * ty_n) {
+        f32x4 q0[U], q1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          q1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          f(r + (long)u * ty_n, c4, q0[u], q1[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0[e] += q0[u][e];
+            if (NQ > 1) s1[e] += q1[u][e];
+          }
+      }
+    }
+    for (; r < r1; r += ty_n) {
       f32x4 q0, q1 = {0.f, 0.f, 0.f, 0.f};
       f(r, c4, q0, q1);
 #pragma unroll
@@ -133,12 +154,13 @@ __device__ inline f32x4 rstd4(const float* var, float eps) {
                1.f / sqrtf(v[3] + eps)};
 }
 
+template <int U>
 __global__ void __launch_bounds__(256)
 bn_stats_v4_kernel(const float* __restrict__ z, long rows_per_group, int c, int ldz,
                    double* __restrict__ sums) {
   const int g = blockIdx.y;
   const float* zg = z + (size_t)g * rows_per_group * ldz;
-  group_channel_sums_v4<2>(c, rows_per_group, sums + (size_t)g * gridDim.x * 2 * c,
+  group_channel_sums_v4<2, U>(c, rows_per_group, sums + (size_t)g * gridDim.x * 2 * c,
                            [&](long r, int c4, f32x4& q0, f32x4& q1) {
                              q0 = ldv4(zg + r * ldz + 4 * c4);
                              q1 = q0 * q0;
@@ -343,13 +365,14 @@ struct GradSrc {
   }
 };
 
+template <int U>
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_v4_kernel(GradSrc src, const float* __restrict__ z, const float* __restrict__ mean,
                         const float* __restrict__ var, float eps, long rows_per_group,
                         double* __restrict__ sums) {
   const int g = blockIdx.y, c = src.c;
   const long base = (long)g * rows_per_group;
-  group_channel_sums_v4<2>(c, rows_per_group, sums + (size_t)g * gridDim.x * 2 * c,
+  group_channel_sums_v4<2, U>(c, rows_per_group, sums + (size_t)g * gridDim.x * 2 * c,
                            [&](long r, int c4, f32x4& q0, f32x4& q1) {
                              q0 = src.v4(base + r, c4);
                              const f32x4 zh = (ldv4(z + (base + r) * c + 4 * c4) - ldv4(mean + g * c + 4 * c4)) *
@@ -527,9 +550,10 @@ channel_sum_kernel(const float* __restrict__ x, long rows, int c, int ld, double
   });
 }
 
+template <int U>
 __global__ void __launch_bounds__(256)
 channel_sum_v4_kernel(const float* __restrict__ x, long rows, int c, int ld, double* __restrict__ sums) {
-  group_channel_sums_v4<1>(c, rows, sums, [&](long r, int c4, f32x4& q0, f32x4& q1) {
+  group_channel_sums_v4<1, U>(c, rows, sums, [&](long r, int c4, f32x4& q0, f32x4& q1) {
     q0 = ldv4(x + r * ld + 4 * c4);
     (void)q1;
   });
@@ -765,11 +789,15 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// DN_BN_LEGACY=1: the general apply kernels and one row per iteration in the reductions (tests: the bitwise A/B; tools)
+bool bn_legacy() {
+  static const bool legacy = [] { const char* e = getenv("DN_BN_LEGACY"); return e && e[0] == '1'; }();
+  return legacy;
+}
 // the one-group fast kernels (bn_apply_v4_fast_kernel, bn_bwd_apply_v4_fast_kernel): log2(c / 4) when they apply, else -1
 int bn_fast_shift(int n_groups, int c, long total) {
-  static const bool legacy = [] { const char* e = getenv("DN_BN_LEGACY"); return e && e[0] == '1'; }();
   const int c4n = c >> 2;
-  if (legacy || n_groups != 1 || c % 4 != 0 || c > kMaxC || c4n <= 0 || (c4n & (c4n - 1)) != 0 || total / 4 >= (1L << 31)) return -1;
+  if (bn_legacy() || n_groups != 1 || c % 4 != 0 || c > kMaxC || c4n <= 0 || (c4n & (c4n - 1)) != 0 || total / 4 >= (1L << 31)) return -1;
   int sh = 0;
   while ((1 << sh) < c4n) ++sh;
   return sh;
@@ -833,7 +861,7 @@ extern "C" int dn_bn_train_stats_partial(const float* z, int n_groups, long rows
   const int nblk = blocks_per_group(rows_per_group, n_groups);
   double* part = sums + (size_t)2 * c * n_groups;
   if (vec4_ok(c, {ldz}, {z}))
-    hipLaunchKernelGGL(bn_stats_v4_kernel, dim3(nblk, n_groups), dim3(256), 0, s, z, rows_per_group, c, ldz, part);
+    hipLaunchKernelGGL(bn_legacy() ? bn_stats_v4_kernel<1> : bn_stats_v4_kernel<4>, dim3(nblk, n_groups), dim3(256), 0, s, z, rows_per_group, c, ldz, part);
   else
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, n_groups), dim3(256), 0, s, z, rows_per_group, c, ldz, part);
   hipLaunchKernelGGL(fold_partials_kernel, dim3((n_groups * 2 * c + 3) / 4), dim3(256), 0, s, part, nblk, 2 * c,
@@ -929,7 +957,7 @@ extern "C" int dn_bn_train_backward_partial(const float* dy_a, int ld_a, int up_
   const int nblk = blocks_per_group(rows_per_group, n_groups);
   double* part = sums + (size_t)2 * c * n_groups;      // workspace layout: see dn_bn_train_stats_partial
   if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var}))
-    hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel, dim3(nblk, n_groups), dim3(256), 0, s, src, z, mean, var, eps,
+    hipLaunchKernelGGL(bn_legacy() ? bn_bwd_reduce_v4_kernel<1> : bn_bwd_reduce_v4_kernel<2>, dim3(nblk, n_groups), dim3(256), 0, s, src, z, mean, var, eps,
                        rows_per_group, part);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, n_groups), dim3(256), 0, s, src, z, mean, var, eps,
@@ -1034,7 +1062,7 @@ extern "C" int dn_channel_sum(const float* x, long rows, int c, int ld, double* 
   const int nblk = blocks_per_group(rows, 1);
   double* part = sums + c;                              // [c] folded sums, then the workgroups' partials [blocks][c]
   if (vec4_ok(c, {ld}, {x}))
-    hipLaunchKernelGGL(channel_sum_v4_kernel, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
+    hipLaunchKernelGGL(bn_legacy() ? channel_sum_v4_kernel<1> : channel_sum_v4_kernel<4>, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
   else
     hipLaunchKernelGGL(channel_sum_kernel, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
   hipLaunchKernelGGL(fold_partials_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, nblk, c, 1, sums);

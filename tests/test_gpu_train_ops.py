@@ -450,15 +450,17 @@ for shape, up_a, sp, two in (((20, 64, 64, 128), 0, True, True), ((3, 16, 32, 64
     spt = ops.SpTensor(n, h, w, c, device=dev) if sp else None
     dz = train_ops.bn_backward(dy, y, z, mean, var, gm, 1e-5, dg, db, up_a=up_a, dy_b=dyb, sp_out=spt, sp_lift=2.0 ** 12, relu_mask=mask)
     dz2 = train_ops.bn_backward(dy, y, z, mean, var, gm, 1e-5, dg, db, up_a=up_a, dy_b=dyb)
-    out += [t.cpu() for t in (y, y2, mask, dz, dz2, dg, db)] + ([spt.data.view(torch.int16).cpu()] if sp else [])
+    bias = train_ops.channel_sum(dz, torch.empty(c, device=dev))
+    out += [t.cpu() for t in (mean, var, y, y2, mask, dz, dz2, dg, db, bias)] + ([spt.data.view(torch.int16).cpu()] if sp else [])
 torch.save(out, sys.argv[1])
 """
 
 
 def test_bn_fast_kernels_equal_the_general_kernels_bit_for_bit(tmp_path):
     """The one-group fast forms of the BatchNorm apply / backward-apply kernels (per-channel constants once per workgroup in LDS,
-    shift-and-mask indexing) against the general kernels (DN_BN_LEGACY=1, a child process: the switch is read once): y, the ReLU
-    byte mask, dz, the SP copy, dgamma, dbeta -- bit for bit, over the gradient forms (dense, x2 block sum, space-to-depth, second
+    shift-and-mask indexing) and the reductions that fetch several rows before they add them (in row order) against the general
+    kernels / one row per iteration (DN_BN_LEGACY=1, a child process: the switch is read once): mean, var, y, the ReLU byte mask,
+    dz, the SP copy, dgamma, dbeta, the bias sum -- bit for bit, over the gradient forms (dense, x2 block sum, space-to-depth, second
     consumer) and layer shapes incl. a 20-image batch and a full-resolution map."""
     import os
     import subprocess
@@ -470,7 +472,7 @@ def test_bn_fast_kernels_equal_the_general_kernels_bit_for_bit(tmp_path):
         env = dict(os.environ, DN_BN_LEGACY=legacy)
         subprocess.run([sys.executable, "-c", _BN_AB_SCRIPT % ROOT, f], check=True, env=env, timeout=600)
         files.append(torch.load(f))
-    assert len(files[0]) == len(files[1]) > 40
+    assert len(files[0]) == len(files[1]) > 60
     for a, b in zip(*files):
         assert a.dtype == b.dtype and a.shape == b.shape
         assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
