@@ -59,7 +59,7 @@ def _sp_bevs(ops, indices, offsets, n_img, dims):
 
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -113,9 +113,12 @@ def parse():
                          "`agent_sharded` when the GPU count divides 8")
     ap.add_argument("--force-process-group", action="store_true",
                     help="create the RCCL process group even for one rank (exercises the N>1 code path)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="--gpus N > 1 without a launcher: print the torch.distributed.run command that would be "
+                         "exec'd (one JSON object on stdout) and exit 0")
     ap.add_argument("--cpu-baseline-child", nargs=3, metavar=("STATE", "OUT", "THREADS"),
                     help=argparse.SUPPRESS)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def usable_cores():
@@ -318,6 +321,7 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
                        "launch": "hipGraph A (rebuild + encoder) -> all-gather -> hipGraph B (fusion + decoder + heads)",
                        "parallelism": "agent-parallel x%d" % world},
             "phases_us": phases,
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
             "exchanged_bytes_per_rank_per_step": int(stepper.feat_all.numel() * stepper.feat_all.element_size()
                                                      * (world - 1) // max(world, 1)),
         }
@@ -410,14 +414,15 @@ def agent_sharded_bench(args, world, rank, dist):
         dist.destroy_process_group()
 
 
-def _time_train_steps(mod, data, batch, steps, warm=4):
+def _time_train_steps(mod, data, batch, steps, warm=4, losses=False):
     """-> (first, last, mean seconds per step, per-step milliseconds).  `warm` untimed steps first: the calibration pass (the
     first backward measures the gradient maps' lifts in fp32), then the split-f16 path's own warm-up (allocator, LDS
     attributes, clocks after the idle CPU-baseline phase).  A step ends in a host read of its losses, so the per-step wall
     times cost nothing extra; the reported mean is over the whole timed region, synchronised on both sides."""
     first = mod.step(data, batch)
+    traj = [first["loss"]]
     for _ in range(max(warm - 1, 0)):
-        mod.step(data, batch)
+        traj.append(mod.step(data, batch)["loss"])
     torch.cuda.synchronize()
     per = []
     t0 = time.perf_counter()
@@ -425,8 +430,12 @@ def _time_train_steps(mod, data, batch, steps, warm=4):
         t1 = time.perf_counter()
         last = mod.step(data, batch)
         per.append(round(1e3 * (time.perf_counter() - t1), 3))
+        traj.append(last["loss"])
     torch.cuda.synchronize()
-    return first, last, (time.perf_counter() - t0) / steps, per
+    dt = (time.perf_counter() - t0) / steps
+    if losses:      # the loss of every step from the first (untimed warm-up steps included)
+        return first, last, dt, per, [round(float(x), 4) for x in traj]
+    return first, last, dt, per
 
 
 def seg_bench(args, world, rank, dist, use_pg):
@@ -598,17 +607,97 @@ def emit(result):
         os.write(_RESULT_FD, line)
 
 
-def main():
-    args = parse()
+def line_summary(result):
+    """The line's figures without its notes, as the LAST key: the driver keeps the parsed contract keys and the last
+    2000 characters of stdout, so everything a reader needs beside `roofline` / `cpu_baseline` is repeated here, short."""
+    def pick(d, *keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+    out = {"value": result.get("value"), "n_gpus": result.get("n_gpus"), "ms_per_step": result.get("ms_per_step")}
+    roof = result.get("roofline")
+    if roof:
+        out["roofline"] = pick(roof, "frac", "frac_executed", "kernel_ms_per_step", "achieved")
+        out["other_kernels_ms"] = roof.get("other_kernels_ms_per_step")
+    alt = result.get("alt_math")
+    if alt:
+        out["alt_math"] = pick(alt, "conv_math", "value", "ms_per_step")
+        if "roofline" in alt:
+            out["alt_math"]["roofline"] = pick(alt["roofline"], "frac", "peak", "achieved")
+    for key in ("agent_sharded", "agent_sharded_batch16"):
+        a = result.get(key)
+        if isinstance(a, dict):
+            o = pick(a, "value", "n_gpus", "ms_per_step", "rccl_ranks", "exchanged_bytes_per_rank_per_step", "phases_us", "error")
+            if "emulated_share" in a:
+                o["emulated_share"] = pick(a["emulated_share"], "world", "ms_per_step", "projected_speedup",
+                                           "outputs_equal_unsharded_rows")
+            out[key] = o
+    t = result.get("train_step")
+    if isinstance(t, dict):
+        o = pick(t, "ms_per_step", "losses", "f32_fallback_steps", "sp_vs_f32_loss_rel_diff_max", "error")
+        if isinstance(t.get("all_gradients_f32"), dict):
+            o["all_gradients_f32"] = pick(t["all_gradients_f32"], "ms_per_step", "losses", "error")
+        if isinstance(t.get("with_kd"), dict):
+            o["with_kd"] = pick(t["with_kd"], "ms_per_step", "kd_loss")
+        out["train_step"] = o
+    cb = result.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = pick(cb, "value", "cores", "parity_max_abs_err", "map_vs_oracle_detections")
+        if isinstance(out["cpu_baseline"].get("map_vs_oracle_detections"), dict):
+            out["cpu_baseline"]["map_vs_oracle_detections"].pop("note", None)
+    for k in ("graph_equals_eager", "range_flags_after_run", "invalid"):
+        if k in result:
+            out[k] = result[k]
+    return out
+
+
+def launcher_command(gpus, argv):
+    """`python bench.py --gpus N` launched bare (no WORLD_SIZE): the command that runs it as N ranks of one node, one
+    per GPU -- the form the driver uses for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    ... bench.py --gpus N ...`), --standalone so no port has to be agreed on, rendezvous on 127.0.0.1 (the container's
+    host name may not resolve)."""
+    rest = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+            "--nproc-per-node", str(gpus), os.path.abspath(__file__)] + rest
+
+
+def self_launch(args, argv):
+    """Re-runs this command under torch.distributed.run and relays rank 0's ONE JSON line (the ranks point their fd 1 at
+    stderr for everything else, claim_stdout) and the launcher's return code."""
+    import subprocess
+    cmd = launcher_command(args.gpus, argv)
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "gpus": args.gpus, "cmd": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in proc.stdout.read().decode(errors="replace").splitlines() if ln.strip()]
+    rc = proc.wait()
+    result = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in result[-1:]:
+            print(ln, file=sys.stderr)      # anything else a rank or the launcher wrote to stdout
+    if result:
+        print(result[-1], flush=True)
+    if rc == 0 and not result:
+        print("bench: the %d-rank run printed no result line" % args.gpus, file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
     if args.cpu_baseline_child:
         return cpu_baseline_child(*args.cpu_baseline_child)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch):
+        raise SystemExit(self_launch(args, argv))
     claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+    if world != args.gpus and args.gpus > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's rank count must equal --gpus" % (args.gpus, world))
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     use_pg = world > 1 or args.force_process_group
@@ -1049,6 +1138,8 @@ def main():
             try:
                 from disconet_amd import CoDetModule
                 from disconet_amd.synthetic import make_train_targets
+                TRAIN_SEED = 1234      # both arithmetic modes start from the SAME initial weights
+                torch.manual_seed(TRAIN_SEED)
                 tmodel = DiscoNet(Config(map_hw=MAP_HW), kd_flag=0, num_agent=AGENTS)
                 tmodel.conv_math = args.math
                 tmodel.cuda()
@@ -1057,11 +1148,13 @@ def main():
                         "trans_matrices": trans, "num_agent": na, "labels": labels.cuda(),
                         "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda()}
                 mod = CoDetModule(tmodel, lr=1e-3)
-                first, last, dt, per = _time_train_steps(mod, data, BATCH, args.train_steps)
+                first, last, dt, per, traj = _time_train_steps(mod, data, BATCH, args.train_steps, losses=True)
                 result["train_step"] = {
                     "ms_per_step": round(1e3 * dt, 3), "scenes_per_s": round(BATCH / dt, 2),
                     "steps": args.train_steps, "batch_per_gpu": BATCH, "loss_first": round(first["loss"], 4),
-                    "loss_last": round(last["loss"], 4), "step_ms": per, "warmup_steps": 4, "dgrad_math": mod.engine.dgrad_math,
+                    "loss_last": round(last["loss"], 4), "losses": traj, "init_seed": TRAIN_SEED,
+                    "f32_fallback_steps": getattr(mod.engine, "f32_fallback_steps", 0),
+                    "step_ms": per, "warmup_steps": 4, "dgrad_math": mod.engine.dgrad_math,
                     "wgrad_math": mod.engine.wgrad_math,
                     "layers_with_a_measured_gradient_lift": len(mod.engine._dz_lift),
                     "note": "train() forward (batch-stat BN) + focal/smooth-L1 loss + explicit HIP backward (3x3 stride-1 data "
@@ -1072,13 +1165,19 @@ def main():
                 del mod
                 # the same step with every data and weight gradient on the exact-fp32 MFMA (rounds 2-4's step)
                 try:
+                    torch.manual_seed(TRAIN_SEED)
                     fmodel = DiscoNet(Config(map_hw=MAP_HW), kd_flag=0, num_agent=AGENTS)
                     fmodel.conv_math = args.math
                     fmodel.cuda()
                     fmod = CoDetModule(fmodel, lr=1e-3, dgrad_math="f32", wgrad_math="f32")
-                    _, flast, dtf, perf32 = _time_train_steps(fmod, data, BATCH, args.train_steps)
+                    ffirst, flast, dtf, perf32, ftraj = _time_train_steps(fmod, data, BATCH, args.train_steps, losses=True)
                     result["train_step"]["all_gradients_f32"] = {"ms_per_step": round(1e3 * dtf, 3), "scenes_per_s": round(BATCH / dtf, 2),
-                                                         "loss_last": round(flast["loss"], 4), "step_ms": perf32}
+                                                         "loss_first": round(ffirst["loss"], 4),
+                                                         "loss_last": round(flast["loss"], 4), "losses": ftraj, "step_ms": perf32,
+                                                         "note": "same initial weights (init_seed) and batch as train_step: the two "
+                                                                 "loss trajectories are comparable step for step"}
+                    result["train_step"]["sp_vs_f32_loss_rel_diff_max"] = round(max(
+                        abs(a - b) / max(abs(b), 1e-30) for a, b in zip(traj, ftraj)), 6)
                     del fmod, fmodel
                 except Exception as e:
                     result["train_step"]["all_gradients_f32"] = {"error": repr(e)}
@@ -1099,6 +1198,7 @@ def main():
                                                    "kd_loss": round(klast["kd_loss"], 4), "step_ms": perkd}
             except Exception as e:
                 result.setdefault("train_step", {})["error"] = repr(e)
+        result["summary"] = line_summary(result)
         emit(result)
 
     if use_pg:

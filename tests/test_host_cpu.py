@@ -227,3 +227,50 @@ def test_bench_stdout_carries_only_the_result_line(tmp_path):
     assert json.loads(r.stdout) == {"metric": "x", "value": 1.5}
     assert r.stdout.count("\n") == 1
     assert "banner from a C library" in r.stderr and "python noise" in r.stderr
+
+
+def test_bench_gpus_n_launches_itself_under_torch_distributed_run():
+    """`python bench.py --gpus N` launched bare (the driver's N = 1 command form with another N) must not stop at
+    "needs torch.distributed.run": it re-runs itself as N ranks of one node and relays rank 0's line.  --dry-launch
+    prints the launcher command instead of running it (missing #1)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    cmd = d["cmd"]
+    assert d["dry_launch"] is True and d["gpus"] == 2
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--standalone" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and "127.0.0.1" in cmd
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "2", "--steps", "7"]            # the ranks get the caller's own arguments, minus --dry-launch
+    # a rank (WORLD_SIZE set) never launches again; a rank count that contradicts --gpus is refused
+    import bench
+    assert bench.launcher_command(8, ["--gpus", "8"])[-2:] == ["--gpus", "8"]
+
+
+def test_bench_summary_is_short_and_last():
+    """the driver keeps the last 2000 characters of the line: the figures (alt_math, train_step, agent_sharded) are repeated
+    without their notes in `summary`, the line's last key"""
+    import json
+    import bench
+    losses = [71933.6816] * 10
+    r = {"value": 2287.6, "n_gpus": 1, "ms_per_step": 1.7486,
+         "roofline": {"frac": 0.1528, "frac_executed": 0.378, "kernel_ms_per_step": 1.6418, "achieved": 382.0, "note": "x" * 500,
+                      "other_kernels_ms_per_step": {"disco_fuse_mlp": 0.075, "warp_neighbors": 0.037, "scatter": 0.013}},
+         "alt_math": {"conv_math": "f32", "value": 718.0, "ms_per_step": 5.57, "dtype": "y" * 300,
+                      "roofline": {"frac": 0.73, "peak": 157.3, "achieved": 114.8, "note": "z" * 500}},
+         "agent_sharded": {"value": 400.0, "n_gpus": 1, "ms_per_step": 2.7, "rccl_ranks": 1, "exchanged_bytes_per_rank_per_step": 0,
+                           "phases_us": {"graph_a_encode": 1.0, "allgather": 2.0, "graph_b_fuse_decode_heads": 3.0},
+                           "emulated_share": {"world": 8, "ms_per_step": 0.625, "projected_speedup": 4.33,
+                                              "outputs_equal_unsharded_rows": True, "note": "n" * 400}},
+         "train_step": {"ms_per_step": 15.27, "losses": losses, "note": "t" * 900,
+                        "all_gradients_f32": {"ms_per_step": 21.3, "losses": losses}, "with_kd": {"ms_per_step": 17.6, "kd_loss": 1.0}},
+         "cpu_baseline": {"value": 1.64, "cores": 16, "parity_max_abs_err": {"cls": 1.2e-5, "loc": 1.6e-5}, "sample": "s" * 300}}
+    s = bench.line_summary(r)
+    assert len(json.dumps(s)) < 1900
+    assert s["alt_math"]["roofline"]["frac"] == 0.73 and s["train_step"]["all_gradients_f32"]["losses"] == losses
+    assert s["agent_sharded"]["emulated_share"]["projected_speedup"] == 4.33
