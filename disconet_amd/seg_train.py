@@ -107,8 +107,9 @@ class SegTrainEngine(TrainEngine):
         return logits
 
     # ------------------------------------------------------------------
-    def backward(self, dlogits, G=None):
-        """dlogits [A*B, H, W, n_classes] NHWC -> every parameter's gradient (into the flat buffer G)"""
+    def _backward_pass(self, dlogits, G=None):
+        """dlogits [A*B, H, W, n_classes] NHWC -> every parameter's gradient (into the flat buffer G); TrainEngine.backward
+        runs it, polls the split-f16 range guard and re-runs it on the fp32 kernels when a gradient map was clamped"""
         m, L, c = self.model, self.L, self.sctx
         G = self.flat_g if G is None else G
         if not dlogits.is_contiguous():
@@ -136,7 +137,6 @@ class SegTrainEngine(TrainEngine):
         dp2 = double_bwd("down2", T.maxpool2_backward(c["x3"], dp3), dy_b=dskip3)
         dp1 = double_bwd("down1", T.maxpool2_backward(c["x2"], dp2), dy_b=dskip2)
         double_bwd("inc", T.maxpool2_backward(c["x1"], dp1), dy_b=dskip1, need_dx=False)
-        self._check_dz_range()
         return G
 
 

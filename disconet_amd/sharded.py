@@ -42,9 +42,10 @@ def all_gather_agent_major(x_local, group=None, out=None):
     if out is None:
         out = x_local.new_empty((x_local.shape[0] * world,) + tuple(x_local.shape[1:]))
     x_local = x_local.contiguous()
-    try:
+    # the form follows the group's backend (gloo has no *_into_tensor collectives); an RCCL error is never caught here
+    if str(dist.get_backend(group)).lower() != "gloo":
         dist.all_gather_into_tensor(out, x_local, group=group)
-    except (RuntimeError, NotImplementedError):
+    else:
         parts = list(out.chunk(world, 0))
         dist.all_gather(parts, x_local, group=group)
     return out
@@ -195,6 +196,10 @@ class AgentShard:
         self.rank = dist.get_rank(group) if on else 0
         self.first, self.count = agent_range(num_agent, self.world, self.rank)
         self.num_agent = num_agent
+        # the collective forms are chosen ONCE from the group's backend -- not by catching the other form's error: a genuine
+        # RCCL failure on one rank (timeout, abort) must propagate, not turn into a collective its peers never posted
+        self.backend = str(dist.get_backend(group)).lower() if on else "none"
+        self.tensor_collectives = self.backend != "gloo"       # gloo: no reduce_scatter, no *_into_tensor forms
 
     # -- sums --------------------------------------------------------------------------------------------------
     def sum_(self, t):
@@ -214,9 +219,9 @@ class AgentShard:
         if self.world == 1:
             return all_rows
         assert all_rows.shape[0] == n * self.world and lo == self.rank * n
-        try:
+        if self.tensor_collectives:
             dist.all_gather_into_tensor(all_rows, all_rows[lo:lo + n], group=self.group)
-        except (RuntimeError, NotImplementedError):
+        else:
             dist.all_gather(list(all_rows.chunk(self.world, 0)), all_rows[lo:lo + n].clone(), group=self.group)
         return all_rows
 
@@ -226,9 +231,9 @@ class AgentShard:
             return all_rows[lo:lo + n]
         assert all_rows.shape[0] == n * self.world and lo == self.rank * n
         out = all_rows.new_empty((n,) + tuple(all_rows.shape[1:]))
-        try:
+        if self.tensor_collectives:
             dist.reduce_scatter_tensor(out, all_rows.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
-        except (RuntimeError, NotImplementedError):      # gloo: no reduce-scatter
+        else:                                            # gloo: no reduce-scatter
             full = all_rows.clone()
             dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
             out.copy_(full[lo:lo + n])
@@ -241,9 +246,9 @@ class AgentShard:
         if self.world == 1:
             return pad.unsqueeze(0)
         out = pad.new_empty((self.world * max_rows,) + tuple(pad.shape[1:]))
-        try:
+        if self.tensor_collectives:
             dist.all_gather_into_tensor(out, pad, group=self.group)
-        except (RuntimeError, NotImplementedError):
+        else:
             dist.all_gather(list(out.chunk(self.world, 0)), pad, group=self.group)
         return out.view((self.world, max_rows) + tuple(pad.shape[1:]))
 

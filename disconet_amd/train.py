@@ -172,6 +172,9 @@ class TrainEngine:
         if self.wgrad_math not in ("f32", "sp"):
             raise ValueError("wgrad_math must be 'f32' or 'sp' (got %r)" % (self.wgrad_math,))
         self._dz_lift = {}           # layer name -> (power-of-two lift of its dz, step it was measured at)
+        self.f32_fallback_steps = 0  # backward passes that were re-run on the fp32 kernels after a clamped dz (backward())
+        self.last_fallback_step = None
+        self._force_range_flags = []  # tests: flag words OR-ed into the next range polls
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.generation = 0          # bumped by every forward(): the saved activations belong to it
@@ -354,7 +357,7 @@ class TrainEngine:
         largest element near 2^8 (19 binades of full precision below it, 256 x of head room above; include/disconet_train.h ::
         dn_bn_train_backward_finish_sp).  The lift of a layer is measured (max |dz|, a host read) on the first step, which runs
         that layer's data gradient in fp32, and again every 64 steps; a dz that outgrows it is clamped AND flagged (the range
-        guard polled at the end of the step raises: the step's gradients are invalid)."""
+        guard polled at the end of the pass: backward() then drops the lifts and repeats the pass on the fp32 kernels)."""
         d = c["desc"]
         if (self.dgrad_math != "sp" or not need_dx or d.ksize != 3 or c["groups"] != 1
                 or d.c_out % 16 != 0 or (d.c0 + d.c1) % 4 != 0):
@@ -647,10 +650,36 @@ class TrainEngine:
     # ------------------------------------------------------------------
     # backward: d(loss)/d(cls), d(loss)/d(loc) -> every parameter's gradient (into flat G)
     # ------------------------------------------------------------------
-    def backward(self, dcls, dloc, G=None, dkd=None):
+    def backward(self, *args, **kw):
+        """The reverse pass (`_backward_pass`) and the split-f16 range check behind it.  A gradient map that outgrew the
+        measured power-of-two lift of its split-f16 copy was CLAMPED in that copy: the gradients of the pass are wrong.  The
+        reference's CoDetModule.step never throws on a finite loss, so neither does this: the saved activations of the
+        forward are all still there -- the lifts are dropped and the SAME backward runs again with every data and weight
+        gradient on the exact-fp32 kernels (which is also the calibration pass: it measures the new lifts), counted in
+        `f32_fallback_steps`.  Agent-parallel ranks decide on the MAX of their flag words, so that all of them take the second
+        pass (it holds collectives) or none does.  Only a pass that is flagged again -- a NaN, or an overflow in the fp32
+        pass's own operands -- raises."""
+        G = self._backward_pass(*args, **kw)
+        flags = self._range_flags()
+        if flags & 1:
+            self._dz_lift.clear()
+            self.f32_fallback_steps += 1
+            self.last_fallback_step = self.step_count
+            G = self._backward_pass(*args, **kw)
+            flags = self._range_flags()
+            if flags & 1:
+                raise ops._lib.DnError(
+                    "backward: the split-f16 range guard tripped again in the all-fp32 second pass (an activation of the "
+                    "forward beyond the f16 range?); the gradients of this step are invalid and were NOT applied")
+        if flags & 4:
+            raise ops._lib.DnError("backward: a NaN reached a split-f16 epilogue")
+        return G
+
+    def _backward_pass(self, dcls, dloc, G=None, dkd=None):
         """dkd (knowledge distillation): optional dict of dense NHWC gradients w.r.t. the student's
         x5 / x6 / x7 / fused maps; each is a second consumer of that map, added in the BN backward
-        that already reads the decoder's gradient."""
+        that already reads the decoder's gradient.  Idempotent: reads the saved activations and its arguments, writes G
+        and fresh buffers only (backward() may run it twice)."""
         m, L = self.model, self.L
         G = self.flat_g if G is None else G
         dkd = dkd or {}
@@ -692,7 +721,7 @@ class TrainEngine:
         # (layer 4: the fused map reaches conv5_1 through the upsample -- undo it before the fusion)
         dfused = T.upsample2_sum(d_dec[4]) if lay_k == 4 else d_dec[lay_k]
         if dkd.get("fused") is not None:
-            dfused = T.add_rows(dkd["fused"], dfused)      # in place on the KD gradient buffer
+            dfused = T.add_rows(dkd["fused"].clone(), dfused)      # (a copy: the pass may run a second time on the same dkd)
         # encoder, top down: e[k] feeds conv{k+1}_1 (gradient d) and the decoder / the fusion (d_dec[k])
         def group_bwd(k, d):
             names = _ENC_GROUPS[k]
@@ -725,30 +754,28 @@ class TrainEngine:
             d.record_stream(main)
         for k in range(lay_k, -1, -1):
             d = group_bwd(k, d)
-        self._check_dz_range()
         return G
 
-    def _check_dz_range(self):
-        """dgrad_math = "sp": did a dz outgrow its lift?  A blocking read of the engine's sticky range flags BEFORE the optimizer
-        step (the step ends in a host read of the losses anyway): a clamped dz means wrong gradients -- the lifts are dropped
-        (the next backward measures them again, in fp32) and the step is refused with the parameters untouched."""
-        if (self.dgrad_math != "sp" and self.wgrad_math != "sp") or not self._dz_lift:
-            return
+    def _range_flags(self):
+        """dgrad_math / wgrad_math = "sp": did a dz outgrow its lift (bit 0: |dz| * lift > 65504, or an activation times
+        _WGRAD_X_LIFT did in the split-f16 weight gradient), did a NaN reach a split-f16 epilogue (bit 2)?  A read of the
+        engine's sticky range flags BEFORE the optimizer step (the step ends in a host read of the losses anyway).  With an
+        agent shard the word is the MAX over the ranks: every rank must take the same branch in backward() -- one rank
+        re-running the pass (or raising) alone would leave its peers in a collective nobody else posts."""
+        sharded_run = self.shard is not None and self.shard.world > 1
+        if (self.dgrad_math != "sp" and self.wgrad_math != "sp") or (not self._dz_lift and not sharded_run):
+            return 0
         # stream-ordered collect into a word this engine keeps + one host read: the blocking dn_sp_range_flags synchronises the
         # whole device and allocates / frees its scratch word per call (measured ~2 ms per step inside a large process)
         word = self.__dict__.get("_range_word")
         if word is None or word.device != self.flat_p.device:
             word = self._range_word = torch.zeros(1, dtype=torch.int32, device=self.flat_p.device)
-        flags = int(ops.sp_range_flags_into(word, zero_first=True, reset=True).item()) & 0xffffffff
-        if flags & 1:
-            self._dz_lift.clear()
-            raise ops._lib.DnError(
-                "backward: a gradient map outgrew the power-of-two lift of its split-f16 copy (|dz| * lift > 65504; or an "
-                "activation times %g did, in the split-f16 weight gradient); the gradients of this step are invalid and were NOT "
-                "applied.  The lifts are re-measured by the next step; a run that keeps tripping this wants dgrad_math = 'f32' "
-                "and wgrad_math = 'f32'." % _WGRAD_X_LIFT)
-        if flags & 4:
-            raise ops._lib.DnError("backward: a NaN reached a split-f16 epilogue")
+        word = ops.sp_range_flags_into(word, zero_first=True, reset=True)
+        if self._force_range_flags:                      # tests: pretend the guard tripped (on this rank only)
+            word |= int(self._force_range_flags.pop(0))
+        if sharded_run:
+            self.shard.max_(word)
+        return int(word.item()) & 0xffffffff
 
     def _fusion_bwd(self, dfused, G):
         m, L, F, c = self.model, self.L, self.F, self.fctx
@@ -885,11 +912,14 @@ class CoDetModule:
     def __init__(self, model, teacher=None, config=None, optimizer=None, kd_flag=0, lr=1e-3,
                  alpha=0.25, gamma=2.0, sigma=3.0, shard=None, dgrad_math=None, wgrad_math=None):
         """shard (sharded.AgentShard): agent-parallel training -- step() then takes THIS rank's agents' images, labels and
-        targets (agent-major, [count * B, ...]); trans_matrices / num_agent stay the whole scenes'.  Not with kd_flag."""
+        targets (agent-major, [count * B, ...]); trans_matrices / num_agent stay the whole scenes'.
+        With kd_flag = 1 (BASELINE configs[2] + [4] together): the frozen teacher is replicated and has no communication --
+        one image in, that image's pyramid out -- so every rank runs it on data["bev_seq_teacher"] of ITS agents (the
+        holistic views in their frames, [count * B, ...] like bev_seq) and adds its share of the KD term: the KL means are
+        normalised by the GLOBAL row count, the ranks' terms (and their gradients, through the one summed all-reduce of the
+        flat gradient) add up to the un-sharded step's."""
         if kd_flag and teacher is None:
             raise ValueError("kd_flag = 1 needs the teacher network")
-        if kd_flag and shard is not None:
-            raise NotImplementedError("agent-parallel training does not carry the KD teacher (it sees every agent's points)")
         self.model, self.teacher, self.kd_flag = model, teacher, int(bool(kd_flag))
         if self.kd_flag:
             teacher.eval()
@@ -932,8 +962,12 @@ class CoDetModule:
                 t8, t7, t6, t5, t3, t2 = self.teacher.forward_nhwc(data["bev_seq_teacher"])
                 kd = torch.zeros(1, dtype=torch.float64, device=dev)
                 o = eng.outs
-                dkd = {k: T.kd_kl_loss(o[k], t, kd_weight, kd)
+                world = eng.shard.world if eng.shard is not None else 1
+                dkd = {k: T.kd_kl_loss(o[k], t, kd_weight, kd,
+                                       norm_rows=(o[k].numel() // o[k].shape[-1]) * world if world > 1 else None)
                        for k, t in (("x5", t5), ("x6", t6), ("x7", t7), ("fused", t3))}
+                if world > 1:
+                    eng.shard.sum_(kd)                # reported KD loss: the whole scenes', as without a shard
             eng.backward(dcls, dloc, dkd=dkd)
             if update:
                 eng.allreduce_grads()

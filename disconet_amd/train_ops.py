@@ -342,16 +342,18 @@ def det_loss(cls, labels, loc, targets, mask, norm, alpha=0.25, gamma=2.0, sigma
     return losses, dcls, dloc
 
 
-def kd_kl_loss(student, teacher, kd_weight, loss, zero=False):
+def kd_kl_loss(student, teacher, kd_weight, loss, zero=False, norm_rows=None):
     """student, teacher [..., c] dense NHWC maps of equal shape; adds kd_weight * KLDiv (mean over
-    all elements) to loss[0] (float64, zeroed first if zero) and returns d(term)/d(student)."""
+    all elements) to loss[0] (float64, zeroed first if zero) and returns d(term)/d(student).
+    norm_rows (agent-parallel training): the rows the mean runs over when this call sees only THIS rank's share of them
+    (the reference's KLDivLoss averages over all A * B images' pixels); the ranks' terms then sum to the un-sharded one."""
     _need_gpu(student, teacher, loss)
     assert student.shape == teacher.shape and student.is_contiguous() and teacher.is_contiguous()
     c = student.shape[-1]
     rows = student.numel() // c
     d = torch.empty_like(student)
     check(_lib.load().dn_kd_kl_loss(_ptr(student), _ptr(teacher), rows, c,
-                                    float(kd_weight) / float(rows * c), _ptr(loss), _ptr(d), int(zero),
+                                    float(kd_weight) / float((rows if norm_rows is None else int(norm_rows)) * c), _ptr(loss), _ptr(d), int(zero),
                                     _stream()), "dn_kd_kl_loss")
     return d
 

@@ -136,9 +136,11 @@ class _GatherRowsFn(torch.autograd.Function):
 
 
 def oracle_agent_sharded_train_step(ref, shard, optimizer, bevs_local, trans, num_agent_tensor, batch_size, labels,
-                                    reg_targets, reg_loss_mask):
+                                    reg_targets, reg_loss_mask, kd=None):
     """One CoDetModule.step of the oracle `ref` (already .double() or float) on THIS rank's agents.  ref is modified in
-    place (its BatchNorms of encoder / decoder / heads are wrapped once).  Returns (loss_cls, loss_loc) of the whole scenes."""
+    place (its BatchNorms of encoder / decoder / heads are wrapped once).  Returns (loss_cls, loss_loc) of the whole scenes --
+    (loss_cls, loss_loc, loss_kd) with kd = (teacher, bevs_teacher_local, kd_weight): the frozen teacher (replicated, no
+    communication) on this rank's agents' holistic views, the KL means over the GLOBAL row count."""
     from oracle.train_ref import det_loss
     from disconet_amd.train import fusion_call_counts
     A, B = ref.agent_num, batch_size
@@ -179,14 +181,31 @@ def oracle_agent_sharded_train_step(ref, shard, optimizer, bevs_local, trans, nu
                 s = sum(e)
                 fused[il * B + b] = sum((ek / s) * nb for ek, nb in zip(e, nbrs))
         enc[ref.layer] = torch.stack(fused, 0)
-        x = ref.decoder(*enc, B, kd_flag=False)[0]
+        dec = ref.decoder(*enc, B, kd_flag=kd is not None)
+        x = dec[0]
         cls = ref.classification(x).permute(0, 2, 3, 1).contiguous()
         loc = ref.regression(x).permute(0, 2, 3, 1).contiguous()
         result = {"cls": cls.view(cls.shape[0], -1, ref.category_num),
                   "loc": loc.view(-1, loc.size(1), loc.size(2), ref.anchor_num_per_loc, ref.out_seq_len, ref.box_code_size)}
         l_cls, l_loc = det_loss(result, labels, reg_targets, reg_loss_mask, norm=A * B)      # the reference's N: every image
+        l_kd = None
+        if kd is not None:
+            import torch.nn.functional as F
+            teacher, bevs_t, kd_weight = kd
+            with torch.no_grad():
+                t8, t7, t6, t5, t3, t2 = teacher(bevs_t.to(x.dtype))
+            x8, x7, x6, x5 = dec
+            l_kd = 0.0
+            for s_map, t_map in ((x5, t5), (x6, t6), (x7, t7), (enc[ref.layer], t3)):
+                C = s_map.shape[1]
+                s_rows = s_map.permute(0, 2, 3, 1).reshape(-1, C)
+                t_rows = t_map.permute(0, 2, 3, 1).reshape(-1, C)
+                # KLDivLoss(reduction="mean") of the un-sharded step divides by (all rows) * C: this rank's rows are 1 / world of them
+                l_kd = l_kd + F.kl_div(F.log_softmax(s_rows, 1), F.softmax(t_rows, 1), reduction="sum") / (
+                    s_rows.shape[0] * shard.world * C)
+            l_kd = kd_weight * l_kd
         optimizer.zero_grad()
-        (l_cls + l_loc).backward()
+        (l_cls + l_loc + (l_kd if l_kd is not None else 0.0)).backward()
     finally:
         for h in hooks:
             h.remove()
@@ -215,6 +234,6 @@ def oracle_agent_sharded_train_step(ref, shard, optimizer, bevs_local, trans, nu
         p.grad = flat[off:off + p.numel()].view_as(p).clone()
         off += p.numel()
     optimizer.step()
-    losses = torch.stack([l_cls.detach(), l_loc.detach()]).double()
+    losses = torch.stack([l_cls.detach(), l_loc.detach()] + ([l_kd.detach()] if l_kd is not None else [])).double()
     shard.sum_(losses)
-    return float(losses[0]), float(losses[1])
+    return tuple(float(v) for v in losses)

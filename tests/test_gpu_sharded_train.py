@@ -140,3 +140,154 @@ def test_two_ranks_agent_parallel_step_matches_oracle(math, kw, monkeypatch):
         assert np.array_equal(got[0][3][name], got[1][3][name]), name
     for name in got[0][2]:
         assert np.array_equal(got[0][2][name], got[1][2][name]), name
+
+
+def _worker_forced_clamp(rank, world, port, case, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disconet_amd import CoDetModule, sharded
+        c, ref, model, inputs, targets = _setup(case, "f16x3")
+        shard = sharded.AgentShard(c["agents"])
+        per = shard.count * c["batch"]
+        sl = slice(shard.first * c["batch"], shard.first * c["batch"] + per)
+        mod = CoDetModule(model, lr=1e-3, shard=shard, dgrad_math="sp", wgrad_math="sp")
+        eng = mod.engine
+        data = _data(inputs, targets, sl)
+        losses = [mod.step(data, c["batch"])["loss"]]           # calibration pass: measures the lifts
+        lifts_before = dict(eng._dz_lift)
+        if rank == 1:
+            eng._force_range_flags = [1]                        # the guard "trips" on THIS rank only, in the next backward
+        losses.append(mod.step(data, c["batch"])["loss"])
+        fallbacks_after_2 = eng.f32_fallback_steps
+        losses.append(mod.step(data, c["batch"])["loss"])
+        params = {n: p.detach().cpu().numpy() for n, p in model.named_parameters()}
+        q.put((rank, losses, fallbacks_after_2, eng.f32_fallback_steps, eng.step_count, len(lifts_before), len(eng._dz_lift), params))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_clamped_gradient_on_one_rank_sends_every_rank_through_the_fp32_pass():
+    """the range flags were read per rank -- the rank that saw a clamped dz raised (or re-measured its
+    lifts with all-reduces) alone and its peers hung in the next collective.  Now the flag word is MAX-reduced over the shard
+    before anyone decides: a clamp on rank 1 only makes BOTH ranks drop their lifts and repeat the backward on the fp32
+    kernels (which holds the BatchNorm all-reduces and the reduce-scatter), nobody raises, no step is dropped, and the replicas
+    stay bit-identical."""
+    import numpy as np
+    case, world = "ragged_a4", 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_forced_clamp, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=600)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(world):
+        losses, fb2, fb3, steps, n_lifts0, n_lifts1, _ = got[r]
+        assert fb2 == 1 and fb3 == 1, (r, fb2, fb3)             # both ranks took the second pass, once
+        assert steps == 3                                       # no step was dropped
+        assert n_lifts0 > 0 and n_lifts1 == n_lifts0            # the fp32 pass re-measured every lift
+        assert losses[2] < losses[1] < losses[0], (r, losses)
+    assert got[0][0] == got[1][0]                               # the whole scenes' losses, identical on both ranks
+    for name in got[0][6]:
+        assert np.array_equal(got[0][6][name], got[1][6][name]), name
+
+
+def _worker_kd(rank, world, port, case, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disconet_amd import CoDetModule, sharded
+        from tests.test_gpu_train_step import _teacher_pair
+        c, ref, model, inputs, targets = _setup(case, "f16x3")
+        model.kd_flag = 1
+        _, t_hip, bevs_t = _teacher_pair(c)
+        shard = sharded.AgentShard(c["agents"])
+        per = shard.count * c["batch"]
+        sl = slice(shard.first * c["batch"], shard.first * c["batch"] + per)
+        mod = CoDetModule(model, t_hip, None, None, kd_flag=1, lr=1e-3, shard=shard)
+        data = dict(_data(inputs, targets, sl), bev_seq_teacher=bevs_t[sl].cuda(), kd_weight=1e5)
+        out = mod.step(data, c["batch"])
+        grads = {n: mod.engine.g(p).cpu().numpy() for n, p in model.named_parameters()}
+        q.put((rank, out, grads))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_agent_parallel_kd_step_matches_oracle(monkeypatch):
+    """VERDICT round 5, missing #5: BASELINE configs[2] (teacher KD) and configs[4] (agents sharded) together.  Two processes,
+    two agents each; every rank runs the replicated frozen teacher on ITS agents' holistic views and adds its share of the KD
+    term (KL means over the global row count).  Losses (cls, loc, kd) and the summed gradient of every parameter against the
+    un-sharded oracle KD step (float64 run as the truth, the criteria of test_kd_train_step_matches_oracle)."""
+    import copy
+    import torch.nn.functional as F
+    from oracle.teacher_ref import kd_loss
+    from oracle.train_ref import det_loss
+    from tests.test_gpu_train_step import _teacher_pair
+    case, world = "ragged_a4", 2
+    c, ref, _, (bevs, trans, na), (labels, targets, mask) = _setup(case, "f16x3")
+    ref.kd_flag = 1
+    t_ref, _, bevs_t = _teacher_pair(c)
+
+    def oracle_step(m, tm, dt):
+        m.train()
+        res, x8, x7, x6, x5, fused = m(bevs, trans, na, c["batch"])
+        with torch.no_grad():
+            t8, t7, t6, t5, t3, t2 = tm(bevs_t.to(dt))
+        l_cls, l_loc = det_loss(res, labels, targets, mask, norm=bevs.shape[0])
+        l_kd = kd_loss((x5, x6, x7, fused), (t5, t6, t7, t3), 1e5)
+        (l_cls + l_loc + l_kd).backward()
+        return float(l_cls.detach()), float(l_loc.detach()), float(l_kd.detach())
+
+    orig = F.grid_sample
+    monkeypatch.setattr(F, "grid_sample", lambda inp, grid, **kw: orig(inp, grid.to(inp.dtype), **kw))
+    ref64, t64 = copy.deepcopy(ref).double(), copy.deepcopy(t_ref).double()
+    for m_ in (ref64.u_encoder, t64.stpn):
+        m_.conv_pre_1.register_forward_pre_hook(lambda m, inp: (inp[0].double(),))
+    oracle_step(ref64, t64, torch.float64)
+    monkeypatch.undo()
+    g64 = {n: p.grad for n, p in ref64.named_parameters() if p.grad is not None}
+    l_ref = oracle_step(ref, t_ref, torch.float32)
+    ref_named = dict(ref.named_parameters())
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_kd, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=600)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    gmax = max(float(g.abs().max()) for g in g64.values())
+    for r in range(world):
+        out, grads = got[r]
+        assert abs(out["cls_loss"] - l_ref[0]) < 2e-5 * abs(l_ref[0]), (r, out, l_ref)
+        assert abs(out["loc_loss"] - l_ref[1]) < 2e-5 * abs(l_ref[1]), (r, out, l_ref)
+        assert abs(out["kd_loss"] - l_ref[2]) < 1e-4 * abs(l_ref[2]), (r, out, l_ref)
+        rows = {}
+        for name, t in g64.items():
+            den = max(float(t.abs().max()), 1e-4 * gmax)
+            g = torch.from_numpy(grads[name]).double()
+            e_hip = float((g - t).abs().max()) / den
+            e_ora = float((ref_named[name].grad.double() - t).abs().max()) / den
+            cos = float((g * t).sum() / (g.norm() * t.norm()).clamp_min(1e-300))
+            rows[name] = (e_hip, e_ora, cos, float(t.abs().max()) > 1e-4 * gmax)
+        _assert_grads(rows)
+    import numpy as np
+    for name in got[0][1]:
+        assert np.array_equal(got[0][1][name], got[1][1][name]), name

@@ -115,12 +115,23 @@ def test_flat_gradient_average_is_the_mean_over_ranks():
 _ATRAIN = dict(map_hw=64, agents=4, batch=2, live=[3, 2], jitter=7, lr=0.02)
 
 
-def _atrain_setup(only_v2i=False):
+def _atrain_teacher():
+    """float64 oracle teacher + the agents' holistic views (BASELINE configs[2]'s KD term under the agent split)"""
+    from disconet_amd.synthetic import make_bevs
+    from oracle.disconet_ref import RefConfig
+    from oracle.teacher_ref import build_teacher
+    c = _ATRAIN
+    t = build_teacher(RefConfig(c["map_hw"])).double().eval()
+    t.stpn.conv_pre_1.register_forward_pre_hook(lambda m, inp: (inp[0].double(),))
+    return t, make_bevs(c["batch"], c["agents"], c["map_hw"], p=0.05), 1e3
+
+
+def _atrain_setup(only_v2i=False, kd=False):
     """float64 oracle + inputs of the agent-parallel training case (every rank and the parent build the same)"""
     import torch.nn.functional as F
     from disconet_amd.synthetic import make_scene_batch, make_train_targets
     c = _ATRAIN
-    ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=0, only_v2i=only_v2i).double()
+    ref = cases.ref_model(c["map_hw"], c["agents"], kd_flag=1 if kd else 0, only_v2i=only_v2i).double()
     ref.u_encoder.conv_pre_1.register_forward_pre_hook(lambda m, inp: (inp[0].double(),))
     bevs, trans, na = make_scene_batch(c["batch"], c["agents"], c["map_hw"], live=c["live"], jitter_seed=c["jitter"])
     labels, targets, mask = make_train_targets(bevs.shape[0], c["map_hw"], p_fg=0.02)
@@ -137,7 +148,7 @@ def _state(ref):
     return {k.replace(".bn.", "."): v.detach().clone() for k, v in ref.state_dict().items()}
 
 
-def _atrain_worker(rank, world, port, q, only_v2i=False):
+def _atrain_worker(rank, world, port, q, only_v2i=False, kd=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
@@ -146,19 +157,39 @@ def _atrain_worker(rank, world, port, q, only_v2i=False):
         from disconet_amd import sharded
         from tests.oracle_engine import oracle_agent_sharded_train_step
         c = _ATRAIN
-        ref, (bevs, trans, na), (labels, targets, mask) = _atrain_setup(only_v2i)
+        ref, (bevs, trans, na), (labels, targets, mask) = _atrain_setup(only_v2i, kd)
         shard = sharded.AgentShard(c["agents"])
         mine = lambda t: sharded.local_bevs(t, c["agents"], c["batch"], world, rank)
         opt = torch.optim.SGD(ref.parameters(), lr=c["lr"])      # (why not Adam: see the test)
+        kd_arg = None
+        if kd:
+            teacher, bevs_t, kd_weight = _atrain_teacher()
+            kd_arg = (teacher, mine(bevs_t), kd_weight)          # the teacher sees THIS rank's agents' holistic views only
         losses = [oracle_agent_sharded_train_step(ref, shard, opt, mine(bevs), trans, na, c["batch"], mine(labels),
-                                                  mine(targets), mine(mask)) for _ in range(2)]
+                                                  mine(targets), mine(mask), kd=kd_arg) for _ in range(2)]
         q.put((rank, losses, {k: v.numpy() for k, v in _state(ref).items()}))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("only_v2i", [False, True])
-def test_agent_sharded_training_step_matches_unsharded_oracle(only_v2i):
+def _unsharded_kd_step(ref, opt, teacher, bevs_t, kd_weight, bevs, trans, na, batch, labels, targets, mask):
+    """CoDetModule.step with kd_flag = 1 on the un-sharded oracle (oracle/train_ref.py :: train_step + teacher_ref.kd_loss)"""
+    from oracle.teacher_ref import kd_loss
+    from oracle.train_ref import det_loss
+    ref.train()
+    res, x8, x7, x6, x5, fused = ref(bevs, trans, na, batch)
+    with torch.no_grad():
+        t8, t7, t6, t5, t3, t2 = teacher(bevs_t.double())
+    l_cls, l_loc = det_loss(res, labels, targets, mask, norm=bevs.shape[0])
+    l_kd = kd_loss((x5, x6, x7, fused), (t5, t6, t7, t3), kd_weight)
+    opt.zero_grad()
+    (l_cls + l_loc + l_kd).backward()
+    opt.step()
+    return float(l_cls.detach()), float(l_loc.detach()), float(l_kd.detach())
+
+
+@pytest.mark.parametrize("only_v2i,kd", [(False, False), (True, False), (False, True)])
+def test_agent_sharded_training_step_matches_unsharded_oracle(only_v2i, kd):
     """"Backward of (ii) is a reduce-scatter".  Two gloo ranks, two agents each of 4-agent scenes (one scene
     with 3 live agents, one with 2: rank 1 holds a padded agent in one scene and nothing live in the other), TWO consecutive
     steps of the oracle twin (tests/oracle_engine.py) through disconet_amd.sharded.AgentShard -- the collectives the HIP
@@ -169,16 +200,22 @@ def test_agent_sharded_training_step_matches_unsharded_oracle(only_v2i):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_atrain_worker, args=(r, world, port, q, only_v2i)) for r in range(world)]
+    procs = [ctx.Process(target=_atrain_worker, args=(r, world, port, q, only_v2i, kd)) for r in range(world)]
     for p in procs:
         p.start()
     torch.set_num_threads(2)
-    ref, (bevs, trans, na), (labels, targets, mask) = _atrain_setup(only_v2i)
+    ref, (bevs, trans, na), (labels, targets, mask) = _atrain_setup(only_v2i, kd)
     # Plain SGD on purpose: a conv bias in front of a BatchNorm has a gradient that is exactly zero in mathematics and rounding
     # noise (~1e-17) in any backward; Adam normalises that noise into a +-lr step whose sign depends on the summation order,
     # which would force a loose comparison.  The collectives under test do not depend on the optimizer.
     opt = torch.optim.SGD(ref.parameters(), lr=c["lr"])
-    want_losses = [train_step(ref, opt, bevs, trans, na, c["batch"], labels, targets, mask) for _ in range(2)]
+    if kd:      # kd_flag = 1 under the agent split (missing #5): the teacher is replicated, the KL means are global
+        teacher, bevs_t, kd_weight = _atrain_teacher()
+        want_losses = [_unsharded_kd_step(ref, opt, teacher, bevs_t, kd_weight, bevs, trans, na, c["batch"], labels, targets, mask)
+                       for _ in range(2)]
+        assert want_losses[0][2] > 1e-3 * (want_losses[0][0] + want_losses[0][1])      # the KD term is live in this case
+    else:
+        want_losses = [train_step(ref, opt, bevs, trans, na, c["batch"], labels, targets, mask) for _ in range(2)]
     want = _state(ref)
     got = {}
     for _ in range(world):
@@ -190,15 +227,17 @@ def test_agent_sharded_training_step_matches_unsharded_oracle(only_v2i):
     moved = 0
     for r in range(world):
         losses, state = got[r]
-        for (a0, a1), (b0, b1) in zip(losses, want_losses):
-            assert abs(a0 - b0) <= 1e-9 * abs(b0) and abs(a1 - b1) <= 1e-9 * abs(b1), (r, losses, want_losses)
+        for a, b in zip(losses, want_losses):
+            assert len(a) == len(b) == (3 if kd else 2)
+            for av, bv in zip(a, b):
+                assert abs(av - bv) <= 1e-9 * abs(bv), (r, losses, want_losses)
         assert set(state) == set(want)
         for k, w in want.items():
             g = torch.from_numpy(state[k])
             scale = float(w.abs().max()) if w.numel() else 0.0
             assert float((g - w).abs().max()) <= 1e-8 * max(scale, 1e-3), (r, k, float((g - w).abs().max()), scale)
     # the step did move the parameters of every part (encoder, fusion MLP, decoder, heads)
-    init = _state(_atrain_setup(only_v2i)[0])
+    init = _state(_atrain_setup(only_v2i, kd)[0])
     for key in ("u_encoder.conv1_1.weight", "pixel_weighted_fusion.conv1_1.weight", "decoder.conv5_1.weight",
                 "classification.conv2.weight", "pixel_weighted_fusion.bn1_2.running_mean"):
         assert float((want[key] - init[key]).abs().max()) > 0, key

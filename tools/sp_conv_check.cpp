@@ -17,6 +17,61 @@
 #define CK(x) do { int rc_ = (x); if (rc_ != 0) { printf("FAILED %s -> %d: %s\n", #x, rc_, dn_last_error()); exit(2); } } while (0)
 #define HCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP %s: %s\n", #x, hipGetErrorString(e_)); exit(3); } } while (0)
 
+// ---- guard bands (SPCHECK_GUARD=1): every device buffer of the run sits between two 256 KiB bands of a byte pattern that
+// are verified after EVERY case -- an out-of-bounds WRITE of any launch (epilogue stores, K-slice partials, weight packing)
+// lands in a band and is reported with the buffer and the offset.  (Out-of-bounds READS cannot fault on this path: every
+// operand access is a buffer load against a descriptor of the exact image / weight bytes and returns 0 past num_records.)
+static const size_t kGuard = 256 * 1024;
+static const unsigned char kPat = 0xA5;
+static bool g_guard = false;
+struct GuardedAlloc { unsigned char* base; size_t bytes; };
+static std::vector<GuardedAlloc> g_allocs;
+static hipError_t gmalloc(void** p, size_t bytes) {
+  if (!g_guard) return hipMalloc(p, bytes);
+  const size_t padded = (bytes + 255) / 256 * 256;          // (the band behind starts at the next 256-byte boundary)
+  unsigned char* base = nullptr;
+  hipError_t e = hipMalloc(&base, padded + 2 * kGuard);
+  if (e != hipSuccess) return e;
+  e = hipMemset(base, kPat, padded + 2 * kGuard);
+  g_allocs.push_back({base, bytes});
+  *p = base + kGuard;
+  return e;
+}
+static int g_guard_fail = 0;
+static void check_guards(const char* after) {
+  if (!g_guard) return;
+  hipDeviceSynchronize();
+  std::vector<unsigned char> h(kGuard + 256);
+  for (size_t i = 0; i < g_allocs.size(); ++i) {
+    const auto& a = g_allocs[i];
+    for (int side = 0; side < 2; ++side) {
+      const size_t off = side ? kGuard + a.bytes : 0, len = side ? kGuard + ((a.bytes + 255) / 256 * 256 - a.bytes) : kGuard;
+      if (hipMemcpy(h.data(), a.base + off, len, hipMemcpyDeviceToHost) != hipSuccess) { printf("guard read failed\n"); exit(3); }
+      for (size_t k = 0; k < len; ++k)
+        if (h[k] != kPat) {
+          printf("   GUARD BAND OVERWRITTEN after [%s]: buffer #%zu (%zu bytes), %s band, byte %zu = 0x%02x\n", after, i, a.bytes,
+                 side ? "rear" : "front", k, h[k]);
+          ++g_guard_fail;
+          hipMemset(a.base + off, kPat, len);
+          break;
+        }
+    }
+  }
+}
+static hipError_t gfree(void* p) {
+  if (!g_guard || p == nullptr) return hipFree(p);
+  for (size_t i = 0; i < g_allocs.size(); ++i)
+    if (g_allocs[i].base + kGuard == (unsigned char*)p) {
+      GuardedAlloc a = g_allocs[i];
+      g_allocs.erase(g_allocs.begin() + i);
+      return hipFree(a.base);
+    }
+  printf("   gfree: %p is not a guarded buffer\n", p);
+  return hipErrorInvalidValue;
+}
+#define hipMalloc(pp, n) gmalloc((void**)(pp), (n))
+#define hipFree(p) (check_guards(__func__), gfree(p))
+
 static unsigned g_seed = 12345;
 static float frand() { g_seed = g_seed * 1664525u + 1013904223u; return ((g_seed >> 8) / 8388608.0f) - 1.0f; }
 
@@ -387,6 +442,7 @@ static void roundtrip() {
 int main(int argc, char** argv) {
   // sp_conv_check.bin [n_images] [layer-name filter | all] [tiles | auto | abl]
   const int n = argc > 1 ? atoi(argv[1]) : 20;
+  g_guard = getenv("SPCHECK_GUARD") && atoi(getenv("SPCHECK_GUARD"));
   if (argc > 2 && strcmp(argv[2], "all")) g_filter = argv[2];
   if (argc > 3) g_mode = !strcmp(argv[3], "auto") ? 1 : !strcmp(argv[3], "abl") ? 2 : 0;
   const bool quick = g_mode == 1;
@@ -452,6 +508,9 @@ int main(int argc, char** argv) {
     run_ks("ks conv2_2 64^2 128->128 (4)", n, 64, 64, 128, 0, 0, 128, 1, 4);
     run_ks("ks conv3_1 64^2 128->256 s2", n, 64, 64, 128, 0, 0, 256, 2, 2);
   }
+  check_guards("end of run");
+  if (g_guard) printf("guard bands: %zu buffers, %d overwritten\n", g_allocs.size(), g_guard_fail);
+  g_fail += g_guard_fail;
   printf("%s (%d failures)\n", g_fail ? "SP CONV CHECK FAILED" : "SP CONV CHECK PASSED", g_fail);
   return g_fail ? 1 : 0;
 }
