@@ -158,6 +158,8 @@ SIGNATURES = {
                                   c_int, c_long, c_int, c_int, c_void_p, c_void_p]),
     "dn_bn_train_apply_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_long, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p]),
+    "dn_bn_train_apply_mask_sp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_long, c_int, c_int, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "dn_bn_update_running": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_void_p, c_float,
                                      c_void_p, c_void_p, c_void_p]),
     "dn_bn_train_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,

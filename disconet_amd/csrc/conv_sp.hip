@@ -1798,8 +1798,7 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
   SpArgs a;
   if (int rc = fill_args(d, src0, src1, packed, scale, shift, out, a)) return rc;
   a.out_b = out_nhwc; a.ldo_b = ld_nhwc;      // POST 0: optional fp32 NHWC copy of the output
-  DN_REQUIRE(!out_nhwc || (up_mode(*d) != 2 && g_sp_force < 100),
-             "spconv dual: not available on the tap-merged up-conv kernel");
+  DN_REQUIRE(!out_nhwc || g_sp_force < 100, "spconv dual: not with a forced tools configuration");
   hipStream_t s = (hipStream_t)stream;
   // K slices: a property of the LAYER (the caller passes the same count whatever the batch): results do not depend
   // on how a launch distributes the slices.  Layers with fewer chunks than slices, 1x1 layers, the row-merged image
@@ -1811,7 +1810,7 @@ int spconv2d_impl(const dn_conv_desc* d, const void* src0, const void* src1, con
     return dn::spq_conv(d, src0, src1, packed, (size_t)a.wpk_bytes, scale, shift, out, a.cout_pad,
                         g_sp_force == 20 ? 32 : g_sp_force == 21 ? 64 : g_sp_force == 22 ? 33 :
                         (g_sp_force >= 23 && g_sp_force <= 25) ? 78 + g_sp_force : 0, s, kslices, (float*)workspace,
-                        workspace_bytes);
+                        workspace_bytes, out_nhwc, ld_nhwc);
   }
   if (kslices > 1) {
     a.ks.count = kslices;

@@ -52,7 +52,9 @@ struct SpqArgs {
   const unsigned char* wpk;
   const float* scale;
   const float* shift;
-  unsigned char* out;
+  unsigned char* out;          // SP tensor; nullptr: the fp32 rows below are the only output
+  float* out_f32;              // optional second output: the same values as fp32 NHWC rows (pixel stride ldo_f32 floats) --
+  int ldo_f32;                 // the training step's forward (z = conv + bias, read by the BatchNorm statistics)
   int n_images, h, w;          // conv input = output size (src0 is stored at h / 2 x w / 2)
   int c0g, c1g;                // 16-channel chunks from src0 / src1
   int c_out, cog, relu;
@@ -401,6 +403,30 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
     const int img_bytes = a.cog * 4 * plane;
     const auto rsrc_o = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)tc.img * img_bytes, 0, img_bytes, 0x00020000);
     const float lo_clamp = a.relu ? 0.f : -65504.f;
+    if (a.out_f32 != nullptr) {   // fp32 NHWC rows (as conv_sp_kernel's second output): a block of its own behind ONE uniform branch
+      const float floor_v = a.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+      for (int wm = 0; wm < 2; ++wm) {
+        const int oy = tc.oy0 + prow[wm], ox = tc.ox0 + pcol;
+        const bool inside = oy < a.h && ox < a.w;
+        float* orow = a.out_f32 + (((size_t)tc.img * a.h + oy) * a.w + ox) * a.ldo_f32;
+#pragma unroll
+        for (int wn = 0; wn < WTN; ++wn)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int co = tc.n0 + 32 * wn + 8 * g + 4 * lh;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(aff_s + wn * 32 + 8 * g + 4 * lh);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(aff_s + 64 + wn * 32 + 8 * g + 4 * lh);
+            f32x4 v = affine4(quad_of(acc[wm][wn], g), sc, sh);
+            nan_seen |= !(fabsf(v[0]) <= 3.4028235e38f) | !(fabsf(v[1]) <= 3.4028235e38f) | !(fabsf(v[2]) <= 3.4028235e38f) |
+                        !(fabsf(v[3]) <= 3.4028235e38f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);
+            if (inside && co < a.c_out) *reinterpret_cast<f32x4*>(orow + co) = v;
+          }
+      }
+      if (a.out == nullptr) return;      // nothing is split: no magnitude to track
+    }
 #pragma unroll
     for (int wm = 0; wm < 2; ++wm) {
       const int oy = tc.oy0 + prow[wm], ox = tc.ox0 + pcol;
@@ -749,10 +775,11 @@ int spq_pack_weights(const float* weight_oihw, void* packed, int c_out, int c_in
 // bn: 32 or 64 output channels per workgroup; 33 = 32 in the one-step-per-chunk (DEEP) form; 0 = choose
 int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed, size_t packed_bytes,
              const float* scale, const float* shift, void* out, int cout_pad, int bn, hipStream_t stream,
-             int kslices, float* workspace, size_t workspace_bytes) {
+             int kslices, float* workspace, size_t workspace_bytes, float* out_nhwc, int ld_nhwc) {
   SpqArgs a;
   a.src0 = (const unsigned char*)src0; a.src1 = (const unsigned char*)src1; a.wpk = (const unsigned char*)packed;
   a.scale = scale; a.shift = shift; a.out = (unsigned char*)out;
+  a.out_f32 = out_nhwc; a.ldo_f32 = ld_nhwc;
   a.n_images = d->n_images; a.h = d->h_in; a.w = d->w_in;
   a.c0g = (d->c0 + 15) / 16; a.c1g = (d->c1 + 15) / 16;
   a.c_out = d->c_out; a.cog = (d->c_out + 15) / 16; a.relu = d->relu;

@@ -46,7 +46,8 @@ int spq_pack_weights(const float* weight_oihw, void* packed, int c_out, int c_in
                      float wmul, hipStream_t stream);
 int spq_conv(const dn_conv_desc* d, const void* src0, const void* src1, const void* packed, size_t packed_bytes,
              const float* scale, const float* shift, void* out, int cout_pad, int bn, hipStream_t stream,
-             int kslices = 1, float* workspace = nullptr, size_t workspace_bytes = 0);
+             int kslices = 1, float* workspace = nullptr, size_t workspace_bytes = 0, float* out_nhwc = nullptr,
+             int ld_nhwc = 0);
 
 // per-translation-unit words of the split-f16 range flags (sp_device.h); dn_sp_range_flags() ORs them
 void range_collect_conv_sp(unsigned* dst, bool reset, hipStream_t stream);

@@ -193,14 +193,17 @@ bn_apply_v4_kernel(const float* __restrict__ z, const float* __restrict__ mean,
 // HBM-bound (round 5: rocprofv3 counters, profiles/r05_train_pmc.txt).  Here 1 / sqrtf(var + eps) is computed once per workgroup
 // into LDS (the same expression: the same bits) and (row, channel quad) come from a shift and a mask.  DN_BN_LEGACY=1 routes
 // every call to the general kernels (tests: bitwise A/B).
+template <bool SP>
 __global__ void __launch_bounds__(256)
 bn_apply_v4_fast_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ var,
                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu, int c, int sh,
-                        int ldz, unsigned total4, float* __restrict__ y, unsigned char* __restrict__ relu_mask) {
+                        int ldz, unsigned total4, float* __restrict__ y, unsigned char* __restrict__ relu_mask,
+                        unsigned char* __restrict__ y_sp, unsigned hw, unsigned* __restrict__ flags) {
   __shared__ __attribute__((aligned(16))) float rstd_s[kMaxC];
   for (int i = threadIdx.x; i < c; i += 256) rstd_s[i] = 1.f / sqrtf(var[i] + eps);
   __syncthreads();
   const unsigned c4m = (1u << sh) - 1u;
+  float amax = 0.f;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total4; idx += gridDim.x * 256u) {
     const unsigned row = idx >> sh;
     const int c4 = (int)(idx & c4m);
@@ -210,6 +213,32 @@ bn_apply_v4_fast_kernel(const float* __restrict__ z, const float* __restrict__ m
     if (relu_mask) relu_mask[idx] = (unsigned char)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
     if (relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
     *reinterpret_cast<f32x4*>(y + (size_t)row * c + 4 * c4) = v;
+    if constexpr (SP) {
+      // the SP copy of y (the next layer's forward operand on the split-f16 engine): the piece assembly of
+      // bn_bwd_apply_v4_kernel<true> -- two adjacent threads hold the 8 channels of a piece and swap halves
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      f32x4 x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[e] = fminf(fmaxf(v[e], -65504.f), 65504.f);
+        amax = fmaxf(amax, fabsf(x[e]));
+      }
+      const h4 hi = __builtin_convertvector(x, h4);
+      const h4 lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), h4);
+      const u2 hu = __builtin_bit_cast(u2, hi), lu = __builtin_bit_cast(u2, lo);
+      const bool odd = c4 & 1;
+      const unsigned t0 = __shfl_xor(odd ? hu[0] : lu[0], 1), t1 = __shfl_xor(odd ? hu[1] : lu[1], 1);
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      const u4 piece = odd ? u4{t0, t1, lu[0], lu[1]} : u4{hu[0], hu[1], t0, t1};
+      const unsigned img = row / hw, px = row - img * hw;
+      const int oct8 = c4 >> 1, cg = oct8 >> 1, oct = oct8 & 1, cg_total = c >> 4;
+      const size_t q = ((size_t)img * cg_total + cg) * 4 + (odd ? 2 : 0) + oct;
+      *reinterpret_cast<u4*>(y_sp + (q * hw + px) * 16) = piece;
+    }
+  }
+  if constexpr (SP) {
+    if (amax > 16384.f && flags) atomicOr(flags, amax >= 65504.f ? 3u : 2u);
   }
 }
 
@@ -895,8 +924,9 @@ extern "C" int dn_bn_train_apply(const float* z, const float* mean, const float*
   const long total = (long)n_groups * rows_per_group * c;
   const int fsh = bn_fast_shift(n_groups, c, total);
   if (vec4_ok(c, {ldz}, {z, y, mean, var, gamma, beta}) && fsh >= 0)
-    hipLaunchKernelGGL(bn_apply_v4_fast_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, z, mean, var,
-                       gamma, beta, eps, relu, c, fsh, ldz, (unsigned)(total / 4), y, (unsigned char*)nullptr);
+    hipLaunchKernelGGL(bn_apply_v4_fast_kernel<false>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, z, mean, var,
+                       gamma, beta, eps, relu, c, fsh, ldz, (unsigned)(total / 4), y, (unsigned char*)nullptr,
+                       (unsigned char*)nullptr, 1u, (unsigned*)nullptr);
   else if (vec4_ok(c, {ldz}, {z, y, mean, var, gamma, beta}))
     hipLaunchKernelGGL(bn_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0,
                        (hipStream_t)stream, z, mean, var, gamma, beta, eps, relu, rows_per_group, c, ldz,
@@ -916,12 +946,33 @@ extern "C" int dn_bn_train_apply_mask(const float* z, const float* mean, const f
   const long total = (long)n_groups * rows_per_group * c;
   const int fsh = bn_fast_shift(n_groups, c, total);
   if (fsh >= 0)
-    hipLaunchKernelGGL(bn_apply_v4_fast_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, z, mean, var,
-                       gamma, beta, eps, 1, c, fsh, ldz, (unsigned)(total / 4), y, relu_mask);
+    hipLaunchKernelGGL(bn_apply_v4_fast_kernel<false>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, z, mean, var,
+                       gamma, beta, eps, 1, c, fsh, ldz, (unsigned)(total / 4), y, relu_mask, (unsigned char*)nullptr, 1u,
+                       (unsigned*)nullptr);
   else
     hipLaunchKernelGGL(bn_apply_v4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, z, mean, var,
                        gamma, beta, eps, 1, rows_per_group, c, ldz, total / 4, y, relu_mask);
   return dn::check_launch("bn_apply_kernel (mask)");
+}
+
+extern "C" int dn_bn_train_apply_mask_sp(const float* z, const float* mean, const float* var, const float* gamma,
+                                         const float* beta, float eps, long rows, int hw, int c, int ldz, float* y,
+                                         unsigned char* relu_mask, void* y_sp, void* stream) {
+  DN_REQUIRE(z && mean && var && gamma && beta && y && relu_mask && y_sp, "bn apply (mask + SP): null pointer");
+  DN_REQUIRE(rows > 0 && hw > 0 && rows % hw == 0 && c > 0 && c % 16 == 0 && ldz >= c, "bn apply (mask + SP): bad shape");
+  DN_REQUIRE(vec4_ok(c, {ldz}, {z, y, mean, var, gamma, beta}) && (reinterpret_cast<uintptr_t>(y_sp) & 15) == 0,
+             "bn apply (mask + SP): needs 16-byte aligned tensors");
+  const long total = rows * c;
+  const int c4n = c >> 2;      // (its own test: the SP form has no general-kernel twin for DN_BN_LEGACY to select)
+  DN_REQUIRE(c <= kMaxC && (c4n & (c4n - 1)) == 0 && total / 4 < (1L << 31),
+             "bn apply (mask + SP): c / 4 must be a power of two and the map below 2^31 float4s (c = %d)", c);
+  int fsh = 0;
+  while ((1 << fsh) < c4n) ++fsh;
+  unsigned* flags = dn::sp_range_word();
+  DN_REQUIRE(flags, "bn apply (mask + SP): the range word of the split-f16 engine is not addressable");
+  hipLaunchKernelGGL(bn_apply_v4_fast_kernel<true>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, z, mean, var,
+                     gamma, beta, eps, 1, c, fsh, ldz, (unsigned)(total / 4), y, relu_mask, (unsigned char*)y_sp, (unsigned)hw, flags);
+  return dn::check_launch("bn_apply_kernel (mask + SP)");
 }
 
 extern "C" int dn_bn_update_running(const float* mean, const float* var, int n_groups,

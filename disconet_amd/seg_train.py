@@ -27,6 +27,7 @@ _DOUBLES = ("inc", "down1", "down2", "down3", "down4", "up1", "up2", "up3", "up4
 
 class SegTrainEngine(TrainEngine):
     FUSE_LEVEL_CHANNELS = 512
+    _FWD_SP_OK = False      # the UNet's convs are fed by max-pool / bilinear-upsample kernels that write fp32 rows only: NHWC engine
 
     def _param_order(self, model):
         return list(model.parameters())

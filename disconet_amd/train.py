@@ -34,6 +34,7 @@ _EPS = 1e-5          # nn.BatchNorm default
 _DGRAD_MATH_DEFAULT = "sp"        # measured (round 5): per-tensor gradient error vs the float64 oracle equal to the fp32 form's to 3 digits
 _WGRAD_MATH_DEFAULT = "sp"        # the weight gradients of the layers dn_conv_wgrad_sp takes on the f16 MFMA with split operands
 _WGRAD_X_LIFT = 16.0              # power-of-two lift of the activations in that kernel (post-BatchNorm maps: |x| << 4094)
+_FWD_MATH_DEFAULT = "sp"          # round 6: the training forward's 3x3 / 1x1 convs on the inference engine's split-f16 LDS-DMA kernels
 _MOMENTUM = 0.1
 
 
@@ -150,9 +151,18 @@ class TrainEngine:
                                lambda self, v: setattr(self, "_overlap_streams",
                                                        ops.check_overlap_request(v, "TrainEngine.overlap_streams")))
 
+    # the training forward may run its convs on the SP engine (fwd_math = "sp"): subclasses whose graph feeds the convs from
+    # kernels that do not write SP copies (the segmentation variant's pooling / bilinear upsampling) switch it off
+    _FWD_SP_OK = True
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, shard=None, dgrad_math=None,
-                 wgrad_math=None):
-        """wgrad_math: arithmetic of the weight gradients -- "f32" (the exact fp32 MFMA kernels) or "sp" (dn_conv_wgrad_sp where
+                 wgrad_math=None, fwd_math=None):
+        """fwd_math: where the training FORWARD's convs run while model.conv_math is a split-f16 mode -- "sp" (round 6: the
+        inference engine's LDS-DMA kernels, dn_spconv2d_nhwc: every BatchNorm apply writes its y a second time as an SP tensor
+        and the next conv reads that, writing z as fp32 rows for the statistics) or "nhwc" (rounds 2-5: the fp32-NHWC engine,
+        which splits the rows on the VALU while staging them); same arithmetic (hi + lo operands, three products, fp32
+        accumulation) in another summation order.  None: DISCONET_FWD_MATH, default _FWD_MATH_DEFAULT.
+        wgrad_math: arithmetic of the weight gradients -- "f32" (the exact fp32 MFMA kernels) or "sp" (dn_conv_wgrad_sp where
         it takes the layer: f16 hi + lo operands split while staging, dz lifted by the same measured power of two as below; the
         other layers stay fp32); None: DISCONET_WGRAD_MATH, default _WGRAD_MATH_DEFAULT.
         dgrad_math: arithmetic of the 3x3 data gradients -- "f32" (the exact fp32 MFMA) or "sp" (the inference engine's
@@ -171,6 +181,9 @@ class TrainEngine:
         self.wgrad_math = wgrad_math if wgrad_math is not None else os.environ.get("DISCONET_WGRAD_MATH", _WGRAD_MATH_DEFAULT)
         if self.wgrad_math not in ("f32", "sp"):
             raise ValueError("wgrad_math must be 'f32' or 'sp' (got %r)" % (self.wgrad_math,))
+        self.fwd_math = fwd_math if fwd_math is not None else os.environ.get("DISCONET_FWD_MATH", _FWD_MATH_DEFAULT)
+        if self.fwd_math not in ("nhwc", "sp"):
+            raise ValueError("fwd_math must be 'nhwc' or 'sp' (got %r)" % (self.fwd_math,))
         self._dz_lift = {}           # layer name -> (power-of-two lift of its dz, step it was measured at)
         self.f32_fallback_steps = 0  # backward passes that were re-run on the fp32 kernels after a clamped dz (backward())
         self.last_fallback_step = None
@@ -257,6 +270,20 @@ class TrainEngine:
                           ld0=src0.stride(2), ld1=src1.stride(2) if src1 is not None else None,
                           ldo=out.stride(2) if out is not None else None, math=self._math())
         dev = src0.device
+        sp0, sp1 = self._sp_copy(src0), (self._sp_copy(src1) if src1 is not None else None)
+        if (self._sp_forward() and d.math == 1 and sp0 is not None and (src1 is None or sp1 is not None) and lift_of is None
+                and c_out % 4 == 0 and (c1 == 0 or c0 % 16 == 0)):
+            # the inference engine's kernels on the SP copies the BatchNorm applies wrote (d stays the fp32 tensors' descriptor:
+            # the backward's weight / data gradients read those)
+            ds = ops.conv_desc(n, h_in, w_in, c0, c_out, ksize, stride, False, c1=c1, up0=up0)
+            wmul = self._wmul_of(w)
+            packed, _ = ops.sp_pack_conv_weights(ds, w, wmul)
+            if out is None:
+                ho, wo = ops.conv_out_hw(ds)
+                out = torch.empty((n, ho, wo, c_out), dtype=torch.float32, device=dev)
+            ops.sp_conv2d_nhwc(ds, sp0, packed, self._const(dev, c_out, 1.0 / wmul),
+                               bias if bias is not None else self._const(dev, c_out, 0.0), out, src1=sp1)
+            return out, d
         wmul = self._wmul_of(w if lift_of is None else lift_of) if d.math == 1 else 1.0
         packed = ops.pack_conv_weights(d, w if wmul == 1.0 else w.detach() * wmul)
         one = self._const(dev, c_out, 1.0 / wmul)
@@ -266,6 +293,20 @@ class TrainEngine:
             out = torch.empty((n, ho, wo, c_out), dtype=torch.float32, device=dev)
         ops.conv2d(d, src0, packed, one, shift, src1=src1, out=out)
         return out, d
+
+    def _sp_forward(self):
+        return self._FWD_SP_OK and self.fwd_math == "sp"
+
+    @staticmethod
+    def _sp_copy(t):
+        """the SP twin of an fp32 NHWC activation, where a BatchNorm apply (or _attach_sp) left one"""
+        return getattr(t, "_dn_sp", None)
+
+    def _attach_sp(self, t):
+        """an activation that no BatchNorm apply of this engine wrote (the input voxels, the fused map): one dn_sp_from_nhwc pass"""
+        if self._sp_forward() and self._math() == 1 and self._sp_copy(t) is None:
+            t._dn_sp = ops.SpTensor.from_nhwc(t)
+        return t
 
     def _wmul_of(self, w):
         """power-of-two lift of a layer's weights for the split-f16 forward (ops._pow2_lift: keeps the lo halves
@@ -292,7 +333,9 @@ class TrainEngine:
         return cache[key]
 
     def _layer_fwd(self, lay, src0, src1=None, up0=0, groups=1, w=None, b=None, gamma=None, beta=None,
-                   y_out=None):
+                   y_out=None, want_sp=True):
+        """want_sp: a conv of this engine reads y (write its SP twin with the BatchNorm apply when the forward runs on the SP
+        engine); False where only other kernels do (the heads' hidden layer feeds two 1x1 convs on channel slices)"""
         w = lay.w if w is None else w
         b = lay.b if b is None else b
         z, d = self._conv(w, b, src0, src1, up0, lay.stride, lay.ksize)
@@ -301,7 +344,12 @@ class TrainEngine:
         beta = lay.bn.bias if beta is None else beta
         # the backward's ReLU gate as one byte per four channels: its two passes then do not read y (1/16 of the bytes)
         mask = torch.empty(z.numel() // 4, dtype=torch.uint8, device=z.device) if z.shape[-1] % 4 == 0 else None
-        y = T.bn_apply(z, mean, var, gamma, beta, _EPS, relu=True, out=y_out, relu_mask=mask)
+        y_sp = None
+        if (want_sp and self._sp_forward() and self._math() == 1 and mask is not None and T.bn_apply_sp_supported(z, groups)):
+            y_sp = ops.SpTensor(z.shape[0], z.shape[1], z.shape[2], z.shape[3], device=z.device)
+        y = T.bn_apply(z, mean, var, gamma, beta, _EPS, relu=True, out=y_out, relu_mask=mask, sp_out=y_sp)
+        if y_sp is not None:
+            y._dn_sp = y_sp
         lay.ctx = dict(src0=src0, src1=src1, up0=up0, z=z, y=y, mean=mean, var=var, desc=d,
                        groups=groups, w=w, gamma=gamma, mask=mask)
         return y
@@ -505,6 +553,7 @@ class TrainEngine:
         x = bevs.reshape(n, bevs.shape[2], bevs.shape[3], bevs.shape[4])
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
+        self._attach_sp(x)
         trans = trans_matrices.to(device=dev, dtype=torch.float32).contiguous()
         self._num_agent_cpu, self._batch = num_agent_tensor[:, 0].cpu(), B
         F = self._fusion_lists(trans, self._num_agent_cpu, B, dev)
@@ -553,7 +602,7 @@ class TrainEngine:
         for t in e[lay_k + 1:]:
             t.record_stream(main)
         sk = list(e)
-        sk[lay_k] = fused                                     # the decoder sees the fused map
+        sk[lay_k] = self._attach_sp(fused)                    # the decoder sees the fused map
         a = self._layer_fwd(L["conv5_1"], sk[4], sk[3], up0=1)
         x5 = self._layer_fwd(L["conv5_2"], a)
         a = self._layer_fwd(L["conv6_1"], x5, sk[2], up0=1)
@@ -576,7 +625,7 @@ class TrainEngine:
         beo, _, _ = self.grad_of[id(cls.bn1.bias)]
         beta = self.flat_p[beo:beo + 64]
         self.head1 = _Layer("heads1", w1, b1, None, 3)
-        h1 = self._layer_fwd(self.head1, x8, w=w1, b=b1, gamma=gamma, beta=beta)
+        h1 = self._layer_fwd(self.head1, x8, w=w1, b=b1, gamma=gamma, beta=beta, want_sp=False)
         cls_out, dc = self._conv(cls.conv2.weight, cls.conv2.bias, h1[..., :32], ksize=1)
         loc_out, dr = self._conv(reg[3].weight, reg[3].bias, h1[..., 32:], ksize=1)
         self.head_ctx = dict(h1=h1, dc=dc, dr=dr)

@@ -116,14 +116,31 @@ def bn_stats(z, n_groups=1, sync=None, norm_rows=None):
     return mean, var
 
 
-def bn_apply(z, mean, var, gamma, beta, eps, relu=True, out=None, relu_mask=None):
+def bn_apply_sp_supported(z, n_groups=1):
+    """can bn_apply(..., sp_out=...) also write y as an SP tensor?  (one group, [n, h, w, c] with c % 16 == 0, c / 4 a power of two)"""
+    c = z.shape[-1]
+    return z.dim() == 4 and n_groups == 1 and c % 16 == 0 and ((c // 4) & (c // 4 - 1)) == 0 and c <= 1024
+
+
+def bn_apply(z, mean, var, gamma, beta, eps, relu=True, out=None, relu_mask=None, sp_out=None):
     """relu_mask: a uint8 tensor of z.numel() / 4 bytes that receives the backward's ReLU gate, one byte per four channels
-    (dn_bn_train_apply_mask; relu must be on, c % 4 == 0) -- bn_backward(relu_mask=...) reads it instead of y."""
+    (dn_bn_train_apply_mask; relu must be on, c % 4 == 0) -- bn_backward(relu_mask=...) reads it instead of y.
+    sp_out: an ops.SpTensor of z's shape that ALSO receives y as f16 hi / lo planes (dn_bn_train_apply_mask_sp: the operand of
+    the next layer's forward conv on the split-f16 engine; needs relu_mask, bn_apply_sp_supported)."""
     _need_gpu(z, mean, var, gamma, beta, relu_mask)
     c = z.shape[-1]
     n_groups = mean.shape[0]
     rows = z.numel() // c
     y = torch.empty_like(z) if out is None else out
+    if sp_out is not None:
+        if relu_mask is None or not relu or not bn_apply_sp_supported(z, n_groups) or tuple(sp_out.shape) != tuple(z.shape) \
+                or sp_out.hi_only or sp_out.bits or relu_mask.dtype != torch.uint8 or relu_mask.numel() * 4 != z.numel():
+            raise _lib.DnError("bn_apply: sp_out needs relu + relu_mask, one group, c % 16 == 0 with c / 4 a power of two, and a "
+                               "full SP tensor of z's shape")
+        check(_lib.load().dn_bn_train_apply_mask_sp(_ptr(z), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), float(eps), rows,
+                                                    z.shape[1] * z.shape[2], c, c, _ptr(y), _ptr(relu_mask), _ptr(sp_out.data),
+                                                    _stream()), "dn_bn_train_apply_mask_sp")
+        return y
     if relu_mask is not None:
         if not relu or relu_mask.dtype != torch.uint8 or relu_mask.numel() * 4 != z.numel() or not relu_mask.is_contiguous():
             raise _lib.DnError("bn_apply: relu_mask must be a contiguous uint8 tensor of z.numel() / 4 bytes, with relu on")

@@ -264,7 +264,7 @@ size_t dn_spconv_workspace_bytes(const dn_conv_desc* d, int kslices);
 int dn_spconv_ks_supported(const dn_conv_desc* d, int kslices);
 int dn_spconv2d_ks(const dn_conv_desc* d, int kslices, const void* src0, const void* src1, const void* packed,
                    const float* scale, const float* shift, void* out, float* out_nhwc /* may be NULL: the second,
-                   fp32 NHWC output of dn_spconv2d_dual (not on the tap-merged up-conv) */, int ld_nhwc,
+                   fp32 NHWC output of dn_spconv2d_dual */, int ld_nhwc,
                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* The encoder stem's first two layers in one launch (conv_pre_1 -> conv_pre_2, both 3x3 + BN + ReLU at the
@@ -280,14 +280,15 @@ int dn_spconv2d_pre_pair(const dn_conv_desc* d1, const dn_conv_desc* d2, const u
 /* The same conv with a SECOND copy of its output as float32 NHWC rows [n][h_out][w_out][ld_nhwc] (first c_out
  * columns; c_out % 4 == 0), written from the same epilogue registers before the f16 split: the level a
  * consumer outside the conv engine reads (the fusion kernels' maps, the agent all-gather) needs no
- * dn_sp_to_nhwc pass.  Not available on the tap-merged up-conv kernel (up0 = 1 layers). */
+ * dn_sp_to_nhwc pass.  (Round 6: also on the tap-merged up-conv kernel, up0 = 1 layers.) */
 int dn_spconv2d_dual(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp, const void* packed,
                      const float* scale, const float* shift, void* out_sp, float* out_nhwc, int ld_nhwc,
                      void* stream);
 /* dn_spconv2d whose ONLY output is the float32 NHWC copy (no SP tensor is written, nothing is split, no magnitude is
  * tracked): the training step's split-f16 data gradient -- src0 = dz as an SP tensor (dn_bn_train_backward_finish_sp),
- * packed = the flipped / transposed weights, scale = 1 / (sp_lift * wmul), shift = 0, relu = 0.  Same restrictions as
- * dn_spconv2d_dual (not on the tap-merged up-conv kernel). */
+ * packed = the flipped / transposed weights, scale = 1 / (sp_lift * wmul), shift = 0, relu = 0 -- and (round 6) the training
+ * step's FORWARD convs: src = the previous layer's y as the SP tensor dn_bn_train_apply_mask_sp writes, scale = 1 / wmul,
+ * shift = bias, out = z (what the BatchNorm statistics read).  Same restrictions as dn_spconv2d_dual. */
 int dn_spconv2d_nhwc(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp, const void* packed,
                      const float* scale, const float* shift, float* out_nhwc, int ld_nhwc, void* stream);
 /* Fused 3x3 (64 channels) + affine + ReLU, then 1x1 + affine (+ReLU): the 64-channel tile

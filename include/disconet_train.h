@@ -111,6 +111,17 @@ int dn_bn_train_apply_mask(const float* z, const float* mean, const float* var, 
                            float eps, int n_groups, long rows_per_group, int c, int ldz, float* y,
                            unsigned char* relu_mask, void* stream);
 
+/* dn_bn_train_apply_mask (one group) that ALSO writes y as an SP tensor (include/disconet_hip.h "SP tensor":
+ * [image][c / 16][4 quarters][hw][8 halves]; y_sp of dn_sp_tensor_bytes(rows / hw, ., ., c) bytes) -- the operand of the NEXT
+ * layer's forward conv on the split-f16 LDS-DMA engine (dn_spconv2d_nhwc), so that the training forward runs the inference
+ * engine's kernels instead of splitting fp32 rows on the VALU while staging them (round 6).  The split is dn_sp_from_nhwc's
+ * (clamp to +-65504, hi = half(y), lo = half(y - hi)); a clamped value sets the engine's sticky range flag.  y (fp32) is
+ * still written: the weight gradient of the next layer and the skip consumers read it.  rows % hw == 0, c % 16 == 0, c / 4 a
+ * power of two, 16-byte aligned tensors. */
+int dn_bn_train_apply_mask_sp(const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
+                              float eps, long rows, int hw, int c, int ldz, float* y, unsigned char* relu_mask, void* y_sp,
+                              void* stream);
+
 /* running = (1 - momentum) * running + momentum * batch stat, group after group in the order
  * `order` lists them (null = 0..n_groups-1); running_var takes the unbiased variance. */
 int dn_bn_update_running(const float* mean, const float* var, int n_groups, long rows_per_group,

@@ -55,6 +55,11 @@ static int errors_only(void) {
   /* round 5: two-phase BatchNorm reductions (agent-parallel training) and the K-slice query */
   CHECK(dn_bn_train_stats_partial(NULL, 1, 10, 8, 8, NULL, 0, NULL) == DN_ERR_ARG, "bn stats partial null");
   CHECK(dn_bn_train_stats_finish(NULL, 1, 10, 8, NULL, NULL, NULL) == DN_ERR_ARG, "bn stats finish null");
+  CHECK(dn_bn_train_apply_mask_sp(NULL, NULL, NULL, NULL, NULL, 1e-5f, 16, 16, 16, 16, NULL, NULL, NULL, NULL) == DN_ERR_ARG,
+        "bn apply (mask + SP) null");
+  CHECK(dn_bn_train_apply_mask_sp((const float*)16, (const float*)16, (const float*)16, (const float*)16, (const float*)16, 1e-5f,
+                                  16, 16, 24, 24, (float*)16, (unsigned char*)16, (void*)16, NULL) == DN_ERR_ARG,
+        "bn apply (mask + SP): c %% 16");
   CHECK(dn_bn_train_stats_finish((const double*)16, 1, 0, 8, (float*)16, (float*)16, NULL) == DN_ERR_ARG, "bn stats finish: zero rows");
   CHECK(dn_bn_train_backward_partial(NULL, 8, 0, NULL, 0, NULL, NULL, NULL, NULL, 1e-5f, 0, 1, 4, 4, 1, 8, NULL, 0, NULL, NULL, 0,
                                      NULL) == DN_ERR_ARG, "bn bwd partial null");

@@ -681,3 +681,56 @@ def test_adam_matches_torch_optim():
         opt.step()
         train_ops.adam_step(p, grad.to(_dev()), m, v, step, lr=1e-3)
     assert float((p.cpu() - p_ref.detach()).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 24, 64), (2, 32, 32, 256), (1, 64, 64, 32), (2, 8, 8, 512)])
+def test_bn_apply_writes_y_a_second_time_as_an_sp_tensor(shape):
+    """Round 6 (the training forward on the inference engine): dn_bn_train_apply_mask_sp = dn_bn_train_apply_mask bit for bit
+    (y, the byte mask) + y as the split-planar f16 hi / lo tensor -- the bits dn_sp_from_nhwc makes of that y."""
+    from disconet_amd import ops, train_ops
+    g = torch.Generator().manual_seed(17)
+    n, h, w, c = shape
+    z = (torch.randn(shape, generator=g) * 2 + 0.3).to(_dev())
+    gm, bt = (torch.rand(c, generator=g) + 0.5).to(_dev()), (torch.randn(c, generator=g) * 0.2).to(_dev())
+    mean, var = train_ops.bn_stats(z)
+    m0 = torch.empty(z.numel() // 4, dtype=torch.uint8, device=_dev())
+    y0 = train_ops.bn_apply(z, mean, var, gm, bt, 1e-5, relu=True, relu_mask=m0)
+    m1 = torch.zeros_like(m0)
+    sp = ops.SpTensor(n, h, w, c, device=_dev())
+    sp.data.fill_(7.0)
+    y1 = train_ops.bn_apply(z, mean, var, gm, bt, 1e-5, relu=True, relu_mask=m1, sp_out=sp)
+    assert torch.equal(y0, y1) and torch.equal(m0, m1)
+    assert torch.equal(sp.data, ops.SpTensor.from_nhwc(y0).data)
+    assert ops.sp_range_flags(reset=True) & 5 == 0
+    assert not train_ops.bn_apply_sp_supported(torch.empty(1, 4, 4, 24))          # c % 16
+    assert not train_ops.bn_apply_sp_supported(torch.empty(1, 4, 4, 48))          # c / 4 not a power of two
+    with pytest.raises(Exception):
+        train_ops.bn_apply(z, mean, var, gm, bt, 1e-5, relu=True, sp_out=sp)      # needs the mask
+
+
+@pytest.mark.parametrize("n,h,w,c0,c1,c_out", [(2, 32, 32, 512, 256, 256), (3, 16, 64, 64, 32, 32), (2, 24, 40, 128, 64, 64), (1, 64, 64, 256, 0, 96)])
+def test_tap_merged_up_conv_writes_fp32_rows(n, h, w, c0, c1, c_out):
+    """Round 6: the decoder's upsample + concat + 3x3 layers (conv_spq_kernel) also take dn_spconv2d_nhwc / _dual -- the
+    training forward's z.  The fp32 rows are the epilogue's values BEFORE the split: they agree with the SP output to the split's
+    2^-22, the SP output of the dual launch is bit for bit the plain launch's, and a channel slice of a wider tensor is honoured."""
+    from disconet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(n, h // 2, w // 2, c0, generator=g).relu().to(_dev())
+    x1 = torch.randn(n, h, w, c1, generator=g).relu().to(_dev()) if c1 else None
+    wgt = (torch.randn(c_out, c0 + c1, 3, 3, generator=g) * (2.0 / (9 * (c0 + c1))) ** 0.5).to(_dev())
+    bias = (torch.randn(c_out, generator=g) * 0.1).to(_dev())
+    d = ops.conv_desc(n, h, w, c0, c_out, 3, 1, False, c1=c1, up0=True)
+    packed, wmul = ops.sp_pack_conv_weights(d, wgt)
+    scale = torch.full((c_out,), 1.0 / wmul, device=_dev())
+    s0, s1 = ops.SpTensor.from_nhwc(x0), (ops.SpTensor.from_nhwc(x1) if c1 else None)
+    want_sp = ops.sp_conv2d(d, s0, packed, scale, bias, src1=s1)
+    wide = torch.full((n, h, w, c_out + 4), -3.0, device=_dev())
+    rows = ops.sp_conv2d_nhwc(d, s0, packed, scale, bias, wide[..., 4:], src1=s1)
+    assert float(wide[..., :4].min()) == -3.0 and float(wide[..., :4].max()) == -3.0
+    ref = F.conv2d(torch.cat([F.interpolate(x0.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").double().cpu()]
+                             + ([x1.permute(0, 3, 1, 2).double().cpu()] if c1 else []), 1),
+                   wgt.double().cpu(), bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(rows, ref) < 3e-6
+    assert float((want_sp.nhwc() - rows).abs().max()) <= 2.0 ** -21 * float(rows.abs().max())
+    got_sp, flat = ops.sp_conv2d(d, s0, packed, scale, bias, src1=s1, nhwc_copy=True)
+    assert torch.equal(got_sp.data, want_sp.data) and torch.equal(flat, rows)

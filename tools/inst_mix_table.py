@@ -1,4 +1,4 @@
-"""Per-launch instruction mix from the two counter passes of tools/r04_lease_inst_mix.sh (last 24 product launches)."""
+"""Per-launch instruction mix from the two counter passes of tools/leases/r04_lease_inst_mix.sh (last 24 product launches)."""
 import collections
 import csv
 import sys

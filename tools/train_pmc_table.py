@@ -1,4 +1,4 @@
-"""Per-KERNEL-NAME summary of rocprofv3 --pmc CSVs of the training step (tools/r05_wgrad_pmc.sh: pmc1 = busy counters, pmc2 =
+"""Per-KERNEL-NAME summary of rocprofv3 --pmc CSVs of the training step (tools/leases/r05_wgrad_pmc.sh: pmc1 = busy counters, pmc2 =
 FETCH_SIZE, pmc3 = WRITE_SIZE; the last `steps` steady steps of tools/train_step_probe.py are what the dispatches of the split-f16
 kernels belong to -- the calibration step runs their fp32 counterparts).  Per name: launches, mean microseconds, per-XCD clock, MFMA
 pipe busy share, wave wait / active shares, LDS bank-conflict share of the LDS-active cycles, HBM fetch (x2: gfx950) and write MB per
