@@ -202,9 +202,19 @@ def load():
     # what the tree says.  DISCONET_NO_AUTOBUILD=1: raise instead.  A/B variants (tools/ab) carry other flags and therefore
     # other ids: DISCONET_HIP_LIB / DISCONET_ALLOW_STALE_LIB=1 say so explicitly and skip the check.
     variant = bool(os.environ.get("DISCONET_HIP_LIB")) or os.environ.get("DISCONET_ALLOW_STALE_LIB") == "1"
+    want = None
     if not variant:
         from .csrc import build as _build
-        want, have = _build.tree_hash(), _build.built_id(LIB_PATH)
+        have = _build.built_id(LIB_PATH)
+        if not _build.sources_present():
+            # a deployment without csrc/*.hip (the built library shipped as an artefact): nothing to compare with or rebuild
+            # from -- the library's own baked id stands; a library without one (or none at all) is still refused
+            if have is None:
+                raise DnError("libdisconet_hip.so is missing or carries no build id (%s), and this tree has no sources to "
+                              "build it from. There is no CPU fallback." % LIB_PATH)
+            want = have
+        else:
+            want = _build.tree_hash()
         if have != want:
             why = ("libdisconet_hip.so is not built (%s)" % LIB_PATH if have is None and not os.path.exists(LIB_PATH) else
                    "libdisconet_hip.so is stale: built from tree %s, the sources here hash to %s" % (have, want))

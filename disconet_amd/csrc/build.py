@@ -39,9 +39,26 @@ def tree_files():
     return sorted(os.path.relpath(f, ROOT) for f in files)
 
 
+def sources_present():
+    """Is this a SOURCE tree?  A deployment may ship the built library without csrc/*.hip (the .so is a build artefact):
+    there is then nothing to hash and nothing to rebuild from -- _lib.load() accepts the library's baked id."""
+    return all(os.path.exists(os.path.join(HERE, s)) for s in SOURCES)
+
+
+_HASH_CACHE = {}
+
+
 def tree_hash(extra_flags=(), unit=None):
     """16 hex digits of SHA-256(flags, (name, content) of every tree file): the library's build id.
-    With `unit` (a .hip name): the key of that object file -- its own source plus every header / .inl."""
+    With `unit` (a .hip name): the key of that object file -- its own source plus every header / .inl.
+    Cached per process by the files' (name, size, mtime): a second import / call does not re-read 0.5 MB of sources."""
+    try:
+        stamp = (tuple(extra_flags), unit, tuple((rel,) + tuple(os.stat(os.path.join(ROOT, rel))[k] for k in (6, 8))
+                                                  for rel in tree_files()))
+    except OSError:
+        stamp = None
+    if stamp is not None and stamp in _HASH_CACHE:
+        return _HASH_CACHE[stamp]
     h = hashlib.sha256()
     h.update(" ".join(FLAGS + list(extra_flags)).encode())
     for rel in tree_files():
@@ -50,6 +67,8 @@ def tree_hash(extra_flags=(), unit=None):
         h.update(b"\0" + rel.encode() + b"\0")
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
+    if stamp is not None:
+        _HASH_CACHE[stamp] = h.hexdigest()[:16]
     return h.hexdigest()[:16]
 
 

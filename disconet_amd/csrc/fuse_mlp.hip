@@ -618,6 +618,23 @@ extern "C" int dn_fuse_mlp_pack(const float* w1, const float* w2, const float* w
 }
 
 namespace {
+// the weight-in-LDS form of <C, WL tiles per workgroup>: a FUNCTION template, so that every instantiation has its own
+// per-device "attribute set" flag (a generic lambda taking the kernel pointer instantiates ONCE for all nine kernels -- they
+// share the type void (*)(FuseMlpArgs) -- and raised the dynamic-LDS limit of the first variant launched only)
+template <int CC, int WL>
+int launch_wl(const FuseMlpArgs& a, dim3 grid, int lds, hipStream_t s) {
+  auto kern = disco_fuse_mlp_kernel<CC, FUSE_GL, 1, WL>;
+  static dn::PerDeviceFlag flag;
+  bool& done = flag.here();
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return dn::fail(DN_ERR_LAUNCH, "fuse_mlp: cannot reserve %d B of dynamic LDS", lds);
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WL), lds, s, a);
+  return dn::check_launch("disco_fuse_mlp_kernel (weights in LDS)");
+}
+
 int fuse_mlp_impl(const float* feat, const float* warped, int warped_fm, const int32_t* num_agent, const dn_fuse_mlp_params* p,
                   int batch, int agents, int hw, int c, int only_v2i, int ego_first, int ego_count, void* fused_sp,
                   float* fused_nhwc, float* weights_out, void* stream);
@@ -689,21 +706,9 @@ int fuse_mlp_impl(const float* feat, const float* warped, int warped_fm, const i
     const int wl = a.total_tiles <= 2 * 256 ? 2 : a.total_tiles <= 3 * 256 ? 3 : 4;
     const dim3 g2((a.total_tiles + wl - 1) / wl);
     const int lds = 4 * (c / 16) * 2 * 2 * 32 * 16;
-    auto go = [&](auto kern) {
-      static dn::PerDeviceFlag flag;      // (one per instantiation: the lambda's operator() is a template)
-      bool& done = flag.here();
-      if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-          return dn::fail(DN_ERR_LAUNCH, "fuse_mlp: cannot reserve %d B of dynamic LDS", lds);
-        done = true;
-      }
-      hipLaunchKernelGGL(kern, g2, dim3(64 * wl), lds, s, a);
-      return DN_OK;
-    };
     int rc = DN_OK;
 #define DN_FUSE_WL(CC)                                                                        \
-    rc = wl == 2 ? go(disco_fuse_mlp_kernel<CC, FUSE_GL, 1, 2>) : wl == 3 ? go(disco_fuse_mlp_kernel<CC, FUSE_GL, 1, 3>) \
-                                                                 : go(disco_fuse_mlp_kernel<CC, FUSE_GL, 1, 4>)
+    rc = wl == 2 ? launch_wl<CC, 2>(a, g2, lds, s) : wl == 3 ? launch_wl<CC, 3>(a, g2, lds, s) : launch_wl<CC, 4>(a, g2, lds, s)
     if (c == 256) DN_FUSE_WL(256);
     else if (c == 128) DN_FUSE_WL(128);
     else DN_FUSE_WL(64);

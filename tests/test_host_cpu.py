@@ -64,6 +64,15 @@ def test_library_build_id_is_the_trees_hash(tmp_path):
     assert r.returncode != 0 and "rebuild failed" in r.stderr and "loaded" not in r.stdout, r.stderr[-400:]
     r = run({"DISCONET_ALLOW_STALE_LIB": "1"})
     assert r.returncode == 0 and "loaded" in r.stdout, r.stderr[-400:]
+    # a deployment that ships the built library WITHOUT csrc/*.hip: nothing to hash or rebuild from -- the
+    # library's baked id stands and the import neither fails nor spawns hipcc; without a library it still refuses
+    for f in (pkg / "csrc").glob("*.hip"):
+        f.unlink()
+    r = run({"HIPCC": "/bin/false"})
+    assert r.returncode == 0 and "loaded" in r.stdout and "rebuilding" not in r.stderr, r.stderr[-400:]
+    (pkg / "libdisconet_hip.so").unlink()
+    r = run({})
+    assert r.returncode != 0 and "no sources" in r.stderr, r.stderr[-400:]
 
 
 def test_struct_layouts_match_header():

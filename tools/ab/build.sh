@@ -12,7 +12,10 @@ for v in "$@"; do
   if [ "$M" = FLAGS ]; then d=$R/tools/ab/FLAGS_${v%%:*}; X="${v#*:}"; else d=$R/tools/ab/${M}_$v; X="-D$M=$v"; fi
   mkdir -p $d
   for f in $FILES; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment -I $R/include -I $C $X -c $C/$f.hip -o $d/$f.o &
+    # (common.hip refuses to compile without the build id: an A/B variant carries a marker, never a tree hash -- it is loaded
+    #  through DISCONET_HIP_LIB / DISCONET_ALLOW_STALE_LIB=1, which skip the id check)
+    ID=""; [ "$f" = common ] && ID='-DDN_BUILD_ID="ab-variant------"'
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment -I $R/include -I $C $X $ID -c $C/$f.hip -o $d/$f.o &
   done
   wait
   objs=$(ls $C/build/*.o | grep -v -E "/($(echo $FILES | tr ' ' '|'))\.o")
