@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <initializer_list>
+#include <type_traits>
 
 #include "disconet_train.h"
 #include "dn_internal.h"
@@ -472,12 +473,18 @@ bn_bwd_apply_v4_kernel(GradSrc src, const float* __restrict__ z, const float* __
 // The one-group fast form of bn_bwd_apply_v4_kernel (see bn_apply_v4_fast_kernel): per channel 1 / sqrtf(var + eps) and the two
 // means (double sum / norm_rows, rounded to float -- eight fp64 divisions per float4 in the general kernel) once per workgroup
 // into LDS, the same expressions; (row, channel quad) by shift and mask; the pixel decode of the incoming gradient in 32 bits.
-template <bool SP>
+// BIAS: the per-channel sums of dz -- the gradient of the conv bias in front of this BatchNorm -- leave this launch as one
+// double per (workgroup, channel) in `bias_part` (folded by fold_partials_kernel in a fixed order: deterministic), instead of
+// a dn_channel_sum pass that reads dz again (round 6: 0.5 ms of the det step).  A thread's channel quad never changes (the
+// grid stride is a multiple of c / 4): it adds its own dz values in fp32 in loop order, the workgroup adds the threads of a
+// quad in thread order in double.
+template <bool SP, bool BIAS = false>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_v4_fast_kernel(GradSrc src, const float* __restrict__ z, const float* __restrict__ mean,
                             const float* __restrict__ var, const float* __restrict__ gamma, float eps, long norm_rows,
                             const double* __restrict__ sums, int sh, unsigned total4, float* __restrict__ dz,
-                            unsigned char* __restrict__ dz_sp, float sp_lift, unsigned hw, unsigned* __restrict__ flags) {
+                            unsigned char* __restrict__ dz_sp, float sp_lift, unsigned hw, unsigned* __restrict__ flags,
+                            double* __restrict__ bias_part = nullptr) {
   __shared__ __attribute__((aligned(16))) float rstd_s[kMaxC], m1_s[kMaxC], m2_s[kMaxC];
   const int c = src.c;
   for (int i = threadIdx.x; i < c; i += 256) {
@@ -488,6 +495,7 @@ bn_bwd_apply_v4_fast_kernel(GradSrc src, const float* __restrict__ z, const floa
   __syncthreads();
   const unsigned c4m = (1u << sh) - 1u;
   float amax = 0.f;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total4; idx += gridDim.x * 256u) {
     const unsigned row = idx >> sh;
     const int c4 = (int)(idx & c4m);
@@ -496,6 +504,7 @@ bn_bwd_apply_v4_fast_kernel(GradSrc src, const float* __restrict__ z, const floa
     const f32x4 m1 = *reinterpret_cast<const f32x4*>(&m1_s[4 * c4]), m2 = *reinterpret_cast<const f32x4*>(&m2_s[4 * c4]);
     const f32x4 v = ldv4(gamma + 4 * c4) * rs * (src.v4u(row, c4) - m1 - zh * m2);
     *reinterpret_cast<f32x4*>(dz + (size_t)row * c + 4 * c4) = v;
+    if constexpr (BIAS) bsum += v;
     if constexpr (SP) {
       typedef _Float16 h4 __attribute__((ext_vector_type(4)));
       typedef unsigned u2 __attribute__((ext_vector_type(2)));
@@ -520,6 +529,17 @@ bn_bwd_apply_v4_fast_kernel(GradSrc src, const float* __restrict__ z, const floa
   }
   if constexpr (SP) {
     if (amax > 16384.f && flags) atomicOr(flags, amax >= 65504.f ? 3u : 2u);
+  }
+  if constexpr (BIAS) {
+    __shared__ __attribute__((aligned(16))) float bred[256][4];
+    *reinterpret_cast<f32x4*>(bred[threadIdx.x]) = bsum;
+    __syncthreads();
+    const int c4n = 1 << sh;
+    for (int cc = threadIdx.x; cc < c; cc += 256) {
+      double t = 0.0;
+      for (int k = cc >> 2; k < 256; k += c4n) t += (double)bred[k][cc & 3];      // the quad's threads, in thread order
+      bias_part[(size_t)blockIdx.x * c + cc] = t;
+    }
   }
 }
 
@@ -873,6 +893,19 @@ extern "C" size_t dn_reduce_workspace_bytes(int n_groups, long rows_per_group, i
   return sizeof(double) * 2 * c * n_groups * (size_t)(1 + blocks_per_group(rows_per_group, n_groups));
 }
 
+// workspace of the fused bias gradient of dn_bn_train_backward_finish_bias: [c] folded sums + one double per (workgroup of
+// the apply launch, channel)
+// workgroups of the apply launch when it also leaves the bias partials: every workgroup is one row of partials for the fold
+// (one wavefront per channel walks them), so fewer than the plain launch's 8192 (DN_BN_BIAS_BLOCKS: tools)
+static int bias_blocks_cap() {
+  static const int cap = [] { const char* e = getenv("DN_BN_BIAS_BLOCKS"); const int v = e ? atoi(e) : 1024; return v < 64 ? 64 : (v > 8192 ? 8192 : v); }();
+  return cap;
+}
+extern "C" size_t dn_bn_bias_workspace_bytes(long rows, int c) {
+  if (rows <= 0 || c <= 0) return 0;
+  return sizeof(double) * (size_t)c * (size_t)(1 + grid_for(rows * (long)c / 4, bias_blocks_cap()));
+}
+
 // Two-phase forms (round 5: agent-parallel training, sharded.py).  A rank that holds only SOME images of a BatchNorm batch
 // reduces its own rows (`_partial`: the folded sums [n_groups][2 c] doubles land at the start of `sums`), the caller
 // all-reduces those doubles over the ranks, and `_finish` normalises by the GLOBAL row count.  The one-call forms below are
@@ -1026,7 +1059,8 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
                             const float* y, const float* z, const float* mean, const float* var,
                             const float* gamma, float eps, int relu, int n_groups, int h, int w,
                             int images_per_group, int c, const double* sums, long norm_rows, float* dz,
-                            void* dz_sp, float sp_lift, void* stream) {
+                            void* dz_sp, float sp_lift, void* stream, float* dbias = nullptr, double* bias_ws = nullptr,
+                            size_t bias_ws_bytes = 0) {
   DN_REQUIRE(dy_a && z && mean && var && gamma && sums && dz, "bn backward finish: null pointer");
   DN_REQUIRE(!relu || y, "bn backward: relu needs y");
   DN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || c % 4 == 0), "bn backward: relu = 2 (y is the byte mask) needs c %% 4 == 0");
@@ -1039,6 +1073,20 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
   const long rows_per_group = (long)images_per_group * h * w;
   GradSrc src{dy_a, dy_b, y, ld_a, up_a, ld_b, relu, h, w, c};
   const long total = (long)n_groups * rows_per_group * c;
+  // the fused bias gradient (round 6): the apply launch leaves one double per (workgroup, channel), folded in a fixed order
+  auto bias_launch = [&](auto sp_c, void* sp_ptr, float lift, unsigned* fl, int fsh) -> int {
+    constexpr bool SPF = decltype(sp_c)::value;
+    const int blocks = grid_for(total / 4, bias_blocks_cap());
+    DN_REQUIRE(bias_ws && bias_ws_bytes >= dn_bn_bias_workspace_bytes(rows_per_group, c),
+               "bn backward: bias workspace of %zu bytes, dn_bn_bias_workspace_bytes() asks for %zu", bias_ws_bytes,
+               dn_bn_bias_workspace_bytes(rows_per_group, c));
+    double* part = bias_ws + c;      // [c] folded sums, then [blocks][c] partials
+    hipLaunchKernelGGL((bn_bwd_apply_v4_fast_kernel<SPF, true>), dim3(blocks), dim3(256), 0, s, src, z, mean, var, gamma, eps,
+                       norm_rows, sums, fsh, (unsigned)(total / 4), dz, (unsigned char*)sp_ptr, lift, (unsigned)(h * w), fl, part);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, blocks, c, 1, bias_ws);
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, s, bias_ws, c, dbias, 0);
+    return dn::check_launch("bn backward apply kernel (+ bias gradient)");
+  };
   if (dz_sp) {
     DN_REQUIRE(n_groups == 1 && c % 16 == 0 && vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz}) &&
                    (reinterpret_cast<uintptr_t>(dz_sp) & 15) == 0 && rows_per_group < (1L << 31),
@@ -1047,6 +1095,9 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
     unsigned* flags = dn::sp_range_word();
     DN_REQUIRE(flags, "bn backward: the range word of the split-f16 engine is not addressable");
     const int fsh = bn_fast_shift(n_groups, c, total);
+    if (fsh >= 0 && dbias)
+      return bias_launch(std::true_type{}, dz_sp, sp_lift, flags, fsh);
+    DN_REQUIRE(!dbias, "bn backward: the fused bias gradient needs the one-group fast form (c / 4 a power of two; DN_BN_LEGACY unset)");
     if (fsh >= 0)
       hipLaunchKernelGGL(bn_bwd_apply_v4_fast_kernel<true>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z, mean, var, gamma,
                          eps, norm_rows, sums, fsh, (unsigned)(total / 4), dz, (unsigned char*)dz_sp, sp_lift, (unsigned)(h * w), flags);
@@ -1056,6 +1107,11 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
     return dn::check_launch("bn backward apply kernel (SP copy)");
   }
   const int fsh = bn_fast_shift(n_groups, c, total);
+  if (dbias) {
+    DN_REQUIRE(vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz}) && fsh >= 0,
+               "bn backward: the fused bias gradient needs the one-group fast form (c / 4 a power of two, aligned tensors; DN_BN_LEGACY unset)");
+    return bias_launch(std::false_type{}, nullptr, 1.f, nullptr, fsh);
+  }
   if (vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz}) && fsh >= 0)
     hipLaunchKernelGGL(bn_bwd_apply_v4_fast_kernel<false>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z, mean, var, gamma,
                        eps, norm_rows, sums, fsh, (unsigned)(total / 4), dz, nullptr, 1.f, 1u, nullptr);
@@ -1068,6 +1124,16 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
   return dn::check_launch("bn_backward apply kernels");
 }
 }  // namespace
+
+extern "C" int dn_bn_train_backward_finish_bias(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
+                                                const float* y, const float* z, const float* mean, const float* var,
+                                                const float* gamma, float eps, int relu, int h, int w, int images, int c,
+                                                const double* sums, long norm_rows, float* dz, void* dz_sp, float sp_lift,
+                                                float* dbias, double* bias_ws, size_t bias_ws_bytes, void* stream) {
+  DN_REQUIRE(dbias && bias_ws, "bn backward finish (+ bias gradient): null pointer");
+  return bn_backward_finish_impl(dy_a, ld_a, up_a, dy_b, ld_b, y, z, mean, var, gamma, eps, relu, 1, h, w, images, c, sums,
+                                 norm_rows, dz, dz_sp, sp_lift, stream, dbias, bias_ws, bias_ws_bytes);
+}
 
 extern "C" int dn_bn_train_backward_finish(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
                                            const float* y, const float* z, const float* mean, const float* var,

@@ -385,13 +385,15 @@ class TrainEngine:
         sp, lift = self._dz_sp_plan(lay, c, need_dx, s2d_ok)
         wsp = self._wgrad_sp_layer(c)
         ent = self._dz_lift.get(lay.name)
+        # the bias gradient (sum of dz per channel) from the launch that writes dz, where its one-group fast form runs
+        fused_bias = gb is not None and T.bn_backward_bias_supported(c["z"], c["groups"])
         dz = T.bn_backward(dy_a, c["y"], c["z"], c["mean"], c["var"], c["gamma"], _EPS, ggamma, gbeta,
                            relu=True, dy_b=dy_b, up_a=up_a, sp_out=sp, sp_lift=lift, relu_mask=c.get("mask"),
-                           **self._bn_sync(c["z"], c["groups"]))
+                           dbias=gb if fused_bias else None, **self._bn_sync(c["z"], c["groups"]))
         if lift is not None or wsp:
             self._dz_lift_refresh(lay, dz)
-        return self._conv_bwd(c["desc"], c["w"], c["src0"], c["src1"], dz, gw, gb, need_dx, dz_sp=sp, dz_lift=lift,
-                              wgrad_lift=ent[0] if (wsp and ent is not None) else None)
+        return self._conv_bwd(c["desc"], c["w"], c["src0"], c["src1"], dz, gw, None if fused_bias else gb, need_dx,
+                              dz_sp=sp, dz_lift=lift, wgrad_lift=ent[0] if (wsp and ent is not None) else None)
 
     def _wgrad_sp_layer(self, c):
         """does this layer's weight gradient run on the split-f16 kernel (wgrad_math = "sp")?  Like the data gradient it needs the

@@ -6,6 +6,8 @@ as (tensor_view, ld) with the view's data_ptr at the first channel.
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -163,16 +165,30 @@ def bn_update_running(mean, var, rows_per_group, running_mean, running_var, mome
                                            _ptr(running_var), _stream()), "dn_bn_update_running")
 
 
+_BIAS_WS = {}      # the fused bias gradient's partials: never the buffer the reduction's sums live in (read by the same launch)
+
+
+def bn_backward_bias_supported(z, n_groups=1):
+    """can bn_backward(..., dbias=...) fuse the conv bias gradient (sum of dz per channel) into its apply launch?"""
+    c = z.shape[-1]
+    return (z.dim() == 4 and n_groups == 1 and c % 4 == 0 and ((c // 4) & (c // 4 - 1)) == 0 and c <= 1024
+            and z.numel() // 4 < (1 << 31) and os.environ.get("DN_BN_LEGACY", "0") != "1"
+            and os.environ.get("DN_BN_FUSED_BIAS", "1") != "0")
+
+
 def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_b=None, up_a=False,
-                accumulate=False, out=None, sync=None, norm_rows=None, sp_out=None, sp_lift=1.0, relu_mask=None):
+                accumulate=False, out=None, sync=None, norm_rows=None, sp_out=None, sp_lift=1.0, relu_mask=None, dbias=None):
     """z, y [n, h, w, c] dense.  dy_a: [n, h, w, c'] view (or [n, 2h, 2w, c'] when up_a = 1 / True; up_a = 2: the
     space-to-depth image [n, h/2, w/2, 4c] of the gradient, train.py :: _dgrad's one-launch stride-2 data gradient), dy_b
     optional second gradient (same resolution as y).  Returns dz; fills dgamma / dbeta.
     sync / norm_rows (agent-parallel training, see bn_stats): dgamma / dbeta are then THIS rank's share (sums over its rows).
     sp_out / sp_lift: an ops.SpTensor [n, h, w, c] that also receives dz * sp_lift as f16 hi / lo planes
     (dn_bn_train_backward_finish_sp: the operand of the split-f16 data gradient; one group, c % 16 == 0).
-    relu_mask: bn_apply's byte mask of (y > 0) -- read in place of y by both passes (relu = 2 of the C entry points)."""
-    _need_gpu(dy_a, dy_b, y, z, mean, var, gamma, relu_mask)
+    relu_mask: bn_apply's byte mask of (y > 0) -- read in place of y by both passes (relu = 2 of the C entry points).
+    dbias [c]: also receives sum over this call's rows of dz -- the gradient of the conv bias in front of this BatchNorm --
+    from the launch that writes dz (dn_bn_train_backward_finish_bias; bn_backward_bias_supported), instead of a channel_sum
+    pass over dz."""
+    _need_gpu(dy_a, dy_b, y, z, mean, var, gamma, relu_mask, dbias)
     n, h, w, c = z.shape
     if relu_mask is not None:
         if not relu or relu_mask.dtype != torch.uint8 or relu_mask.numel() * 4 != z.numel():
@@ -183,6 +199,26 @@ def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_
     dz = torch.empty_like(z) if out is None else out
     lib = _lib.load()
     sums = _ws(z.device, lib.dn_reduce_workspace_bytes(n_groups, (n // n_groups) * h * w, c))
+    if dbias is not None:
+        if not bn_backward_bias_supported(z, n_groups) or dbias.numel() != c or not dbias.is_contiguous():
+            raise _lib.DnError("bn_backward: dbias needs one group, c / 4 a power of two and a contiguous [c] tensor")
+        if sp_out is not None and (tuple(sp_out.shape) != (n, h, w, c) or sp_out.hi_only or sp_out.bits):
+            raise _lib.DnError("bn_backward: sp_out must be a full SP tensor of z's shape")
+        src = (_ptr(dy_a), _ld(dy_a), int(up_a), _ptr(dy_b), _ld(dy_b) if dy_b is not None else 0, _ptr(y), _ptr(z),
+               _ptr(mean), _ptr(var))
+        check(lib.dn_bn_train_backward_partial(*src, float(eps), int(relu), n_groups, h, w, n, c, _ptr(sums),
+                                               sums.numel(), _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)), _stream()),
+              "dn_bn_train_backward_partial")
+        if sync is not None:
+            sync(_folded(sums, n_groups, c))
+        rows = int(norm_rows if norm_rows is not None else n * h * w)
+        nb = int(lib.dn_bn_bias_workspace_bytes(n * h * w, c))
+        bws = _ws(z.device, nb, _BIAS_WS)
+        check(lib.dn_bn_train_backward_finish_bias(*src, _ptr(gamma), float(eps), int(relu), h, w, n, c, _ptr(sums), rows, _ptr(dz),
+                                                   _ptr(sp_out.data) if sp_out is not None else None,
+                                                   float(sp_lift) if sp_out is not None else 1.0, _ptr(dbias),
+                                                   _ptr(bws), bws.numel(), _stream()), "dn_bn_train_backward_finish_bias")
+        return dz
     if sp_out is not None:
         if tuple(sp_out.shape) != (n, h, w, c) or sp_out.hi_only or sp_out.bits:
             raise _lib.DnError("bn_backward: sp_out must be a full SP tensor of z's shape")

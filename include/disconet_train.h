@@ -170,6 +170,17 @@ int dn_bn_train_backward_finish_sp(const float* dy_a, int ld_a, int up_a, const 
                                    int n_groups, int h, int w, int images_per_group, int c, const double* sums, long norm_rows,
                                    float* dz, void* dz_sp, float sp_lift, void* stream);
 
+/* dn_bn_train_backward_finish (dz_sp NULL) / _finish_sp with the BIAS GRADIENT of the conv in front of this BatchNorm fused in
+ * (round 6): dbias[ch] = sum over this call's rows of dz[.][ch], written by the same launch that writes dz (a thread adds its
+ * own values in fp32, a workgroup its threads in double, fold in a fixed order: deterministic) -- in place of a
+ * dn_channel_sum pass that reads dz again.  One group; c / 4 a power of two; bias_ws of dn_bn_bias_workspace_bytes(rows, c). */
+size_t dn_bn_bias_workspace_bytes(long rows, int c);
+int dn_bn_train_backward_finish_bias(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b, const float* y,
+                                     const float* z, const float* mean, const float* var, const float* gamma, float eps,
+                                     int relu, int h, int w, int images, int c, const double* sums, long norm_rows, float* dz,
+                                     void* dz_sp /* may be NULL */, float sp_lift, float* dbias, double* bias_ws,
+                                     size_t bias_ws_bytes, void* stream);
+
 /* out[c] (+)= sum over rows of x[row][c] (bias gradients); sums: dn_reduce_workspace_bytes(1, rows, c) bytes */
 int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, size_t sums_bytes, float* out,
                    int accumulate, void* stream);

@@ -734,3 +734,41 @@ def test_tap_merged_up_conv_writes_fp32_rows(n, h, w, c0, c1, c_out):
     assert float((want_sp.nhwc() - rows).abs().max()) <= 2.0 ** -21 * float(rows.abs().max())
     got_sp, flat = ops.sp_conv2d(d, s0, packed, scale, bias, src1=s1, nhwc_copy=True)
     assert torch.equal(got_sp.data, want_sp.data) and torch.equal(flat, rows)
+
+
+@pytest.mark.parametrize("shape,up_a,sp", [((2, 16, 24, 32), False, True), ((3, 32, 32, 64), True, True), ((20, 64, 64, 128), False, False),
+                                           ((2, 8, 8, 512), False, True), ((1, 40, 72, 16), False, False)])
+def test_bn_backward_fuses_the_conv_bias_gradient(shape, up_a, sp):
+    """Round 6: bn_backward(dbias=...) -- the sum of dz per channel (the gradient of the conv bias in front of the BatchNorm)
+    leaves the launch that writes dz.  dz, its SP copy, dgamma, dbeta are bit for bit the plain call's; dbias equals the
+    float64 sum of that dz to fp32 rounding of the terms, equals dn_channel_sum's to the same, and is bitwise repeatable."""
+    from disconet_amd import ops, train_ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(41)
+    z = (torch.randn(shape, generator=g) * 2 + 0.5).to(_dev())
+    gm, bt = (torch.rand(c, generator=g) + 0.5).to(_dev()), (torch.randn(c, generator=g) * 0.2).to(_dev())
+    mean, var = train_ops.bn_stats(z)
+    mask = torch.empty(z.numel() // 4, dtype=torch.uint8, device=_dev())
+    y = train_ops.bn_apply(z, mean, var, gm, bt, 1e-5, relu=True, relu_mask=mask)
+    dy = (torch.randn((n, 2 * h, 2 * w, c) if up_a else shape, generator=g) * 1e-3).to(_dev())
+    assert train_ops.bn_backward_bias_supported(z)
+    runs = []
+    for fused in (False, True, True):
+        dg, db = torch.empty(c, device=_dev()), torch.empty(c, device=_dev())
+        spt = ops.SpTensor(n, h, w, c, device=_dev()) if sp else None
+        dbias = torch.full((c,), 7.0, device=_dev())
+        dz = train_ops.bn_backward(dy, y, z, mean, var, gm, 1e-5, dg, db, up_a=up_a, sp_out=spt, sp_lift=2.0 ** 10, relu_mask=mask,
+                                   dbias=dbias if fused else None)
+        if not fused:
+            train_ops.channel_sum(dz, dbias)
+        runs.append((dz, dg, db, spt.data.clone() if sp else dz, dbias))
+    for k in range(4):
+        a, b = runs[0][k], runs[1][k]
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a.view(torch.int16),
+                           b.view(torch.int32) if b.dtype == torch.float32 else b.view(torch.int16)), k
+    assert torch.equal(runs[1][4], runs[2][4])                                   # repeatable bit for bit
+    want = runs[0][0].double().sum((0, 1, 2)).cpu()
+    scale = float(runs[0][0].double().abs().sum((0, 1, 2)).max())
+    assert float((runs[1][4].double().cpu() - want).abs().max()) <= 2e-6 * scale
+    assert float((runs[0][4].double().cpu() - want).abs().max()) <= 2e-6 * scale
+    assert not train_ops.bn_backward_bias_supported(torch.empty(1, 4, 4, 24))    # c / 4 = 6: the general kernels, channel_sum stays
