@@ -113,6 +113,9 @@ def parse(argv=None):
                          "`agent_sharded` when the GPU count divides 8")
     ap.add_argument("--force-process-group", action="store_true",
                     help="create the RCCL process group even for one rank (exercises the N>1 code path)")
+    ap.add_argument("--via-launcher", action="store_true",
+                    help="go through the self-launcher (torch.distributed.run --standalone) even for --gpus 1: the N > 1 launch "
+                         "path -- launcher, rank environment, RCCL process group, relay of rank 0's line -- on a one-GPU box")
     ap.add_argument("--dry-launch", action="store_true",
                     help="--gpus N > 1 without a launcher: print the torch.distributed.run command that would be "
                          "exec'd (one JSON object on stdout) and exit 0")
@@ -654,7 +657,7 @@ def launcher_command(gpus, argv):
     per GPU -- the form the driver uses for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     ... bench.py --gpus N ...`), --standalone so no port has to be agreed on, rendezvous on 127.0.0.1 (the container's
     host name may not resolve)."""
-    rest = [a for a in argv if a != "--dry-launch"]
+    rest = [a for a in argv if a not in ("--dry-launch", "--via-launcher")]
     return [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
             "--nproc-per-node", str(gpus), os.path.abspath(__file__)] + rest
 
@@ -690,7 +693,7 @@ def main(argv=None):
     args = parse(argv)
     if args.cpu_baseline_child:
         return cpu_baseline_child(*args.cpu_baseline_child)
-    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch):
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch or args.via_launcher):
         raise SystemExit(self_launch(args, argv))
     claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -700,6 +703,9 @@ def main(argv=None):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's rank count must equal --gpus" % (args.gpus, world))
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
+    launched = "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_WORLD_SIZE" in os.environ      # under torch.distributed.run
+    if world == 1 and launched and args.mode != "agent":
+        args.force_process_group = True      # a one-rank launch still runs the RCCL code path (barriers, max-over-ranks, agent leg)
     use_pg = world > 1 or args.force_process_group
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

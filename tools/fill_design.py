@@ -1,7 +1,6 @@
-"""Fills DESIGN.md's @@PLACEHOLDERS@@ and the per-layer table from the round's final GPU run (tools/final_set.sh r05 ->
-gpurun_out/r05final, gpurun_out/r05prof) and copies that run's summaries into profiles/r05_*.  Run once, at the end:
-    python tools/fill_design.py [--dry]      (RD below names the round; PREV = the previous round's per-layer microseconds)"""
-import csv
+"""Fills DESIGN.md's @@PLACEHOLDERS@@ and the per-layer table from the round's final GPU run (tools/final_set.sh r06 ->
+gpurun_out/r06final, gpurun_out/r06prof) and copies that run's summaries into profiles/r06_*.  Run once, at the end:
+    python tools/fill_design.py [--dry] [--ncpu N]      (N = tests of the CPU suite that passed)"""
 import json
 import os
 import re
@@ -10,18 +9,31 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RD = "r05"
+RD = "r06"
 F, P = os.path.join(ROOT, "gpurun_out", RD + "final"), os.path.join(ROOT, "gpurun_out", RD + "prof")
-R3 = {"conv_pre_1 + conv_pre_2": 98, "conv1_1 (s2)": 52, "conv1_2 + Conv3D 1x1": 82, "conv2_1 (s2)": 47, "conv2_2": 55,      # round 4 (its fastest lease)
-      "conv3d_2 (1x1)": 20, "conv3_1 (s2)": 42, "conv3_2": 61, "conv4_1 (s2)": 54, "conv4_2": 65, "conv5_1 (up+cat)": 132, "conv5_2": 60,
-      "conv6_1 (up+cat)": 123, "conv6_2": 54, "conv7_1 (up+cat)": 122, "conv7_2": 56, "conv8_1 (up+cat)": 152, "conv8_2": 89,
-      "heads (3x3 + block-diag 1x1)": 151}
-SHAPE = {"conv_pre_1 + conv_pre_2": "13→32→32 @256², one launch (occupancy words in, intermediate map in LDS)", "conv1_1 (s2)": "32→64 s2 → 128²",
-         "conv1_2 + Conv3D 1x1": "64→64 (+1×1) @128²", "conv2_1 (s2)": "64→128 s2 → 64²", "conv2_2": "128→128 @64²", "conv3d_2 (1x1)": "128→128 1×1 @64²",
-         "conv3_1 (s2)": "128→256 s2 → 32²", "conv3_2": "256→256 @32² (+ fp32 NHWC copy)", "conv4_1 (s2)": "256→512 s2 → 16²", "conv4_2": "512→512 @16²",
-         "conv5_1 (up+cat)": "768→256 @32² (tap-merged BN 32, 4 K slices)", "conv5_2": "256→256 @32²", "conv6_1 (up+cat)": "384→128 @64² (tap-merged BN 32)",
-         "conv6_2": "128→128 @64²", "conv7_1 (up+cat)": "192→64 @128² (tap-merged BN 64)", "conv7_2": "64→64 @128²",
-         "conv8_1 (up+cat)": "96→32 @256² (tap-merged BN 32)", "conv8_2": "32→32 @256²", "heads (3x3 + block-diag 1x1)": "32→64→(12, 36) @256², fp32 out"}
+# (label of tools/layers_from_trace.py, short name, shape, executed MFMA work / algorithmic: 3 products per multiply; 2 on conv_pre_1's
+#  hi-only operand; 4 of 9 taps on the upsampled 2/3 of the tap-merged layers' channels)
+LAYERS = [
+    ("conv_pre_1 + conv_pre_2", "stem pair", "13→32→32 @256², one launch", (2 * 9.80 + 3 * 24.16) / 33.96),
+    ("conv1_1 (s2)", "conv1_1", "32→64 s2 → 128²", 3.0),
+    ("conv1_2 + Conv3D 1x1", "conv1_2+Conv3D", "64→64 (+1×1) @128²", 3.0),
+    ("conv2_1 (s2)", "conv2_1", "64→128 s2 → 64²", 3.0),
+    ("conv2_2", "conv2_2", "128→128 @64²", 3.0),
+    ("conv3d_2 (1x1)", "conv3d_2", "128→128 1×1 @64²", 3.0),
+    ("conv3_1 (s2)", "conv3_1", "128→256 s2 → 32²", 3.0),
+    ("conv3_2", "conv3_2", "256→256 @32² (+ fp32 copy)", 3.0),
+    ("conv4_1 (s2)", "conv4_1", "256→512 s2 → 16²", 3.0),
+    ("conv4_2", "conv4_2", "512→512 @16²", 3.0),
+    ("conv5_1 (up+cat)", "conv5_1", "768→256 @32², tap-merged, 4 K slices", 3.0 * 17 / 27),
+    ("conv5_2", "conv5_2", "256→256 @32²", 3.0),
+    ("conv6_1 (up+cat)", "conv6_1", "384→128 @64², tap-merged", 3.0 * 17 / 27),
+    ("conv6_2", "conv6_2", "128→128 @64²", 3.0),
+    ("conv7_1 (up+cat)", "conv7_1", "192→64 @128², tap-merged", 3.0 * 17 / 27),
+    ("conv7_2", "conv7_2", "64→64 @128²", 3.0),
+    ("conv8_1 (up+cat)", "conv8_1", "96→32 @256², tap-merged", 3.0 * 17 / 27),
+    ("conv8_2", "conv8_2", "32→32 @256²", 3.0),
+    ("heads (3x3 + block-diag 1x1)", "heads", "32→64→(12, 36) @256², fp32 out", 3.0),
+]
 
 
 def j(path):
@@ -29,12 +41,12 @@ def j(path):
 
 
 def layer_table():
-    layers = []
+    names = {l[0] for l in LAYERS}
+    layers = {}
     for line in open(os.path.join(P, "bench_layers.txt")):
         m = re.match(r"^(\S.*?)\s{2,}([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+(.*)$", line.rstrip())
-        if m and m.group(1) in R3:
-            layers.append((m.group(1), float(m.group(2)), float(m.group(4))))
-    # counters: the last 24 product launches of the eager pass = zero fill, scatter, 10 encoder convs, warp, fuse, conv5_1 (+ fix-up), 8 more
+        if m and m.group(1) in names:
+            layers[m.group(1)] = (float(m.group(2)), float(m.group(3)), float(m.group(4)))      # us, GFLOP, TFLOP/s
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_table.py"), P, "24"], capture_output=True, text=True, check=True).stdout
     rows = [l.split() for l in out.splitlines()[1:]]
     conv = [r for r in rows if r[0].startswith("sp<") or r[0].startswith("spq<") or r[0].startswith("conv_pre_pair")]
@@ -46,67 +58,85 @@ def layer_table():
             merged[-1][1][7] += vals[7]; merged[-1][1][8] += vals[8]
             continue
         merged.append([name, vals])
-    assert len(merged) == len(layers) == 19, (len(merged), len(layers))
-    lines = ["| layer (shape at batch 4 × 5 agents) | µs (round 4, its fastest lease) | TFLOP/s (alg.) | MFMA busy | clock | busy × GHz ÷ 2.4 | HBM r + w (MB) |", "|---|---|---|---|---|---|---|"]
-    for (name, us, tf), (kname, v) in zip(layers, merged):
-        lines.append("| %s %s | %.0f (%d) | %.0f | %.0f %% | %.2f GHz | %.2f | %.0f + %.0f |" % (
-            name.split(" (")[0].replace(" + Conv3D 1x1", "+Conv3D"), SHAPE[name], us, R3[name], tf, v[3], v[2], v[3] / 100 * v[2] / 2.4, v[7], v[8]))
+    assert len(merged) == len(LAYERS) == 19 and len(layers) == 19, (len(merged), len(layers))
+    lines = ["| layer | shape (20 images) | µs | floor µs | % of floor | MFMA busy | busy × GHz ÷ 2.4 | wAny | HBM r + w MB |", "|---|---|---|---|---|---|---|---|---|"]
+    tot_us = tot_floor = 0.0
+    for (label, short, shape, factor), (_, v) in zip(LAYERS, merged):
+        us, gflop, _ = layers[label]
+        # floor in us: executed GFLOP at 2.5 PFLOP/s (= 2.5e3 GFLOP per ms = 2.5 GFLOP per us) or PMC megabytes at 6.3 TB/s (= 6.3e3 MB per ms = 6.3 MB per us)
+        floor = max(gflop * factor / 2.5, (v[7] + v[8]) / 6.3)
+        tot_us += us; tot_floor += floor
+        lines.append("| %s | %s | %.0f | %.0f | %.0f | %.0f %% | %.2f | %.0f %% | %.0f + %.0f |" % (
+            short, shape, us, floor, 100 * floor / us, v[3], v[3] / 100 * v[2] / 2.4, v[5], v[7], v[8]))
+    lines.append("| **all 19 launches** | | **%.0f** | **%.0f** | **%.0f** | | | | |" % (tot_us, tot_floor, 100 * tot_floor / tot_us))
     return "\n".join(lines)
 
 
-def main(dry):
+def main(dry, ncpu):
     d = j(os.path.join(F, "bench_default.json"))
     seg = j(os.path.join(F, "bench_seg.json"))
-    sh = {b: j(os.path.join(F, "agent_share%s.json" % ("" if b == 4 else "_b%d" % b))) for b in (4, 8, 16, 32)}
-    rp = j(os.path.join(P, "rocprof_conv_sp.json"))
-    tr = j(os.path.join(P, "pmc_traffic_sp.json"))
-    r, c, a = d["roofline"], d["cpu_baseline"], d["alt_math"]
+    tg = j(os.path.join(P, "train_groups.json"))
+    r, c, a, t = d["roofline"], d["cpu_baseline"], d["alt_math"], d["train_step"]
     es = d["agent_sharded"]["emulated_share"]
-    flop = r["flop_per_step"]
+    es16 = d["agent_sharded_batch16"]["emulated_share"]
+    other = r["other_kernels_ms_per_step"]
+    gpu_log = open(os.path.join(F, "pytest_gpu.log")).read()
+    m = re.search(r"(\d+) passed", gpu_log)
+    ab = [l.split() for l in open(os.path.join(ROOT, "profiles", "r06_bias_ab.txt")) if l.startswith("fused_bias")]
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+    b0 = med([float(x[2]) for x in ab if x[0] == "fused_bias=0"])
+    b1 = med([float(x[2]) for x in ab if x[0] == "fused_bias=1" and x[1] == "blocks=1024"])
+    g = lambda k: tg.get(k, {"ms_per_step": 0.0})["ms_per_step"]
     v = {
-        "VALUE": "%.0f" % d["value"], "MS": "%.3f" % d["ms_per_step"], "CONV_ROCPROF_MS": "%.3f" % rp["conv_ms_per_step"],
-        "CONV_EVENTS_MS": "%.3f" % r["kernel_ms_per_step"], "CONV_TF": "%.0f" % (flop / rp["conv_ms_per_step"] / 1e9),
-        "FRAC": "%.3f" % (flop / rp["conv_ms_per_step"] / 1e9 / 2500), "F32_VALUE": "%.0f" % a["value"], "F32_MS": "%.2f" % a["ms_per_step"],
-        "F32_TF": "%.0f" % a["roofline"]["achieved"], "F32_FRAC": "%.2f" % a["roofline"]["frac"],
-        "SEG_VALUE": "%.0f" % seg["value"], "SEG_MS": "%.2f" % seg["ms_per_step"], "SEG_TF": "%.0f" % seg["roofline"]["achieved"],
-        "SEG_FRAC": "%.3f" % seg["roofline"]["frac"], "CPU4": "%.2f" % c["value"], "CPU1": "%.2f" % c["batch_1"]["value"],
-        "TRAIN_MS": "%.1f" % d["train_step"]["ms_per_step"], "TRAIN_SPS": "%.0f" % d["train_step"]["scenes_per_s"],
-        "TRAINKD_MS": "%.1f" % d["train_step"]["with_kd"]["ms_per_step"], "SEGTRAIN_MS": "%.1f" % seg["train_step"]["ms_per_step"],
-        "AG4_SPS": "%.0f" % d["agent_sharded"]["value"], "AG4_MS": "%.2f" % d["agent_sharded"]["ms_per_step"],
-        "AG16_SPS": "%.0f" % d["agent_sharded_batch16"]["value"], "AG16_MS": "%.2f" % d["agent_sharded_batch16"]["ms_per_step"],
-        "SH4R": "%.3f" % es["ms_per_step"], "SP4R": "%.2f" % es["projected_speedup"],
-        "TRAFFIC_MB": "%.0f" % (tr["hbm_bytes_per_launch"] / 1e6), "ALG_MB": "%.0f" % (r["algorithmic_bytes_per_launch"] / 1e6),
-        "PARITY": "cls %.1e / loc %.1e against logits of max |%.1f| / |%.1f|" % (
-            c["parity_max_abs_err"]["cls"], c["parity_max_abs_err"]["loc"], c["parity_ref_max_abs"]["cls"], c["parity_ref_max_abs"]["loc"]),
-        "AG8_MS": "%.2f" % sh[8]["ms_per_step"], "AG16B_MS": "%.2f" % sh[16]["ms_per_step"], "AG32_MS": "%.2f" % sh[32]["ms_per_step"],
+        "VALUE": "%.0f" % d["value"], "MS": "%.3f" % d["ms_per_step"], "CONVMS": "%.3f" % r["kernel_ms_per_step"],
+        "FRAC": "%.3f" % r["frac"], "FRACX": "%.2f" % r["frac_executed"],
+        "ALTV": "%.0f" % a["value"], "ALTFRAC": "%.2f" % a["roofline"]["frac"],
+        "CPUV": "%.2f" % c["value"], "CPUC": "%d" % c["cores"],
+        "TRAINMS": "%.1f" % t["ms_per_step"], "TRAINF32": "%.1f" % t["all_gradients_f32"]["ms_per_step"],
+        "TRAINKD": "%.1f" % t["with_kd"]["ms_per_step"],
+        "AGENTMS": "%.2f" % d["agent_sharded"]["ms_per_step"], "SHAREMS": "%.3f" % es["ms_per_step"],
+        "PROJ": "%.2f" % es["projected_speedup"], "PROJ16": "%.2f" % es16["projected_speedup"],
+        "PCLS": "%.1e" % c["parity_max_abs_err"]["cls"], "PLOC": "%.1e" % c["parity_max_abs_err"]["loc"],
+        "NCPU": str(ncpu), "NGPU": m.group(1) if m else "?",
+        "VOXUS": "%.0f" % d["voxelize"]["us_per_cloud"],
+        "WARPUS": "%.0f" % (1e3 * other.get("warp", 0.0)), "FUSEUS": "%.0f" % (1e3 * other.get("fuse_mlp", 0.0)),
+        "SEGV": "%.0f" % seg["value"], "SEGFRAC": "%.3f" % seg["roofline"]["frac"],
+        "T_CONVSP": "%.2f" % g("conv_engine_sp"), "T_CONVNHWC": "%.2f" % g("conv_engine_nhwc"), "T_WGRAD": "%.2f" % g("wgrad"),
+        "T_BNF": "%.2f" % g("bn_forward"), "T_BNB": "%.2f" % g("bn_backward"), "T_FOLDS": "%.2f" % g("folds_and_bias_sums"),
+        "T_PACK": "%.2f" % (g("packing") + g("copies")),
+        "T_MISC": "%.2f" % g("other (loss, warp, combine, Adam, torch elementwise)"), "T_TOTAL": "%.2f" % tg["total_ms_per_step"],
+        "BIASAB": "%.2f → %.2f ms per step, medians of three interleaved runs" % (b0, b1),
+        "LAYER_TABLE": layer_table(),
     }
-    for b in (4, 8, 16, 32):
-        e = sh[b]["emulated_share"]
-        v["SH%d" % b] = "%.3f" % e.get("ms_per_step_without_collective", e["ms_per_step"])
-        v["SP%d" % b] = "%.2f" % e.get("projected_speedup_without_collective", e["projected_speedup"])
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
     missing = sorted(set(re.findall(r"@@([A-Z0-9_]+)@@", text)) - set(v))
     assert not missing, missing
+    if dry:
+        print(v["LAYER_TABLE"])
+        print(json.dumps({k: x for k, x in v.items() if k != "LAYER_TABLE"}, indent=1))
+        return
     for k, val in v.items():
         text = text.replace("@@%s@@" % k, val)
-    text = re.sub(r"(<!-- LAYER_TABLE_BEGIN[^\n]*-->\n).*?(<!-- LAYER_TABLE_END -->)", lambda m: m.group(1) + layer_table() + "\n" + m.group(2), text, flags=re.S)
-    if dry:
-        print(layer_table())
-        print(json.dumps(v, indent=1))
-        return
     open(os.path.join(ROOT, "DESIGN.md"), "w").write(text)
     cp = [(os.path.join(F, "bench_default.json"), RD + "_bench_default.json"), (os.path.join(F, "bench_seg.json"), RD + "_bench_seg.json"),
-          (os.path.join(F, "agent_share.json"), RD + "_agent_share.json"), (os.path.join(P, "kernel_stats.csv"), RD + "_bench_kernel_stats.csv"),
+          (os.path.join(F, "agent_share.json"), RD + "_agent_share.json"), (os.path.join(F, "guard_bands.txt"), RD + "_guard_bands.txt"),
+          (os.path.join(F, "pytest_gpu.log"), RD + "_pytest_gpu.txt"),
+          (os.path.join(P, "kernel_stats.csv"), RD + "_bench_kernel_stats.csv"),
           (os.path.join(P, "kernel_trace.csv"), RD + "_bench_kernel_trace.csv"), (os.path.join(P, "bench_layers.txt"), RD + "_bench_layers.txt"),
           (os.path.join(P, "step_timeline.txt"), RD + "_step_timeline.txt"), (os.path.join(P, "rocprof_conv_sp.json"), RD + "_rocprof_conv_sp.json"),
           (os.path.join(P, "pmc_traffic_sp.json"), RD + "_pmc_traffic_sp.json"), (os.path.join(P, "pmc_traffic_seg.json"), RD + "_pmc_traffic_seg.json"),
-          (os.path.join(P, "train_step_kernel_stats.csv"), RD + "_train_step_kernel_stats.csv")]
+          (os.path.join(P, "train_step_kernel_stats.csv"), RD + "_train_step_kernel_stats.csv"),
+          (os.path.join(P, "train_groups.json"), RD + "_train_groups.json")]
     cp += [(os.path.join(F, "agent_share_b%d.json" % b), RD + "_agent_share_b%d.json" % b) for b in (8, 16, 32)]
     for src, dst in cp:
-        shutil.copy(src, os.path.join(ROOT, "profiles", dst))
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(ROOT, "profiles", dst))
+        else:
+            print("missing", src, file=sys.stderr)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_table.py"), P, "24"], capture_output=True, text=True, check=True).stdout
     open(os.path.join(ROOT, "profiles", RD + "_pmc_conv_sp.txt"), "w").write(out)
 
 
 if __name__ == "__main__":
-    main("--dry" in sys.argv)
+    n = sys.argv[sys.argv.index("--ncpu") + 1] if "--ncpu" in sys.argv else "?"
+    main("--dry" in sys.argv, n)

@@ -2,7 +2,7 @@
 # Validation + profile set of a round on the GPU box:  bash tools/final_set.sh r05  -> gpurun_out/r05final/
 #   full -m gpu suite, smoke(), tools/profile_set.sh $RD (its summaries are copied into profiles/ of the box's copy so
 #   that the bench lines quote the profile of THIS build), then the bench lines that profiles/ keeps.
-RD=${1:-r05}
+RD=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${RD}final
 mkdir -p $O
@@ -10,6 +10,8 @@ cd $R
 ( timeout 1500 python -m pytest tests -q -m gpu --durations=12 > $O/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.log )
 tail -22 $O/pytest_gpu.log | cut -c1-200
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?" >> $O/smoke.log ); tail -2 $O/smoke.log
+# guard bands around every buffer of the conv check (SPCHECK_GUARD=1): all shapes at 20 / 7 / 3 images, K-sliced and ragged included
+( for n in 20 7 3; do SPCHECK_GUARD=1 timeout 300 tools/sp_conv_check.bin $n all auto 2>&1 | grep -E "guard bands|GUARD BAND|SP CONV CHECK|dn_version"; done ) > $O/guard_bands.txt 2>&1; cat $O/guard_bands.txt
 bash tools/profile_set.sh $RD > $O/profile.log 2>&1
 P=$R/gpurun_out/${RD}prof
 cp $P/rocprof_conv_sp.json profiles/${RD}_rocprof_conv_sp.json

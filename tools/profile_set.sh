@@ -2,7 +2,7 @@
 # Round-4 profile set (on the GPU box):  tools/profile_set.sh $RD  -> gpurun_out/${RD}prof/...
 #   1. rocprofv3 --kernel-trace --stats over the default bench command (graph replay, one stream)
 #   2. three --pmc passes over the eager bench (busy counters / FETCH_SIZE / WRITE_SIZE), kernel-trace only
-RD=${1:-r05}
+RD=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${RD}prof
 mkdir -p $OUT
@@ -34,8 +34,10 @@ for i in 2 3; do
   f=$(find /tmp/${RD}_s$i -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/seg/pmc$i.csv
 done
 python3 $R/tools/pmc_traffic.py $OUT/seg seg conv_sp_kernel,conv_spq_kernel > $OUT/pmc_traffic_seg.json 2> $OUT/pmc_traffic_seg.err
-# 4. training step (eager launches): per-kernel totals of 6 steps (+ 3 forward-only bench steps, < 2 % of the time)
-T="python $R/bench.py --steps 2 --warmup 1 --no-alt-math --no-cpu-baseline --no-kernel-events --no-voxelize --no-agent-leg --train-steps 6"
+# 4. training step (eager launches), timed alone: per-kernel totals of 10 steps of the default step (tools/train_step_probe.py: the first
+#    is the fp32 calibration pass), grouped into DESIGN.md section 8's rows by tools/train_groups.py
+T="python $R/tools/train_step_probe.py --dgrad sp --wgrad sp --steps 8"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${RD}_tr -o tr -- $T > $OUT/train.log 2>&1
 p=$(find /tmp/${RD}_tr -name "*kernel_stats.csv" | head -1); [ -n "$p" ] && cp "$p" $OUT/train_step_kernel_stats.csv
+python3 $R/tools/train_groups.py $OUT/train_step_kernel_stats.csv 10 > $OUT/train_groups.json 2> $OUT/train_groups.err
 ls -la $OUT

@@ -1,0 +1,215 @@
+// BEST-CASE timing probe of a fused Winograd F(2x2, 3x3) conv kernel for conv3_2 of the detector (256 -> 256 channels at 32 x 32,
+// 20 images) on gfx950, in the split-f16 arithmetic of the conv engine (hi + lo operands, three f16 MFMAs per product).
+// NOT a convolution: the kernel executes the instruction MIX of the only workgroup shape of such an engine that fits the part
+//  on random bytes and is timed at the layer's launch geometry -- every cost a real kernel adds on top
+// (address arithmetic of a halo patch, the output transform's LDS exchange, the affine / split / store epilogue, range tracking) is
+// left out, so the figure bounds a real kernel from below.
+//
+//   workgroup = 64 Winograd tiles (16 x 16 output pixels) x 64 output channels, 4 waves; wave w owns positions 4w .. 4w + 3 of the
+//   16, a 2 x 2 block of 32 x 32 accumulator tiles each: 16 tiles = 256 accumulator registers per lane (one wave per SIMD).
+//   per 16-channel chunk of K (16 chunks for 256 input channels):
+//     stage      U chunk (16 positions x 4 quarters x 64 c_out x 16 B = 64 KB) + raw 18 x 18 patch (4 quarters: 20.7 KB)  -- LDS-DMA
+//     transform  every thread: 16 b128 LDS reads of raw pieces, the B^T d B adds in fp32 on 8 channels (hi + lo -> fp32 first),
+//                the re-split, 16 b128 LDS writes of V pieces (V chunk: 16 x 64 tiles x 4 quarters x 16 B = 64 KB)
+//     multiply   per wave 4 positions x [8 fragment reads + 12 MFMAs]
+//   LDS: 64 + 64 + 20.7 = 149 KB: nothing can be double-buffered, the three phases are barrier-separated.
+//   work items: 80 tile groups x 4 channel blocks = 320 on 256 CUs.
+//
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I disconet_amd/csrc tools/winograd_probe.hip -o tools/winograd_probe.bin
+//   tools/winograd_probe.bin            -> one line per variant: us per launch, MFMA rate
+// variants: 0 = all three phases; 1 = no transform (stage + multiply); 2 = multiply only (operands resident); 3 = stage + transform.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include "sp_device.h"
+
+namespace {
+constexpr int kUBytes = 16 * 4 * 64 * 16;        // 64 KB
+constexpr int kVBytes = 16 * 64 * 4 * 16;        // 64 KB
+constexpr int kRawPieces = 18 * 18 * 4;          // 1296 pieces of 16 B
+constexpr int kRawBytes = ((kRawPieces + 63) / 64) * 1024;   // whole DMA instructions: 21 KB
+constexpr int kLds = kUBytes + kVBytes + kRawBytes;
+static_assert(kLds <= 160 * 1024, "LDS");
+
+struct ProbeArgs {
+  const unsigned char* u;      // [chunk 16][64 KB]
+  const unsigned char* x;      // [item][chunk][21 KB] raw patches (L2-resident: 320 x 16 x 21 KB = 107 MB is the real volume; here reused)
+  float* out;
+  int items, chunks, x_items;
+};
+
+template <int VAR>
+__global__ void __launch_bounds__(256, 1) wino_probe_kernel(const ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* U = smem;
+  unsigned char* V = smem + kUBytes;
+  unsigned char* R = smem + kUBytes + kVBytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const auto rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.u), 0, a.chunks * kUBytes, 0x00020000);
+
+  f32x16 acc[4][2][2];      // [position of this wave][tile block][channel block]
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][m][n][r] = 0.f;
+  float sink = 0.f, amax = 0.f;
+
+  if (VAR == 2) {   // operands resident: fill the LDS once with something finite
+    for (int i = tid; i < kLds / 16; i += 256) *reinterpret_cast<u32x4*>(smem + i * 16) = u32x4{0x3c003800u, 0x34003000u, 0x2c002800u, 0x3a003600u};
+    __syncthreads();
+  }
+  for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
+    const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x + (size_t)(item % a.x_items) * a.chunks * kRawBytes), 0,
+                                                       a.chunks * kRawBytes, 0x00020000);
+    for (int c = 0; c < a.chunks; ++c) {
+      if (VAR != 2) {
+        // ---- stage: 64 + 21 DMA instructions of 1 KB, 16 + 5..6 per wave
+        for (int q = wave; q < kUBytes / 1024; q += 4) dma16(rsu, U + q * 1024, (unsigned)(c * kUBytes + q * 1024 + lane * 16), 0);
+        for (int q = wave; q < kRawBytes / 1024; q += 4) dma16(rsx, R + q * 1024, (unsigned)(c * kRawBytes + q * 1024 + lane * 16), 0);
+        wait_vm0();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if (VAR == 0 || VAR == 3) {
+        // ---- transform: thread = (tile t of 64, octet o of 2, row half rh of 2): rows 2 rh, 2 rh + 1 of V for 8 channels, in two
+        // passes of 4 channels (b64 LDS accesses): beside 256 accumulator registers a lane has ~200 for this phase, the 8-channel
+        // form (128 + 64 live floats) spills
+        const int t = tid >> 2, o = (tid >> 1) & 1, rh = tid & 1;
+        const int ty = t >> 3, tx = t & 7;
+#pragma unroll 1
+        for (int ch = 0; ch < 2; ++ch) {
+          // B^T d column by column: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3), of which this thread keeps rows 2 rh, 2 rh + 1
+          float w[2][4][4];
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            float d[4][4];      // one column of the 4 x 4 input tile, 4 channels, fp32 (hi + lo)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int px = (2 * ty + r) * 18 + 2 * tx + s2;
+              const half4 h = *reinterpret_cast<const half4*>(R + ((o * 324 + px) * 16) + 8 * ch);
+              const half4 l = *reinterpret_cast<const half4*>(R + (((2 + o) * 324 + px) * 16) + 8 * ch);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) d[r][e] = (float)h[e] + (float)l[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              w[0][s2][e] = rh ? d[2][e] - d[1][e] : d[0][e] - d[2][e];
+              w[1][s2][e] = rh ? d[1][e] - d[3][e] : d[1][e] + d[2][e];
+            }
+          }
+          // (.) B: columns likewise; split; half a hi and half a lo piece per position
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+              f32x4 v0;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v0[e] = s2 == 0 ? w[r][0][e] - w[r][2][e] : s2 == 1 ? w[r][1][e] + w[r][2][e] : s2 == 2 ? w[r][2][e] - w[r][1][e] : w[r][1][e] - w[r][3][e];
+              u32x2 h0, l0;
+              split4(v0, h0, l0, amax);
+              const int pos = (2 * rh + r) * 4 + s2;
+              *reinterpret_cast<u32x2*>(V + ((pos * 4 + o) * 64 + t) * 16 + 8 * ch) = h0;
+              *reinterpret_cast<u32x2*>(V + ((pos * 4 + 2 + o) * 64 + t) * 16 + 8 * ch) = l0;
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if (VAR != 3) {
+        // ---- multiply: positions 4 wave .. 4 wave + 3; fragments of the next position read before this one's MFMAs
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int pos = 4 * wave + p;
+          half8 bh[2], bl[2], ah[2], al[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            bh[m] = *reinterpret_cast<const half8*>(V + ((pos * 4 + lh) * 64 + m * 32 + li) * 16);
+            bl[m] = *reinterpret_cast<const half8*>(V + ((pos * 4 + 2 + lh) * 64 + m * 32 + li) * 16);
+          }
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            ah[n] = *reinterpret_cast<const half8*>(U + ((pos * 4 + lh) * 64 + n * 32 + li) * 16);
+            al[n] = *reinterpret_cast<const half8*>(U + ((pos * 4 + 2 + lh) * 64 + n * 32 + li) * 16);
+          }
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[p][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[n], bh[m], acc[p][m][n], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[p][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bl[m], acc[p][m][n], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[p][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bh[m], acc[p][m][n], 0, 0, 0);
+        }
+        if (VAR != 2) {
+          __builtin_amdgcn_s_barrier();      // every wave is done with U / V before the next chunk's DMA lands
+          asm volatile("" ::: "memory");
+        }
+      }
+    }
+    // (no output transform, no epilogue: one value per accumulator tile keeps the MFMAs alive)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) sink += acc[p][m][n][(p + m + n) & 15];
+  }
+  if (sink == 12345.678f || amax == 3.21f) a.out[tid] = sink;
+}
+
+template <int VAR>
+float run(const ProbeArgs& a, int grid, int iters) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_probe_kernel<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(wino_probe_kernel<VAR>, dim3(grid), dim3(256), kLds, 0, a);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(wino_probe_kernel<VAR>, dim3(grid), dim3(256), kLds, 0, a);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); exit(2); }
+  return ms / iters * 1e3f;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  const int items = argc > 1 ? atoi(argv[1]) : 320, chunks = 16, x_items = 64;
+  std::vector<unsigned short> hu((size_t)chunks * kUBytes / 2), hx((size_t)x_items * chunks * kRawBytes / 2);
+  unsigned s = 12345;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (unsigned short)(0x3000 + ((s >> 9) & 0x0fff) + ((s >> 8) & 0x8000 ? 0 : 0)); };   // f16 in [0.125, 0.5): finite, toggling
+  for (auto& v : hu) v = rnd();
+  for (auto& v : hx) v = (s = s * 1664525u + 1013904223u, (s >> 30) == 0 ? 0 : rnd());   // a quarter zeros (post-ReLU maps have more)
+  unsigned char *du, *dx;
+  float* dout;
+  hipMalloc(&du, hu.size() * 2); hipMalloc(&dx, hx.size() * 2); hipMalloc(&dout, 4096);
+  hipMemcpy(du, hu.data(), hu.size() * 2, hipMemcpyHostToDevice);
+  hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+  ProbeArgs a{du, dx, dout, items, chunks, x_items};
+  const double mfma_per_launch = (double)items * chunks * 4 /*waves*/ * 48;      // 32x32x16 MFMAs
+  const double direct_us = 64.0;      // conv3_2 on the shipped engine (profiles/r06_bench_layers.txt), 2.25 x the MFMAs
+  const char* names[4] = {"stage + transform + multiply (the whole chunk loop)", "stage + multiply (no input transform)",
+                          "multiply only (operands resident in LDS)", "stage + transform (no MFMAs)"};
+  printf("winograd_probe: %d work items of 64 tiles x 64 channels, %d chunks of K; LDS %d B per workgroup (one per CU)\n", items, chunks, kLds);
+  for (int grid : {256, items}) {
+    float us[4] = {run<0>(a, grid, 20), run<1>(a, grid, 20), run<2>(a, grid, 20), run<3>(a, grid, 20)};
+    for (int v = 0; v < 4; ++v)
+      printf("grid %3d  variant %d  %-55s %7.1f us%s\n", grid, v, names[v], us[v],
+             v == 3 ? "" : (std::string("   ") + std::to_string(mfma_per_launch * 16384 * 2 / (us[v] * 1e-6) / 1e12).substr(0, 6) + " TFLOP/s executed").c_str());
+  }
+  printf("the shipped direct kernel runs this layer in %.0f us (2.25 x these MFMAs, with its epilogue); acceptance of the Winograd probe was <= 48 us\n", direct_us);
+  return 0;
+}
