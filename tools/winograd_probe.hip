@@ -168,6 +168,166 @@ __global__ void __launch_bounds__(256, 1) wino_probe_kernel(const ProbeArgs a) {
   if (sink == 12345.678f || amax == 3.21f) a.out[tid] = sink;
 }
 
+
+// ---- the pipelined form (variants 4..6): the transformed WEIGHTS never enter the LDS -- every wave streams the A fragments of its
+// four positions from L2 into a register ring (one chunk ahead) -- so the LDS holds V twice (2 x 64 KB) + the raw patch once (21 KB):
+// 149 KB.  Per chunk: issue the raw patch of chunk c + 1 (LDS-DMA) -> multiply chunk c from V[c & 1] and the ring, refilling each ring
+// slot behind its MFMAs -> wait for the patch, barrier -> transform chunk c + 1 into V[(c + 1) & 1] -> barrier.  The transform maps a
+// lane to a tile (consecutive lanes write consecutive 16-byte pieces: no bank conflicts) and a wave to (octet, row half).
+//   4 = everything; 5 = no transform (V written once); 6 = transform only (no MFMAs, no weight stream)
+template <int VAR>
+__global__ void __launch_bounds__(256, 1) wino_pipe_kernel(const ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  auto Vb = [&](int k) { return smem + k * kVBytes; };
+  unsigned char* R = smem + 2 * kVBytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  f32x16 acc[4][2][2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][m][n][r] = 0.f;
+  float sink = 0.f, amax = 0.f;
+  const int t = lane, o = wave & 1, rh = wave >> 1, ty = t >> 3, tx = t & 7;
+
+  auto transform = [&](unsigned char* V) {
+    float w[2][4][8];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      float d[4][8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int px = (2 * ty + r) * 18 + 2 * tx + s2;
+        const half8 h = *reinterpret_cast<const half8*>(R + ((o * 324 + px) * 16));
+        const half8 l = *reinterpret_cast<const half8*>(R + (((2 + o) * 324 + px) * 16));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[r][e] = (float)h[e] + (float)l[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        w[0][s2][e] = rh ? d[2][e] - d[1][e] : d[0][e] - d[2][e];
+        w[1][s2][e] = rh ? d[1][e] - d[3][e] : d[1][e] + d[2][e];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = s2 == 0 ? w[r][0][e] - w[r][2][e] : s2 == 1 ? w[r][1][e] + w[r][2][e] : s2 == 2 ? w[r][2][e] - w[r][1][e] : w[r][1][e] - w[r][3][e];
+          v1[e] = s2 == 0 ? w[r][0][e + 4] - w[r][2][e + 4] : s2 == 1 ? w[r][1][e + 4] + w[r][2][e + 4]
+                  : s2 == 2 ? w[r][2][e + 4] - w[r][1][e + 4] : w[r][1][e + 4] - w[r][3][e + 4];
+        }
+        u32x2 h0, l0, h1, l1;
+        split4(v0, h0, l0, amax);
+        split4(v1, h1, l1, amax);
+        const int pos = (2 * rh + r) * 4 + s2;
+        *reinterpret_cast<u32x4*>(V + ((pos * 4 + o) * 64 + t) * 16) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<u32x4*>(V + ((pos * 4 + 2 + o) * 64 + t) * 16) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+      }
+  };
+  // A fragments of position p of chunk c: [chunk][pos][quarter][c_out 64] x 16 B in global memory
+  half8 ah[4][2], al[4][2];
+  auto uload = [&](int c, int p) {
+    const unsigned char* base = a.u + (size_t)c * kUBytes;
+    const int pos = 4 * wave + p;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      ah[p][n] = *reinterpret_cast<const half8*>(base + ((pos * 4 + lh) * 64 + n * 32 + li) * 16);
+      al[p][n] = *reinterpret_cast<const half8*>(base + ((pos * 4 + 2 + lh) * 64 + n * 32 + li) * 16);
+    }
+  };
+
+  for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
+    const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.x + (size_t)(item % a.x_items) * a.chunks * kRawBytes), 0,
+                                                       a.chunks * kRawBytes, 0x00020000);
+    auto raw_dma = [&](int c) {
+      for (int q = wave; q < kRawBytes / 1024; q += 4) dma16(rsx, R + q * 1024, (unsigned)(c * kRawBytes + q * 1024 + lane * 16), 0);
+    };
+    // prologue: patch 0 -> V[0]; the ring for chunk 0
+    raw_dma(0);
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    transform(Vb(0));
+    if (VAR != 6) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) uload(0, p);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int c = 0; c < a.chunks; ++c) {
+      const bool more = c + 1 < a.chunks;
+      if (more) raw_dma(c + 1);
+      if (VAR != 6) {
+        const unsigned char* V = Vb(c & 1);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int pos = 4 * wave + p;
+          half8 bh[2], bl[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            bh[m] = *reinterpret_cast<const half8*>(V + ((pos * 4 + lh) * 64 + m * 32 + li) * 16);
+            bl[m] = *reinterpret_cast<const half8*>(V + ((pos * 4 + 2 + lh) * 64 + m * 32 + li) * 16);
+          }
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[p][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[p][n], bh[m], acc[p][m][n], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[p][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[p][n], bl[m], acc[p][m][n], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[p][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[p][n], bh[m], acc[p][m][n], 0, 0, 0);
+          if (more) uload(c + 1, p);      // the slot's next occupant, behind the MFMAs that read it
+        }
+      }
+      if (more) {
+        // the patch was issued BEFORE this chunk's 16 weight loads: wait until only those are outstanding
+        if (VAR != 6) wait_vm<16>(); else wait_vm0();
+        __builtin_amdgcn_s_barrier();      // every wave's share of the patch has landed
+        asm volatile("" ::: "memory");
+        if (VAR != 5) transform(Vb((c + 1) & 1));
+      }
+      __builtin_amdgcn_s_barrier();        // V[(c + 1) & 1] complete; every wave is done with V[c & 1] and with the patch
+      asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) sink += acc[p][m][n][(p + m + n) & 15];
+  }
+  if (sink == 12345.678f || amax == 3.21f) a.out[tid] = sink;
+}
+
+template <int VAR>
+float run_pipe(const ProbeArgs& a, int grid, int iters) {
+  constexpr int lds = 2 * kVBytes + kRawBytes;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_pipe_kernel<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(wino_pipe_kernel<VAR>, dim3(grid), dim3(256), lds, 0, a);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(wino_pipe_kernel<VAR>, dim3(grid), dim3(256), lds, 0, a);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); exit(2); }
+  return ms / iters * 1e3f;
+}
+
 template <int VAR>
 float run(const ProbeArgs& a, int grid, int iters) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(wino_probe_kernel<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
@@ -209,6 +369,14 @@ int main(int argc, char** argv) {
     for (int v = 0; v < 4; ++v)
       printf("grid %3d  variant %d  %-55s %7.1f us%s\n", grid, v, names[v], us[v],
              v == 3 ? "" : (std::string("   ") + std::to_string(mfma_per_launch * 16384 * 2 / (us[v] * 1e-6) / 1e12).substr(0, 6) + " TFLOP/s executed").c_str());
+  }
+  const char* pnames[3] = {"pipelined: weights L2 -> registers, V double-buffered, transform + multiply", "pipelined, no input transform",
+                           "pipelined, transform only (no MFMAs, no weight stream)"};
+  for (int grid : {256, items}) {
+    float us[3] = {run_pipe<4>(a, grid, 20), run_pipe<5>(a, grid, 20), run_pipe<6>(a, grid, 20)};
+    for (int v = 0; v < 3; ++v)
+      printf("grid %3d  variant %d  %-75s %7.1f us%s\n", grid, 4 + v, pnames[v], us[v],
+             v == 2 ? "" : (std::string("   ") + std::to_string(mfma_per_launch * 16384 * 2 / (us[v] * 1e-6) / 1e12).substr(0, 6) + " TFLOP/s executed").c_str());
   }
   printf("the shipped direct kernel runs this layer in %.0f us (2.25 x these MFMAs, with its epilogue); acceptance of the Winograd probe was <= 48 us\n", direct_us);
   return 0;
