@@ -325,6 +325,7 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
                        "parallelism": "agent-parallel x%d" % world},
             "phases_us": phases,
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
+            "collective_backend": str(dist.get_backend()) if dist.is_initialized() else "none",
             "exchanged_bytes_per_rank_per_step": int(stepper.feat_all.numel() * stepper.feat_all.element_size()
                                                      * (world - 1) // max(world, 1)),
         }
@@ -702,12 +703,20 @@ def main(argv=None):
     if world != args.gpus and args.gpus > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's rank count must equal --gpus" % (args.gpus, world))
     import torch.distributed as dist
+    # tests only: DN_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and uses gloo (on CUDA tensors) for the collectives --
+    # RCCL refuses two ranks on one device -- so that the N > 1 control flow of this file (barriers, max over ranks, the
+    # agent-sharded leg's exchange) runs end to end on a one-GPU box; the line then says `collective_backend: "gloo"`
+    share_device = os.environ.get("DN_BENCH_SHARE_DEVICE") == "1"
+    if share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     launched = "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_WORLD_SIZE" in os.environ      # under torch.distributed.run
     if world == 1 and launched and args.mode != "agent":
         args.force_process_group = True      # a one-rank launch still runs the RCCL code path (barriers, max-over-ranks, agent leg)
     use_pg = world > 1 or args.force_process_group
-    if world > 1:
+    if world > 1 and share_device:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     elif args.force_process_group and args.mode != "agent":
         import datetime

@@ -61,3 +61,28 @@ def test_bench_through_its_own_launcher_on_one_gpu():
     assert a["rccl_ranks"] == 1 and a["n_gpus"] == 1 and a["value"] > 0, a
     assert a["emulated_share"]["outputs_equal_unsharded_rows"] is True
     assert list(d)[-1] == "summary" and d["summary"]["agent_sharded"]["rccl_ranks"] == 1
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """`python bench.py --gpus 2` launched bare: the self-launcher starts two ranks; with DN_BENCH_SHARE_DEVICE=1 (tests only) both
+    sit on device 0 and the collectives run over gloo (RCCL refuses two ranks on one device), so the N > 1 control flow -- barriers
+    around the timed region, max over ranks, scene-parallel `value` of both ranks' scenes, and the agent-sharded leg with a REAL
+    two-rank exchange (4 agents per rank, exchanged bytes > 0) -- runs end to end on the one-GPU box.  What it cannot show is RCCL
+    itself with N > 1 ranks."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DN_BENCH_SHARE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pre-roll", "2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 4 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-2 * d["value"]      # both ranks' scenes over the max time
+    for key in ("agent_sharded", "agent_sharded_batch16"):
+        a = d[key]
+        assert "error" not in a, a
+        assert a["n_gpus"] == 2 and a["rccl_ranks"] == 2 and a["collective_backend"] == "gloo", a
+        assert a["exchanged_bytes_per_rank_per_step"] > 0 and a["value"] > 0 and a["scaling"] == "strong"
+    assert "cpu_baseline" not in d and "alt_math" not in d          # N = 1 extras stay out of the N > 1 line
