@@ -118,6 +118,11 @@ def main(dry, ncpu):
     for k, val in v.items():
         text = text.replace("@@%s@@" % k, val)
     open(os.path.join(ROOT, "DESIGN.md"), "w").write(text)
+    readme = open(os.path.join(ROOT, "README.md")).read()      # the same placeholders in the README's status paragraph
+    for k, val in v.items():
+        readme = readme.replace("@@%s@@" % k, val)
+    assert "@@" not in readme, sorted(set(re.findall(r"@@([A-Z0-9_]+)@@", readme)))
+    open(os.path.join(ROOT, "README.md"), "w").write(readme)
     cp = [(os.path.join(F, "bench_default.json"), RD + "_bench_default.json"), (os.path.join(F, "bench_seg.json"), RD + "_bench_seg.json"),
           (os.path.join(F, "agent_share.json"), RD + "_agent_share.json"), (os.path.join(F, "guard_bands.txt"), RD + "_guard_bands.txt"),
           (os.path.join(F, "pytest_gpu.log"), RD + "_pytest_gpu.txt"),
