@@ -1,4 +1,4 @@
-"""Fills DESIGN.md's @@PLACEHOLDERS@@ and the per-layer table from the round's final GPU run (tools/final_set.sh r06 ->
+"""Generates DESIGN.md and README.md from tools/templates/{DESIGN,README}.tmpl.md: fills their @@PLACEHOLDERS@@ and the per-layer table from the round's final GPU run (tools/final_set.sh r06 ->
 gpurun_out/r06final, gpurun_out/r06prof) and copies that run's summaries into profiles/r06_*.  Run once, at the end:
     python tools/fill_design.py [--dry] [--ncpu N]      (N = tests of the CPU suite that passed)"""
 import json
@@ -108,7 +108,9 @@ def main(dry, ncpu):
         "BIASAB": "%.2f → %.2f ms per step, medians of three interleaved runs" % (b0, b1),
         "LAYER_TABLE": layer_table(),
     }
-    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    # the documents are generated from tools/templates/*.tmpl.md (the same text with @@PLACEHOLDERS@@): edit the templates, re-run
+    tdir = os.path.join(ROOT, "tools", "templates")
+    text = open(os.path.join(tdir, "DESIGN.tmpl.md")).read()
     missing = sorted(set(re.findall(r"@@([A-Z0-9_]+)@@", text)) - set(v))
     assert not missing, missing
     if dry:
@@ -118,7 +120,7 @@ def main(dry, ncpu):
     for k, val in v.items():
         text = text.replace("@@%s@@" % k, val)
     open(os.path.join(ROOT, "DESIGN.md"), "w").write(text)
-    readme = open(os.path.join(ROOT, "README.md")).read()      # the same placeholders in the README's status paragraph
+    readme = open(os.path.join(tdir, "README.tmpl.md")).read()      # the same placeholders in the README's status paragraph
     for k, val in v.items():
         readme = readme.replace("@@%s@@" % k, val)
     assert "@@" not in readme, sorted(set(re.findall(r"@@([A-Z0-9_]+)@@", readme)))
