@@ -666,6 +666,18 @@ def test_det_loss_and_gradients_match_the_oracle():
     assert abs(float(losses[1]) - float(l_loc)) < 1e-5 * abs(float(l_loc))
     assert rel_err(dcls, cls.grad.reshape(-1, 2)) < 2e-5
     assert rel_err(dloc, loc.grad.reshape(-1, code)) < 2e-5
+    # round 6: the float4-stream kernel (even n, 16-byte aligned tensors) against the per-anchor kernel (what an unaligned tensor
+    # still gets): the same formulas per element -> dcls / dloc bit for bit, the loss values to the rounding of another summation order
+    cd = cls.detach().float().reshape(-1, 2).to(_dev())
+    pad = torch.zeros(cd.numel() + 2, device=_dev())
+    pad[2:] = cd.reshape(-1)
+    cls_unaligned = pad[2:].view(-1, 2)
+    assert cls_unaligned.data_ptr() % 16 == 8 and cd.data_ptr() % 16 == 0
+    args = (labels.to(_dev()), loc.detach().float().reshape(-1, code).to(_dev()), targets.to(_dev()), mask.to(_dev()))
+    l1, dc1, dl1 = train_ops.det_loss(cd, *args, norm=n_img)
+    l0, dc0, dl0 = train_ops.det_loss(cls_unaligned, *args, norm=n_img)
+    assert torch.equal(dc0, dc1) and torch.equal(dl0, dl1)
+    assert float((l0 - l1).abs().max()) <= 1e-12 * float(l0.abs().max())
 
 
 def test_adam_matches_torch_optim():
