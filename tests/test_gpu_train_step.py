@@ -680,3 +680,36 @@ def test_training_forward_on_the_sp_engine_agrees_with_the_nhwc_engine(case, mon
     train_step(ref, torch.optim.Adam(ref.parameters(), lr=1e-3), *inputs, c["batch"], *tg)      # fills ref's fp32 gradients
     for mode in ("nhwc", "sp"):
         _assert_grads(_grad_report(g64, ref, outs[mode][4], outs[mode][5]))
+
+
+def test_fallback_pass_is_the_fp32_engine_bit_for_bit_with_kd():
+    """The second, all-fp32 backward that replaces a pass with a clamped gradient map (TrainEngine.backward) must be exactly the
+    fp32 engine's pass -- it reads the same saved activations and its own arguments, nothing the first pass wrote (the KD
+    gradient of the fused map is ADDED to the decoder's: a copy, since round 6).  kd_flag = 1, two engines from one state:
+    A (split-f16 gradients) takes the calibration step, then a step whose range poll is forced to report a clamp;
+    B (dgrad = wgrad = "f32") takes the same two steps.  Parameters, Adam moments and BatchNorm buffers equal bit for bit."""
+    from disconet_amd import CoDetModule
+    c, ref, model_a, (bevs, trans, na), (labels, targets, mask) = _setup("cfg1", "f16x3")
+    _, _, model_b, _, _ = _setup("cfg1", "f16x3")
+    _, t_hip, bevs_t = _teacher_pair(c)
+    data = {"bev_seq": bevs.cuda(), "trans_matrices": trans.cuda(), "num_agent": na.cuda(), "labels": labels.cuda(),
+            "reg_targets": targets.cuda(), "reg_loss_mask": mask.cuda(), "bev_seq_teacher": bevs_t.cuda(), "kd_weight": 1e5}
+    model_a.kd_flag = model_b.kd_flag = 1
+    mod_a = CoDetModule(model_a, t_hip, None, None, kd_flag=1, lr=1e-3, dgrad_math="sp", wgrad_math="sp")
+    mod_b = CoDetModule(model_b, t_hip, None, None, kd_flag=1, lr=1e-3, dgrad_math="f32", wgrad_math="f32")
+    outs = []
+    for mod in (mod_a, mod_b):
+        o1 = mod.step(data, c["batch"])
+        if mod is mod_a:
+            assert len(mod.engine._dz_lift) > 10
+            mod.engine._force_range_flags = [1]
+        o2 = mod.step(data, c["batch"])
+        outs.append((o1, o2))
+    assert mod_a.engine.f32_fallback_steps == 1 and mod_b.engine.f32_fallback_steps == 0
+    assert torch.equal(mod_a.engine.flat_p, mod_b.engine.flat_p)
+    assert torch.equal(mod_a.engine.flat_m, mod_b.engine.flat_m) and torch.equal(mod_a.engine.flat_v, mod_b.engine.flat_v)
+    for (n1, b1), (n2, b2) in zip(model_a.named_buffers(), model_b.named_buffers()):
+        assert n1 == n2 and torch.equal(b1, b2), n1
+    for k in ("cls_loss", "loc_loss", "kd_loss"):
+        for i in (0, 1):
+            assert abs(outs[0][i][k] - outs[1][i][k]) <= 1e-12 * abs(outs[1][i][k]), (k, i)

@@ -40,15 +40,34 @@ def j(path):
     return json.load(open(path))
 
 
+FROM_PROFILES = False
+
+
+def srcpath(kind, name):
+    """kind "F" (final_set outputs) / "P" (profile_set outputs) -> path; --from-profiles: the committed copy under profiles/"""
+    if FROM_PROFILES:
+        m = {"bench_default.json": "_bench_default.json", "bench_seg.json": "_bench_seg.json", "pytest_gpu.log": "_pytest_gpu.txt",
+             "train_groups.json": "_train_groups.json", "bench_layers.txt": "_bench_layers.txt"}
+        return os.path.join(ROOT, "profiles", RD + m[name])
+    return os.path.join(F if kind == "F" else P, name)
+
+
+def pmc_rows():
+    if FROM_PROFILES:
+        out = open(os.path.join(ROOT, "profiles", RD + "_pmc_conv_sp.txt")).read()
+    else:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_table.py"), P, "24"], capture_output=True, text=True, check=True).stdout
+    return [l.split() for l in out.splitlines()[1:]]
+
+
 def layer_table():
     names = {l[0] for l in LAYERS}
     layers = {}
-    for line in open(os.path.join(P, "bench_layers.txt")):
+    for line in open(srcpath("P", "bench_layers.txt")):
         m = re.match(r"^(\S.*?)\s{2,}([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+(.*)$", line.rstrip())
         if m and m.group(1) in names:
             layers[m.group(1)] = (float(m.group(2)), float(m.group(3)), float(m.group(4)))      # us, GFLOP, TFLOP/s
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_table.py"), P, "24"], capture_output=True, text=True, check=True).stdout
-    rows = [l.split() for l in out.splitlines()[1:]]
+    rows = pmc_rows()
     conv = [r for r in rows if r[0].startswith("sp<") or r[0].startswith("spq<") or r[0].startswith("conv_pre_pair")]
     merged = []
     for r in conv:       # the K-sliced layer's fix-up launch belongs to the row before it
@@ -73,14 +92,14 @@ def layer_table():
 
 
 def main(dry, ncpu):
-    d = j(os.path.join(F, "bench_default.json"))
-    seg = j(os.path.join(F, "bench_seg.json"))
-    tg = j(os.path.join(P, "train_groups.json"))
+    d = j(srcpath("F", "bench_default.json"))
+    seg = j(srcpath("F", "bench_seg.json"))
+    tg = j(srcpath("P", "train_groups.json"))
     r, c, a, t = d["roofline"], d["cpu_baseline"], d["alt_math"], d["train_step"]
     es = d["agent_sharded"]["emulated_share"]
     es16 = d["agent_sharded_batch16"]["emulated_share"]
     other = r["other_kernels_ms_per_step"]
-    gpu_log = open(os.path.join(F, "pytest_gpu.log")).read()
+    gpu_log = open(srcpath("F", "pytest_gpu.log")).read()
     m = re.search(r"(\d+) passed", gpu_log)
     ab = [l.split() for l in open(os.path.join(ROOT, "profiles", "r06_bias_ab.txt")) if l.startswith("fused_bias")]
     med = lambda xs: sorted(xs)[len(xs) // 2]
@@ -125,6 +144,8 @@ def main(dry, ncpu):
         readme = readme.replace("@@%s@@" % k, val)
     assert "@@" not in readme, sorted(set(re.findall(r"@@([A-Z0-9_]+)@@", readme)))
     open(os.path.join(ROOT, "README.md"), "w").write(readme)
+    if FROM_PROFILES:
+        return
     cp = [(os.path.join(F, "bench_default.json"), RD + "_bench_default.json"), (os.path.join(F, "bench_seg.json"), RD + "_bench_seg.json"),
           (os.path.join(F, "agent_share.json"), RD + "_agent_share.json"), (os.path.join(F, "guard_bands.txt"), RD + "_guard_bands.txt"),
           (os.path.join(F, "pytest_gpu.log"), RD + "_pytest_gpu.txt"),
@@ -145,5 +166,6 @@ def main(dry, ncpu):
 
 
 if __name__ == "__main__":
+    FROM_PROFILES = "--from-profiles" in sys.argv
     n = sys.argv[sys.argv.index("--ncpu") + 1] if "--ncpu" in sys.argv else "?"
     main("--dry" in sys.argv, n)
