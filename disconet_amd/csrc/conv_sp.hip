@@ -30,6 +30,9 @@
 #ifndef DN_MFMA_PRIO
 #define DN_MFMA_PRIO 0
 #endif
+#ifndef DN_MMA_GRAY
+#define DN_MMA_GRAY 1      // Gray order of the accumulator tiles inside a product group (compute :: mma; 0 = rounds 2-5's row-major order: same bits, conv launches +0.3 %, profiles/r06_mma_gray_ab.txt)
+#endif
 // tools/ab: 1 = the weight-stationary kernels time their phases with s_memtime (wave 0 of every workgroup, summed into
 // g_phase_cycles: [0] wait for the patch + barrier, [1] issue of the next patch, [2] MFMA loop, [3] epilogue, [4] tile decode + rest,
 // [5] tiles, [6] total) -- read with dn_sp_phase_cycles().  Never in the shipped build.
@@ -463,23 +466,31 @@ conv_sp_kernel(const SpArgs a) {
       __builtin_amdgcn_s_setprio(DN_MFMA_PRIO);     // tools/ab: the wave that has its fragments issues MFMAs ahead of a neighbour's epilogue VALU
 #endif
       // D[i = channel][j = pixel]; small terms first; independent accumulators interleaved
+      // DN_MMA_GRAY (tools/ab): walk the accumulator tiles of a product group in Gray order -- consecutive MFMAs then differ in ONE
+      // operand register set, not two (every accumulator still receives its three products in the same order: same bits)
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
-        for (int wn = 0; wn < WTN; ++wn)
+        for (int k = 0; k < WTN; ++k) {
+          const int wn = (DN_MMA_GRAY && (wm & 1)) ? WTN - 1 - k : k;
           acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s][wn], ah[s][wm], acc[wm][wn], 0, 0, 0);
+        }
       if constexpr (AHI == 0) {
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
-        for (int wn = 0; wn < WTN; ++wn)
+        for (int k = 0; k < WTN; ++k) {
+          const int wn = (DN_MMA_GRAY && (wm & 1)) ? WTN - 1 - k : k;
           acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s][wn], al[s][wm], acc[wm][wn], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int wm = 0; wm < WTM; ++wm)
 #pragma unroll
-        for (int wn = 0; wn < WTN; ++wn)
+        for (int k = 0; k < WTN; ++k) {
+          const int wn = (DN_MMA_GRAY && (wm & 1)) ? WTN - 1 - k : k;
           acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s][wn], ah[s][wm], acc[wm][wn], 0, 0, 0);
+        }
 #if DN_MFMA_PRIO
       __builtin_amdgcn_s_setprio(0);
 #endif

@@ -27,6 +27,9 @@
 #ifndef DN_MFMA_PRIO
 #define DN_MFMA_PRIO 0
 #endif
+#ifndef DN_MMA_GRAY
+#define DN_MMA_GRAY 1      // see conv_sp.hip
+#endif
 #include "dn_internal.h"
 #include "sp_layout.h"
 #include "sp_device.h"
@@ -284,21 +287,29 @@ __global__ void __launch_bounds__(QNT, 2) conv_spq_kernel(const SpqArgs a) {
 #if DN_MFMA_PRIO
     __builtin_amdgcn_s_setprio(DN_MFMA_PRIO);
 #endif
+    // (Gray order of the accumulator tiles inside a product group, as conv_sp_kernel's mma: consecutive MFMAs differ in one
+    // operand register set; every accumulator receives its three products in the same order -- same bits)
 #pragma unroll
     for (int wm = 0; wm < 2; ++wm)
 #pragma unroll
-      for (int wn = 0; wn < WTN; ++wn)
+      for (int k = 0; k < WTN; ++k) {
+        const int wn = (DN_MMA_GRAY && (wm & 1)) ? WTN - 1 - k : k;
         acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[wn], f.ah[wm], acc[wm][wn], 0, 0, 0);
+      }
 #pragma unroll
     for (int wm = 0; wm < 2; ++wm)
 #pragma unroll
-      for (int wn = 0; wn < WTN; ++wn)
+      for (int k = 0; k < WTN; ++k) {
+        const int wn = (DN_MMA_GRAY && (wm & 1)) ? WTN - 1 - k : k;
         acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[wn], f.al[wm], acc[wm][wn], 0, 0, 0);
+      }
 #pragma unroll
     for (int wm = 0; wm < 2; ++wm)
 #pragma unroll
-      for (int wn = 0; wn < WTN; ++wn)
+      for (int k = 0; k < WTN; ++k) {
+        const int wn = (DN_MMA_GRAY && (wm & 1)) ? WTN - 1 - k : k;
         acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[wn], f.ah[wm], acc[wm][wn], 0, 0, 0);
+      }
 #if DN_MFMA_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
