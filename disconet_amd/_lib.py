@@ -154,6 +154,8 @@ SIGNATURES = {
     "dn_bn_train_backward_finish_sp": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long,
                                                c_void_p, c_void_p, c_float, c_void_p]),
+    "dn_bn_train_stats_running": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_float, c_void_p]),
     "dn_bn_bias_workspace_bytes": (c_size_t, [c_long, c_int]),
     "dn_bn_train_backward_finish_bias": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long,

@@ -301,6 +301,70 @@ __global__ void bn_update_running_kernel(const float* __restrict__ mean, const f
   rvar[cc] = rv;
 }
 
+// ---- fold + finish in ONE launch (round 6: the step ran ~75 fold_partials launches of 6.7 us each plus as many 3-5 us finalize
+// launches behind them).  One wavefront per (group, channel) folds BOTH quantities of its channel in fold_partials_kernel's order
+// (lane l adds blocks l, l + 64, ...; xor butterfly): the same sums bit for bit, then the finish arithmetic of the kernel it
+// replaces -- bn_stats_finalize_kernel (+ optionally bn_update_running_kernel: one group), bn_param_grad_kernel (one group),
+// channel_sum_finalize_kernel.
+__device__ inline double fold_one(const double* __restrict__ p, int n_blocks, size_t stride, int lane) {
+  double t = 0.0;
+  for (int b = lane; b < n_blocks; b += 64) t += p[(size_t)b * stride];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  return t;
+}
+__global__ void __launch_bounds__(256)
+fold_stats_finish_kernel(const double* __restrict__ part, int n_blocks, int c, int n_groups, long norm_rows, double* __restrict__ sums,
+                         float* __restrict__ mean, float* __restrict__ var, float* __restrict__ rmean, float* __restrict__ rvar,
+                         float momentum, long unbias_rows) {
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (idx >= n_groups * c) return;
+  const int g = idx / c, cc = idx % c;
+  const double* p = part + (size_t)g * n_blocks * 2 * c + cc;
+  const double t0 = fold_one(p, n_blocks, 2 * c, lane), t1 = fold_one(p + c, n_blocks, 2 * c, lane);
+  if (lane == 0) {
+    sums[(size_t)g * 2 * c + cc] = t0;
+    sums[(size_t)g * 2 * c + c + cc] = t1;
+    const double m = t0 / norm_rows;
+    const double v = t1 / norm_rows - m * m;
+    const float mf = (float)m, vf = (float)(v > 0.0 ? v : 0.0);
+    mean[idx] = mf;
+    var[idx] = vf;
+    if (rmean) {      // (one group) bn_update_running_kernel's arithmetic
+      const float unbias = unbias_rows > 1 ? (float)unbias_rows / (float)(unbias_rows - 1) : 1.f;
+      rmean[cc] = (1.f - momentum) * rmean[cc] + momentum * mf;
+      rvar[cc] = (1.f - momentum) * rvar[cc] + momentum * (vf * unbias);
+    }
+  }
+}
+__global__ void __launch_bounds__(256)
+fold_param_grad_kernel(const double* __restrict__ part, int n_blocks, int c, double* __restrict__ sums, float* __restrict__ dgamma,
+                       float* __restrict__ dbeta, int accumulate) {      // one group
+  const int cc = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (cc >= c) return;
+  const double t0 = fold_one(part + cc, n_blocks, 2 * c, lane), t1 = fold_one(part + c + cc, n_blocks, 2 * c, lane);
+  if (lane == 0) {
+    sums[cc] = t0;
+    sums[c + cc] = t1;
+    double s1 = 0.0, s2 = 0.0;      // (bn_param_grad_kernel's sum over its one group)
+    s1 += t0;
+    s2 += t1;
+    dbeta[cc] = (accumulate ? dbeta[cc] : 0.f) + (float)s1;
+    dgamma[cc] = (accumulate ? dgamma[cc] : 0.f) + (float)s2;
+  }
+}
+__global__ void __launch_bounds__(256)
+fold_channel_sum_kernel(const double* __restrict__ part, int n_blocks, int c, double* __restrict__ sums, float* __restrict__ out,
+                        int accumulate) {
+  const int cc = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (cc >= c) return;
+  const double t = fold_one(part + cc, n_blocks, c, lane);
+  if (lane == 0) {
+    sums[cc] = t;
+    out[cc] = (accumulate ? out[cc] : 0.f) + (float)t;
+  }
+}
+
 // incoming gradient of one element: dy_a (optionally the 2 x 2 block sum of a map at twice
 // the resolution) + dy_b, gated by the ReLU
 struct GradSrc {
@@ -1023,11 +1087,38 @@ extern "C" int dn_bn_train_stats_finish(const double* sums, int n_groups, long n
   return dn::check_launch("bn_stats_finalize_kernel");
 }
 
+namespace {
+int bn_stats_one_call(const float* z, int n_groups, long rows_per_group, int c, int ldz, double* sums, size_t sums_bytes,
+                      float* mean, float* var, float* rmean, float* rvar, float momentum, long unbias_rows, void* stream) {
+  DN_REQUIRE(z && sums && mean && var, "bn stats: null pointer");
+  DN_REQUIRE(n_groups > 0 && rows_per_group > 0 && c > 0 && c <= kMaxC && ldz >= c, "bn stats: bad shape");
+  DN_REQUIRE(sums_bytes >= dn_reduce_workspace_bytes(n_groups, rows_per_group, c),
+             "bn stats: workspace of %zu bytes, dn_reduce_workspace_bytes() asks for %zu", sums_bytes,
+             dn_reduce_workspace_bytes(n_groups, rows_per_group, c));
+  DN_REQUIRE(!rmean || (rvar && n_groups == 1), "bn stats: the fused running-statistics update takes one group");
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = blocks_per_group(rows_per_group, n_groups);
+  double* part = sums + (size_t)2 * c * n_groups;      // workspace layout: see dn_bn_train_stats_partial
+  if (vec4_ok(c, {ldz}, {z}))
+    hipLaunchKernelGGL(bn_legacy() ? bn_stats_v4_kernel<1> : bn_stats_v4_kernel<4>, dim3(nblk, n_groups), dim3(256), 0, s, z, rows_per_group, c, ldz, part);
+  else
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk, n_groups), dim3(256), 0, s, z, rows_per_group, c, ldz, part);
+  // fold + finish (+ the running statistics) in one launch: the sums and statistics of the two-launch path, bit for bit
+  hipLaunchKernelGGL(fold_stats_finish_kernel, dim3((n_groups * c + 3) / 4), dim3(256), 0, s, part, nblk, c, n_groups, rows_per_group, sums,
+                     mean, var, rmean, rvar, momentum, unbias_rows);
+  return dn::check_launch("bn_stats_kernel");
+}
+}  // namespace
+
 extern "C" int dn_bn_train_stats(const float* z, int n_groups, long rows_per_group, int c, int ldz,
                                  double* sums, size_t sums_bytes, float* mean, float* var, void* stream) {
-  DN_REQUIRE(mean && var, "bn stats: null pointer");
-  if (int rc = dn_bn_train_stats_partial(z, n_groups, rows_per_group, c, ldz, sums, sums_bytes, stream)) return rc;
-  return dn_bn_train_stats_finish(sums, n_groups, rows_per_group, c, mean, var, stream);
+  return bn_stats_one_call(z, n_groups, rows_per_group, c, ldz, sums, sums_bytes, mean, var, nullptr, nullptr, 0.f, 0, stream);
+}
+
+extern "C" int dn_bn_train_stats_running(const float* z, long rows, int c, int ldz, double* sums, size_t sums_bytes, float* mean,
+                                         float* var, float* running_mean, float* running_var, float momentum, void* stream) {
+  DN_REQUIRE(running_mean && running_var, "bn stats (+ running): null pointer");
+  return bn_stats_one_call(z, 1, rows, c, ldz, sums, sums_bytes, mean, var, running_mean, running_var, momentum, rows, stream);
 }
 
 extern "C" int dn_bn_train_apply(const float* z, const float* mean, const float* var,
@@ -1128,6 +1219,10 @@ extern "C" int dn_bn_train_backward_partial(const float* dy_a, int ld_a, int up_
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, n_groups), dim3(256), 0, s, src, z, mean, var, eps,
                        rows_per_group, part);
+  if (n_groups == 1 && !bn_legacy()) {      // fold + parameter gradients in one launch (same sums, same bits)
+    hipLaunchKernelGGL(fold_param_grad_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, nblk, c, sums, dgamma, dbeta, accumulate);
+    return dn::check_launch("bn_backward reduce kernels");
+  }
   hipLaunchKernelGGL(fold_partials_kernel, dim3((n_groups * 2 * c + 3) / 4), dim3(256), 0, s, part, nblk, 2 * c,
                      n_groups, sums);
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((c + 63) / 64), dim3(64), 0, s, sums, n_groups, c,
@@ -1165,8 +1260,7 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
     double* part = bias_ws + c;      // [c] folded sums, then [blocks][c] partials
     hipLaunchKernelGGL((bn_bwd_apply_v4_fast_kernel<SPF, true>), dim3(blocks), dim3(256), 0, s, src, z, mean, var, gamma, eps,
                        norm_rows, sums, fsh, (unsigned)(total / 4), dz, (unsigned char*)sp_ptr, lift, (unsigned)(h * w), fl, part);
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, blocks, c, 1, bias_ws);
-    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, s, bias_ws, c, dbias, 0);
+    hipLaunchKernelGGL(fold_channel_sum_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, blocks, c, bias_ws, dbias, 0);
     return dn::check_launch("bn backward apply kernel (+ bias gradient)");
   };
   if (dz_sp) {
@@ -1264,9 +1358,7 @@ extern "C" int dn_channel_sum(const float* x, long rows, int c, int ld, double* 
     hipLaunchKernelGGL(bn_legacy() ? channel_sum_v4_kernel<1> : channel_sum_v4_kernel<4>, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
   else
     hipLaunchKernelGGL(channel_sum_kernel, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
-  hipLaunchKernelGGL(fold_partials_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, nblk, c, 1, sums);
-  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, s, sums, c, out,
-                     accumulate);
+  hipLaunchKernelGGL(fold_channel_sum_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, nblk, c, sums, out, accumulate);
   return dn::check_launch("channel_sum_kernel");
 }
 

@@ -98,11 +98,15 @@ class SegTrainEngine(TrainEngine):
         logits, d_out = self._conv(m.outc.conv.weight, m.outc.conv.bias, x9, ksize=1)
         self.sctx = dict(x1=x1, x2=x2, x3=x3, fused=fused, x9=x9, d_out=d_out)
 
-        for lay in L.values():          # running statistics, the reference's momentum update
-            if lay.name.startswith("mlp"):
+        self._tracked = []
+        for lay in L.values():          # running statistics, the reference's momentum update (inside the statistics' launch where
+            if lay.name.startswith("mlp"):      # _layer_fwd could fuse it: `running_done`)
                 continue
             c = lay.ctx
-            self._update_running(lay.bn, c["mean"], c["var"], c["z"].numel() // c["z"].shape[-1])
+            self._update_running(lay.bn, c["mean"], c["var"], c["z"].numel() // c["z"].shape[-1], done=c.get("running_done", False))
+        if self._tracked:
+            torch._foreach_add_(self._tracked, 1)
+        self._tracked = []
         self.outs = dict(x9=x9, x8=x8, x7=x7, x6=x6, x5=x5, fused=fused)
         self.last_logits = logits
         return logits

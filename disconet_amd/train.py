@@ -339,7 +339,12 @@ class TrainEngine:
         w = lay.w if w is None else w
         b = lay.b if b is None else b
         z, d = self._conv(w, b, src0, src1, up0, lay.stride, lay.ksize)
-        mean, var = T.bn_stats(z, groups, **self._bn_sync(z, groups))
+        # one process, one group, the layer's own BatchNorm: the running-statistics update rides in the statistics' finish launch
+        # (the momentum updates of different BatchNorms touch different buffers: their order is free)
+        fused_running = (lay.bn is not None and groups == 1 and (self.shard is None or self.shard.world == 1)
+                         and os.environ.get("DN_BN_FUSED_RUNNING", "1") != "0")
+        mean, var = T.bn_stats(z, groups, running=(lay.bn.running_mean, lay.bn.running_var, _MOMENTUM) if fused_running else None,
+                               **self._bn_sync(z, groups))
         gamma = lay.bn.weight if gamma is None else gamma
         beta = lay.bn.bias if beta is None else beta
         # the backward's ReLU gate as one byte per four channels: its two passes then do not read y (1/16 of the bytes)
@@ -351,7 +356,7 @@ class TrainEngine:
         if y_sp is not None:
             y._dn_sp = y_sp
         lay.ctx = dict(src0=src0, src1=src1, up0=up0, z=z, y=y, mean=mean, var=var, desc=d,
-                       groups=groups, w=w, gamma=gamma, mask=mask)
+                       groups=groups, w=w, gamma=gamma, mask=mask, running_done=fused_running)
         return y
 
     def _bn_sync(self, z, groups):
@@ -362,11 +367,16 @@ class TrainEngine:
             return {}
         return {"sync": self.shard.sum_, "norm_rows": (z.numel() // z.shape[-1]) * self.shard.world}
 
-    def _update_running(self, bn, mean, var, rows, order=None, calls=1):
-        if self.shard is not None and order is None:
-            rows = rows * self.shard.world            # the unbiased variance's n / (n - 1) is the global batch's
-        T.bn_update_running(mean, var, rows, bn.running_mean, bn.running_var, _MOMENTUM, order)
-        bn.num_batches_tracked += calls
+    def _update_running(self, bn, mean, var, rows, order=None, calls=1, done=False):
+        """done: the momentum update already ran inside the statistics' finish launch (_layer_fwd); only the call counter is left"""
+        if not done:
+            if self.shard is not None and order is None:
+                rows = rows * self.shard.world            # the unbiased variance's n / (n - 1) is the global batch's
+            T.bn_update_running(mean, var, rows, bn.running_mean, bn.running_var, _MOMENTUM, order)
+        if calls == 1 and getattr(self, "_tracked", None) is not None:
+            self._tracked.append(bn.num_batches_tracked)      # forward() adds 1 to all of them in one launch
+        else:
+            bn.num_batches_tracked.add_(calls)
 
     def _layer_bwd(self, lay, dy_a, G, dy_b=None, up_a=False, need_dx=True, gw=None, gb=None,
                    ggamma=None, gbeta=None, s2d_ok=False):
@@ -633,19 +643,21 @@ class TrainEngine:
         self.head_ctx = dict(h1=h1, dc=dc, dr=dr)
 
         # running statistics (momentum updates in the reference's call order)
+        self._tracked = []
         for lay in L.values():
             if lay.name.startswith("mlp"):
                 continue
             c = lay.ctx
-            self._update_running(lay.bn, c["mean"], c["var"], c["z"].numel() // c["z"].shape[-1])
+            self._update_running(lay.bn, c["mean"], c["var"], c["z"].numel() // c["z"].shape[-1], done=c.get("running_done", False))
         hc = self.head1.ctx
         rows = (hc["z"].numel() // 64) * (sh.world if sh is not None else 1)
         T.bn_update_running(hc["mean"][:, :32], hc["var"][:, :32], rows, cls.bn1.running_mean,
                             cls.bn1.running_var, _MOMENTUM)
         T.bn_update_running(hc["mean"][:, 32:], hc["var"][:, 32:], rows, reg[1].running_mean,
                             reg[1].running_var, _MOMENTUM)
-        cls.bn1.num_batches_tracked += 1
-        reg[1].num_batches_tracked += 1
+        self._tracked += [cls.bn1.num_batches_tracked, reg[1].num_batches_tracked]
+        torch._foreach_add_(self._tracked, 1)      # every layer's call counter in one launch (25 one-element adds before)
+        self._tracked = []
 
         nI, h, w = cls_out.shape[0], cls_out.shape[1], cls_out.shape[2]
         self.outs = dict(x5=x5, x6=x6, x7=x7, x8=x8, fused=x3f)

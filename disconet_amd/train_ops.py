@@ -94,10 +94,12 @@ def _folded(sums, n_groups, c):
     return sums[:n_groups * 2 * c * 8].view(torch.float64)
 
 
-def bn_stats(z, n_groups=1, sync=None, norm_rows=None):
+def bn_stats(z, n_groups=1, sync=None, norm_rows=None, running=None):
     """z [..., c] dense NHWC rows -> (mean, biased var) each [n_groups, c].
     sync (agent-parallel training): callable that all-reduces a float64 tensor in place -- this rank's sums are reduced,
-    `sync` adds the other ranks', and the statistics are normalised by `norm_rows` rows per group (the global count)."""
+    `sync` adds the other ranks', and the statistics are normalised by `norm_rows` rows per group (the global count).
+    running = (running_mean, running_var, momentum): one group, no sync -- the momentum update of the running statistics leaves
+    the launch that finishes the statistics (dn_bn_train_stats_running), bit for bit bn_update_running's."""
     _need_gpu(z)
     c = z.shape[-1]
     rows = z.numel() // c
@@ -106,6 +108,14 @@ def bn_stats(z, n_groups=1, sync=None, norm_rows=None):
     var = torch.empty_like(mean)
     lib = _lib.load()
     sums = _ws(z.device, lib.dn_reduce_workspace_bytes(n_groups, rows // n_groups, c))
+    if running is not None:
+        if sync is not None or n_groups != 1:
+            raise _lib.DnError("bn_stats: the fused running-statistics update takes one group and no sync")
+        rm, rv, momentum = running
+        _need_gpu(rm, rv)
+        check(lib.dn_bn_train_stats_running(_ptr(z), rows, c, c, _ptr(sums), sums.numel(), _ptr(mean), _ptr(var), _ptr(rm), _ptr(rv),
+                                            float(momentum), _stream()), "dn_bn_train_stats_running")
+        return mean, var
     if sync is None:
         check(lib.dn_bn_train_stats(_ptr(z), n_groups, rows // n_groups, c, c, _ptr(sums), sums.numel(),
                                     _ptr(mean), _ptr(var), _stream()), "dn_bn_train_stats")

@@ -98,6 +98,12 @@ int dn_bn_train_stats_partial(const float* z, int n_groups, long rows_per_group,
                               double* sums, size_t sums_bytes, void* stream);
 int dn_bn_train_stats_finish(const double* sums, int n_groups, long norm_rows, int c, float* mean, float* var, void* stream);
 
+/* dn_bn_train_stats for ONE group that also applies the running-statistics update of dn_bn_update_running (momentum, unbiased
+ * variance with rows / (rows - 1)) from the launch that finishes the statistics (round 6: one launch instead of three behind the
+ * reduction).  Bit for bit the separate calls. */
+int dn_bn_train_stats_running(const float* z, long rows, int c, int ldz, double* sums, size_t sums_bytes, float* mean, float* var,
+                              float* running_mean, float* running_var, float momentum, void* stream);
+
 /* y = act((z - mean) * rsqrt(var + eps) * gamma + beta), act = ReLU if relu */
 int dn_bn_train_apply(const float* z, const float* mean, const float* var, const float* gamma,
                       const float* beta, float eps, int relu, int n_groups, long rows_per_group,

@@ -55,6 +55,7 @@ static int errors_only(void) {
   /* round 5: two-phase BatchNorm reductions (agent-parallel training) and the K-slice query */
   CHECK(dn_bn_train_stats_partial(NULL, 1, 10, 8, 8, NULL, 0, NULL) == DN_ERR_ARG, "bn stats partial null");
   CHECK(dn_bn_train_stats_finish(NULL, 1, 10, 8, NULL, NULL, NULL) == DN_ERR_ARG, "bn stats finish null");
+  CHECK(dn_bn_train_stats_running(NULL, 16, 16, 16, NULL, 0, NULL, NULL, NULL, NULL, 0.1f, NULL) == DN_ERR_ARG, "bn stats (+ running) null");
   CHECK(dn_bn_bias_workspace_bytes(0, 32) == 0 && dn_bn_bias_workspace_bytes(1024, 32) == 8u * 32u * (1 + 32), "bn bias workspace");
   CHECK(dn_bn_train_backward_finish_bias(NULL, 8, 0, NULL, 0, NULL, NULL, NULL, NULL, NULL, 1e-5f, 0, 4, 4, 1, 16, NULL, 16, NULL, NULL,
                                          1.f, NULL, NULL, 0, NULL) == DN_ERR_ARG, "bn backward finish (+ bias) null");
