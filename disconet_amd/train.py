@@ -75,6 +75,9 @@ def fusion_call_counts(agents, only_v2i, num_agent_cpu, B):
     return out
 
 
+_LIST_CACHE = {}      # (agents, only_v2i, live counts, B, device, ego range) -> the index tensors of fusion_lists (they do not depend on the poses)
+
+
 def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev, ego_first=0, ego_count=None):
     """Index lists of the DiscoGraph fusion for one batch, in the reference's loop order
     (upstream DiscoNet.forward: for b, for ego i < n_b: [ego] + [warp(j -> i) for j < n_b, j != i],
@@ -83,7 +86,36 @@ def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev, ego_first=0, eg
 
     ego_first / ego_count (agent-parallel training: a rank fuses ITS egos against every agent's map): the lists cover the
     egos [ego_first, ego_first + ego_count) only; map / pair indices still address the buffer [all A*B maps | this rank's
-    warps], `ego_out` is the LOCAL image index (i - ego_first) * B + b of the fused output."""
+    warps], `ego_out` is the LOCAL image index (i - ego_first) * B + b of the fused output.
+
+    The index tensors depend on the live-agent counts only, not on the poses: they are built (a dozen small host -> device
+    copies) once per distinct (counts, B, ego range) and cached (round 6: the step's start was the GPU's longest idle gap);
+    every call gathers the poses and tests them for rigidity."""
+    key = (agents, bool(only_v2i), tuple(int(v) for v in num_agent_cpu[:B]), B, str(dev), ego_first, ego_count)
+    hit = _LIST_CACHE.get(key)
+    if hit is None:
+        if len(_LIST_CACHE) > 64:
+            _LIST_CACHE.clear()
+        hit = _fusion_index_lists(agents, only_v2i, num_agent_cpu, B, dev, ego_first, ego_count)
+        _LIST_CACHE[key] = hit
+    out = dict(hit)
+    nw, bi = out["n_warps"], out.pop("_poses_idx")
+    if nw:
+        poses = trans[bi[:, 0], bi[:, 1], bi[:, 2]].contiguous()
+    else:
+        poses = torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
+    # rigid poses (rotation + translation: what V2X agents' relative poses are) take the deterministic
+    # gather form of the warp backward
+    rigid = True
+    if nw:
+        R = poses[:, :2, :2].double()
+        eye = torch.eye(2, dtype=torch.float64, device=R.device)
+        rigid = bool(((R @ R.transpose(1, 2) - eye).abs().max() < 1e-3).item())
+    out["poses"], out["rigid"] = poses, rigid
+    return out
+
+
+def _fusion_index_lists(agents, only_v2i, num_agent_cpu, B, dev, ego_first=0, ego_count=None):
     A = agents
     E = A if ego_count is None else ego_count
     NI = A * B
@@ -127,19 +159,8 @@ def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev, ego_first=0, eg
     for lst in per:
         efirst.append(efirst[-1] + len(lst))
     i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
-    if nw:
-        bi = torch.tensor(poses_idx, dtype=torch.long, device=dev)
-        poses = trans[bi[:, 0], bi[:, 1], bi[:, 2]].contiguous()
-    else:
-        poses = torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
-    # rigid poses (rotation + translation: what V2X agents' relative poses are) take the deterministic
-    # gather form of the warp backward
-    rigid = True
-    if nw:
-        R = poses[:, :2, :2].double()
-        eye = torch.eye(2, dtype=torch.float64, device=R.device)
-        rigid = bool(((R @ R.transpose(1, 2) - eye).abs().max() < 1e-3).item())
-    return dict(n_warps=nw, rigid=rigid, src_image=i32(src_image), poses=poses, first=i32(first),
+    bi = torch.tensor(poses_idx, dtype=torch.long, device=dev) if nw else None
+    return dict(n_warps=nw, src_image=i32(src_image), first=i32(first), _poses_idx=bi,
                 pair_index=i32(pair_index), map_image=i32(map_image), ego_out=i32(ego_out),
                 ego_image=i32(ego_image), efirst=i32(efirst), epairs=i32([p for l in per for p in l]),
                 order=i32(order), n_calls=len(order))
