@@ -144,10 +144,12 @@ def main(argv=None):
         lr = fafmodule.scheduler_step(epoch)
         dt = time.perf_counter() - t0
         if rank == 0:
-            print("epoch %d: mean loss %.4f  (%s)  %.1f scenes/s  lr %.2e" % (
+            fb = fafmodule.engine.f32_fallback_steps      # backward passes repeated on the fp32 kernels (a gradient outgrew its lift)
+            print("epoch %d: mean loss %.4f  (%s)  %.1f scenes/s  lr %.2e%s" % (
                 epoch, running / args.steps_per_epoch,
                 ", ".join("%s %.4f" % (k, v) for k, v in out.items() if k != "loss"),
-                world * args.batch * args.steps_per_epoch / dt, lr))
+                world * args.batch * args.steps_per_epoch / dt, lr,
+                "  [%d fp32 fallback step(s) so far]" % fb if fb else ""))
             if args.logpath:
                 os.makedirs(args.logpath, exist_ok=True)
                 torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
