@@ -382,6 +382,14 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
             share = sharded.GraphedAgentStep(engine, rank_inputs(0, cnt), trans, na, batch, 0, cnt, range_guard=False,
                                              emulate_feat_all=full_feat, emulate_collective=True)
             t_share = time_steps(share, args.steps, args.warmup)
+        one_graph = None
+        if os.environ.get("DN_AGENT_ONE_GRAPH") == "1":      # opt-in: A + exchange (collective included) + B as ONE captured graph
+            err = share.capture_one_graph()
+            if err is None:
+                t_one = time_steps(share, args.steps, args.warmup)
+                one_graph = {"ms_per_step": round(1e3 * t_one / args.steps, 4), "projected_speedup": round(elapsed / t_one, 3)}
+            else:
+                one_graph = {"error": err}
         got = share()
         torch.cuda.synchronize()
         rows = cnt * batch
@@ -396,6 +404,7 @@ def agent_sharded_leg(args, world, rank, dist, emulate_world=0, check_steps=0):
             "ms_per_step_without_collective": round(1e3 * t_plain / args.steps, 4),
             "projected_speedup_without_collective": round(elapsed / t_plain, 3),
             "outputs_equal_unsharded_rows": same,
+            **({"one_graph": one_graph} if one_graph is not None else {}),
             "note": "rank 0's share of a %d-rank run timed on one GPU: the peers' maps arrive by a device copy and, when a "
                     "process group exists, the real RCCL all-gather kernel runs between the two graphs (its launch + "
                     "kernel latency; no link time, no rank skew); projected_speedup = T(8 agents, 1 GPU) / T(share) "

@@ -126,6 +126,7 @@ class GraphedAgentStep:
         self.emulate_collective = bool(emulate_collective and self.emulated and dist.is_available() and dist.is_initialized())
         self._own_gather = None
         layer = engine.layer
+        self.graph_all = None
         with torch.no_grad():
             # (the range flags are sticky: graph B's captured poll covers graph A's launches too)
             self.graph_a = GraphedStep(lambda: engine.encode(make_bevs()), range_guard=False)
@@ -151,8 +152,16 @@ class GraphedAgentStep:
         with torch.no_grad():
             self.graph_b = GraphedStep(fuse_decode, range_guard=range_guard)
 
-    def exchange(self):
-        x_local = self.enc[self.engine.layer]
+        def whole():      # the same step from the functions, for capture_one_graph(): its own encoder outputs and gathered buffer
+            enc = list(engine.encode(make_bevs()))
+            self.exchange(enc[layer])
+            fused = engine.fuse(self.feat_all, trans, num_agent, batch_size, first, count)
+            enc[layer] = fused
+            return engine.decode_heads(enc), fused
+        self._whole_fn = whole
+
+    def exchange(self, x_local=None):
+        x_local = self.enc[self.engine.layer] if x_local is None else x_local
         if self.emulated:
             if self.emulate_collective:                          # the collective's own launch + kernel, on one rank
                 if self._own_gather is None:
@@ -168,9 +177,29 @@ class GraphedAgentStep:
             all_gather_agent_major(x_local, self.group, out=self.feat_all)
 
     def __call__(self):
+        if self.graph_all is not None:
+            return self.graph_all()
         self.graph_a()
         self.exchange()
         return self.graph_b()
+
+    def capture_one_graph(self, range_guard=False):
+        """OPT-IN measurement form (bench.py: DN_AGENT_ONE_GRAPH=1): graph A, the exchange -- the collective included -- and graph B
+        captured as ONE hipGraph, one host call per step instead of three.  Whether RCCL's kernel can be captured depends on the
+        runtime; on failure the three-launch form stays and the error is returned.  Not the default anywhere: a captured
+        collective has never run with N > 1 ranks here."""
+        from .graph import GraphedStep
+        try:
+            with torch.no_grad():
+                # (graph A's outputs live in ITS private pool and graph B's closure reads those: the one-graph form does not
+                # reuse either -- it captures the whole step again from the functions, with its own buffers)
+                g = GraphedStep(self._whole_fn, range_guard=range_guard)
+            self.graph_all = g
+            return None
+        except Exception as e:      # noqa: BLE001 -- a runtime that refuses the capture keeps the three-launch form
+            torch.cuda.synchronize()
+            self.graph_all = None
+            return repr(e)
 
 
 class AgentShard:
