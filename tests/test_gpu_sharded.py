@@ -116,3 +116,9 @@ def test_graphed_emulated_share_equals_unsharded_rows(world):
         torch.cuda.synchronize()
         rows = slice(r * cnt * B, (r + 1) * cnt * B)
         assert torch.equal(got["cls"], want["cls"][rows]) and torch.equal(got["loc"], want["loc"][rows]), (world, r)
+        if r == 0:      # the opt-in one-graph form (graph A + exchange + graph B in ONE capture): the same bits, replayed twice
+            assert share.capture_one_graph() is None
+            for _ in range(2):
+                got1, _ = share()
+            torch.cuda.synchronize()
+            assert torch.equal(got1["cls"], want["cls"][rows]) and torch.equal(got1["loc"], want["loc"][rows]), (world, "one graph")
