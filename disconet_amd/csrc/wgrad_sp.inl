@@ -246,12 +246,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_kernel(const WgradSpArgs
 // j = 0..16: tap columns 0 and 2) and E (columns 2 (ox0 + j), j = 0..15: tap column 1), 9 + 8 pixel pairs per row.  Tap column 0
 // reads O pairs 4 kb .. 4 kb + 3, tap column 1 the same E pairs, tap column 2 is O one entry on: v_alignbit of neighbouring dwords,
 // as tap column 1 of the stride-1 kernel.  Output row r sees patch rows 2 r + ty.  The patch of a tile is ~4 x the stride-1 kernel's
-// per output pixel, so the tiles are short: CB = 64: 1 x 16 outputs (3 patch rows), the four waves = the four quadrants;
+// per output pixel, so the tiles are short: CB = 64: DN_WSP_S2_TH64 x 16 outputs (3 patch rows at 1), the four waves = the four quadrants;
 // CB = 32: 4 x 16 outputs (9 patch rows), one output row per wave, fixed-order LDS sum at the end.  No upsample / concat (the
 // stride-2 layers have one source).
+#ifndef DN_WSP_S2_TH64
+#define DN_WSP_S2_TH64 1          // output rows per tile of the CB = 64 stride-2 kernel; 2 (58 KB of LDS, 255 VGPRs) measured equal: profiles/r06_wgrad_s2_tile.txt
+#endif
 template <int CB>
 struct WspShape2 {
-  static constexpr int TH = CB == 64 ? 1 : 4, TW = 16, PH = 2 * TH + 1;
+  static constexpr int TH = CB == 64 ? DN_WSP_S2_TH64 : 4, TW = 16, PH = 2 * TH + 1;
+  static constexpr int ROWS = CB == 64 ? TH : 1;                    // output rows each wave walks (CB = 32: one row per wave)
   static constexpr int QN = CB / 4;
   static constexpr int RP = 17;                                     // pixel pairs per patch row: 9 of plane O, 8 of plane E
   static constexpr int XPAIRS = PH * RP;
@@ -371,34 +375,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_s2_kernel(const WgradSpA
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
       const unsigned* X = part ? Xl : Xh;
-      u32x4 ah;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ah[i] = Dh[i * PITCH + acol];
-      const half8 ahh = __builtin_bit_cast(half8, ah);
-      half8 alh = ahh;
-      if (part == 0) {
-        u32x4 al;
+      for (int r = 0; r < S::ROWS; ++r) {
+        const int ac = acol + r * 8 * PITCH, bc = bcol + 2 * r * RP * PITCH;
+        u32x4 ah;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) al[i] = Dl[i * PITCH + acol];
-        alh = __builtin_bit_cast(half8, al);
-      }
-#pragma unroll
-      for (int ty = 0; ty < 3; ++ty) {
-        unsigned o[5], ev[4];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) o[i] = X[(ty * RP + i) * PITCH + bcol];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ev[i] = X[(ty * RP + 9 + i) * PITCH + bcol];
-        half8 f[3];
-        f[0] = __builtin_bit_cast(half8, u32x4{o[0], o[1], o[2], o[3]});
-        f[1] = __builtin_bit_cast(half8, u32x4{ev[0], ev[1], ev[2], ev[3]});
-        f[2] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(o[1], o[0], 16), __builtin_amdgcn_alignbit(o[2], o[1], 16),
-                                               __builtin_amdgcn_alignbit(o[3], o[2], 16), __builtin_amdgcn_alignbit(o[4], o[3], 16)});
-#pragma unroll
-        for (int tx = 0; tx < 3; ++tx) acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahh, f[tx], acc[ty * 3 + tx], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) ah[i] = Dh[i * PITCH + ac];
+        const half8 ahh = __builtin_bit_cast(half8, ah);
+        half8 alh = ahh;
         if (part == 0) {
+          u32x4 al;
 #pragma unroll
-          for (int tx = 0; tx < 3; ++tx) acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alh, f[tx], acc[ty * 3 + tx], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) al[i] = Dl[i * PITCH + ac];
+          alh = __builtin_bit_cast(half8, al);
+        }
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          unsigned o[5], ev[4];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) o[i] = X[(ty * RP + i) * PITCH + bc];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ev[i] = X[(ty * RP + 9 + i) * PITCH + bc];
+          half8 f[3];
+          f[0] = __builtin_bit_cast(half8, u32x4{o[0], o[1], o[2], o[3]});
+          f[1] = __builtin_bit_cast(half8, u32x4{ev[0], ev[1], ev[2], ev[3]});
+          f[2] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(o[1], o[0], 16), __builtin_amdgcn_alignbit(o[2], o[1], 16),
+                                                 __builtin_amdgcn_alignbit(o[3], o[2], 16), __builtin_amdgcn_alignbit(o[4], o[3], 16)});
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahh, f[tx], acc[ty * 3 + tx], 0, 0, 0);
+          if (part == 0) {
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alh, f[tx], acc[ty * 3 + tx], 0, 0, 0);
+          }
         }
       }
     }
