@@ -292,10 +292,22 @@ __global__ void bn_update_running_kernel(const float* __restrict__ mean, const f
   if (cc >= c) return;
   float rm = rmean[cc], rv = rvar[cc];
   const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
-  for (int k = 0; k < n_groups; ++k) {
-    const int g = order ? order[k] : k;
-    rm = (1.f - momentum) * rm + momentum * mean[g * c + cc];
-    rv = (1.f - momentum) * rv + momentum * (var[g * c + cc] * unbias);
+  // the recurrence runs in group order; the groups' statistics are fetched eight at a time (one round trip instead of eight)
+  for (int k0 = 0; k0 < n_groups; k0 += 8) {
+    float m[8], v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u < n_groups ? k0 + u : n_groups - 1;
+      const int g = order ? order[k] : k;
+      m[u] = mean[g * c + cc];
+      v[u] = var[g * c + cc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u < n_groups) {
+        rm = (1.f - momentum) * rm + momentum * m[u];
+        rv = (1.f - momentum) * rv + momentum * (v[u] * unbias);
+      }
   }
   rmean[cc] = rm;
   rvar[cc] = rv;
@@ -306,12 +318,60 @@ __global__ void bn_update_running_kernel(const float* __restrict__ mean, const f
 // (lane l adds blocks l, l + 64, ...; xor butterfly): the same sums bit for bit, then the finish arithmetic of the kernel it
 // replaces -- bn_stats_finalize_kernel (+ optionally bn_update_running_kernel: one group), bn_param_grad_kernel (one group),
 // channel_sum_finalize_kernel.
+// DN_FOLD_BATCH: partials a lane fetches before it adds them (in the same order: the same bits).  With one load per iteration a
+// lane's up to 16 partials were 16 L2 round trips in a row: 7-11 us per launch, 72 launches per step (profiles/r06_fold_batch_ab.txt).
+#ifndef DN_FOLD_BATCH
+#define DN_FOLD_BATCH 8
+#endif
 __device__ inline double fold_one(const double* __restrict__ p, int n_blocks, size_t stride, int lane) {
   double t = 0.0;
-  for (int b = lane; b < n_blocks; b += 64) t += p[(size_t)b * stride];
+  int b = lane;
+  if constexpr (DN_FOLD_BATCH > 1) {
+    for (; b + 64 * (DN_FOLD_BATCH - 1) < n_blocks; b += 64 * DN_FOLD_BATCH) {
+      double v[DN_FOLD_BATCH];
+#pragma unroll
+      for (int u = 0; u < DN_FOLD_BATCH; ++u) v[u] = p[(size_t)(b + 64 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < DN_FOLD_BATCH; ++u) t += v[u];
+    }
+  }
+  for (; b < n_blocks; b += 64) t += p[(size_t)b * stride];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
   return t;
+}
+// two quantities of one channel (p0, p1: the same blocks): both fetches of a batch in flight together, each sum in fold_one's order
+__device__ inline void fold_two(const double* __restrict__ p0, const double* __restrict__ p1, int n_blocks, size_t stride, int lane,
+                                double& t0, double& t1) {
+  double a = 0.0, c = 0.0;
+  int b = lane;
+  if constexpr (DN_FOLD_BATCH > 1) {
+    for (; b + 64 * (DN_FOLD_BATCH - 1) < n_blocks; b += 64 * DN_FOLD_BATCH) {
+      double v[DN_FOLD_BATCH], w[DN_FOLD_BATCH];
+#pragma unroll
+      for (int u = 0; u < DN_FOLD_BATCH; ++u) {
+        v[u] = p0[(size_t)(b + 64 * u) * stride];
+        w[u] = p1[(size_t)(b + 64 * u) * stride];
+      }
+#pragma unroll
+      for (int u = 0; u < DN_FOLD_BATCH; ++u) {
+        a += v[u];
+        c += w[u];
+      }
+    }
+  }
+  for (; b < n_blocks; b += 64) {
+    const double v = p0[(size_t)b * stride], w = p1[(size_t)b * stride];
+    a += v;
+    c += w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    c += __shfl_xor(c, o, 64);
+  }
+  t0 = a;
+  t1 = c;
 }
 __global__ void __launch_bounds__(256)
 fold_stats_finish_kernel(const double* __restrict__ part, int n_blocks, int c, int n_groups, long norm_rows, double* __restrict__ sums,
@@ -321,7 +381,8 @@ fold_stats_finish_kernel(const double* __restrict__ part, int n_blocks, int c, i
   if (idx >= n_groups * c) return;
   const int g = idx / c, cc = idx % c;
   const double* p = part + (size_t)g * n_blocks * 2 * c + cc;
-  const double t0 = fold_one(p, n_blocks, 2 * c, lane), t1 = fold_one(p + c, n_blocks, 2 * c, lane);
+  double t0, t1;
+  fold_two(p, p + c, n_blocks, 2 * c, lane, t0, t1);
   if (lane == 0) {
     sums[(size_t)g * 2 * c + cc] = t0;
     sums[(size_t)g * 2 * c + c + cc] = t1;
@@ -342,7 +403,8 @@ fold_param_grad_kernel(const double* __restrict__ part, int n_blocks, int c, dou
                        float* __restrict__ dbeta, int accumulate) {      // one group
   const int cc = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (cc >= c) return;
-  const double t0 = fold_one(part + cc, n_blocks, 2 * c, lane), t1 = fold_one(part + c + cc, n_blocks, 2 * c, lane);
+  double t0, t1;
+  fold_two(part + cc, part + c + cc, n_blocks, 2 * c, lane, t0, t1);
   if (lane == 0) {
     sums[cc] = t0;
     sums[c + cc] = t1;
@@ -647,7 +709,21 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sums, int n_grou
   const int cc = blockIdx.x * blockDim.x + threadIdx.x;
   if (cc >= c) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int g = 0; g < n_groups; ++g) {
+  int g = 0;
+  for (; g + 7 < n_groups; g += 8) {      // group order, eight groups' sums in flight
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = sums[(size_t)(g + u) * 2 * c + cc];
+      b[u] = sums[(size_t)(g + u) * 2 * c + c + cc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s1 += a[u];
+      s2 += b[u];
+    }
+  }
+  for (; g < n_groups; ++g) {
     s1 += sums[(size_t)g * 2 * c + cc];
     s2 += sums[(size_t)g * 2 * c + c + cc];
   }
