@@ -280,6 +280,138 @@ warp_gather1_kernel(const float* __restrict__ d_out1, const float* __restrict__ 
   }
 }
 
+// ---- lane-parallel candidate search of the two gathers (round 6).  The kernels above evaluate their 16 / 25 candidate pixels one
+// after the other with wave-uniform arithmetic -- 64 lanes computing the same tap set, ~100 evaluations per output pixel in pass 1:
+// VALU-bound at 228 + 92 us per step for 32 x 32 x 256 maps.  Here lane k evaluates candidate k (the same expressions: pass1_taps /
+// pass2_taps of the same integers), a ballot gives the hits, and the hits are added in ascending candidate order -- the order of the
+// loops above -- four rows in flight at a time.  Deterministic like them; against them the sums agree to a few ulp, not bit for bit
+// (the compiler contracts the tap arithmetic per kernel: weights differ in their last bit).  PIXW: output pixels per wave.
+#ifndef DN_GATHER_PIXW
+#define DN_GATHER_PIXW 1
+#endif
+constexpr int GATHER_PIXW = DN_GATHER_PIXW;
+struct GatherHits {
+  unsigned long long mask;
+  float wt;
+  int off;
+};
+// adds the hit rows (row offset `off`, weight `wt` of the lanes in `mask`, ascending) of `gin` into acc
+__device__ inline void gather_add_hits(GatherHits hs, const float* __restrict__ gin, int c, int c4n, int lane, f32x4 (&acc)[4]) {
+  while (hs.mask) {
+    int n = 0;
+    float wk[4];
+    int ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (hs.mask) {
+        const int kk = __builtin_ctzll(hs.mask);
+        hs.mask &= hs.mask - 1;
+        wk[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hs.wt), kk));
+        ok[j] = __builtin_amdgcn_readlane(hs.off, kk);
+        n = j + 1;
+      } else {
+        wk[j] = 0.f;
+        ok[j] = 0;
+      }
+    }
+    f32x4 v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < n) {                                   // wave-uniform
+        const float* g = gin + (size_t)ok[j] * c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (lane + 64 * i < c4n) v[j][i] = ld4(g + 4 * (lane + 64 * i));
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < n) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (lane + 64 * i < c4n) acc[i] += v[j][i] * wk[j];
+      }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+warp_gather2_lanes_kernel(const float* __restrict__ d_warped, const float* __restrict__ poses, int h, int w,
+                          int c, float* __restrict__ d_out1) {
+  const int wi = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4n = c >> 2, hw = h * w;
+  const PoseTerms t = pose_terms(poses + 16 * (size_t)wi);
+  const int fsx = (int)floorf(t.x_trans * w * 0.5f), fsy = (int)floorf(t.y_trans * h * 0.5f);
+  const float* gin = d_warped + (size_t)wi * hw * c;
+  const int k = lane & 15, dy = (k >> 2) - 2, dx = (k & 3) - 2;      // candidate k of the scalar kernel's (dy, dx) loops
+  for (int pp = 0; pp < GATHER_PIXW; ++pp) {
+    const int q = (blockIdx.x * 4 + wave) * GATHER_PIXW + pp;
+    if (q >= hw) break;
+    const int qx = q % w, qy = q / w;
+    f32x4 acc[4];                                  // c <= 1024
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int py = qy - fsy + dy, px = qx - fsx + dx;
+    bool hit = lane < 16 && py >= 0 && py < h && px >= 0 && px < w;
+    const Bilinear b = pass2_taps(t, px, py, w, h);
+    const int ox = qx - b.x0, oy = qy - b.y0;
+    hit = hit && ox >= 0 && ox <= 1 && oy >= 0 && oy <= 1;
+    GatherHits hs;
+    hs.wt = oy ? (ox ? b.w_se : b.w_sw) : (ox ? b.w_ne : b.w_nw);
+    hs.off = py * w + px;
+    hs.mask = __ballot(hit);
+    gather_add_hits(hs, gin, c, c4n, lane, acc);
+    float* out = d_out1 + ((size_t)wi * hw + q) * c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < c4n) *reinterpret_cast<f32x4*>(out + 4 * (lane + 64 * i)) = acc[i];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+warp_gather1_lanes_kernel(const float* __restrict__ d_out1, const float* __restrict__ poses,
+                          const int32_t* __restrict__ src_image, int n_warps, int h, int w, int c,
+                          float* __restrict__ d_src) {
+  const int m = blockIdx.y;                       // source image
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4n = c >> 2, hw = h * w;
+  const int k = lane < 25 ? lane : 24, dy = k / 5 - 2, dx = k % 5 - 2;   // candidate k of the scalar kernel's (dy, dx) loops
+  for (int pp = 0; pp < GATHER_PIXW; ++pp) {
+    const int r = (blockIdx.x * 4 + wave) * GATHER_PIXW + pp;
+    if (r >= hw) break;
+    const int rx = r % w, ry = r / w;
+    const float rbx = (2.f * rx + 1.f) / w - 1.f, rby = (2.f * ry + 1.f) / h - 1.f;
+    float* out = d_src + ((size_t)m * hw + r) * c;
+    f32x4 acc[4];                                  // c <= 1024
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[i] = (lane + 64 * i < c4n) ? ld4(out + 4 * (lane + 64 * i)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int w0 = 0; w0 < n_warps; w0 += 64) {
+      unsigned long long wmask = __ballot(w0 + lane < n_warps && src_image[w0 + lane < n_warps ? w0 + lane : 0] == m);
+      while (wmask) {                              // the warps of this source image, ascending
+        const int wi = w0 + __builtin_ctzll(wmask);
+        wmask &= wmask - 1;
+        const PoseTerms t = pose_terms(poses + 16 * (size_t)wi);
+        const float det = t.r00 * t.r11 - t.r01 * t.r10;
+        const float qbx = (t.r11 * rbx - t.r01 * rby) / det, qby = (-t.r10 * rbx + t.r00 * rby) / det;
+        const int cx = (int)rintf(((qbx + 1.f) * w - 1.f) * 0.5f), cy = (int)rintf(((qby + 1.f) * h - 1.f) * 0.5f);
+        const int qy = cy + dy, qx = cx + dx;
+        bool hit = lane < 25 && qy >= 0 && qy < h && qx >= 0 && qx < w;
+        const Bilinear b = pass1_taps(t, qx, qy, w, h);
+        const int ox = rx - b.x0, oy = ry - b.y0;
+        hit = hit && ox >= 0 && ox <= 1 && oy >= 0 && oy <= 1;
+        GatherHits hs;
+        hs.wt = oy ? (ox ? b.w_se : b.w_sw) : (ox ? b.w_ne : b.w_nw);
+        hs.off = qy * w + qx;
+        hs.mask = __ballot(hit);
+        gather_add_hits(hs, d_out1 + (size_t)wi * hw * c, c, c4n, lane, acc);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < c4n) *reinterpret_cast<f32x4*>(out + 4 * (lane + 64 * i)) = acc[i];
+  }
+}
+
 // ---- tile-shared form of the same two passes.  Every output pixel p of an 8x8 tile reads the four
 // rotated-map pixels q = (x0(p) + {0,1}, y0(p) + {0,1}); the translation is one offset per (ego, neighbour)
 // pair, so the tile's q pixels form a (T+1)^2 block (T+2 allowed for a rounding split of floor()).  The
@@ -482,9 +614,17 @@ extern "C" int dn_warp_backward(const float* d_warped, const float* poses, const
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((h * w + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK, n_warps);
   if (rigid && h == w) {
-    hipLaunchKernelGGL(warp_gather2_kernel, grid, dim3(256), 0, s, d_warped, poses, h, w, c, scratch);
-    hipLaunchKernelGGL(warp_gather1_kernel, dim3(grid.x, n_src_images), dim3(256), 0, s, scratch, poses,
-                       src_image, n_warps, h, w, c, d_src);
+    static const bool legacy = [] { const char* e = getenv("DN_WARP_GATHER_LEGACY"); return e && e[0] == '1'; }();
+    if (legacy) {     // round 5's one-candidate-at-a-time kernels (tests, A/B runs)
+      hipLaunchKernelGGL(warp_gather2_kernel, grid, dim3(256), 0, s, d_warped, poses, h, w, c, scratch);
+      hipLaunchKernelGGL(warp_gather1_kernel, dim3(grid.x, n_src_images), dim3(256), 0, s, scratch, poses,
+                         src_image, n_warps, h, w, c, d_src);
+    } else {
+      const int gx = (h * w + 4 * GATHER_PIXW - 1) / (4 * GATHER_PIXW);
+      hipLaunchKernelGGL(warp_gather2_lanes_kernel, dim3(gx, n_warps), dim3(256), 0, s, d_warped, poses, h, w, c, scratch);
+      hipLaunchKernelGGL(warp_gather1_lanes_kernel, dim3(gx, n_src_images), dim3(256), 0, s, scratch, poses,
+                         src_image, n_warps, h, w, c, d_src);
+    }
     return dn::check_launch("warp_gather kernels");
   }
   if (dn::zero_fill(scratch, sizeof(float) * (size_t)n_warps * h * w * c, s) != hipSuccess)

@@ -606,6 +606,52 @@ def test_warp_list_and_backward_match_autograd(rigid, c):
         assert torch.equal(again, d_src)
 
 
+_WARP_AB_SCRIPT = """
+import sys
+sys.path.insert(0, %r)
+import math, torch
+from disconet_amd import train_ops
+out = []
+for n_src, n, hw, c, seed in ((4, 7, 32, 256, 1), (20, 80, 32, 256, 2), (3, 70, 16, 1024, 3), (2, 5, 24, 64, 4)):
+    g = torch.Generator().manual_seed(seed)
+    poses = torch.zeros(n, 4, 4)
+    for k in range(n):
+        a = float(torch.rand((), generator=g)) * 2 * math.pi
+        poses[k] = torch.eye(4)
+        poses[k, 0, 0], poses[k, 0, 1], poses[k, 1, 0], poses[k, 1, 1] = math.cos(a), -math.sin(a), math.sin(a), math.cos(a)
+        poses[k, 0, 3], poses[k, 1, 3] = (torch.rand(2, generator=g) - 0.5) * 40
+    poses[0] = torch.eye(4)                                  # taps on the grid: weights of exactly 0 and 1
+    src = torch.randint(0, n_src, (n,), generator=g, dtype=torch.int32)
+    d_warped = torch.randn(n, hw, hw, c, generator=g).cuda()
+    d_src = torch.randn(n_src, hw, hw, c, generator=g).cuda()
+    train_ops.warp_backward(d_warped, poses.cuda(), src.cuda(), d_src, rigid=True)
+    out.append(d_src.cpu())
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_lane_parallel_warp_gathers_agree_with_the_scalar_kernels(tmp_path):
+    """dn_warp_backward's rigid form: the kernels whose lanes evaluate one candidate pixel each (round 6) against the ones that walk
+    the candidates one after the other (DN_WARP_GATHER_LEGACY=1, a child process: the switch is read once) -- the same hits added in
+    the same order; the tap weights may differ in their last bit (the compiler contracts the pose arithmetic per kernel), so the
+    gradients agree to a few ulp, not bit for bit; 80 warps of 20 source images (the detector's batch), more warps than lanes (two
+    ballots), 1024 channels (four rows per lane), a map that is no multiple of the pixels per workgroup."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    files = []
+    for legacy in ("0", "1"):
+        f = str(tmp_path / ("warp_%s.pt" % legacy))
+        subprocess.run([sys.executable, "-c", _WARP_AB_SCRIPT % ROOT, f], check=True, env=dict(os.environ, DN_WARP_GATHER_LEGACY=legacy),
+                       timeout=600)
+        files.append(torch.load(f))
+    assert len(files[0]) == len(files[1]) == 4
+    for a, b in zip(*files):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
 def test_fuse_combine_forward_backward():
     from disconet_amd import train_ops
     g = torch.Generator().manual_seed(12)
