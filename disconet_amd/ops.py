@@ -17,8 +17,15 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _stream_handle():
+    """the current device's current stream as an integer handle -- torch's raw getter: torch.cuda.current_stream() builds a Stream
+    object behind three device-index lookups (one of them an environment read), ~3 us of the ~15 us a launch costs on the host,
+    and the training step is launch-bound on the host through its first hundred launches (profiles/r06_train_gap_sites.txt)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_stream_handle())
 
 
 def _need_gpu(*tensors):

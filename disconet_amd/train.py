@@ -78,7 +78,46 @@ def fusion_call_counts(agents, only_v2i, num_agent_cpu, B):
 _LIST_CACHE = {}      # (agents, only_v2i, live counts, B, device, ego range) -> the index tensors of fusion_lists (they do not depend on the poses)
 
 
-def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev, ego_first=0, ego_count=None):
+class _DeviceFlag:
+    """A boolean computed on the device whose host copy is read when it is first asked for: the copy into pinned memory and an
+    event are queued behind the kernels that compute it, bool() waits for THAT event -- not for whatever the stream holds by
+    then (an .item() where the flag is used would drain the whole stream; an .item() where it is computed stalls the launch
+    queue at the start of the step, when the GPU is idle and waiting for its first conv: profiles/r06_train_gap_sites.txt)."""
+
+    def __init__(self, flag):
+        self._host = torch.empty(1, dtype=torch.bool, pin_memory=True)
+        self._host.copy_(flag.reshape(1), non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self._value = None
+
+    def __bool__(self):
+        if self._value is None:
+            self._event.synchronize()
+            self._value = bool(self._host[0])
+        return self._value
+
+
+def fusion_poses(out, trans):
+    """adds the warps' poses (gathered from trans [B, A, A, 4, 4]) and their rigidity to the lists of fusion_lists(poses=False)"""
+    nw, bi, dev = out["n_warps"], out.pop("_poses_idx"), trans.device
+    if nw:
+        poses = trans[bi[:, 0], bi[:, 1], bi[:, 2]].contiguous()
+    else:
+        poses = torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
+    # rigid poses (rotation + translation: what V2X agents' relative poses are) take the deterministic
+    # gather form of the warp backward
+    rigid = True
+    if nw:
+        R = poses[:, :2, :2].double()
+        eye = torch.eye(2, dtype=torch.float64, device=R.device)
+        flag = (R @ R.transpose(1, 2) - eye).abs().max() < 1e-3
+        rigid = _DeviceFlag(flag) if flag.is_cuda else bool(flag.item())
+    out["poses"], out["rigid"] = poses, rigid
+    return out
+
+
+def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev, ego_first=0, ego_count=None, poses=True):
     """Index lists of the DiscoGraph fusion for one batch, in the reference's loop order
     (upstream DiscoNet.forward: for b, for ego i < n_b: [ego] + [warp(j -> i) for j < n_b, j != i],
     honouring only_v2i).  Images are agent-major (agent * B + b); maps / pairs = own maps then warps.
@@ -90,7 +129,8 @@ def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev, ego_first=0, eg
 
     The index tensors depend on the live-agent counts only, not on the poses: they are built (a dozen small host -> device
     copies) once per distinct (counts, B, ego range) and cached (round 6: the step's start was the GPU's longest idle gap);
-    every call gathers the poses and tests them for rigidity."""
+    every call gathers the poses and tests them for rigidity -- poses=False leaves that to a later fusion_poses(lists, trans)
+    (the training forward queues its encoder first: the GPU is idle until the first conv arrives)."""
     key = (agents, bool(only_v2i), tuple(int(v) for v in num_agent_cpu[:B]), B, str(dev), ego_first, ego_count)
     hit = _LIST_CACHE.get(key)
     if hit is None:
@@ -99,20 +139,7 @@ def fusion_lists(agents, only_v2i, trans, num_agent_cpu, B, dev, ego_first=0, eg
         hit = _fusion_index_lists(agents, only_v2i, num_agent_cpu, B, dev, ego_first, ego_count)
         _LIST_CACHE[key] = hit
     out = dict(hit)
-    nw, bi = out["n_warps"], out.pop("_poses_idx")
-    if nw:
-        poses = trans[bi[:, 0], bi[:, 1], bi[:, 2]].contiguous()
-    else:
-        poses = torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
-    # rigid poses (rotation + translation: what V2X agents' relative poses are) take the deterministic
-    # gather form of the warp backward
-    rigid = True
-    if nw:
-        R = poses[:, :2, :2].double()
-        eye = torch.eye(2, dtype=torch.float64, device=R.device)
-        rigid = bool(((R @ R.transpose(1, 2) - eye).abs().max() < 1e-3).item())
-    out["poses"], out["rigid"] = poses, rigid
-    return out
+    return fusion_poses(out, trans) if poses else out
 
 
 def _fusion_index_lists(agents, only_v2i, num_agent_cpu, B, dev, ego_first=0, ego_count=None):
@@ -549,10 +576,10 @@ class TrainEngine:
     # ------------------------------------------------------------------
     # fusion lists (host side, from num_agent / only_v2i)
     # ------------------------------------------------------------------
-    def _fusion_lists(self, trans, num_agent_cpu, B, dev):
+    def _fusion_lists(self, trans, num_agent_cpu, B, dev, poses=True):
         sh = self.shard
         return fusion_lists(self.model.agent_num, self.model.only_v2i, trans, num_agent_cpu, B, dev,
-                            ego_first=sh.first if sh is not None else 0, ego_count=sh.count if sh is not None else None)
+                            ego_first=sh.first if sh is not None else 0, ego_count=sh.count if sh is not None else None, poses=poses)
 
     # ------------------------------------------------------------------
     # forward (training mode)
@@ -589,7 +616,7 @@ class TrainEngine:
         self._attach_sp(x)
         trans = trans_matrices.to(device=dev, dtype=torch.float32).contiguous()
         self._num_agent_cpu, self._batch = num_agent_tensor[:, 0].cpu(), B
-        F = self._fusion_lists(trans, self._num_agent_cpu, B, dev)
+        F = self._fusion_lists(trans, self._num_agent_cpu, B, dev, poses=False)     # the poses: once the encoder is queued
         self.F = F
 
         # encoder: groups of layers, the last one of group k yields e[k]; the maps of the fusion layer
@@ -613,6 +640,7 @@ class TrainEngine:
         for k in range(lay_k + 1):
             a = group(k, a)
             e.append(a)
+        fusion_poses(F, trans)
         # the encoder levels above the exchanged one could run beside the fusion block on a second
         # stream (self.overlap_streams, default off and meant to stay off: no kernel-source rule rules out
         # the co-residency defect of DESIGN.md 3.6 (B)), else in stream order
@@ -1029,7 +1057,8 @@ class CoDetModule:
         tests, and the calibration pass of dgrad_math = "sp" (the first backward measures the gradient maps' lifts)"""
         bev_seq = data["bev_seq"]
         eng = self.engine
-        self.model.train()
+        if not self.model.training:          # (Module.train() walks every submodule: 0.2 ms of host time with the GPU idle)
+            self.model.train()
         with torch.no_grad():
             res = eng.forward(bev_seq, data["trans_matrices"], data["num_agent"], batch_size)
             code = res["loc"].shape[-1]

@@ -12,13 +12,13 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .ops import _need_gpu, _ptr, _stream, conv_desc
+from .ops import _need_gpu, _ptr, _stream, _stream_handle, conv_desc
 
 
 def _ws(device, nbytes, cache={}):
     """grow-only scratch buffer per (device, stream): two streams may run backward kernels side by
     side (train.py), each needs its own partial-sum space"""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream_handle())       # (the launches that use it go to the current device's current stream)
     buf = cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
