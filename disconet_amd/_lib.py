@@ -25,6 +25,12 @@ class ConvDesc(Structure):
         "ld0", "ld1", "ldo", "math")]
 
 
+class PackJob(Structure):
+    """struct dn_pack_job"""
+    _fields_ = [("desc", ConvDesc), ("weight", c_void_p), ("packed", c_void_p), ("mode", c_int32), ("cin_total", c_int32),
+                ("ci_first", c_int32), ("n_in", c_int32), ("wmul", c_float), ("reserved", c_int32)]
+
+
 class Post1x1Desc(Structure):
     """struct dn_post1x1_desc"""
     _fields_ = [(n, c_int32) for n in ("c_out2", "relu2", "split", "ldo_a", "ldo_b", "block_diag")]
@@ -77,6 +83,9 @@ SIGNATURES = {
     "dn_sp_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dn_spconv_packed_weight_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "dn_spconv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_float, c_void_p, c_void_p]),
+    "dn_spconv_pack_multi_table_bytes": (c_size_t, [c_int]),
+    "dn_spconv_pack_multi_prepare": (c_int, [POINTER(PackJob), c_int, c_void_p, POINTER(c_int)]),
+    "dn_spconv_pack_weights_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "dn_spconv2d": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p]),
     "dn_spconv_ks_supported": (c_int, [POINTER(ConvDesc), c_int]),

@@ -1349,6 +1349,65 @@ __global__ void sp_pack_weights_kernel(const float* __restrict__ w, unsigned cha
   }
 }
 
+// ---- every plain-layout pack of a training step in ONE launch (dn_spconv_pack_weights_multi).  A job = one call of
+// sp_pack_weights_kernel whose weight tensor W[n][ci][tap] is given by a SOURCE VIEW of a forward weight tensor `w`:
+//   mode 0: W = w                                                              (the layer's own forward)
+//   mode 1: W[n][ci][t] = w[ci][ci_first + n][taps - 1 - t]                    (dn_conv_dgrad_weights: flipped, transposed cut)
+//   mode 2: W[k n_in + j][ci][v] = class (py, px) = (k / 2, k % 2) of dn_conv_dgrad_class_weights over columns ci_first + j
+// -- the values the two-launch forms write through a temporary, so the packed images are the same bytes.  A workgroup finds its
+// job from the table's first-block column and walks that job's pieces with the single launch's grid-stride loop.
+struct PackJob {
+  const float* w;
+  unsigned char* out;
+  int c_out, c_in, taps, cout_pad, nchunks, mode, cin_total, ci_first, n_in, block_first, n_blocks, pad_;
+  float wmul, padf_;
+  long total;
+};
+static_assert(sizeof(PackJob) == 80, "dn_spconv_pack_multi_table_bytes");
+
+__device__ inline float pack_job_elem(const PackJob& j, int n, int ci, int tap) {
+  if (j.mode == 0) return j.w[((size_t)n * j.c_in + ci) * j.taps + tap];
+  if (j.mode == 1) return j.w[((size_t)ci * j.cin_total + j.ci_first + n) * j.taps + (j.taps - 1 - tap)];
+  const int k = n / j.n_in, jj = n - k * j.n_in, py = k >> 1, px = k & 1, vy = tap / 3, vx = tap - 3 * vy;
+  auto src_tap = [](int p, int vv) { return p == 0 ? (vv == 1 ? 1 : -1) : (vv == 1 ? 2 : vv == 2 ? 0 : -1); };
+  const int ty = src_tap(py, vy), tx = src_tap(px, vx);
+  return (ty < 0 || tx < 0) ? 0.f : j.w[((size_t)ci * j.cin_total + j.ci_first + jj) * 9 + ty * 3 + tx];
+}
+
+__global__ void __launch_bounds__(256) sp_pack_weights_multi_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
+  __shared__ PackJob job;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n_jobs - 1;                 // the last job whose first block is <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].block_first <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    job = jobs[lo];
+  }
+  __syncthreads();
+  const PackJob& j = job;
+  const int vb = blockIdx.x - j.block_first;
+  for (long idx = vb * (long)blockDim.x + threadIdx.x; idx < j.total; idx += (long)j.n_blocks * blockDim.x) {
+    long r = idx;
+    const int n = r % j.cout_pad; r /= j.cout_pad;
+    const int oct = r % 2; r /= 2;
+    const int tap = r % j.taps;
+    const int cg = r / j.taps;
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ci = cg * 16 + oct * 8 + e;
+      float v = (n < j.c_out && ci < j.c_in) ? pack_job_elem(j, n, ci, tap) * j.wmul : 0.f;
+      v = fminf(fmaxf(v, -65504.f), 65504.f);
+      hi[e] = (_Float16)v;
+      lo[e] = (_Float16)(v - (float)hi[e]);
+    }
+    unsigned char* d = j.out + ((((size_t)cg * j.taps + tap) * 4 + oct) * j.cout_pad + n) * 16;
+    *reinterpret_cast<half8*>(d) = hi;
+    *reinterpret_cast<half8*>(d + (size_t)2 * j.cout_pad * 16) = lo;
+  }
+}
+
 // w2 [c_out2][c_in2] * wmul -> [nt 2][ks 4][part 2][h 2][n 32] pieces (A-operand fragments)
 __global__ void sp_pack_post_kernel(const float* __restrict__ w2, unsigned char* __restrict__ out,
                                     int c_out2, int c_in2, float wmul) {
@@ -1681,6 +1740,50 @@ extern "C" int dn_spconv_pack_weights(const dn_conv_desc* d, const float* weight
                      weight_oihw, (unsigned char*)packed, d->c_out, d->c0 + d->c1, taps, cp, nch, wmul,
                      total);
   return dn::check_launch("sp_pack_weights_kernel");
+}
+
+extern "C" size_t dn_spconv_pack_multi_table_bytes(int n_jobs) { return n_jobs > 0 ? sizeof(PackJob) * (size_t)n_jobs : 0; }
+
+extern "C" int dn_spconv_pack_multi_prepare(const dn_pack_job* jobs, int n_jobs, void* table_host, int* total_blocks) {
+  DN_REQUIRE(jobs && table_host && total_blocks && n_jobs > 0, "spconv pack multi: null pointer / no jobs");
+  PackJob* t = static_cast<PackJob*>(table_host);
+  int first = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const dn_pack_job& q = jobs[i];
+    const dn_conv_desc* d = &q.desc;
+    if (int rc = validate(d)) return rc;
+    DN_REQUIRE(q.weight && q.packed, "spconv pack multi: job %d: null pointer", i);
+    DN_REQUIRE(d->c1 == 0 || d->c0 % 16 == 0, "spconv pack multi: job %d: concat needs c0 %% 16 == 0", i);
+    if (up_mode(*d) != 0)
+      return dn::fail(DN_ERR_UNSUPPORTED, "spconv pack multi: job %d is packed tap-merged (dn_spconv_pack_weights only)", i);
+    const int c_in = d->c0 + d->c1, taps = d->ksize * d->ksize;
+    DN_REQUIRE(q.mode >= 0 && q.mode <= 2, "spconv pack multi: job %d: mode %d", i, q.mode);
+    if (q.mode == 1)
+      DN_REQUIRE(q.ci_first >= 0 && q.ci_first + d->c_out <= q.cin_total, "spconv pack multi: job %d: columns %d + %d of %d", i,
+                 q.ci_first, d->c_out, q.cin_total);
+    if (q.mode == 2)
+      DN_REQUIRE(taps == 9 && q.n_in > 0 && d->c_out == 4 * q.n_in && q.ci_first >= 0 && q.ci_first + q.n_in <= q.cin_total,
+                 "spconv pack multi: job %d: class form needs a 3x3 layer of 4 * n_in outputs", i);
+    PackJob& j = t[i];
+    j.w = q.weight;
+    j.out = static_cast<unsigned char*>(q.packed);
+    j.c_out = d->c_out; j.c_in = c_in; j.taps = taps; j.cout_pad = cout_pad_of(d->c_out); j.nchunks = packed_chunks(*d);
+    j.mode = q.mode; j.cin_total = q.cin_total; j.ci_first = q.ci_first; j.n_in = q.n_in;
+    j.wmul = q.wmul; j.pad_ = 0; j.padf_ = 0.f;
+    j.total = (long)j.nchunks * taps * 2 * j.cout_pad;
+    j.n_blocks = (int)((j.total + 255) / 256 < 4096 ? (j.total + 255) / 256 : 4096);      // the single launch's grid
+    j.block_first = first;
+    first += j.n_blocks;
+  }
+  *total_blocks = first;
+  return DN_OK;
+}
+
+extern "C" int dn_spconv_pack_weights_multi(const void* table_device, int n_jobs, int total_blocks, void* stream) {
+  DN_REQUIRE(table_device && n_jobs > 0 && total_blocks > 0, "spconv pack multi: bad arguments");
+  hipLaunchKernelGGL(sp_pack_weights_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const PackJob*>(table_device), n_jobs);
+  return dn::check_launch("sp_pack_weights_multi_kernel");
 }
 
 extern "C" size_t dn_sp_post1x1_packed_bytes(void) { return 2 * 4 * 2 * 2 * 32 * 16; }

@@ -432,6 +432,58 @@ def sp_pack_conv_weights(d, weight, wmul=None):
     return packed, wmul
 
 
+class SpPackSet:
+    """Many plain-layout weight packs as ONE launch (dn_spconv_pack_weights_multi).  A job = (conv descriptor, forward weight
+    tensor, mode, cin_total, ci_first, n_in) -- include/disconet_hip.h :: dn_pack_job; its packed image lives in a buffer this
+    object owns.  run(wmuls) packs every job from the weights as they are now."""
+
+    def __init__(self, jobs, device):
+        lib = _lib.load()
+        self.n = len(jobs)
+        self._jobs = (_lib.PackJob * self.n)()
+        self.buffers = []
+        self._keep = []
+        for q, (d, weight, mode, cin_total, ci_first, n_in) in zip(self._jobs, jobs):
+            _need_gpu(weight)
+            if weight.dtype != torch.float32 or not weight.is_contiguous():
+                raise _lib.DnError("SpPackSet: weights must be contiguous float32 tensors (the views are read in place)")
+            nbytes = lib.dn_spconv_packed_weight_bytes(ctypes.byref(d))
+            if nbytes == 0:
+                check(-1, "dn_spconv_packed_weight_bytes")
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.buffers.append(buf)
+            self._keep.append(weight)
+            q.desc, q.weight, q.packed = d, weight.data_ptr(), buf.data_ptr()
+            q.mode, q.cin_total, q.ci_first, q.n_in, q.wmul = int(mode), int(cin_total), int(ci_first), int(n_in), 1.0
+        self._host = torch.empty(lib.dn_spconv_pack_multi_table_bytes(self.n), dtype=torch.uint8).pin_memory()
+        self._table = torch.empty(self._host.numel(), dtype=torch.uint8, device=device)
+        self._wmuls, self._blocks = None, 0
+
+    def supported(d):
+        """is the layer `d` packed in the plain layout (not tap-merged)?  -- what a job must be"""
+        probe = (_lib.PackJob * 1)()
+        probe[0].desc, probe[0].weight, probe[0].packed, probe[0].wmul = d, 16, 16, 1.0
+        host = (ctypes.c_ubyte * int(_lib.load().dn_spconv_pack_multi_table_bytes(1)))()
+        blocks = ctypes.c_int(0)
+        return _lib.load().dn_spconv_pack_multi_prepare(probe, 1, host, ctypes.byref(blocks)) == 0
+    supported = staticmethod(supported)
+
+    def run(self, wmuls):
+        lib = _lib.load()
+        wmuls = [float(v) for v in wmuls]
+        if wmuls != self._wmuls:
+            if self._wmuls is not None:
+                torch.cuda.current_stream().synchronize()      # the copy of the previous image out of the pinned buffer
+            for q, v in zip(self._jobs, wmuls):
+                q.wmul = v
+            blocks = ctypes.c_int(0)
+            check(lib.dn_spconv_pack_multi_prepare(self._jobs, self.n, ctypes.c_void_p(self._host.data_ptr()), ctypes.byref(blocks)),
+                  "dn_spconv_pack_multi_prepare")
+            self._table.copy_(self._host, non_blocking=True)
+            self._wmuls, self._blocks = wmuls, blocks.value
+        check(lib.dn_spconv_pack_weights_multi(_ptr(self._table), self.n, self._blocks, _stream()), "dn_spconv_pack_weights_multi")
+
+
 _KS_WORKSPACE_CAP = 32 << 20      # bytes of partial sums per K-sliced launch (the launcher splits fewer tiles beyond)
 
 

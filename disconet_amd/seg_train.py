@@ -61,6 +61,7 @@ class SegTrainEngine(TrainEngine):
         """x: [A*B, H, W, n_channels] float32 NHWC (dense).  -> logits [A*B, H, W, n_classes] NHWC"""
         self.check_aliasing()
         self.generation += 1
+        self._pack_multi()
         m, L = self.model, self.L
         A, B = m.agent_num, batch_size
         n, H, W = x.shape[0], x.shape[1], x.shape[2]

@@ -48,6 +48,16 @@ class _Layer:
         self.ctx = None
 
 
+def _desc_key(d):
+    """a conv descriptor's fields as a tuple (part of the key of a packed weight form: the image follows the layer's shape)"""
+    return tuple(getattr(d, f) for f, _ in d._fields_)
+
+
+def _desc_copy(d):
+    """a private copy of a conv descriptor (launch wrappers write into theirs: math, leading dimensions)"""
+    return type(d).from_buffer_copy(d)
+
+
 def _param_order(model):
     """flat-buffer order: the two heads' first convs / BNs adjacent (they run as one 64-channel
     layer), then everything else in module order"""
@@ -325,7 +335,7 @@ class TrainEngine:
             # the backward's weight / data gradients read those)
             ds = ops.conv_desc(n, h_in, w_in, c0, c_out, ksize, stride, False, c1=c1, up0=up0)
             wmul = self._wmul_of(w)
-            packed, _ = ops.sp_pack_conv_weights(ds, w, wmul)
+            packed = self._packed_form(w, 0, ds, 0, 0, lambda: ops.sp_pack_conv_weights(ds, w, wmul)[0])
             if out is None:
                 ho, wo = ops.conv_out_hw(ds)
                 out = torch.empty((n, ho, wo, c_out), dtype=torch.float32, device=dev)
@@ -520,26 +530,29 @@ class TrainEngine:
             # form runs, on an engine 16 x as fast per MFMA -- and dz is read once instead of four times.
             n_in = (w4.shape[1] - ci_first) if c_in is None else c_in
             dev = dz.device
-            wt = torch.empty((4 * n_in, d.c_out, 3, 3), dtype=torch.float32, device=dev)
-            for py in (0, 1):
-                for px in (0, 1):
-                    k = py * 2 + px
-                    T.dgrad_class_weights(w4, py, px, ci_first, n_in, out=wt[k * n_in:(k + 1) * n_in])
             dd = ops.conv_desc(d.n_images, d.h_in // 2, d.w_in // 2, d.c_out, 4 * n_in, 3, 1, False)
             wmul = self._wmul_of(w)
-            packed, _ = ops.sp_pack_conv_weights(dd, wt, wmul)
+
+            def pack_classes():
+                wt = torch.empty((4 * n_in, d.c_out, 3, 3), dtype=torch.float32, device=dev)
+                for py in (0, 1):
+                    for px in (0, 1):
+                        k = py * 2 + px
+                        T.dgrad_class_weights(w4, py, px, ci_first, n_in, out=wt[k * n_in:(k + 1) * n_in])
+                return ops.sp_pack_conv_weights(dd, wt, wmul)[0]
+            packed = self._packed_form(w, 2, dd, ci_first, n_in, pack_classes)
             out = torch.empty((d.n_images, d.h_in // 2, d.w_in // 2, 4 * n_in), dtype=torch.float32, device=dev)
             ops.sp_conv2d_nhwc(dd, dz_sp, packed, self._const(dev, 4 * n_in, 1.0 / (dz_lift * wmul)),
                                self._const(dev, 4 * n_in, 0.0), out)
             out._dn_s2d = True
             return out
         if dz_sp is not None:
-            wt = T.dgrad_weights(w4, ci_first, c_in)
-            n_in = wt.shape[0]
+            n_in = (w4.shape[1] - ci_first) if c_in is None else c_in
             dev = dz.device
             dd = ops.conv_desc(d.n_images, d.h_in, d.w_in, d.c_out, n_in, 3, 1, False)
             wmul = self._wmul_of(w)
-            packed, _ = ops.sp_pack_conv_weights(dd, wt, wmul)
+            packed = self._packed_form(w, 1, dd, ci_first, n_in,
+                                       lambda: ops.sp_pack_conv_weights(dd, T.dgrad_weights(w4, ci_first, n_in), wmul)[0])
             if dx_out is None:
                 dx_out = torch.empty((d.n_images, d.h_in, d.w_in, n_in), dtype=torch.float32, device=dev)
             ops.sp_conv2d_nhwc(dd, dz_sp, packed, self._const(dev, n_in, 1.0 / (dz_lift * wmul)), self._const(dev, n_in, 0.0),
@@ -582,6 +595,59 @@ class TrainEngine:
                             ego_first=sh.first if sh is not None else 0, ego_count=sh.count if sh is not None else None, poses=poses)
 
     # ------------------------------------------------------------------
+    # the step's packed weights in one launch
+    # ------------------------------------------------------------------
+    # A step packs every 3x3 layer's weights for the split-f16 engine twice -- as they are for the forward, flipped and transposed
+    # (or as the four parity classes of a stride-2 layer) for the data gradient: ~70 launches of 4-7 us plus the flips' ~35, on a
+    # stream with nothing to run beside them and a host that needs ~15 us per launch (profiles/r06_step_start_ab.txt).  A form
+    # that was asked for in an earlier forward is a job of ops.SpPackSet: all jobs are packed by ONE launch at the start of each
+    # forward (dn_spconv_pack_weights_multi: the same bytes), and _conv / _dgrad pick the images up.  A form not in the set
+    # (yet), a tap-merged layer, a temporary weight, DN_TRAIN_PACK_MULTI=0: the single launches, as before.
+    def _pack_multi_on(self):
+        return os.environ.get("DN_TRAIN_PACK_MULTI", "1") != "0"
+
+    def _pack_multi(self):
+        """at the start of a forward (after `generation` moved): pack every known form from the parameters as they are now"""
+        ps = self.__dict__.get("_packset")
+        if ps is None or not self._pack_multi_on():
+            return
+        if ps["pending"]:
+            jobs = dict(ps["jobs"])
+            jobs.update(ps["pending"])
+            # forms nobody asked for in the last 8 forwards leave the set (a change of dgrad_math, of the batch shape)
+            jobs = {k: j for k, j in jobs.items() if self.generation - ps["used"].get(k, self.generation) <= 8}
+            ps["pending"] = {}
+            ps["jobs"] = jobs
+            keys = list(jobs)
+            ps["set"] = ops.SpPackSet([jobs[k][:6] for k in keys], self.flat_p.device) if keys else None
+            ps["image"] = {k: b for k, b in zip(keys, ps["set"].buffers)} if keys else {}
+            ps["params"] = [jobs[k][6] for k in keys]
+        if ps.get("set") is not None:
+            ps["set"].run([self._wmul_of(w) for w in ps["params"]])
+            ps["generation"] = self.generation
+
+    def _packed_form(self, w, mode, dd, ci_first, n_in, single):
+        """the packed image of Parameter `w`'s weight form (mode, ci_first, n_in: ops.SpPackSet) for the conv `dd`: this forward's
+        one-launch image when the form is in the set, else `single()` (the per-layer launches) -- and a place in the next set"""
+        ent = self.grad_of.get(id(w))
+        if ent is None or not self._pack_multi_on():
+            return single()
+        ps = self.__dict__.setdefault("_packset", {"jobs": {}, "pending": {}, "used": {}, "image": {}, "set": None, "generation": -1})
+        key = (ent[0], mode, ci_first, n_in) + _desc_key(dd)
+        ps["used"][key] = self.generation
+        if ps["generation"] == self.generation:
+            img = ps["image"].get(key)
+            if img is not None:
+                return img
+        if key not in ps["jobs"] and key not in ps["pending"] and key not in ps.setdefault("single", set()):
+            w4 = w.detach().reshape(w.shape[0], w.shape[1], -1)
+            if ops.SpPackSet.supported(dd) and w4.is_contiguous() and w4.dtype == torch.float32:
+                ps["pending"][key] = (_desc_copy(dd), w4, mode, w4.shape[1], ci_first, n_in, w)
+            else:
+                ps["single"].add(key)       # a tap-merged layer: its own pack kernel
+        return single()
+
+    # ------------------------------------------------------------------
     # forward (training mode)
     # ------------------------------------------------------------------
     def check_aliasing(self):
@@ -599,6 +665,7 @@ class TrainEngine:
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size):
         self.check_aliasing()
         self.generation += 1
+        self._pack_multi()
         m, L = self.model, self.L
         A, B = m.agent_num, batch_size
         if m.layer != 3 and m.u_encoder.compress_level > 0:

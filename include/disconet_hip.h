@@ -241,6 +241,29 @@ int dn_sp_to_nhwc(const void* src_sp, int n_images, int h, int w, int channels, 
 size_t dn_spconv_packed_weight_bytes(const dn_conv_desc* d);
 int dn_spconv_pack_weights(const dn_conv_desc* d, const float* weight_oihw, float wmul,
                            void* packed, void* stream);
+/* Many plain-layout packs in ONE launch (a training step packs every layer's weights once for its forward and once, flipped
+ * and transposed, for its data gradient: ~70 launches of 4-7 us on a stream that has nothing else to run beside them).
+ * A job packs, for the conv `desc`, the weight tensor W[c_out][c0 + c1][k][k] that a VIEW of `weight` defines:
+ *   mode 0: W = weight                                                          (= dn_spconv_pack_weights)
+ *   mode 1: W[n][ci][t] = weight[ci][ci_first + n][k*k - 1 - t], weight [.][cin_total][k][k]
+ *           (= dn_conv_dgrad_weights (disconet_train.h) then dn_spconv_pack_weights: the data gradient's conv)
+ *   mode 2: W[cls n_in + j] = class (cls / 2, cls % 2) of dn_conv_dgrad_class_weights over column ci_first + j, desc.c_out = 4 n_in
+ *           (the one-launch stride-2 data gradient: four classes as output-channel groups)
+ * -- the same bytes as those calls write.  dn_spconv_pack_multi_prepare validates the jobs and fills the HOST image of the
+ * device table (dn_spconv_pack_multi_table_bytes(n_jobs) bytes; DN_ERR_UNSUPPORTED for a layer that is packed tap-merged);
+ * the caller copies it to the device once and calls dn_spconv_pack_weights_multi(table, n_jobs, total_blocks) whenever the
+ * weights have changed (a job's wmul is part of the table). */
+typedef struct dn_pack_job {
+  dn_conv_desc desc;
+  const float* weight;
+  void* packed;
+  int32_t mode, cin_total, ci_first, n_in;
+  float wmul;
+  int32_t reserved;
+} dn_pack_job;
+size_t dn_spconv_pack_multi_table_bytes(int n_jobs);
+int dn_spconv_pack_multi_prepare(const dn_pack_job* jobs, int n_jobs, void* table_host, int* total_blocks);
+int dn_spconv_pack_weights_multi(const void* table_device, int n_jobs, int total_blocks, void* stream);
 /* out: SP tensor [n_images][ceil(c_out/16)][4][h_out][w_out] */
 int dn_spconv2d(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp,
                 const void* packed, const float* scale, const float* shift, void* out_sp,

@@ -219,6 +219,35 @@ static int gpu_spconv(int up) {
   }
   const float wmul = 4096.f;   /* lifts |w| <= 0.08 out of the f16 subnormal range; undone in the scale */
   CHECK(dn_spconv_pack_weights(&d, dw, wmul, pk, NULL) == DN_OK, "sp pack: %s", dn_last_error());
+  {
+    /* the one-launch form of many packs (dn_spconv_pack_weights_multi): one mode-0 job = the call above, byte for byte; a
+     * tap-merged layer (the upsampled source) is refused by the prepare step */
+    dn_pack_job job;
+    memset(&job, 0, sizeof job);
+    void *pk2, *table;
+    HIP(hipMalloc(&pk2, pkb));
+    job.desc = d; job.weight = dw; job.packed = pk2; job.mode = 0; job.cin_total = cin; job.wmul = wmul;
+    const size_t tb = dn_spconv_pack_multi_table_bytes(1);
+    CHECK(tb > 0, "pack multi table size");
+    void* host = malloc(tb);
+    int blocks = 0;
+    const int rc = dn_spconv_pack_multi_prepare(&job, 1, host, &blocks);
+    if (up) {
+      CHECK(rc == DN_ERR_UNSUPPORTED, "pack multi accepted a tap-merged layer");
+    } else {
+      CHECK(rc == DN_OK && blocks > 0, "pack multi prepare: %s", dn_last_error());
+      HIP(hipMalloc(&table, tb));
+      HIP(hipMemcpy(table, host, tb, hipMemcpyHostToDevice));
+      CHECK(dn_spconv_pack_weights_multi(table, 1, blocks, NULL) == DN_OK, "pack multi: %s", dn_last_error());
+      HIP(hipDeviceSynchronize());
+      unsigned char *a = malloc(pkb), *b = malloc(pkb);
+      HIP(hipMemcpy(a, pk, pkb, hipMemcpyDeviceToHost)); HIP(hipMemcpy(b, pk2, pkb, hipMemcpyDeviceToHost));
+      CHECK(memcmp(a, b, pkb) == 0, "pack multi differs from dn_spconv_pack_weights");
+      printf("C ABI spconv pack multi: %zu bytes equal to the single launch's\n", pkb);
+      free(a); free(b); HIP(hipFree(table));
+    }
+    free(host); HIP(hipFree(pk2));
+  }
   CHECK(dn_fold_bn(db, NULL, NULL, NULL, NULL, 0.f, cout, dsc, dsh, NULL) == DN_OK, "fold: %s", dn_last_error());
   float* hsc = malloc(cout * 4);
   HIP(hipMemcpy(hsc, dsc, cout * 4, hipMemcpyDeviceToHost));

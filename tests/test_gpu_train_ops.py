@@ -652,6 +652,58 @@ def test_lane_parallel_warp_gathers_agree_with_the_scalar_kernels(tmp_path):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_one_launch_pack_of_many_weight_forms_writes_the_single_launches_bytes(seed):
+    """dn_spconv_pack_weights_multi (ops.SpPackSet) against the calls it stands for -- dn_spconv_pack_weights of the weight (mode 0),
+    of dn_conv_dgrad_weights' flipped / transposed cut (mode 1), of the four dn_conv_dgrad_class_weights classes stacked (mode 2):
+    every packed image byte for byte, over 3x3 and 1x1 layers, channel counts off the 16 / 64 padding, column cuts of a concat
+    layer's weight, and a second run after the weights and the lifts moved; a tap-merged layer is refused."""
+    from disconet_amd import ops, train_ops
+    g = torch.Generator().manual_seed(seed)
+    dev = _dev()
+    jobs, singles = [], []
+
+    def weight(c_out, c_in, k):
+        return (torch.randn(c_out, c_in, k, k, generator=g) * 0.05).to(dev)
+
+    def single(j, wmul):
+        d, w, mode, cin_total, ci_first, n_in = j
+        if mode == 0:
+            return ops.sp_pack_conv_weights(d, w, wmul)[0]
+        if mode == 1:
+            return ops.sp_pack_conv_weights(d, train_ops.dgrad_weights(w, ci_first, d.c_out), wmul)[0]
+        wt = torch.empty((4 * n_in, w.shape[0], 3, 3), device=dev)
+        for py in (0, 1):
+            for px in (0, 1):
+                k = py * 2 + px
+                train_ops.dgrad_class_weights(w, py, px, ci_first, n_in, out=wt[k * n_in:(k + 1) * n_in])
+        return ops.sp_pack_conv_weights(d, wt, wmul)[0]
+
+    for c_out, c_in, k in ((32, 13, 3), (64, 32, 3), (72, 40, 3), (512, 256, 3), (32, 64, 1), (12, 32, 1)):
+        w = weight(c_out, c_in, k)
+        jobs.append((ops.conv_desc(3, 16, 16, c_in, c_out, k, 1, False), w, 0, c_in, 0, 0))
+    for c_out, cin_total, ci_first, n_in in ((64, 96, 0, 64), (64, 96, 64, 32), (128, 64, 0, 64), (32, 13, 0, 13)):
+        w = weight(c_out, cin_total, 3)
+        jobs.append((ops.conv_desc(2, 16, 16, c_out, n_in, 3, 1, False), w, 1, cin_total, ci_first, n_in))
+    for c_out, cin_total, ci_first, n_in in ((64, 32, 0, 32), (128, 64, 0, 64), (64, 48, 16, 32)):
+        w = weight(c_out, cin_total, 3)
+        jobs.append((ops.conv_desc(2, 8, 8, c_out, 4 * n_in, 3, 1, False), w, 2, cin_total, ci_first, n_in))
+    ps = ops.SpPackSet(jobs, dev)
+    for trial in range(2):
+        wmuls = [float(2.0 ** (3 + (i + trial) % 5)) for i in range(len(jobs))]
+        if trial:
+            for j in jobs:
+                j[1].mul_(1.37)
+        for b in ps.buffers:
+            b.fill_(0xAB)
+        ps.run(wmuls)
+        for i, (j, b) in enumerate(zip(jobs, ps.buffers)):
+            want = single(j, wmuls[i])
+            assert want.numel() == b.numel() and torch.equal(want, b), (trial, i)
+    up = ops.conv_desc(2, 16, 16, 64, 32, 3, 1, False, c1=32, up0=1)
+    assert not ops.SpPackSet.supported(up) and ops.SpPackSet.supported(jobs[0][0])
+
+
 def test_fuse_combine_forward_backward():
     from disconet_amd import train_ops
     g = torch.Generator().manual_seed(12)
