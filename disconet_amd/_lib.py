@@ -31,6 +31,12 @@ class PackJob(Structure):
                 ("ci_first", c_int32), ("n_in", c_int32), ("wmul", c_float), ("reserved", c_int32)]
 
 
+class FoldJob(Structure):
+    """struct dn_fold_job"""
+    _fields_ = [("partials", c_void_p), ("sums", c_void_p), ("out", c_void_p), ("n_blocks", c_int32), ("c", c_int32),
+                ("accumulate", c_int32), ("reserved", c_int32)]
+
+
 class Post1x1Desc(Structure):
     """struct dn_post1x1_desc"""
     _fields_ = [(n, c_int32) for n in ("c_out2", "relu2", "split", "ldo_a", "ldo_b", "block_diag")]
@@ -86,6 +92,9 @@ SIGNATURES = {
     "dn_spconv_pack_multi_table_bytes": (c_size_t, [c_int]),
     "dn_spconv_pack_multi_prepare": (c_int, [POINTER(PackJob), c_int, c_void_p, POINTER(c_int)]),
     "dn_spconv_pack_weights_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "dn_conv_pack_multi_table_bytes": (c_size_t, [c_int]),
+    "dn_conv_pack_multi_prepare": (c_int, [POINTER(PackJob), c_int, c_void_p, POINTER(c_int)]),
+    "dn_conv_pack_weights_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "dn_spconv2d": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p]),
     "dn_spconv_ks_supported": (c_int, [POINTER(ConvDesc), c_int]),
@@ -169,6 +178,12 @@ SIGNATURES = {
     "dn_bn_train_backward_finish_bias": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long,
                                                  c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dn_bn_train_backward_finish_bias_deferred": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                                          c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                                          c_long, c_void_p, c_void_p, c_float, c_void_p, c_size_t, POINTER(c_int),
+                                                          c_void_p]),
+    "dn_channel_sum_partial": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_size_t, POINTER(c_int), c_void_p]),
+    "dn_channel_sum_fold_multi": (c_int, [POINTER(FoldJob), c_int, c_void_p]),
     "dn_bn_train_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                   c_int, c_long, c_int, c_int, c_void_p, c_void_p]),
     "dn_bn_train_apply_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_long, c_int, c_int,

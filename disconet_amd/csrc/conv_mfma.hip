@@ -801,6 +801,60 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, _Float16*
   }
 }
 
+// ---- many packs of this engine in ONE launch (dn_conv_pack_weights_multi; the split-planar engine's twin is in conv_sp.hip).
+// A job = one call of pack_weights_kernel (split = 0) or pack_weights_split_kernel (split = 1) on the weight tensor a VIEW of
+// `w` defines, times the power of two wmul (what the training engine multiplied in with a torch op before it packed):
+//   mode 0: W[n][ci][t] = w[n][ci_first + ci][t]                   (the tensor itself, or a column cut of it)
+//   mode 1: W[n][ci][t] = w[ci][ci_first + n][taps - 1 - t]        (dn_conv_dgrad_weights: the data gradient's conv)
+struct NhwcPackJob {
+  const float* w;
+  void* out;
+  int c_out, c_in, taps, cout_pad, kcp, mode, cin_total, ci_first, split, block_first, n_blocks, pad_;
+  float wmul, padf_;
+  long total;
+};
+static_assert(sizeof(NhwcPackJob) == 80, "dn_conv_pack_multi_table_bytes");
+
+__global__ void __launch_bounds__(256) pack_weights_multi_kernel(const NhwcPackJob* __restrict__ jobs, int n_jobs) {
+  __shared__ NhwcPackJob job;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n_jobs - 1;                 // the last job whose first block is <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].block_first <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    job = jobs[lo];
+  }
+  __syncthreads();
+  const NhwcPackJob& j = job;
+  const int vb = blockIdx.x - j.block_first;
+  for (long idx = vb * (long)blockDim.x + threadIdx.x; idx < j.total; idx += (long)j.n_blocks * blockDim.x) {
+    long r = idx;
+    const int k = r % j.kcp; r /= j.kcp;
+    const int co = r % j.cout_pad; r /= j.cout_pad;
+    const int tap = r % j.taps;
+    const int chp = r / j.taps;
+    const int ci = chp * j.kcp + k;
+    float v = 0.f;
+    if (co < j.c_out && ci < j.c_in) {
+      v = j.mode == 0 ? j.w[((size_t)co * j.cin_total + j.ci_first + ci) * j.taps + tap]
+                      : j.w[((size_t)ci * j.cin_total + j.ci_first + co) * j.taps + (j.taps - 1 - tap)];
+      v *= j.wmul;
+    }
+    if (j.split) {
+      v = fminf(fmaxf(v, -65504.f), 65504.f);
+      const _Float16 hi = (_Float16)v;
+      const _Float16 lo = (_Float16)(v - (float)hi);
+      const long row = idx / j.kcp;
+      _Float16* o = static_cast<_Float16*>(j.out);
+      o[row * 2 * j.kcp + k] = hi;
+      o[row * 2 * j.kcp + j.kcp + k] = lo;
+    } else {
+      static_cast<float*>(j.out)[idx] = v;
+    }
+  }
+}
+
 __global__ void fold_bn_kernel(const float* bias, const float* gamma, const float* beta,
                                const float* mean, const float* var, float eps, int n,
                                float* scale, float* shift) {
@@ -895,6 +949,43 @@ extern "C" int dn_conv_pack_weights(const dn_conv_desc* d, const float* weight_o
                        weight_oihw, packed, d->c_out, d->c0 + d->c1, d->ksize * d->ksize,
                        cout_pad_of(*d), kcp_of(d->ksize), total);
   return dn::check_launch("pack_weights_kernel");
+}
+
+extern "C" size_t dn_conv_pack_multi_table_bytes(int n_jobs) { return n_jobs > 0 ? sizeof(NhwcPackJob) * (size_t)n_jobs : 0; }
+
+extern "C" int dn_conv_pack_multi_prepare(const dn_pack_job* jobs, int n_jobs, void* table_host, int* total_blocks) {
+  DN_REQUIRE(jobs && table_host && total_blocks && n_jobs > 0, "conv pack multi: null pointer / no jobs");
+  NhwcPackJob* t = static_cast<NhwcPackJob*>(table_host);
+  int first = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const dn_pack_job& q = jobs[i];
+    const dn_conv_desc* d = &q.desc;
+    if (int rc = validate(d)) return rc;
+    DN_REQUIRE(q.weight && q.packed, "conv pack multi: job %d: null pointer", i);
+    DN_REQUIRE(q.mode == 0 || q.mode == 1, "conv pack multi: job %d: mode %d (0 or 1)", i, q.mode);
+    const int c_in = d->c0 + d->c1;
+    DN_REQUIRE(q.ci_first >= 0 && q.ci_first + (q.mode == 0 ? c_in : d->c_out) <= q.cin_total,
+               "conv pack multi: job %d: columns %d + %d of %d", i, q.ci_first, q.mode == 0 ? c_in : d->c_out, q.cin_total);
+    NhwcPackJob& j = t[i];
+    j.w = q.weight;
+    j.out = q.packed;
+    j.c_out = d->c_out; j.c_in = c_in; j.taps = d->ksize * d->ksize; j.cout_pad = cout_pad_of(*d); j.kcp = kcp_of(d->ksize);
+    j.mode = q.mode; j.cin_total = q.cin_total; j.ci_first = q.ci_first; j.split = d->math == 1;
+    j.wmul = q.wmul; j.pad_ = 0; j.padf_ = 0.f;
+    j.total = (long)dn_conv_packed_weight_floats(d);
+    j.n_blocks = (int)((j.total + 255) / 256 < 4096 ? (j.total + 255) / 256 : 4096);      // the single launch's grid
+    j.block_first = first;
+    first += j.n_blocks;
+  }
+  *total_blocks = first;
+  return DN_OK;
+}
+
+extern "C" int dn_conv_pack_weights_multi(const void* table_device, int n_jobs, int total_blocks, void* stream) {
+  DN_REQUIRE(table_device && n_jobs > 0 && total_blocks > 0, "conv pack multi: bad arguments");
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const NhwcPackJob*>(table_device), n_jobs);
+  return dn::check_launch("pack_weights_multi_kernel");
 }
 
 extern "C" int dn_fold_bn(const float* bias, const float* gamma, const float* beta,

@@ -1351,7 +1351,7 @@ __global__ void sp_pack_weights_kernel(const float* __restrict__ w, unsigned cha
 
 // ---- every plain-layout pack of a training step in ONE launch (dn_spconv_pack_weights_multi).  A job = one call of
 // sp_pack_weights_kernel whose weight tensor W[n][ci][tap] is given by a SOURCE VIEW of a forward weight tensor `w`:
-//   mode 0: W = w                                                              (the layer's own forward)
+//   mode 0: W[n][ci][t] = w[n][ci_first + ci][t]                              (the layer's own forward; a column cut)
 //   mode 1: W[n][ci][t] = w[ci][ci_first + n][taps - 1 - t]                    (dn_conv_dgrad_weights: flipped, transposed cut)
 //   mode 2: W[k n_in + j][ci][v] = class (py, px) = (k / 2, k % 2) of dn_conv_dgrad_class_weights over columns ci_first + j
 // -- the values the two-launch forms write through a temporary, so the packed images are the same bytes.  A workgroup finds its
@@ -1366,7 +1366,7 @@ struct PackJob {
 static_assert(sizeof(PackJob) == 80, "dn_spconv_pack_multi_table_bytes");
 
 __device__ inline float pack_job_elem(const PackJob& j, int n, int ci, int tap) {
-  if (j.mode == 0) return j.w[((size_t)n * j.c_in + ci) * j.taps + tap];
+  if (j.mode == 0) return j.w[((size_t)n * j.cin_total + j.ci_first + ci) * j.taps + tap];
   if (j.mode == 1) return j.w[((size_t)ci * j.cin_total + j.ci_first + n) * j.taps + (j.taps - 1 - tap)];
   const int k = n / j.n_in, jj = n - k * j.n_in, py = k >> 1, px = k & 1, vy = tap / 3, vx = tap - 3 * vy;
   auto src_tap = [](int p, int vv) { return p == 0 ? (vv == 1 ? 1 : -1) : (vv == 1 ? 2 : vv == 2 ? 0 : -1); };
@@ -1758,6 +1758,9 @@ extern "C" int dn_spconv_pack_multi_prepare(const dn_pack_job* jobs, int n_jobs,
       return dn::fail(DN_ERR_UNSUPPORTED, "spconv pack multi: job %d is packed tap-merged (dn_spconv_pack_weights only)", i);
     const int c_in = d->c0 + d->c1, taps = d->ksize * d->ksize;
     DN_REQUIRE(q.mode >= 0 && q.mode <= 2, "spconv pack multi: job %d: mode %d", i, q.mode);
+    if (q.mode == 0)
+      DN_REQUIRE(q.ci_first >= 0 && q.ci_first + c_in <= q.cin_total, "spconv pack multi: job %d: columns %d + %d of %d", i,
+                 q.ci_first, c_in, q.cin_total);
     if (q.mode == 1)
       DN_REQUIRE(q.ci_first >= 0 && q.ci_first + d->c_out <= q.cin_total, "spconv pack multi: job %d: columns %d + %d of %d", i,
                  q.ci_first, d->c_out, q.cin_total);

@@ -427,6 +427,32 @@ fold_channel_sum_kernel(const double* __restrict__ part, int n_blocks, int c, do
   }
 }
 
+// ---- the channel-sum folds of a whole backward pass in ONE launch (dn_channel_sum_fold_multi).  The sums they finish -- bias
+// gradients: leaves of the backward -- are not read before the optimizer step, so the launches that leave the partials
+// (dn_bn_train_backward_finish_bias_deferred, dn_channel_sum_partial) need not be followed by a fold each (26 launches of
+// 5 us per step).  Jobs ride in the kernel arguments; one wavefront per (job, channel) runs fold_channel_sum_kernel's body.
+constexpr int kFoldJobs = 32;
+struct FoldJobs {
+  const double* part[kFoldJobs];
+  double* sums[kFoldJobs];
+  float* out[kFoldJobs];
+  int n_blocks[kFoldJobs], c[kFoldJobs], accumulate[kFoldJobs];
+  int first[kFoldJobs + 1];      // first wavefront of job j; first[n_jobs] = all wavefronts
+};
+__global__ void __launch_bounds__(256) fold_channel_sum_multi_kernel(const FoldJobs J, int n_jobs) {
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wv >= J.first[n_jobs]) return;
+  int j = 0;
+  while (j + 1 < n_jobs && J.first[j + 1] <= wv) ++j;      // wave-uniform
+  const int cc = wv - J.first[j], c = J.c[j];
+  const double t = fold_one(J.part[j] + cc, J.n_blocks[j], c, lane);
+  if (lane == 0) {
+    J.sums[j][cc] = t;
+    float* out = J.out[j];
+    out[cc] = (J.accumulate[j] ? out[cc] : 0.f) + (float)t;
+  }
+}
+
 // incoming gradient of one element: dy_a (optionally the 2 x 2 block sum of a map at twice
 // the resolution) + dy_b, gated by the ReLU
 struct GradSrc {
@@ -1313,7 +1339,7 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
                             const float* gamma, float eps, int relu, int n_groups, int h, int w,
                             int images_per_group, int c, const double* sums, long norm_rows, float* dz,
                             void* dz_sp, float sp_lift, void* stream, float* dbias = nullptr, double* bias_ws = nullptr,
-                            size_t bias_ws_bytes = 0) {
+                            size_t bias_ws_bytes = 0, int* defer_blocks = nullptr) {
   DN_REQUIRE(dy_a && z && mean && var && gamma && sums && dz, "bn backward finish: null pointer");
   DN_REQUIRE(!relu || y, "bn backward: relu needs y");
   DN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || c % 4 == 0), "bn backward: relu = 2 (y is the byte mask) needs c %% 4 == 0");
@@ -1336,7 +1362,10 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
     double* part = bias_ws + c;      // [c] folded sums, then [blocks][c] partials
     hipLaunchKernelGGL((bn_bwd_apply_v4_fast_kernel<SPF, true>), dim3(blocks), dim3(256), 0, s, src, z, mean, var, gamma, eps,
                        norm_rows, sums, fsh, (unsigned)(total / 4), dz, (unsigned char*)sp_ptr, lift, (unsigned)(h * w), fl, part);
-    hipLaunchKernelGGL(fold_channel_sum_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, blocks, c, bias_ws, dbias, 0);
+    if (defer_blocks)      // the fold is the caller's (dn_channel_sum_fold_multi): the partials stay in bias_ws
+      *defer_blocks = blocks;
+    else
+      hipLaunchKernelGGL(fold_channel_sum_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, blocks, c, bias_ws, dbias, 0);
     return dn::check_launch("bn backward apply kernel (+ bias gradient)");
   };
   if (dz_sp) {
@@ -1347,9 +1376,9 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
     unsigned* flags = dn::sp_range_word();
     DN_REQUIRE(flags, "bn backward: the range word of the split-f16 engine is not addressable");
     const int fsh = bn_fast_shift(n_groups, c, total);
-    if (fsh >= 0 && dbias)
+    if (fsh >= 0 && (dbias || defer_blocks))
       return bias_launch(std::true_type{}, dz_sp, sp_lift, flags, fsh);
-    DN_REQUIRE(!dbias, "bn backward: the fused bias gradient needs the one-group fast form (c / 4 a power of two; DN_BN_LEGACY unset)");
+    DN_REQUIRE(!dbias && !defer_blocks, "bn backward: the fused bias gradient needs the one-group fast form (c / 4 a power of two; DN_BN_LEGACY unset)");
     if (fsh >= 0)
       hipLaunchKernelGGL(bn_bwd_apply_v4_fast_kernel<true>, dim3(grid_for(total / 4, 8192)), dim3(256), 0, s, src, z, mean, var, gamma,
                          eps, norm_rows, sums, fsh, (unsigned)(total / 4), dz, (unsigned char*)dz_sp, sp_lift, (unsigned)(h * w), flags);
@@ -1359,7 +1388,7 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
     return dn::check_launch("bn backward apply kernel (SP copy)");
   }
   const int fsh = bn_fast_shift(n_groups, c, total);
-  if (dbias) {
+  if (dbias || defer_blocks) {
     DN_REQUIRE(vec4_ok(c, {ld_a, dy_b ? ld_b : 0}, {dy_a, dy_b, y, z, mean, var, gamma, dz}) && fsh >= 0,
                "bn backward: the fused bias gradient needs the one-group fast form (c / 4 a power of two, aligned tensors; DN_BN_LEGACY unset)");
     return bias_launch(std::false_type{}, nullptr, 1.f, nullptr, fsh);
@@ -1385,6 +1414,37 @@ extern "C" int dn_bn_train_backward_finish_bias(const float* dy_a, int ld_a, int
   DN_REQUIRE(dbias && bias_ws, "bn backward finish (+ bias gradient): null pointer");
   return bn_backward_finish_impl(dy_a, ld_a, up_a, dy_b, ld_b, y, z, mean, var, gamma, eps, relu, 1, h, w, images, c, sums,
                                  norm_rows, dz, dz_sp, sp_lift, stream, dbias, bias_ws, bias_ws_bytes);
+}
+
+extern "C" int dn_bn_train_backward_finish_bias_deferred(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
+                                                         const float* y, const float* z, const float* mean, const float* var,
+                                                         const float* gamma, float eps, int relu, int h, int w, int images, int c,
+                                                         const double* sums, long norm_rows, float* dz, void* dz_sp, float sp_lift,
+                                                         double* bias_ws, size_t bias_ws_bytes, int* n_blocks, void* stream) {
+  DN_REQUIRE(bias_ws && n_blocks, "bn backward finish (bias gradient deferred): null pointer");
+  return bn_backward_finish_impl(dy_a, ld_a, up_a, dy_b, ld_b, y, z, mean, var, gamma, eps, relu, 1, h, w, images, c, sums,
+                                 norm_rows, dz, dz_sp, sp_lift, stream, nullptr, bias_ws, bias_ws_bytes, n_blocks);
+}
+
+extern "C" int dn_channel_sum_fold_multi(const dn_fold_job* jobs, int n_jobs, void* stream) {
+  DN_REQUIRE(jobs && n_jobs > 0, "channel sum fold multi: no jobs");
+  for (int j0 = 0; j0 < n_jobs; j0 += kFoldJobs) {
+    const int n = n_jobs - j0 < kFoldJobs ? n_jobs - j0 : kFoldJobs;
+    FoldJobs J;
+    int waves = 0;
+    for (int j = 0; j < n; ++j) {
+      const dn_fold_job& q = jobs[j0 + j];
+      DN_REQUIRE(q.partials && q.sums && q.out && q.n_blocks > 0 && q.c > 0 && q.c <= kMaxC, "channel sum fold multi: job %d", j0 + j);
+      J.part[j] = q.partials; J.sums[j] = q.sums; J.out[j] = q.out;
+      J.n_blocks[j] = q.n_blocks; J.c[j] = q.c; J.accumulate[j] = q.accumulate;
+      J.first[j] = waves;
+      waves += q.c;
+    }
+    for (int j = n; j <= kFoldJobs; ++j) J.first[j] = waves;
+    for (int j = n; j < kFoldJobs; ++j) { J.part[j] = nullptr; J.sums[j] = nullptr; J.out[j] = nullptr; J.n_blocks[j] = J.c[j] = J.accumulate[j] = 0; }
+    hipLaunchKernelGGL(fold_channel_sum_multi_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, J, n);
+  }
+  return dn::check_launch("fold_channel_sum_multi_kernel");
 }
 
 extern "C" int dn_bn_train_backward_finish(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b,
@@ -1435,6 +1495,24 @@ extern "C" int dn_channel_sum(const float* x, long rows, int c, int ld, double* 
   else
     hipLaunchKernelGGL(channel_sum_kernel, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
   hipLaunchKernelGGL(fold_channel_sum_kernel, dim3((c + 3) / 4), dim3(256), 0, s, part, nblk, c, sums, out, accumulate);
+  return dn::check_launch("channel_sum_kernel");
+}
+
+extern "C" int dn_channel_sum_partial(const float* x, long rows, int c, int ld, double* sums, size_t sums_bytes, int* n_blocks,
+                                      void* stream) {
+  DN_REQUIRE(x && sums && n_blocks, "channel sum (partial): null pointer");
+  DN_REQUIRE(rows > 0 && c > 0 && c <= kMaxC && ld >= c, "channel sum: bad shape");
+  DN_REQUIRE(sums_bytes >= dn_reduce_workspace_bytes(1, rows, c),
+             "channel sum: workspace of %zu bytes, dn_reduce_workspace_bytes() asks for %zu", sums_bytes,
+             dn_reduce_workspace_bytes(1, rows, c));
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = blocks_per_group(rows, 1);
+  double* part = sums + c;                              // [c] folded sums (the fold's), then the workgroups' partials [blocks][c]
+  if (vec4_ok(c, {ld}, {x}))
+    hipLaunchKernelGGL(bn_legacy() ? channel_sum_v4_kernel<1> : channel_sum_v4_kernel<4>, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
+  else
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(nblk), dim3(256), 0, s, x, rows, c, ld, part);
+  *n_blocks = nblk;
   return dn::check_launch("channel_sum_kernel");
 }
 

@@ -432,44 +432,53 @@ def sp_pack_conv_weights(d, weight, wmul=None):
     return packed, wmul
 
 
-class SpPackSet:
-    """Many plain-layout weight packs as ONE launch (dn_spconv_pack_weights_multi).  A job = (conv descriptor, forward weight
-    tensor, mode, cin_total, ci_first, n_in) -- include/disconet_hip.h :: dn_pack_job; its packed image lives in a buffer this
-    object owns.  run(wmuls) packs every job from the weights as they are now."""
+class PackSet:
+    """Many weight packs of one conv engine as ONE launch (dn_spconv_pack_weights_multi: engine "sp", plain layout only;
+    dn_conv_pack_weights_multi: engine "nhwc").  A job = (conv descriptor, forward weight tensor [c_out, cin_total, taps], mode,
+    cin_total, ci_first, n_in) -- include/disconet_hip.h :: dn_pack_job; its packed image lives in a buffer this object owns.
+    run(wmuls) packs every job from the weights as they are now."""
+    _FN = {"sp": ("dn_spconv_pack_multi_table_bytes", "dn_spconv_pack_multi_prepare", "dn_spconv_pack_weights_multi"),
+           "nhwc": ("dn_conv_pack_multi_table_bytes", "dn_conv_pack_multi_prepare", "dn_conv_pack_weights_multi")}
 
-    def __init__(self, jobs, device):
+    def __init__(self, jobs, device, engine="sp"):
         lib = _lib.load()
-        self.n = len(jobs)
+        self.engine, self.n = engine, len(jobs)
+        self._bytes, self._prepare, self._launch = (getattr(lib, f) for f in self._FN[engine])
         self._jobs = (_lib.PackJob * self.n)()
         self.buffers = []
         self._keep = []
         for q, (d, weight, mode, cin_total, ci_first, n_in) in zip(self._jobs, jobs):
             _need_gpu(weight)
             if weight.dtype != torch.float32 or not weight.is_contiguous():
-                raise _lib.DnError("SpPackSet: weights must be contiguous float32 tensors (the views are read in place)")
-            nbytes = lib.dn_spconv_packed_weight_bytes(ctypes.byref(d))
-            if nbytes == 0:
-                check(-1, "dn_spconv_packed_weight_bytes")
-            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                raise _lib.DnError("PackSet: weights must be contiguous float32 tensors (the views are read in place)")
+            if engine == "sp":
+                nbytes = lib.dn_spconv_packed_weight_bytes(ctypes.byref(d))
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
+            else:
+                nfloats = lib.dn_conv_packed_weight_floats(ctypes.byref(d))
+                buf = torch.empty(nfloats, dtype=torch.float32, device=device) if nfloats else None
+            if buf is None:
+                check(-1, "packed weight size")
             self.buffers.append(buf)
             self._keep.append(weight)
             q.desc, q.weight, q.packed = d, weight.data_ptr(), buf.data_ptr()
             q.mode, q.cin_total, q.ci_first, q.n_in, q.wmul = int(mode), int(cin_total), int(ci_first), int(n_in), 1.0
-        self._host = torch.empty(lib.dn_spconv_pack_multi_table_bytes(self.n), dtype=torch.uint8).pin_memory()
+        self._host = torch.empty(self._bytes(self.n), dtype=torch.uint8).pin_memory()
         self._table = torch.empty(self._host.numel(), dtype=torch.uint8, device=device)
         self._wmuls, self._blocks = None, 0
 
-    def supported(d):
-        """is the layer `d` packed in the plain layout (not tap-merged)?  -- what a job must be"""
+    @classmethod
+    def supported(cls, d, engine="sp"):
+        """can the layer `d`'s pack be a job?  (the split-planar engine: not when it is packed tap-merged)"""
+        lib = _lib.load()
         probe = (_lib.PackJob * 1)()
         probe[0].desc, probe[0].weight, probe[0].packed, probe[0].wmul = d, 16, 16, 1.0
-        host = (ctypes.c_ubyte * int(_lib.load().dn_spconv_pack_multi_table_bytes(1)))()
+        probe[0].cin_total = d.c0 + d.c1
+        host = (ctypes.c_ubyte * int(getattr(lib, cls._FN[engine][0])(1)))()
         blocks = ctypes.c_int(0)
-        return _lib.load().dn_spconv_pack_multi_prepare(probe, 1, host, ctypes.byref(blocks)) == 0
-    supported = staticmethod(supported)
+        return getattr(lib, cls._FN[engine][1])(probe, 1, host, ctypes.byref(blocks)) == 0
 
     def run(self, wmuls):
-        lib = _lib.load()
         wmuls = [float(v) for v in wmuls]
         if wmuls != self._wmuls:
             if self._wmuls is not None:
@@ -477,11 +486,14 @@ class SpPackSet:
             for q, v in zip(self._jobs, wmuls):
                 q.wmul = v
             blocks = ctypes.c_int(0)
-            check(lib.dn_spconv_pack_multi_prepare(self._jobs, self.n, ctypes.c_void_p(self._host.data_ptr()), ctypes.byref(blocks)),
-                  "dn_spconv_pack_multi_prepare")
+            check(self._prepare(self._jobs, self.n, ctypes.c_void_p(self._host.data_ptr()), ctypes.byref(blocks)),
+                  self._FN[self.engine][1])
             self._table.copy_(self._host, non_blocking=True)
             self._wmuls, self._blocks = wmuls, blocks.value
-        check(lib.dn_spconv_pack_weights_multi(_ptr(self._table), self.n, self._blocks, _stream()), "dn_spconv_pack_weights_multi")
+        check(self._launch(_ptr(self._table), self.n, self._blocks, _stream()), self._FN[self.engine][2])
+
+
+SpPackSet = PackSet
 
 
 _KS_WORKSPACE_CAP = 32 << 20      # bytes of partial sums per K-sliced launch (the launcher splits fewer tiles beyond)

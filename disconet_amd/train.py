@@ -315,15 +315,20 @@ class TrainEngine:
     def _math(self):
         return ops.nhwc_math(self.model.conv_math)      # the training kernels take fp32 NHWC
 
-    def _conv(self, w, bias, src0, src1=None, up0=0, stride=1, ksize=3, out=None, h_in=None, w_in=None, lift_of=None):
+    def _conv(self, w, bias, src0, src1=None, up0=0, stride=1, ksize=3, out=None, h_in=None, w_in=None, lift_of=None, cut=None):
         """raw conv + bias through the forward engine (weights packed on the fly).  lift_of: the Parameter whose
-        power-of-two lift applies when `w` is a temporary cut out of it (the attention MLP's W1 halves)"""
+        power-of-two lift applies when `w` is a temporary cut out of it; cut = (Parameter, first column) with w = None: the 1x1
+        conv over the columns cut[1] .. + c0 of that weight (the attention MLP's W1 halves) -- its pack joins the step's
+        one-launch packs, which read the columns in place"""
         n, h0, w0 = src0.shape[0], src0.shape[1], src0.shape[2]
         c0 = src0.shape[3]
         if h_in is None:
             h_in, w_in = (h0 * 2, w0 * 2) if up0 else (h0, w0)
         c1 = src1.shape[3] if src1 is not None else 0
-        c_out = w.shape[0]
+        if cut is not None and w is None:       # the columns cut[1] .. + c0 of a 1x1 weight, copied out only if a single pack needs them
+            c_out, lift_of = cut[0].shape[0], cut[0]
+        else:
+            c_out = w.shape[0]
         d = ops.conv_desc(n, h_in, w_in, c0, c_out, ksize, stride, False, c1=c1, up0=up0,
                           ld0=src0.stride(2), ld1=src1.stride(2) if src1 is not None else None,
                           ldo=out.stride(2) if out is not None else None, math=self._math())
@@ -335,7 +340,7 @@ class TrainEngine:
             # the backward's weight / data gradients read those)
             ds = ops.conv_desc(n, h_in, w_in, c0, c_out, ksize, stride, False, c1=c1, up0=up0)
             wmul = self._wmul_of(w)
-            packed = self._packed_form(w, 0, ds, 0, 0, lambda: ops.sp_pack_conv_weights(ds, w, wmul)[0])
+            packed = self._packed_form(w, 0, ds, 0, 0, lambda: ops.sp_pack_conv_weights(ds, w, wmul)[0], lift=w)
             if out is None:
                 ho, wo = ops.conv_out_hw(ds)
                 out = torch.empty((n, ho, wo, c_out), dtype=torch.float32, device=dev)
@@ -343,7 +348,13 @@ class TrainEngine:
                                bias if bias is not None else self._const(dev, c_out, 0.0), out, src1=sp1)
             return out, d
         wmul = self._wmul_of(w if lift_of is None else lift_of) if d.math == 1 else 1.0
-        packed = ops.pack_conv_weights(d, w if wmul == 1.0 else w.detach() * wmul)
+        def single():
+            wc = w if w is not None else cut[0].detach().reshape(c_out, -1)[:, cut[1]:cut[1] + c0].contiguous().view(c_out, c0, 1, 1)
+            return ops.pack_conv_weights(d, wc if wmul == 1.0 else wc.detach() * wmul)
+        if cut is not None:       # w = cut[0][:, cut[1] : cut[1] + c_in]: the one-launch pack reads the columns in place
+            packed = self._packed_form(cut[0], 0, d, cut[1], 0, single, engine="nhwc", lift=lift_of if d.math == 1 else None)
+        else:
+            packed = self._packed_form(w, 0, d, 0, 0, single, engine="nhwc", lift=w if d.math == 1 else None)
         one = self._const(dev, c_out, 1.0 / wmul)
         shift = bias if bias is not None else self._const(dev, c_out, 0.0)
         if out is None:
@@ -457,7 +468,8 @@ class TrainEngine:
         fused_bias = gb is not None and T.bn_backward_bias_supported(c["z"], c["groups"])
         dz = T.bn_backward(dy_a, c["y"], c["z"], c["mean"], c["var"], c["gamma"], _EPS, ggamma, gbeta,
                            relu=True, dy_b=dy_b, up_a=up_a, sp_out=sp, sp_lift=lift, relu_mask=c.get("mask"),
-                           dbias=gb if fused_bias else None, **self._bn_sync(c["z"], c["groups"]))
+                           dbias=gb if fused_bias else None, folds=self.__dict__.get("_folds_active") if fused_bias else None,
+                           **self._bn_sync(c["z"], c["groups"]))
         if lift is not None or wsp:
             self._dz_lift_refresh(lay, dz)
         return self._conv_bwd(c["desc"], c["w"], c["src0"], c["src1"], dz, gw, None if fused_bias else gb, need_dx,
@@ -507,7 +519,7 @@ class TrainEngine:
                   w_c_in=None, dx_out=None, dz_sp=None, dz_lift=None, wgrad_lift=None):
         T.conv_wgrad(d, src0, src1, dz, gw, dw_cin_total=dw_cin_total, sp_lift=wgrad_lift, x_lift=_WGRAD_X_LIFT)
         if gb is not None:
-            T.channel_sum(dz, gb)
+            T.channel_sum(dz, gb, folds=self.__dict__.get("_folds_active"))
         if not need_dx:
             return None
         return self._dgrad(d, w, dz, w_ci_first, w_c_in, dx_out, dz_sp, dz_lift)
@@ -540,7 +552,7 @@ class TrainEngine:
                         k = py * 2 + px
                         T.dgrad_class_weights(w4, py, px, ci_first, n_in, out=wt[k * n_in:(k + 1) * n_in])
                 return ops.sp_pack_conv_weights(dd, wt, wmul)[0]
-            packed = self._packed_form(w, 2, dd, ci_first, n_in, pack_classes)
+            packed = self._packed_form(w, 2, dd, ci_first, n_in, pack_classes, lift=w)
             out = torch.empty((d.n_images, d.h_in // 2, d.w_in // 2, 4 * n_in), dtype=torch.float32, device=dev)
             ops.sp_conv2d_nhwc(dd, dz_sp, packed, self._const(dev, 4 * n_in, 1.0 / (dz_lift * wmul)),
                                self._const(dev, 4 * n_in, 0.0), out)
@@ -552,7 +564,7 @@ class TrainEngine:
             dd = ops.conv_desc(d.n_images, d.h_in, d.w_in, d.c_out, n_in, 3, 1, False)
             wmul = self._wmul_of(w)
             packed = self._packed_form(w, 1, dd, ci_first, n_in,
-                                       lambda: ops.sp_pack_conv_weights(dd, T.dgrad_weights(w4, ci_first, n_in), wmul)[0])
+                                       lambda: ops.sp_pack_conv_weights(dd, T.dgrad_weights(w4, ci_first, n_in), wmul)[0], lift=w)
             if dx_out is None:
                 dx_out = torch.empty((d.n_images, d.h_in, d.w_in, n_in), dtype=torch.float32, device=dev)
             ops.sp_conv2d_nhwc(dd, dz_sp, packed, self._const(dev, n_in, 1.0 / (dz_lift * wmul)), self._const(dev, n_in, 0.0),
@@ -574,12 +586,12 @@ class TrainEngine:
                     v, mask = T.dgrad_class_weights(w4, py, px, ci_first, n_in)
                     ops.conv2d_taps(dd, dz, ops.pack_conv_weights(dd, v), one, zero, dx_out[:, py::2, px::2, :], mask)
             return dx_out
-        wt = T.dgrad_weights(w4, ci_first, c_in)
-        c_in = wt.shape[0]
+        c_in = (w4.shape[1] - ci_first) if c_in is None else c_in
         dd = ops.conv_desc(d.n_images, d.h_in, d.w_in, d.c_out, c_in, d.ksize, 1, False,
                            up0=2 if d.stride == 2 else 0, ld0=dz.stride(2),
                            ldo=dx_out.stride(2) if dx_out is not None else None, math=0)
-        packed = ops.pack_conv_weights(dd, wt)
+        packed = self._packed_form(w, 1, dd, ci_first, c_in, lambda: ops.pack_conv_weights(dd, T.dgrad_weights(w4, ci_first, c_in)),
+                                   engine="nhwc")
         dev = dz.device
         if dx_out is None:
             dx_out = torch.empty((d.n_images, d.h_in, d.w_in, c_in), dtype=torch.float32, device=dev)
@@ -607,42 +619,46 @@ class TrainEngine:
         return os.environ.get("DN_TRAIN_PACK_MULTI", "1") != "0"
 
     def _pack_multi(self):
-        """at the start of a forward (after `generation` moved): pack every known form from the parameters as they are now"""
-        ps = self.__dict__.get("_packset")
-        if ps is None or not self._pack_multi_on():
+        """at the start of a forward (after `generation` moved): pack every known form from the parameters as they are now --
+        one launch per conv engine"""
+        if not self._pack_multi_on():
             return
-        if ps["pending"]:
-            jobs = dict(ps["jobs"])
-            jobs.update(ps["pending"])
-            # forms nobody asked for in the last 8 forwards leave the set (a change of dgrad_math, of the batch shape)
-            jobs = {k: j for k, j in jobs.items() if self.generation - ps["used"].get(k, self.generation) <= 8}
-            ps["pending"] = {}
-            ps["jobs"] = jobs
-            keys = list(jobs)
-            ps["set"] = ops.SpPackSet([jobs[k][:6] for k in keys], self.flat_p.device) if keys else None
-            ps["image"] = {k: b for k, b in zip(keys, ps["set"].buffers)} if keys else {}
-            ps["params"] = [jobs[k][6] for k in keys]
-        if ps.get("set") is not None:
-            ps["set"].run([self._wmul_of(w) for w in ps["params"]])
-            ps["generation"] = self.generation
+        for engine, ps in self.__dict__.get("_packset", {}).items():
+            if ps["pending"]:
+                jobs = dict(ps["jobs"])
+                jobs.update(ps["pending"])
+                # forms nobody asked for in the last 8 forwards leave the set (a change of dgrad_math, of the batch shape)
+                jobs = {k: j for k, j in jobs.items() if self.generation - ps["used"].get(k, self.generation) <= 8}
+                ps["pending"] = {}
+                ps["jobs"] = jobs
+                keys = list(jobs)
+                ps["set"] = ops.PackSet([jobs[k][:6] for k in keys], self.flat_p.device, engine) if keys else None
+                ps["image"] = {k: b for k, b in zip(keys, ps["set"].buffers)} if keys else {}
+                ps["lifts"] = [jobs[k][6] for k in keys]
+            if ps["set"] is not None:
+                ps["set"].run([self._wmul_of(w) if w is not None else 1.0 for w in ps["lifts"]])
+                ps["generation"] = self.generation
 
-    def _packed_form(self, w, mode, dd, ci_first, n_in, single):
-        """the packed image of Parameter `w`'s weight form (mode, ci_first, n_in: ops.SpPackSet) for the conv `dd`: this forward's
-        one-launch image when the form is in the set, else `single()` (the per-layer launches) -- and a place in the next set"""
+    def _packed_form(self, w, mode, dd, ci_first, n_in, single, engine="sp", lift=None):
+        """the packed image, for the conv `dd` on `engine`, of Parameter `w`'s weight form (mode, ci_first, n_in: ops.PackSet;
+        lift: the Parameter whose power-of-two lift is multiplied in, None = 1): this forward's one-launch image when the form is
+        in the set, else `single()` (the per-layer launches) -- and a place in the next set"""
         ent = self.grad_of.get(id(w))
-        if ent is None or not self._pack_multi_on():
+        off = ent[0] if ent is not None else getattr(w, "_dn_flat_off", None)      # a Parameter, or a labelled view of the flat buffer
+        if off is None or not self._pack_multi_on():
             return single()
-        ps = self.__dict__.setdefault("_packset", {"jobs": {}, "pending": {}, "used": {}, "image": {}, "set": None, "generation": -1})
-        key = (ent[0], mode, ci_first, n_in) + _desc_key(dd)
+        ps = self.__dict__.setdefault("_packset", {}).setdefault(
+            engine, {"jobs": {}, "pending": {}, "used": {}, "image": {}, "single": set(), "set": None, "generation": -1})
+        key = (off, mode, ci_first, n_in, lift is not None) + _desc_key(dd)
         ps["used"][key] = self.generation
         if ps["generation"] == self.generation:
             img = ps["image"].get(key)
             if img is not None:
                 return img
-        if key not in ps["jobs"] and key not in ps["pending"] and key not in ps.setdefault("single", set()):
-            w4 = w.detach().reshape(w.shape[0], w.shape[1], -1)
-            if ops.SpPackSet.supported(dd) and w4.is_contiguous() and w4.dtype == torch.float32:
-                ps["pending"][key] = (_desc_copy(dd), w4, mode, w4.shape[1], ci_first, n_in, w)
+        if key not in ps["jobs"] and key not in ps["pending"] and key not in ps["single"]:
+            w3 = w.detach().reshape(w.shape[0], w.shape[1], -1)
+            if ops.PackSet.supported(dd, engine) and w3.is_contiguous() and w3.dtype == torch.float32:
+                ps["pending"][key] = (_desc_copy(dd), w3, mode, w3.shape[1], ci_first, n_in, lift)
             else:
                 ps["single"].add(key)       # a tap-merged layer: its own pack kernel
         return single()
@@ -746,6 +762,7 @@ class TrainEngine:
         cls, reg = m.classification, m.regression.box_prediction
         po, _, _ = self.grad_of[id(cls.conv1.weight)]
         w1 = self.flat_p[po:po + 2 * cls.conv1.weight.numel()].view(64, 32, 3, 3)
+        w1._dn_flat_off = po                              # (its place in the flat buffer: the key of its packed forms)
         bo, _, _ = self.grad_of[id(cls.conv1.bias)]
         b1 = self.flat_p[bo:bo + 64]
         go, _, _ = self.grad_of[id(cls.bn1.weight)]
@@ -789,10 +806,9 @@ class TrainEngine:
         hw = maps.shape[1] * maps.shape[2]
         if NW:
             T.warp_list(maps, F["poses"], F["src_image"], out=maps[NI:])
-        w1 = f.conv1_1.weight.reshape(128, 2 * C)
-        w_ego, w_nbr = w1[:, :C].contiguous(), w1[:, C:].contiguous()
-        E, d_e = self._conv(w_ego.view(128, C, 1, 1), None, maps[:NI], ksize=1, lift_of=f.conv1_1.weight)
-        z1, d_f = self._conv(w_nbr.view(128, C, 1, 1), f.conv1_1.bias, maps, ksize=1, lift_of=f.conv1_1.weight)
+        # W1 = [W_ego | W_nbr]: two 1x1 convs over column cuts of one weight
+        E, d_e = self._conv(None, None, maps[:NI], ksize=1, cut=(f.conv1_1.weight, 0))
+        z1, d_f = self._conv(None, f.conv1_1.bias, maps, ksize=1, cut=(f.conv1_1.weight, C))
         T.pair_add_ego(z1, E, F["ego_image"])
         mean1, var1 = T.bn_stats(z1, P)
         h1 = T.bn_apply(z1, mean1, var1, f.bn1_1.weight, f.bn1_1.bias, _EPS, relu=True)
@@ -803,7 +819,7 @@ class TrainEngine:
         fused = torch.empty((n_ego,) + tuple(maps.shape[1:]), dtype=torch.float32, device=maps.device)
         weights = T.fuse_combine(z4, maps, F["first"], F["pair_index"], F["map_image"], F["ego_out"], fused)
         self.fctx = dict(maps=maps, NI=NI, NW=NW, z1=z1, mean1=mean1, var1=var1, h1=h1, d_e=d_e, d_f=d_f,
-                         w_ego=w_ego, w_nbr=w_nbr, h3=h3, z4=z4, d4=d4, weights=weights)
+                         h3=h3, z4=z4, d4=d4, weights=weights)
         stats = ((f.bn1_1, mean1, var1), (f.bn1_2, L["mlp2"].ctx["mean"], L["mlp2"].ctx["var"]),
                  (f.bn1_3, L["mlp3"].ctx["mean"], L["mlp3"].ctx["var"]))
         if self.shard is not None and self.shard.world > 1:
@@ -838,13 +854,13 @@ class TrainEngine:
         `f32_fallback_steps`.  Agent-parallel ranks decide on the MAX of their flag words, so that all of them take the second
         pass (it holds collectives) or none does.  Only a pass that is flagged again -- a NaN, or an overflow in the fp32
         pass's own operands -- raises."""
-        G = self._backward_pass(*args, **kw)
+        G = self._pass_with_folds(*args, **kw)
         flags = self._range_flags()
         if flags & 1:
             self._dz_lift.clear()
             self.f32_fallback_steps += 1
             self.last_fallback_step = self.step_count
-            G = self._backward_pass(*args, **kw)
+            G = self._pass_with_folds(*args, **kw)
             flags = self._range_flags()
             if flags & 1:
                 raise ops._lib.DnError(
@@ -852,6 +868,23 @@ class TrainEngine:
                     "forward beyond the f16 range?); the gradients of this step are invalid and were NOT applied")
         if flags & 4:
             raise ops._lib.DnError("backward: a NaN reached a split-f16 epilogue")
+        return G
+
+    def _pass_with_folds(self, *args, **kw):
+        """one reverse pass; the folds of its bias gradients (sums over dz per channel: leaves, read by the optimizer only) are
+        collected and launched together behind it (train_ops.DeferredFolds; DN_TRAIN_DEFER_FOLDS=0: each behind its sum)"""
+        if os.environ.get("DN_TRAIN_DEFER_FOLDS", "1") == "0":
+            return self._backward_pass(*args, **kw)
+        folds = self.__dict__.get("_folds")
+        if folds is None or len(folds._ws) > 256:      # (workspaces are kept per output tensor: a caller that hands in a new
+            folds = self._folds = T.DeferredFolds()    #  gradient buffer every pass must not grow them without bound)
+        self._folds_active = folds
+        try:
+            G = self._backward_pass(*args, **kw)
+            folds.run()
+        finally:
+            self._folds_active = None
+            folds._jobs, folds._keep = [], []
         return G
 
     def _backward_pass(self, dcls, dloc, G=None, dkd=None):
@@ -973,13 +1006,13 @@ class TrainEngine:
         dh1 = self._layer_bwd(L["mlp2"], dh2, G)
         dz1 = T.bn_backward(dh1, c["h1"], c["z1"], c["mean1"], c["var1"], f.bn1_1.weight, _EPS,
                             self.g(f.bn1_1.weight, G), self.g(f.bn1_1.bias, G), relu=True)
-        T.channel_sum(dz1, self.g(f.conv1_1.bias, G))
+        T.channel_sum(dz1, self.g(f.conv1_1.bias, G), folds=self.__dict__.get("_folds_active"))
         dE = T.pair_sum_ego(dz1, F["efirst"], F["epairs"], NI)
         gw1 = self.g(f.conv1_1.weight, G).view(128, 2 * C)
         T.conv_wgrad(c["d_e"], maps[:NI], None, dE, gw1[:, :C], dw_cin_total=2 * C)
         T.conv_wgrad(c["d_f"], maps, None, dz1, gw1[:, C:], dw_cin_total=2 * C)
-        T.add_rows(dmaps, self._dgrad(c["d_f"], c["w_nbr"].view(128, C, 1, 1), dz1))
-        T.add_rows(dmaps[:NI], self._dgrad(c["d_e"], c["w_ego"].view(128, C, 1, 1), dE))
+        T.add_rows(dmaps, self._dgrad(c["d_f"], f.conv1_1.weight, dz1, ci_first=C, c_in=C))       # W1 = [W_ego | W_nbr]
+        T.add_rows(dmaps[:NI], self._dgrad(c["d_e"], f.conv1_1.weight, dE, ci_first=0, c_in=C))
         if NW:
             T.warp_backward(dmaps[NI:], F["poses"], F["src_image"], dmaps[:NI], rigid=F["rigid"])
         if self.shard is not None:

@@ -5,7 +5,6 @@ Maps are NHWC; a tensor argument that is a channel slice of a wider map is passe
 as (tensor_view, ld) with the view's data_ptr at the first channel.
 """
 import ctypes
-
 import os
 
 import torch
@@ -187,7 +186,8 @@ def bn_backward_bias_supported(z, n_groups=1):
 
 
 def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_b=None, up_a=False,
-                accumulate=False, out=None, sync=None, norm_rows=None, sp_out=None, sp_lift=1.0, relu_mask=None, dbias=None):
+                accumulate=False, out=None, sync=None, norm_rows=None, sp_out=None, sp_lift=1.0, relu_mask=None, dbias=None,
+                folds=None):
     """z, y [n, h, w, c] dense.  dy_a: [n, h, w, c'] view (or [n, 2h, 2w, c'] when up_a = 1 / True; up_a = 2: the
     space-to-depth image [n, h/2, w/2, 4c] of the gradient, train.py :: _dgrad's one-launch stride-2 data gradient), dy_b
     optional second gradient (same resolution as y).  Returns dz; fills dgamma / dbeta.
@@ -197,7 +197,8 @@ def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_
     relu_mask: bn_apply's byte mask of (y > 0) -- read in place of y by both passes (relu = 2 of the C entry points).
     dbias [c]: also receives sum over this call's rows of dz -- the gradient of the conv bias in front of this BatchNorm --
     from the launch that writes dz (dn_bn_train_backward_finish_bias; bn_backward_bias_supported), instead of a channel_sum
-    pass over dz."""
+    pass over dz.  folds (a DeferredFolds): dbias' fold joins it instead of being launched here -- dbias is valid after
+    folds.run()."""
     _need_gpu(dy_a, dy_b, y, z, mean, var, gamma, relu_mask, dbias)
     n, h, w, c = z.shape
     if relu_mask is not None:
@@ -223,6 +224,15 @@ def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_
             sync(_folded(sums, n_groups, c))
         rows = int(norm_rows if norm_rows is not None else n * h * w)
         nb = int(lib.dn_bn_bias_workspace_bytes(n * h * w, c))
+        if folds is not None:
+            bws = folds.workspace(dbias, nb)
+            blocks = ctypes.c_int(0)
+            check(lib.dn_bn_train_backward_finish_bias_deferred(
+                *src, _ptr(gamma), float(eps), int(relu), h, w, n, c, _ptr(sums), rows, _ptr(dz),
+                _ptr(sp_out.data) if sp_out is not None else None, float(sp_lift) if sp_out is not None else 1.0,
+                _ptr(bws), bws.numel(), ctypes.byref(blocks), _stream()), "dn_bn_train_backward_finish_bias_deferred")
+            folds.add(bws, blocks.value, c, dbias, False)
+            return dz
         bws = _ws(z.device, nb, _BIAS_WS)
         check(lib.dn_bn_train_backward_finish_bias(*src, _ptr(gamma), float(eps), int(relu), h, w, n, c, _ptr(sums), rows, _ptr(dz),
                                                    _ptr(sp_out.data) if sp_out is not None else None,
@@ -263,11 +273,50 @@ def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_
     return dz
 
 
-def channel_sum(x, out, accumulate=False):
-    """out[c] (+)= sum over all rows of x [..., c] (x may be a channel slice)"""
+class DeferredFolds:
+    """The channel-sum folds of one backward pass, launched together (dn_channel_sum_fold_multi).  The sums are leaves of the
+    backward (bias gradients): bn_backward(..., dbias=, folds=) and channel_sum(..., folds=) leave their per-workgroup partials
+    in a workspace of their own -- kept per output tensor across steps -- and run() folds them all in one launch; the outputs
+    are valid after it."""
+
+    def __init__(self):
+        self._ws, self._jobs, self._keep = {}, [], []
+
+    def workspace(self, out, nbytes):
+        key = (out.data_ptr(), out.numel(), sum(1 for _, o in self._keep if o.data_ptr() == out.data_ptr()))   # (a second sum into one tensor: its own partials)
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = self._ws[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=out.device)
+        return buf
+
+    def add(self, ws, n_blocks, c, out, accumulate):
+        self._jobs.append((ws.data_ptr() + 8 * c, ws.data_ptr(), out.data_ptr(), int(n_blocks), int(c), int(bool(accumulate))))
+        self._keep.append((ws, out))
+
+    def run(self):
+        if not self._jobs:
+            return
+        jobs = (_lib.FoldJob * len(self._jobs))()
+        for q, (part, sums, out, nb, c, acc) in zip(jobs, self._jobs):
+            q.partials, q.sums, q.out, q.n_blocks, q.c, q.accumulate = part, sums, out, nb, c, acc
+        check(_lib.load().dn_channel_sum_fold_multi(jobs, len(self._jobs), _stream()), "dn_channel_sum_fold_multi")
+        self._jobs, self._keep = [], []
+
+
+def channel_sum(x, out, accumulate=False, folds=None):
+    """out[c] (+)= sum over all rows of x [..., c] (x may be a channel slice).  folds (a DeferredFolds): the fold joins it
+    instead of being launched here -- out is valid after folds.run()."""
     _need_gpu(x, out)
     c = x.shape[-1]
     rows = x.numel() // c
+    if folds is not None:
+        lib = _lib.load()
+        ws = folds.workspace(out, lib.dn_reduce_workspace_bytes(1, rows, c))
+        blocks = ctypes.c_int(0)
+        check(lib.dn_channel_sum_partial(_ptr(x), rows, c, _ld(x), _ptr(ws), ws.numel(), ctypes.byref(blocks), _stream()),
+              "dn_channel_sum_partial")
+        folds.add(ws, blocks.value, c, out, accumulate)
+        return out
     sums = _ws(x.device, _lib.load().dn_reduce_workspace_bytes(1, rows, c))
     check(_lib.load().dn_channel_sum(_ptr(x), rows, c, _ld(x), _ptr(sums), sums.numel(), _ptr(out),
                                      int(bool(accumulate)), _stream()), "dn_channel_sum")

@@ -244,7 +244,8 @@ int dn_spconv_pack_weights(const dn_conv_desc* d, const float* weight_oihw, floa
 /* Many plain-layout packs in ONE launch (a training step packs every layer's weights once for its forward and once, flipped
  * and transposed, for its data gradient: ~70 launches of 4-7 us on a stream that has nothing else to run beside them).
  * A job packs, for the conv `desc`, the weight tensor W[c_out][c0 + c1][k][k] that a VIEW of `weight` defines:
- *   mode 0: W = weight                                                          (= dn_spconv_pack_weights)
+ *   mode 0: W[n][ci][t] = weight[n][ci_first + ci][t], weight [c_out][cin_total][k][k]
+ *           (= dn_spconv_pack_weights; of a column cut when cin_total > c0 + c1)
  *   mode 1: W[n][ci][t] = weight[ci][ci_first + n][k*k - 1 - t], weight [.][cin_total][k][k]
  *           (= dn_conv_dgrad_weights (disconet_train.h) then dn_spconv_pack_weights: the data gradient's conv)
  *   mode 2: W[cls n_in + j] = class (cls / 2, cls % 2) of dn_conv_dgrad_class_weights over column ci_first + j, desc.c_out = 4 n_in
@@ -264,6 +265,11 @@ typedef struct dn_pack_job {
 size_t dn_spconv_pack_multi_table_bytes(int n_jobs);
 int dn_spconv_pack_multi_prepare(const dn_pack_job* jobs, int n_jobs, void* table_host, int* total_blocks);
 int dn_spconv_pack_weights_multi(const void* table_device, int n_jobs, int total_blocks, void* stream);
+/* The same for the fp32-NHWC engine's packs (dn_conv_pack_weights; desc.math == 1: the split-f16 rows): modes 0 and 1, and the
+ * values are multiplied by the job's wmul first (a power of two: what a caller of dn_conv_pack_weights multiplies in itself). */
+size_t dn_conv_pack_multi_table_bytes(int n_jobs);
+int dn_conv_pack_multi_prepare(const dn_pack_job* jobs, int n_jobs, void* table_host, int* total_blocks);
+int dn_conv_pack_weights_multi(const void* table_device, int n_jobs, int total_blocks, void* stream);
 /* out: SP tensor [n_images][ceil(c_out/16)][4][h_out][w_out] */
 int dn_spconv2d(const dn_conv_desc* d, const void* src0_sp, const void* src1_sp,
                 const void* packed, const float* scale, const float* shift, void* out_sp,

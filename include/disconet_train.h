@@ -191,6 +191,27 @@ int dn_bn_train_backward_finish_bias(const float* dy_a, int ld_a, int up_a, cons
 int dn_channel_sum(const float* x, long rows, int c, int ld, double* sums, size_t sums_bytes, float* out,
                    int accumulate, void* stream);
 
+/* The same sums with their FOLDS DEFERRED (round 6).  A bias gradient is a leaf of the backward: nothing reads it before the
+ * optimizer step, so the launch that leaves the per-workgroup partials need not be followed by a fold of its own (26 launches of
+ * ~5 us per training step on a stream with nothing to run beside them).  dn_bn_train_backward_finish_bias_deferred /
+ * dn_channel_sum_partial are dn_bn_train_backward_finish_bias / dn_channel_sum without the fold: the partials stay in the
+ * workspace ([c] doubles for the folded sums, then [*n_blocks][c] partials), which must stay untouched until
+ * dn_channel_sum_fold_multi has folded it: one launch for every job (32 per launch), each in dn_channel_sum's fixed order --
+ * out[ch] = (accumulate ? out[ch] : 0) + (float) sum, the same bits as the undeferred calls. */
+typedef struct dn_fold_job {
+  const double* partials; /* workspace + c */
+  double* sums;           /* workspace: receives the folded doubles */
+  float* out;
+  int32_t n_blocks, c, accumulate, reserved;
+} dn_fold_job;
+int dn_bn_train_backward_finish_bias_deferred(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b, const float* y,
+                                              const float* z, const float* mean, const float* var, const float* gamma, float eps,
+                                              int relu, int h, int w, int images, int c, const double* sums, long norm_rows,
+                                              float* dz, void* dz_sp /* may be NULL */, float sp_lift, double* bias_ws,
+                                              size_t bias_ws_bytes, int* n_blocks, void* stream);
+int dn_channel_sum_partial(const float* x, long rows, int c, int ld, double* sums, size_t sums_bytes, int* n_blocks, void* stream);
+int dn_channel_sum_fold_multi(const dn_fold_job* jobs, int n_jobs, void* stream);
+
 /* Backward of the decoder's nearest x2 upsample as a pass of its own (only needed where no
  * BatchNorm backward follows directly: the fusion on layer 4): out [n, h, w, c] dense = 2 x 2
  * block sums of g [n, 2h, 2w, c'] read with row stride ld. */

@@ -247,6 +247,30 @@ static int gpu_spconv(int up) {
       free(a); free(b); HIP(hipFree(table));
     }
     free(host); HIP(hipFree(pk2));
+    /* the fp32-NHWC engine's twin: one mode-0 job with wmul = 1 == dn_conv_pack_weights, fp32 rows and split-f16 rows */
+    for (int math = 0; math < 2; ++math) {
+      dn_conv_desc dn = d;
+      dn.up0 = 0; dn.c0 = cin; dn.c1 = 0; dn.ld0 = cin; dn.ld1 = 0; dn.ldo = cout; dn.math = math;
+      const size_t nf = dn_conv_packed_weight_floats(&dn);
+      CHECK(nf > 0, "nhwc packed size: %s", dn_last_error());
+      float *p1, *p2;
+      HIP(hipMalloc((void**)&p1, nf * 4)); HIP(hipMalloc((void**)&p2, nf * 4));
+      CHECK(dn_conv_pack_weights(&dn, dw, p1, NULL) == DN_OK, "nhwc pack: %s", dn_last_error());
+      memset(&job, 0, sizeof job);
+      job.desc = dn; job.weight = dw; job.packed = p2; job.mode = 0; job.cin_total = cin; job.wmul = 1.f;
+      const size_t tn = dn_conv_pack_multi_table_bytes(1);
+      void* hostn = malloc(tn);
+      CHECK(dn_conv_pack_multi_prepare(&job, 1, hostn, &blocks) == DN_OK && blocks > 0, "nhwc pack multi prepare: %s", dn_last_error());
+      HIP(hipMalloc(&table, tn));
+      HIP(hipMemcpy(table, hostn, tn, hipMemcpyHostToDevice));
+      CHECK(dn_conv_pack_weights_multi(table, 1, blocks, NULL) == DN_OK, "nhwc pack multi: %s", dn_last_error());
+      HIP(hipDeviceSynchronize());
+      unsigned char *a = malloc(nf * 4), *b = malloc(nf * 4);
+      HIP(hipMemcpy(a, p1, nf * 4, hipMemcpyDeviceToHost)); HIP(hipMemcpy(b, p2, nf * 4, hipMemcpyDeviceToHost));
+      CHECK(memcmp(a, b, nf * 4) == 0, "nhwc pack multi differs from dn_conv_pack_weights (math %d)", math);
+      free(a); free(b); free(hostn); HIP(hipFree(table)); HIP(hipFree(p1)); HIP(hipFree(p2));
+    }
+    printf("C ABI conv pack multi: equal to dn_conv_pack_weights, fp32 and split-f16 rows\n");
   }
   CHECK(dn_fold_bn(db, NULL, NULL, NULL, NULL, 0.f, cout, dsc, dsh, NULL) == DN_OK, "fold: %s", dn_last_error());
   float* hsc = malloc(cout * 4);

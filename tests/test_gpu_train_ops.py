@@ -704,6 +704,41 @@ def test_one_launch_pack_of_many_weight_forms_writes_the_single_launches_bytes(s
     assert not ops.SpPackSet.supported(up) and ops.SpPackSet.supported(jobs[0][0])
 
 
+@pytest.mark.parametrize("math", [0, 1])
+def test_one_launch_pack_of_the_nhwc_engines_weight_forms_writes_the_single_launches_bytes(math):
+    """dn_conv_pack_weights_multi (ops.PackSet, engine "nhwc") against dn_conv_pack_weights of the weight times its lift, of a
+    column cut of it (the attention MLP's W1 halves) and of dn_conv_dgrad_weights' flipped / transposed cut -- fp32 rows
+    (math 0) and split-f16 rows (math 1), 1x1 and 3x3, byte for byte, before and after the weights and lifts moved."""
+    from disconet_amd import ops, train_ops
+    g = torch.Generator().manual_seed(5 + math)
+    dev = _dev()
+    jobs = []
+    for c_out, cin_total, ci_first, c_in, k, mode in ((128, 512, 0, 256, 1, 0), (128, 512, 256, 256, 1, 0), (32, 128, 0, 128, 1, 0),
+                                                      (8, 32, 0, 32, 1, 0), (1, 8, 0, 8, 1, 0), (12, 32, 0, 32, 1, 0), (64, 40, 0, 40, 3, 0),
+                                                      (128, 512, 256, 256, 1, 1), (32, 128, 0, 128, 1, 1), (36, 32, 0, 32, 1, 1),
+                                                      (64, 96, 32, 64, 3, 1)):
+        w = (torch.randn(c_out, cin_total, k, k, generator=g) * 0.05).to(dev)
+        d = (ops.conv_desc(2, 8, 8, c_in, c_out, k, 1, False, math=math) if mode == 0 else
+             ops.conv_desc(2, 8, 8, c_out, c_in, k, 1, False, math=math))
+        jobs.append((d, w, mode, cin_total, ci_first, c_in if mode else 0))
+    ps = ops.PackSet(jobs, dev, "nhwc")
+    for trial in range(2):
+        wmuls = [float(2.0 ** ((i + trial) % 4)) for i in range(len(jobs))]
+        if trial:
+            for j in jobs:
+                j[1].mul_(0.77)
+        for b in ps.buffers:
+            b.fill_(123.0)
+        ps.run(wmuls)
+        for i, ((d, w, mode, cin_total, ci_first, n_in), b) in enumerate(zip(jobs, ps.buffers)):
+            if mode == 0:
+                wc = w[:, ci_first:ci_first + d.c0].contiguous()
+            else:
+                wc = train_ops.dgrad_weights(w, ci_first, d.c_out)
+            want = ops.pack_conv_weights(d, wc * wmuls[i])
+            assert want.numel() == b.numel() and torch.equal(want.view(torch.int32), b.view(torch.int32)), (trial, i)
+
+
 def test_fuse_combine_forward_backward():
     from disconet_amd import train_ops
     g = torch.Generator().manual_seed(12)
