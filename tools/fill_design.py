@@ -106,6 +106,9 @@ def main(dry, ncpu):
     b0 = med([float(x[2]) for x in ab if x[0] == "fused_bias=0"])
     b1 = med([float(x[2]) for x in ab if x[0] == "fused_bias=1" and x[1] == "blocks=1024"])
     g = lambda k: tg.get(k, {"ms_per_step": 0.0})["ms_per_step"]
+    tj = os.path.join(ROOT, "gpurun_out", "r06_trajectory.json")
+    traj = j(tj if (not FROM_PROFILES and os.path.exists(tj)) else os.path.join(ROOT, "profiles", "r06_trajectory.json"))
+    pc = lambda x: "%.1f %%" % (100.0 * x)
     v = {
         "VALUE": "%.0f" % d["value"], "MS": "%.3f" % d["ms_per_step"], "CONVMS": "%.3f" % r["kernel_ms_per_step"],
         "FRAC": "%.3f" % r["frac"], "FRACX": "%.2f" % r["frac_executed"],
@@ -125,6 +128,8 @@ def main(dry, ncpu):
         "T_PACK": "%.2f" % (g("packing") + g("copies")),
         "T_MISC": "%.2f" % g("other (loss, warp, combine, Adam, torch elementwise)"), "T_TOTAL": "%.2f" % tg["total_ms_per_step"],
         "BIASAB": "%.2f → %.2f ms per step, medians of three interleaved runs" % (b0, b1),
+        "TRAJ_FIRST40": pc(traj["first40_sp_vs_f32"]), "TRAJ_MAX": pc(traj["max_rel_sp_vs_f32"]),
+        "TRAJ_FLOOR": pc(traj["max_rel_f32_nhwc_vs_f32_sp (floor)"]),
         "LAYER_TABLE": layer_table(),
     }
     # the documents are generated from tools/templates/*.tmpl.md (the same text with @@PLACEHOLDERS@@): edit the templates, re-run
@@ -156,6 +161,7 @@ def main(dry, ncpu):
           (os.path.join(P, "train_step_kernel_stats.csv"), RD + "_train_step_kernel_stats.csv"),
           (os.path.join(P, "train_groups.json"), RD + "_train_groups.json")]
     cp += [(os.path.join(F, "agent_share_b%d.json" % b), RD + "_agent_share_b%d.json" % b) for b in (8, 16, 32)]
+    cp.append((os.path.join(ROOT, "gpurun_out", "r06_trajectory.json"), RD + "_trajectory.json"))      # written by the GPU suite's trajectory test
     for src, dst in cp:
         if os.path.exists(src):
             shutil.copy(src, os.path.join(ROOT, "profiles", dst))

@@ -15,7 +15,7 @@ GROUPS = [
     ("wgrad", ("conv_wgrad_sp_s2", "conv_wgrad_sp_kernel", "conv_wgrad64", "conv_wgrad_kernel", "wgrad_reduce", "conv_wgrad")),
     ("bn_forward", ("bn_apply", "bn_stats")),
     ("bn_backward", ("bn_bwd_apply", "bn_bwd_reduce", "bn_param_grad")),
-    ("folds_and_bias_sums", ("fold_partials", "channel_sum")),
+    ("folds_and_bias_sums", ("fold_", "channel_sum")),
     ("conv_engine_sp", ("conv_sp_kernel", "conv_spq_kernel", "conv_pre_pair")),
     ("conv_engine_nhwc", ("conv_mfma_kernel",)),
     ("packing", ("sp_pack", "pack", "sp_from_nhwc", "dgrad_weights", "dgrad_class")),
