@@ -155,6 +155,8 @@ SIGNATURES = {
     "dn_conv_wgrad_sp_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "dn_conv_wgrad_sp": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                  c_float, c_void_p]),
+    "dn_conv_wgrad_sp_z": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                                 c_float, c_void_p]),
     "dn_conv_dgrad_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                       c_void_p]),
     "dn_conv_dgrad_class_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

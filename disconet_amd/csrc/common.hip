@@ -30,7 +30,7 @@ hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t stream) {
 }
 }  // namespace dn
 
-extern "C" int dn_version(void) { return 133; }  // 0.1.3: round-5 kernels (profiles carry this number; 131: dn_conv_wgrad_sp; 132: round 6 -- Gray MFMA order, fp32 rows from the tap-merged kernel, fused bias gradients; 133: dn_spconv_pack_weights_multi, lane-parallel warp gathers)
+extern "C" int dn_version(void) { return 134; }  // 0.1.3: round-5 kernels (profiles carry this number; 131: dn_conv_wgrad_sp; 132: round 6 -- Gray MFMA order, fp32 rows from the tap-merged kernel, fused bias gradients; 133: dn_spconv_pack_weights_multi, lane-parallel warp gathers; 134: dn_conv_wgrad_sp_z, dz = NULL in the BatchNorm backward)
 
 // The hash of every source / header / flag this library was built from (csrc/build.py :: tree_hash), behind a marker
 // that build.py also finds in the file without loading it.  _lib.load() refuses a library whose id is not the tree's.

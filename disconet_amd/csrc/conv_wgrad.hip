@@ -533,10 +533,10 @@ Plan make_plan_sp(const dn_conv_desc& d, int cb) {
   p.n_slices = s;
   return p;
 }
-template <int CB, int STRIDE>
+template <int CB, int STRIDE, bool ZSP = false>
 int launch_sp(const WgradSpArgs& a, const Plan& p, hipStream_t stream) {
   constexpr int lds = (STRIDE == 2 ? WspShape2<CB>::LDS_DWORDS : WspShape<CB>::LDS_DWORDS) * 4;
-  auto kern = STRIDE == 2 ? conv_wgrad_sp_s2_kernel<CB> : conv_wgrad_sp_kernel<CB>;
+  auto kern = STRIDE == 2 ? conv_wgrad_sp_s2_kernel<CB, ZSP> : conv_wgrad_sp_kernel<CB, ZSP>;
   static dn::PerDeviceFlag ready_flag;
   bool& ready = ready_flag.here();
   if (!ready) {
@@ -560,19 +560,35 @@ extern "C" size_t dn_conv_wgrad_sp_workspace(const dn_conv_desc* d) {
   return (size_t)p.n_slices * p.n_cot * p.n_cit * 9 * cb * cb * sizeof(float);
 }
 
+namespace {
+int conv_wgrad_sp_impl(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz, const void* dz_sp, void* workspace,
+                       float* dw_oihw, int dw_cin_total, int accumulate, float dz_lift, float x_lift, void* stream);
+}
 extern "C" int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz, void* workspace,
                                 float* dw_oihw, int dw_cin_total, int accumulate, float dz_lift, float x_lift, void* stream) {
+  return conv_wgrad_sp_impl(d, src0, src1, dz, nullptr, workspace, dw_oihw, dw_cin_total, accumulate, dz_lift, x_lift, stream);
+}
+extern "C" int dn_conv_wgrad_sp_z(const dn_conv_desc* d, const float* src0, const float* src1, const void* dz_sp, void* workspace,
+                                  float* dw_oihw, int dw_cin_total, int accumulate, float dz_lift, float x_lift, void* stream) {
+  DN_REQUIRE(dz_sp, "wgrad_sp_z: null pointer");
+  return conv_wgrad_sp_impl(d, src0, src1, nullptr, dz_sp, workspace, dw_oihw, dw_cin_total, accumulate, dz_lift, x_lift, stream);
+}
+namespace {
+int conv_wgrad_sp_impl(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz, const void* dz_sp, void* workspace,
+                       float* dw_oihw, int dw_cin_total, int accumulate, float dz_lift, float x_lift, void* stream) {
   if (int rc = validate(d)) return rc;
   const int cb = sp_block(*d);
   DN_REQUIRE(cb != 0, "wgrad_sp: 3x3 layers with c_out >= 32 only; two sources: 32 k channels each, stride 1 (dn_conv_wgrad_sp_supported)");
-  DN_REQUIRE(src0 && dz && workspace && dw_oihw, "wgrad_sp: null pointer");
+  DN_REQUIRE(src0 && (dz || dz_sp) && workspace && dw_oihw, "wgrad_sp: null pointer");
+  DN_REQUIRE(!dz_sp || (d->c_out % 16 == 0 && (reinterpret_cast<uintptr_t>(dz_sp) & 15) == 0),
+             "wgrad_sp_z: the SP copy of dz needs c_out %% 16 == 0 (got %d) and a 16-byte aligned tensor", d->c_out);
   DN_REQUIRE(dw_cin_total == 0 || dw_cin_total >= d->c0 + d->c1, "wgrad_sp: dw_cin_total %d < c_in", dw_cin_total);
   DN_REQUIRE(d->c1 == 0 || src1, "wgrad_sp: c1 > 0 needs src1");
   auto pow2 = [](float v) { int e; return v > 0.f && std::isfinite(v) && std::frexp(v, &e) == 0.5f; };
   DN_REQUIRE(pow2(dz_lift) && pow2(x_lift), "wgrad_sp: the lifts must be powers of two (got %g, %g)", dz_lift, x_lift);
   auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
   const bool vecx = d->c0 % 4 == 0 && d->ld0 % 4 == 0 && al16(src0) && (d->c1 == 0 || (d->c1 % 4 == 0 && d->ld1 % 4 == 0 && al16(src1)));
-  DN_REQUIRE(al16(dz) && (vecx || (cb == 32 && d->c1 == 0 && d->stride == 1)), "wgrad_sp: dz (and, but for a single-source stride-1 "
+  DN_REQUIRE((dz_sp || al16(dz)) && (vecx || (cb == 32 && d->c1 == 0 && d->stride == 1)), "wgrad_sp: dz (and, but for a single-source stride-1 "
              "32-channel-block layer, the sources) must be 16-byte aligned with rows of 4 k floats");
   const Plan p = make_plan_sp(*d, cb);
   WgradSpArgs a;
@@ -583,9 +599,12 @@ extern "C" int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const 
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles;
   a.n_cot = p.n_cot; a.n_cit = p.n_cit; a.n_slices = p.n_slices;
   a.dz_lift = dz_lift; a.x_lift = x_lift; a.vecx = vecx ? 1 : 0;
+  a.dz_sp = static_cast<const unsigned char*>(dz_sp);
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = d->stride == 2 ? (cb == 64 ? launch_sp<64, 2>(a, p, s) : launch_sp<32, 2>(a, p, s))
-                              : (cb == 64 ? launch_sp<64, 1>(a, p, s) : launch_sp<32, 1>(a, p, s)))
+  if (int rc = dz_sp ? (d->stride == 2 ? (cb == 64 ? launch_sp<64, 2, true>(a, p, s) : launch_sp<32, 2, true>(a, p, s))
+                                       : (cb == 64 ? launch_sp<64, 1, true>(a, p, s) : launch_sp<32, 1, true>(a, p, s)))
+                     : (d->stride == 2 ? (cb == 64 ? launch_sp<64, 2>(a, p, s) : launch_sp<32, 2>(a, p, s))
+                                       : (cb == 64 ? launch_sp<64, 1>(a, p, s) : launch_sp<32, 1>(a, p, s))))
     return rc;
   const long per_slice = (long)p.n_cot * p.n_cit * 9 * cb * cb;
   const int blocks = (int)(per_slice / 64 < 8192 ? per_slice / 64 : 8192);
@@ -594,6 +613,7 @@ extern "C" int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const 
                      1.0f / (dz_lift * x_lift));
   return dn::check_launch("wgrad_reduce_kernel");
 }
+}  // namespace
 
 namespace dn { void range_collect_conv_wgrad(unsigned* dst, bool reset, hipStream_t s) { sp_range_collect_here(dst, reset, s); } }
 

@@ -655,7 +655,7 @@ bn_bwd_apply_v4_fast_kernel(GradSrc src, const float* __restrict__ z, const floa
     const f32x4 zh = (ldv4(z + (size_t)row * c + 4 * c4) - ldv4(mean + 4 * c4)) * rs;
     const f32x4 m1 = *reinterpret_cast<const f32x4*>(&m1_s[4 * c4]), m2 = *reinterpret_cast<const f32x4*>(&m2_s[4 * c4]);
     const f32x4 v = ldv4(gamma + 4 * c4) * rs * (src.v4u(row, c4) - m1 - zh * m2);
-    *reinterpret_cast<f32x4*>(dz + (size_t)row * c + 4 * c4) = v;
+    if (!SP || dz) *reinterpret_cast<f32x4*>(dz + (size_t)row * c + 4 * c4) = v;      // (dz NULL: the SP copy is the only consumer's)
     if constexpr (BIAS) bsum += v;
     if constexpr (SP) {
       typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -1340,8 +1340,12 @@ int bn_backward_finish_impl(const float* dy_a, int ld_a, int up_a, const float* 
                             int images_per_group, int c, const double* sums, long norm_rows, float* dz,
                             void* dz_sp, float sp_lift, void* stream, float* dbias = nullptr, double* bias_ws = nullptr,
                             size_t bias_ws_bytes = 0, int* defer_blocks = nullptr) {
-  DN_REQUIRE(dy_a && z && mean && var && gamma && sums && dz, "bn backward finish: null pointer");
+  DN_REQUIRE(dy_a && z && mean && var && gamma && sums && (dz || dz_sp), "bn backward finish: null pointer");
   DN_REQUIRE(!relu || y, "bn backward: relu needs y");
+  // dz NULL (round 6): only the SP copy is written -- for a layer whose weight gradient (dn_conv_wgrad_sp_z), data gradient and
+  // bias gradient all read dz through this launch's other outputs; the one-group fast kernels only
+  DN_REQUIRE(dz || (n_groups == 1 && bn_fast_shift(n_groups, c, (long)images_per_group * h * w * c) >= 0),
+             "bn backward: dz may be NULL only where the one-group fast form runs (one group, c / 4 a power of two; DN_BN_LEGACY unset)");
   DN_REQUIRE(relu >= 0 && relu <= 2 && (relu != 2 || c % 4 == 0), "bn backward: relu = 2 (y is the byte mask) needs c %% 4 == 0");
   DN_REQUIRE(up_a >= 0 && up_a <= 2 && (up_a != 2 || (h % 2 == 0 && w % 2 == 0 && ld_a >= 4 * c)),
              "bn backward: up_a = 2 (dy_a is the space-to-depth image [h / 2][w / 2][4 c]) needs even h, w and ld_a >= 4 c");

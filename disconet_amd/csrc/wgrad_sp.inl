@@ -25,7 +25,27 @@ struct WgradSpArgs {
   int n_cot, n_cit, n_slices;
   int vecx;            // 0: the sources' rows are not 16-byte loadable (13 input channels): four dword loads, each with its own bound
   float dz_lift, x_lift;
+  const unsigned char* dz_sp;      // ZSP kernels: dz * dz_lift as the SP tensor the BatchNorm backward wrote (include/disconet_hip.h "SP tensor")
 };
+
+// ZSP (round 6): dz comes PRE-SPLIT -- the SP copy of dz * lift that dn_bn_train_backward_finish_sp / _bias write for the data
+// gradient, the same hi / lo halves this kernel's staging pass derives from the fp32 rows (same lift, same split: the results are
+// the same bits) -- so the fp32 copy of dz need not be written at all, and the tile's staging is 16 byte permutes per 16 values
+// instead of a multiply, two conversions and a subtraction per value.  A thread takes the hi and lo pieces (8 channels each) of
+// two adjacent pixels and writes one dword per channel and part, as before.
+__device__ inline void zsp_put(unsigned* H, int slot, const u32x4 a, const u32x4 b) {
+  // a, b: 8 halves (channels 0..7) of pixel 0 / pixel 1 -> per channel one dword: pixel 0 in the low half, pixel 1 in the high half
+  u32x4 lo4, hi4;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    lo4[2 * k] = __builtin_amdgcn_perm(b[k], a[k], 0x05040100u);
+    lo4[2 * k + 1] = __builtin_amdgcn_perm(b[k], a[k], 0x07060302u);
+    hi4[2 * k] = __builtin_amdgcn_perm(b[k + 2], a[k + 2], 0x05040100u);
+    hi4[2 * k + 1] = __builtin_amdgcn_perm(b[k + 2], a[k + 2], 0x07060302u);
+  }
+  *reinterpret_cast<u32x4*>(&H[slot]) = lo4;
+  *reinterpret_cast<u32x4*>(&H[slot + 4]) = hi4;
+}
 
 // CB = channels per side of a workgroup's (co, ci) block.
 //   64: four waves = the four 32 x 32 quadrants, each over all pixels of a 4 x 16 tile (3x3 layers with >= 64 channels both sides).
@@ -46,9 +66,10 @@ struct WspShape {
   static_assert(CB == 64 || LDS_DWORDS >= 9 * 1024, "reduction buffer");
 };
 
-template <int CB>
+template <int CB, bool ZSP = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_kernel(const WgradSpArgs a) {
   using S = WspShape<CB>;
+  constexpr int QN8 = CB / 8, D_IT8 = (S::DPAIRS * QN8 + 255) / 256;      // ZSP: (pixel pair, channel octet) items of the dz tile
   constexpr int PITCH = S::PITCH, QN = S::QN, TW = S::TW, TH = S::TH;
   constexpr unsigned OOB = 0xFFFFFFFFu;
   extern __shared__ __attribute__((aligned(16))) unsigned wsp_smem[];
@@ -83,12 +104,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_kernel(const WgradSpArgs
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  f32x4 rx[S::X_IT][2], rd[S::D_IT][2];
+  f32x4 rx[S::X_IT][2], rd[ZSP ? 1 : S::D_IT][2];
+  u32x4 rz[ZSP ? D_IT8 : 1][4];                       // ZSP: hi pieces of the two pixels, then their lo pieces
   float amax = 0.f;
+  const size_t hw_z = (size_t)a.h_in * a.w_in;        // (stride 1: the output map is the input's size)
 
   auto ld128 = [](auto rsrc, unsigned voff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
   };
+  auto ldu128 = [](auto rsrc, unsigned voff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0)); };
   auto ld32x4 = [](auto rsrc, unsigned voff, int nvalid) {
     f32x4 v;
 #pragma unroll
@@ -122,16 +146,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_kernel(const WgradSpArgs
         rx[it][e] = a.vecx ? ld128(rsx, off) : ld32x4(rsx, off, csrc - c);
       }
     }
+    if constexpr (ZSP) {
+      // image = [c_out / 16][4 quarters][h][w] pieces of 16 bytes, quarter = 2 * part + octet (c_out % 16 == 0: as many bytes as the fp32 image)
+      const auto rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.dz_sp + img * (hw_z * a.c_out * 4)), 0,
+                                                         (int)(hw_z * a.c_out * 4), 0x00020000);
 #pragma unroll
-    for (int it = 0; it < S::D_IT; ++it) {
-      const int idx = tid + it * 256;
-      const int pr = idx / QN, q = idx % QN;
-      const int oy = oy0 + (pr >> 3), c = co0 + 4 * q;
-      const bool rowok = oy < a.h_in && c < a.c_out;
+      for (int it = 0; it < D_IT8; ++it) {
+        const int idx = tid + it * 256;
+        const int pr = idx / QN8, o = idx % QN8;
+        const int oy = oy0 + (pr >> 3), c = co0 + 8 * o;
+        const bool rowok = idx < S::DPAIRS * QN8 && oy < a.h_in && c < a.c_out;
+        const unsigned q0 = (unsigned)((c >> 4) * 4 + ((c >> 3) & 1));
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int ox = ox0 + 2 * (pr & 7) + e;
-        rd[it][e] = ld128(rsz, (rowok && ox < a.w_in) ? (unsigned)(((oy * a.w_in + ox) * a.ldz + c) * 4) : OOB);
+        for (int e = 0; e < 2; ++e) {
+          const int ox = ox0 + 2 * (pr & 7) + e;
+          const bool ok = rowok && ox < a.w_in;
+          const unsigned px = (unsigned)(oy * a.w_in + ox);
+          rz[it][e] = ldu128(rsp, ok ? (unsigned)((q0 * hw_z + px) * 16) : OOB);
+          rz[it][2 + e] = ldu128(rsp, ok ? (unsigned)(((q0 + 2) * hw_z + px) * 16) : OOB);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < S::D_IT; ++it) {
+        const int idx = tid + it * 256;
+        const int pr = idx / QN, q = idx % QN;
+        const int oy = oy0 + (pr >> 3), c = co0 + 4 * q;
+        const bool rowok = oy < a.h_in && c < a.c_out;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int ox = ox0 + 2 * (pr & 7) + e;
+          rd[it][e] = ld128(rsz, (rowok && ox < a.w_in) ? (unsigned)(((oy * a.w_in + ox) * a.ldz + c) * 4) : OOB);
+        }
       }
     }
   };
@@ -149,10 +195,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_kernel(const WgradSpArgs
       const int idx = tid + it * 256;
       if (idx < S::XPAIRS * QN) put(Xh, Xl, (idx / QN) * PITCH + 4 * (idx % QN), rx[it][0], rx[it][1], a.x_lift);
     }
+    if constexpr (ZSP) {
 #pragma unroll
-    for (int it = 0; it < S::D_IT; ++it) {
-      const int idx = tid + it * 256;
-      put(Dh, Dl, (idx / QN) * PITCH + 4 * (idx % QN), rd[it][0], rd[it][1], a.dz_lift);
+      for (int it = 0; it < D_IT8; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < S::DPAIRS * QN8) {
+          const int slot = (idx / QN8) * PITCH + 8 * (idx % QN8);
+          zsp_put(Dh, slot, rz[it][0], rz[it][1]);
+          zsp_put(Dl, slot, rz[it][2], rz[it][3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < S::D_IT; ++it) {
+        const int idx = tid + it * 256;
+        put(Dh, Dl, (idx / QN) * PITCH + 4 * (idx % QN), rd[it][0], rd[it][1], a.dz_lift);
+      }
     }
   };
 
@@ -267,9 +325,10 @@ struct WspShape2 {
   static_assert(CB == 64 || LDS_DWORDS >= 9 * 1024, "reduction buffer");
 };
 
-template <int CB>
+template <int CB, bool ZSP = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_s2_kernel(const WgradSpArgs a) {
   using S = WspShape2<CB>;
+  constexpr int QN8 = CB / 8, D_IT8 = (S::DPAIRS * QN8 + 255) / 256;      // ZSP: (pixel pair, channel octet) items of the dz tile
   constexpr int PITCH = S::PITCH, QN = S::QN, TW = S::TW, TH = S::TH, RP = S::RP;
   constexpr unsigned OOB = 0xFFFFFFFFu;
   extern __shared__ __attribute__((aligned(16))) unsigned wsp_smem[];
@@ -298,12 +357,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_s2_kernel(const WgradSpA
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  f32x4 rx[S::X_IT][2], rd[S::D_IT][2];
+  f32x4 rx[S::X_IT][2], rd[ZSP ? 1 : S::D_IT][2];
+  u32x4 rz[ZSP ? D_IT8 : 1][4];                       // ZSP: hi pieces of the two pixels, then their lo pieces
   float amax = 0.f;
+  const size_t hw_z = (size_t)h_out * w_out;
 
   auto ld128 = [](auto rsrc, unsigned voff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
   };
+  auto ldu128 = [](auto rsrc, unsigned voff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0)); };
   auto load_tile = [&](int tile) {
     int sp = tile;
     const int ox0 = (sp % a.tiles_x) * TW;
@@ -328,16 +390,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_s2_kernel(const WgradSpA
         rx[it][e] = ld128(rsx, ok ? (unsigned)(((iy * a.w_in + ix) * a.ld0 + c) * 4) : OOB);
       }
     }
+    if constexpr (ZSP) {
+      const auto rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.dz_sp + img * (hw_z * a.c_out * 4)), 0,
+                                                         (int)(hw_z * a.c_out * 4), 0x00020000);
 #pragma unroll
-    for (int it = 0; it < S::D_IT; ++it) {
-      const int idx = tid + it * 256;
-      const int pr = idx / QN, q = idx % QN;
-      const int oy = oy0 + (pr >> 3), c = co0 + 4 * q;
-      const bool rowok = idx < S::DPAIRS * QN && oy < h_out && c < a.c_out;
+      for (int it = 0; it < D_IT8; ++it) {
+        const int idx = tid + it * 256;
+        const int pr = idx / QN8, o = idx % QN8;
+        const int oy = oy0 + (pr >> 3), c = co0 + 8 * o;
+        const bool rowok = idx < S::DPAIRS * QN8 && oy < h_out && c < a.c_out;
+        const unsigned q0 = (unsigned)((c >> 4) * 4 + ((c >> 3) & 1));
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int ox = ox0 + 2 * (pr & 7) + e;
-        rd[it][e] = ld128(rsz, (rowok && ox < w_out) ? (unsigned)(((oy * w_out + ox) * a.ldz + c) * 4) : OOB);
+        for (int e = 0; e < 2; ++e) {
+          const int ox = ox0 + 2 * (pr & 7) + e;
+          const bool ok = rowok && ox < w_out;
+          const unsigned px = (unsigned)(oy * w_out + ox);
+          rz[it][e] = ldu128(rsp, ok ? (unsigned)((q0 * hw_z + px) * 16) : OOB);
+          rz[it][2 + e] = ldu128(rsp, ok ? (unsigned)(((q0 + 2) * hw_z + px) * 16) : OOB);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < S::D_IT; ++it) {
+        const int idx = tid + it * 256;
+        const int pr = idx / QN, q = idx % QN;
+        const int oy = oy0 + (pr >> 3), c = co0 + 4 * q;
+        const bool rowok = idx < S::DPAIRS * QN && oy < h_out && c < a.c_out;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int ox = ox0 + 2 * (pr & 7) + e;
+          rd[it][e] = ld128(rsz, (rowok && ox < w_out) ? (unsigned)(((oy * w_out + ox) * a.ldz + c) * 4) : OOB);
+        }
       }
     }
   };
@@ -354,10 +437,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_sp_s2_kernel(const WgradSpA
       const int idx = tid + it * 256;
       if (idx < S::XPAIRS * QN) put(Xh, Xl, (idx / QN) * PITCH + 4 * (idx % QN), rx[it][0], rx[it][1], a.x_lift);
     }
+    if constexpr (ZSP) {
 #pragma unroll
-    for (int it = 0; it < S::D_IT; ++it) {
-      const int idx = tid + it * 256;
-      if (idx < S::DPAIRS * QN) put(Dh, Dl, (idx / QN) * PITCH + 4 * (idx % QN), rd[it][0], rd[it][1], a.dz_lift);
+      for (int it = 0; it < D_IT8; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < S::DPAIRS * QN8) {
+          const int slot = (idx / QN8) * PITCH + 8 * (idx % QN8);
+          zsp_put(Dh, slot, rz[it][0], rz[it][1]);
+          zsp_put(Dl, slot, rz[it][2], rz[it][3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < S::D_IT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < S::DPAIRS * QN) put(Dh, Dl, (idx / QN) * PITCH + 4 * (idx % QN), rd[it][0], rd[it][1], a.dz_lift);
+      }
     }
   };
 

@@ -466,11 +466,16 @@ class TrainEngine:
         ent = self._dz_lift.get(lay.name)
         # the bias gradient (sum of dz per channel) from the launch that writes dz, where its one-group fast form runs
         fused_bias = gb is not None and T.bn_backward_bias_supported(c["z"], c["groups"])
+        # the fp32 copy of dz is written only where something reads it: with the data gradient and the weight gradient on the SP
+        # copy (dn_conv_wgrad_sp_z), the bias gradient out of the same launch and no re-measurement of the lift due this step,
+        # nothing does -- a quarter of the launch's bytes (DN_TRAIN_DZ_SP_ONLY=0: always written)
+        sp_only = (sp is not None and fused_bias and wsp and ent is not None and abs(self.step_count - ent[1]) < 64
+                   and os.environ.get("DN_TRAIN_DZ_SP_ONLY", "1") != "0")
         dz = T.bn_backward(dy_a, c["y"], c["z"], c["mean"], c["var"], c["gamma"], _EPS, ggamma, gbeta,
                            relu=True, dy_b=dy_b, up_a=up_a, sp_out=sp, sp_lift=lift, relu_mask=c.get("mask"),
                            dbias=gb if fused_bias else None, folds=self.__dict__.get("_folds_active") if fused_bias else None,
-                           **self._bn_sync(c["z"], c["groups"]))
-        if lift is not None or wsp:
+                           want_dz=not sp_only, **self._bn_sync(c["z"], c["groups"]))
+        if (lift is not None or wsp) and dz is not None:
             self._dz_lift_refresh(lay, dz)
         return self._conv_bwd(c["desc"], c["w"], c["src0"], c["src1"], dz, gw, None if fused_bias else gb, need_dx,
                               dz_sp=sp, dz_lift=lift, wgrad_lift=ent[0] if (wsp and ent is not None) else None)
@@ -517,7 +522,10 @@ class TrainEngine:
 
     def _conv_bwd(self, d, w, src0, src1, dz, gw, gb, need_dx=True, dw_cin_total=0, w_ci_first=0,
                   w_c_in=None, dx_out=None, dz_sp=None, dz_lift=None, wgrad_lift=None):
-        T.conv_wgrad(d, src0, src1, dz, gw, dw_cin_total=dw_cin_total, sp_lift=wgrad_lift, x_lift=_WGRAD_X_LIFT)
+        # (the weight gradient reads dz from its SP copy where there is one with the same lift: the same bits, less staging work)
+        T.conv_wgrad(d, src0, src1, dz, gw, dw_cin_total=dw_cin_total, sp_lift=wgrad_lift, x_lift=_WGRAD_X_LIFT,
+                     dz_sp=dz_sp if (wgrad_lift is not None and dz_sp is not None and wgrad_lift == dz_lift and d.c_out % 16 == 0
+                                     and os.environ.get("DN_TRAIN_WGRAD_ZSP", "1") != "0") or dz is None else None)
         if gb is not None:
             T.channel_sum(dz, gb, folds=self.__dict__.get("_folds_active"))
         if not need_dx:
@@ -541,7 +549,7 @@ class TrainEngine:
             # BatchNorm backward (up_a = 2).  27 of its 36 (class, tap) weight blocks are zero: 4 x the MFMAs the masked fp32
             # form runs, on an engine 16 x as fast per MFMA -- and dz is read once instead of four times.
             n_in = (w4.shape[1] - ci_first) if c_in is None else c_in
-            dev = dz.device
+            dev = dz_sp.data.device
             dd = ops.conv_desc(d.n_images, d.h_in // 2, d.w_in // 2, d.c_out, 4 * n_in, 3, 1, False)
             wmul = self._wmul_of(w)
 
@@ -560,7 +568,7 @@ class TrainEngine:
             return out
         if dz_sp is not None:
             n_in = (w4.shape[1] - ci_first) if c_in is None else c_in
-            dev = dz.device
+            dev = dz_sp.data.device
             dd = ops.conv_desc(d.n_images, d.h_in, d.w_in, d.c_out, n_in, 3, 1, False)
             wmul = self._wmul_of(w)
             packed = self._packed_form(w, 1, dd, ci_first, n_in,

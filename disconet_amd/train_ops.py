@@ -32,18 +32,27 @@ def _ld(t):
 
 
 # ---- conv backward ------------------------------------------------------------------------
-def conv_wgrad(desc, src0, src1, dz, dw, dw_cin_total=0, accumulate=False, sp_lift=None, x_lift=16.0):
+def conv_wgrad(desc, src0, src1, dz, dw, dw_cin_total=0, accumulate=False, sp_lift=None, x_lift=16.0, dz_sp=None):
     """dw [c_out, c_in(, k, k)] (a column block of a [c_out, dw_cin_total, k, k] tensor when
     dw_cin_total is given) = weight gradient of the layer `desc` (desc.ldo = row stride of dz).
     sp_lift: the power-of-two lift of dz (max |dz| * sp_lift ~ 2^8) -> the split-f16 kernel (dn_conv_wgrad_sp; the layer must
-    pass conv_wgrad_sp_supported); None: the exact-fp32 MFMA kernels."""
+    pass conv_wgrad_sp_supported); None: the exact-fp32 MFMA kernels.
+    dz_sp (with sp_lift): the ops.SpTensor that holds dz * sp_lift (bn_backward's sp_out) -- read in place of dz, which may then
+    be None (dn_conv_wgrad_sp_z: the same bits)."""
     _need_gpu(src0, src1, dz, dw)
     lib = _lib.load()
     if sp_lift is not None:
         nbytes = lib.dn_conv_wgrad_sp_workspace(ctypes.byref(desc))
         if nbytes == 0:
             raise _lib.DnError("conv_wgrad: this layer has no split-f16 weight-gradient kernel (conv_wgrad_sp_supported)")
-        ws = _ws(dz.device, nbytes)
+        ws = _ws(dw.device, nbytes)
+        if dz_sp is not None:
+            if dz_sp.hi_only or dz_sp.bits or desc.c_out % 16:
+                raise _lib.DnError("conv_wgrad: dz_sp must be a full SP tensor of a layer with c_out % 16 == 0")
+            check(lib.dn_conv_wgrad_sp_z(ctypes.byref(desc), _ptr(src0), _ptr(src1), _ptr(dz_sp.data), _ptr(ws), _ptr(dw),
+                                         int(dw_cin_total), int(bool(accumulate)), float(sp_lift), float(x_lift), _stream()),
+                  "dn_conv_wgrad_sp_z")
+            return dw
         check(lib.dn_conv_wgrad_sp(ctypes.byref(desc), _ptr(src0), _ptr(src1), _ptr(dz), _ptr(ws), _ptr(dw), int(dw_cin_total),
                                    int(bool(accumulate)), float(sp_lift), float(x_lift), _stream()), "dn_conv_wgrad_sp")
         return dw
@@ -187,7 +196,7 @@ def bn_backward_bias_supported(z, n_groups=1):
 
 def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_b=None, up_a=False,
                 accumulate=False, out=None, sync=None, norm_rows=None, sp_out=None, sp_lift=1.0, relu_mask=None, dbias=None,
-                folds=None):
+                folds=None, want_dz=True):
     """z, y [n, h, w, c] dense.  dy_a: [n, h, w, c'] view (or [n, 2h, 2w, c'] when up_a = 1 / True; up_a = 2: the
     space-to-depth image [n, h/2, w/2, 4c] of the gradient, train.py :: _dgrad's one-launch stride-2 data gradient), dy_b
     optional second gradient (same resolution as y).  Returns dz; fills dgamma / dbeta.
@@ -198,7 +207,8 @@ def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_
     dbias [c]: also receives sum over this call's rows of dz -- the gradient of the conv bias in front of this BatchNorm --
     from the launch that writes dz (dn_bn_train_backward_finish_bias; bn_backward_bias_supported), instead of a channel_sum
     pass over dz.  folds (a DeferredFolds): dbias' fold joins it instead of being launched here -- dbias is valid after
-    folds.run()."""
+    folds.run().  want_dz = False (with sp_out and dbias): the fp32 dz is not written, None is returned -- for a layer whose
+    weight gradient reads the SP copy (conv_wgrad(..., dz_sp=))."""
     _need_gpu(dy_a, dy_b, y, z, mean, var, gamma, relu_mask, dbias)
     n, h, w, c = z.shape
     if relu_mask is not None:
@@ -207,7 +217,9 @@ def bn_backward(dy_a, y, z, mean, var, gamma, eps, dgamma, dbeta, relu=True, dy_
         y, relu = relu_mask, 2
     n_groups = mean.shape[0]
     assert n % n_groups == 0
-    dz = torch.empty_like(z) if out is None else out
+    if not want_dz and (sp_out is None or dbias is None or out is not None):
+        raise _lib.DnError("bn_backward: want_dz = False needs sp_out and dbias (the fused forms) and no out")
+    dz = (torch.empty_like(z) if out is None else out) if want_dz else None
     lib = _lib.load()
     sums = _ws(z.device, lib.dn_reduce_workspace_bytes(n_groups, (n // n_groups) * h * w, c))
     if dbias is not None:

@@ -61,6 +61,13 @@ int dn_conv_wgrad_sp_supported(const dn_conv_desc* d);
 size_t dn_conv_wgrad_sp_workspace(const dn_conv_desc* d);
 int dn_conv_wgrad_sp(const dn_conv_desc* d, const float* src0, const float* src1, const float* dz, void* workspace, float* dw,
                      int dw_cin_total, int accumulate, float dz_lift, float x_lift, void* stream);
+/* dn_conv_wgrad_sp with dz taken from its SP copy (round 6): dz_sp = dz * dz_lift as the SP tensor [n][c_out / 16][4][h_out][w_out]
+ * that dn_bn_train_backward_finish_sp / _finish_bias(_deferred) write for the data gradient (c_out % 16 == 0) -- the same hi / lo
+ * halves the fp32 form derives while it stages dz, so dw is the same bits; the staging of the dz tile becomes byte permutes, and
+ * a layer whose data gradient and bias gradient do not read the fp32 dz either can pass dz = NULL to those BatchNorm entry
+ * points and save the fp32 copy's write (a quarter of that launch's bytes). */
+int dn_conv_wgrad_sp_z(const dn_conv_desc* d, const float* src0, const float* src1, const void* dz_sp, void* workspace, float* dw,
+                       int dw_cin_total, int accumulate, float dz_lift, float x_lift, void* stream);
 
 /* Weights of the data-gradient conv: wt[ci][co][2-ky][2-kx] = w[co][ci][ky][kx] for the
  * c_in columns starting at `ci_first` of a [c_out][cin_total][k][k] tensor.  dx is then
@@ -179,7 +186,9 @@ int dn_bn_train_backward_finish_sp(const float* dy_a, int ld_a, int up_a, const 
 /* dn_bn_train_backward_finish (dz_sp NULL) / _finish_sp with the BIAS GRADIENT of the conv in front of this BatchNorm fused in
  * (round 6): dbias[ch] = sum over this call's rows of dz[.][ch], written by the same launch that writes dz (a thread adds its
  * own values in fp32, a workgroup its threads in double, fold in a fixed order: deterministic) -- in place of a
- * dn_channel_sum pass that reads dz again.  One group; c / 4 a power of two; bias_ws of dn_bn_bias_workspace_bytes(rows, c). */
+ * dn_channel_sum pass that reads dz again.  One group; c / 4 a power of two; bias_ws of dn_bn_bias_workspace_bytes(rows, c).
+ * dz may be NULL when dz_sp is given (and in dn_bn_train_backward_finish_sp where the one-group fast form runs): only the SP
+ * copy is written (dn_conv_wgrad_sp_z reads that). */
 size_t dn_bn_bias_workspace_bytes(long rows, int c);
 int dn_bn_train_backward_finish_bias(const float* dy_a, int ld_a, int up_a, const float* dy_b, int ld_b, const float* y,
                                      const float* z, const float* mean, const float* var, const float* gamma, float eps,

@@ -127,6 +127,14 @@ def test_conv_wgrad_split_f16_matches_autograd(case):
     train_ops.conv_wgrad(d, a0, a1, adz, fp32)
     assert rel_err(dw, 2 * fp32.double().cpu()) < 2e-5      # and against the exact-fp32 kernels
     assert ops.sp_range_flags(reset=True) & 5 == 0
+    if c_out % 16 == 0:
+        # dz from its SP copy (dn_conv_wgrad_sp_z; the tensor the BatchNorm backward writes for the data gradient): the same halves
+        # the fp32 form derives while staging -- the same bits, with and without the fp32 tensor at hand
+        zsp = ops.SpTensor.from_nhwc(adz * lift)
+        for dz_arg in (adz, None):
+            via_sp = torch.full_like(dw, -3.0)
+            train_ops.conv_wgrad(d, a0, a1, dz_arg, via_sp, sp_lift=lift, dz_sp=zsp)
+            assert torch.equal(via_sp.view(torch.int32), first.view(torch.int32))
 
 
 BASELINE_LAYERS = [
@@ -167,6 +175,9 @@ def test_conv_wgrad_split_f16_equals_the_fp32_kernels_at_baseline_size(layer):
     again = torch.empty_like(want)
     train_ops.conv_wgrad(d, x0, x1, dz, again, sp_lift=lift)
     assert torch.equal(got, again)
+    via_sp = torch.empty_like(want)                        # dz from its SP copy: the same bits
+    train_ops.conv_wgrad(d, x0, x1, None, via_sp, sp_lift=lift, dz_sp=ops.SpTensor.from_nhwc(dz * lift))
+    assert torch.equal(got.view(torch.int32), via_sp.view(torch.int32))
     assert ops.sp_range_flags(reset=True) & 5 == 0
 
 
