@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--agents", type=int, default=5)
     ap.add_argument("--map", type=int, default=256)
+    ap.add_argument("--gc", default="on", choices=["on", "off", "freeze"], help="Python's cyclic collector during the timed steps")
     args = ap.parse_args()
     from disconet_amd import CoDetModule, Config, DiscoNet, ops
     from disconet_amd.synthetic import make_scene_batch, make_train_targets
@@ -39,13 +40,23 @@ def main():
     first = mod.step(data, args.batch)
     mod.step(data, args.batch)
     torch.cuda.synchronize()
+    import gc
+    if args.gc == "off":
+        gc.disable()
+    elif args.gc == "freeze":
+        gc.collect()
+        gc.freeze()
+    per = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        t1 = time.perf_counter()
         last = mod.step(data, args.batch)
+        per.append(round(1e3 * (time.perf_counter() - t1), 3))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    gc.enable()
     print(json.dumps({"dgrad": args.dgrad, "wgrad": args.wgrad, "math": args.math, "ms_per_step": round(1e3 * dt, 3), "loss_first": first["loss"],
-                      "loss_last": last["loss"], "lifts": {k: v[0] for k, v in mod.engine._dz_lift.items()},
+                      "loss_last": last["loss"], "step_ms": per, "gc": args.gc, "lifts": {k: v[0] for k, v in mod.engine._dz_lift.items()},
                       "range_flags": ops.sp_range_flags(reset=False)}))
 
 
