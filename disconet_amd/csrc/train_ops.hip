@@ -10,6 +10,9 @@
 // (nn.BatchNorm2d / BatchNorm3d in train(), F.relu, torch.exp / div / mul of the fusion
 // loop in upstream:.../det/DiscoNet.py :: forward, loss.py's focal / smooth-L1 losses,
 // torch.optim.Adam).
+#ifndef DN_REDUCE_REVERSE
+#define DN_REDUCE_REVERSE 0      // tools/ab: 1 = the per-channel reductions walk the map from its end (profiles/r06_reduce_reverse_ab.txt)
+#endif
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -85,7 +88,13 @@ __device__ inline void group_channel_sums_v4(int c, long rows_per_group, double*
   const int tx_n = lanes_for(c4n), ty_n = blockDim.x / tx_n;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
   const long chunk = (rows_per_group + gridDim.x - 1) / gridDim.x;
-  const long r0 = blockIdx.x * chunk;
+#if DN_REDUCE_REVERSE
+  // tools/ab: the workgroups take their row chunks from the END of the map first (what the producer wrote last), same partial slots
+  const unsigned lb = gridDim.x - 1 - blockIdx.x;
+#else
+  const unsigned lb = blockIdx.x;
+#endif
+  const long r0 = lb * chunk;
   const long r1 = r0 + chunk < rows_per_group ? r0 + chunk : rows_per_group;
   for (int c4 = tx; c4 < c4n; c4 += tx_n) {
     double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
@@ -123,7 +132,7 @@ __device__ inline void group_channel_sums_v4(int c, long rows_per_group, double*
     }
   }
   __syncthreads();
-  double* out = part_g + (size_t)blockIdx.x * NQ * c;
+  double* out = part_g + (size_t)lb * NQ * c;
   for (int i = threadIdx.x; i < NQ * c; i += blockDim.x) {
     const int q = i / c, cc = i % c;
     double t = 0.0;
